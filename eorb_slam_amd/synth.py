@@ -1,0 +1,145 @@
+"""Seeded synthetic stand-ins for the reference's datasets.
+
+Real EvETHZ / MVSEC recordings are not available offline; these generators reproduce their SHAPES:
+240x180 DAVIS event slices (integer raw pixels, optionally LUT-undistorted with the EvETHZ
+intrinsics of Examples/Event/EvETHZ.yaml:62-70, as the reference's loader does at
+src/Event/EventLoader.cpp:111-125 / src/Utils/MyCalibrator.cpp:164-179), textured grey frames and
+256-bit descriptor sets.  Pure numpy, deterministic per seed.
+"""
+import numpy as np
+
+# layout of one event at the drop-in boundary: include/Event/EventData.h:36-58 (24 B, AoS)
+EVENT_DTYPE = np.dtype([("ts", "<f8"), ("x", "<f4"), ("y", "<f4"), ("p", "u1"), ("pad", "u1", (7,))])
+# cv::KeyPoint layout (28 B)
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+EVETHZ_K = dict(fx=199.092366542, fy=198.82882047, cx=132.192071378, cy=110.712660011,
+                k1=-0.368436311798, k2=0.150947243557, p1=-0.000296130534385, p2=-0.000759431726241)
+
+
+def undistort_lut(W=240, H=180, K=EVETHZ_K, iters=8):
+    """Per-raw-pixel undistorted position (radtan model inverted by fixed-point iteration, then
+    re-projected with the same K: what cv::undistortPoints(src, K, D, R=I, P=K) yields)."""
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    x0 = (u - K["cx"]) / K["fx"]; y0 = (v - K["cy"]) / K["fy"]
+    x, y = x0.copy(), y0.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        icd = 1.0 / (1.0 + (K["k2"] * r2 + K["k1"]) * r2)
+        dx = 2 * K["p1"] * x * y + K["p2"] * (r2 + 2 * x * x)
+        dy = K["p1"] * (r2 + 2 * y * y) + 2 * K["p2"] * x * y
+        x = (x0 - dx) * icd; y = (y0 - dy) * icd
+    return (x * K["fx"] + K["cx"]).astype(np.float32), (y * K["fy"] + K["cy"]).astype(np.float32)
+
+
+def shapes_events(n, W=240, H=180, seed=1, undistort=False, n_poly=3, noise_frac=0.05, t0=0.0, dt=1e-6,
+                  motion=1.0):
+    """`n` events from the edges of `n_poly` moving quadrilaterals (K = 4*n_poly = 12 edges by
+    default) plus uniform noise.  Raw coordinates are integer pixels; with undistort=True they are
+    mapped through the EvETHZ LUT and events leaving the image are dropped and re-drawn, like the
+    loader's checkInImage (src/Event/EventLoader.cpp:295-296).  Returns EVENT_DTYPE[n]."""
+    rng = np.random.default_rng(seed)
+    lut = undistort_lut(W, H) if undistort else None
+    out = np.zeros(n, EVENT_DTYPE)
+    filled = 0
+    # polygon vertices at slice start and their displacement over the slice
+    ctr = rng.uniform([0.25 * W, 0.25 * H], [0.75 * W, 0.75 * H], size=(n_poly, 1, 2))
+    rad = rng.uniform(0.12 * H, 0.33 * H, size=(n_poly, 4, 1))
+    ang = np.sort(rng.uniform(0, 2 * np.pi, size=(n_poly, 4)), axis=1)[..., None]
+    v0 = ctr + rad * np.concatenate([np.cos(ang), np.sin(ang)], axis=2)
+    vel = rng.uniform(-6.0, 6.0, size=(n_poly, 1, 2)) * motion
+    while filled < n:
+        m = int((n - filled) * 1.15) + 64
+        tt = rng.uniform(0, 1, m)
+        poly = rng.integers(0, n_poly, m); edge = rng.integers(0, 4, m); s = rng.uniform(0, 1, m)
+        a = v0[poly, edge] + vel[poly, 0] * tt[:, None]
+        b = v0[poly, (edge + 1) % 4] + vel[poly, 0] * tt[:, None]
+        pt = a + (b - a) * s[:, None] + rng.normal(0, 0.6, size=(m, 2))
+        noise = rng.uniform(0, 1, m) < noise_frac
+        pt[noise] = rng.uniform([0, 0], [W, H], size=(int(noise.sum()), 2))
+        xi = np.floor(pt[:, 0]).astype(np.int64); yi = np.floor(pt[:, 1]).astype(np.int64)
+        ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+        xi, yi, tt = xi[ok], yi[ok], tt[ok]
+        if lut is not None:
+            xf = lut[0][yi, xi]; yf = lut[1][yi, xi]
+            ok = (xf >= 0) & (xf < W) & (yf >= 0) & (yf < H)       # MyCalibrator::isInImage on floats
+            xf, yf, tt = xf[ok], yf[ok], tt[ok]
+        else:
+            xf = xi.astype(np.float32); yf = yi.astype(np.float32)
+        k = min(len(xf), n - filled)
+        out["x"][filled:filled + k] = xf[:k]; out["y"][filled:filled + k] = yf[:k]
+        out["ts"][filled:filled + k] = tt[:k]
+        filled += k
+    order = np.argsort(out["ts"], kind="stable")
+    out = out[order]
+    out["ts"] = t0 + np.arange(n) * dt                      # monotone, us resolution
+    out["p"] = rng.integers(0, 2, n).astype(np.uint8)
+    return out
+
+
+def random_events(n, W=240, H=180, seed=0, frac=True, margin=4.0):
+    """Uniform float events, including positions slightly outside the image (stamp clipping)."""
+    rng = np.random.default_rng(seed)
+    ev = np.zeros(n, EVENT_DTYPE)
+    x = rng.uniform(-margin, W + margin, n); y = rng.uniform(-margin, H + margin, n)
+    if not frac:
+        x = np.floor(x); y = np.floor(y)
+    ev["x"] = x.astype(np.float32); ev["y"] = y.astype(np.float32)
+    ev["ts"] = np.arange(n) * 1e-6
+    ev["p"] = rng.integers(0, 2, n).astype(np.uint8)
+    return ev
+
+
+def texture_image(W=240, H=180, seed=3, octaves=4):
+    """Band-limited noise + a few hard-edged rectangles: gives FAST corners on every level."""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((H, W), np.float64)
+    for o in range(octaves):
+        gh, gw = max(2, H >> (o + 2)), max(2, W >> (o + 2))
+        g = rng.uniform(0, 1, (gh, gw))
+        yy = np.linspace(0, gh - 1, H); xx = np.linspace(0, gw - 1, W)
+        y0 = np.floor(yy).astype(int); x0 = np.floor(xx).astype(int)
+        y1 = np.minimum(y0 + 1, gh - 1); x1 = np.minimum(x0 + 1, gw - 1)
+        fy = (yy - y0)[:, None]; fx = (xx - x0)[None, :]
+        up = (g[y0][:, x0] * (1 - fy) * (1 - fx) + g[y0][:, x1] * (1 - fy) * fx +
+              g[y1][:, x0] * fy * (1 - fx) + g[y1][:, x1] * fy * fx)
+        img += up * (0.5 ** (octaves - 1 - o))
+    img = (img - img.min()) / (img.max() - img.min())
+    for _ in range(40):
+        w, h = rng.integers(6, 40), rng.integers(6, 40)
+        x, y = rng.integers(0, W - 6), rng.integers(0, H - 6)
+        img[y:y + h, x:x + w] = np.clip(img[y:y + h, x:x + w] + rng.uniform(-0.5, 0.5), 0, 1)
+    return np.round(img * 255).astype(np.uint8)
+
+
+def random_descriptors(n, seed=4, width=32):
+    return np.random.default_rng(seed).integers(0, 256, (n, width), dtype=np.uint8)
+
+
+def planted_descriptors(train, seed=5, max_flips=40):
+    """Each query = a (permuted) train row with k ~ U[0, max_flips] flipped bits (first 32 B)."""
+    rng = np.random.default_rng(seed)
+    n = len(train)
+    perm = rng.permutation(n)
+    q = train[perm].copy()
+    for i in range(n):
+        k = rng.integers(0, max_flips + 1)
+        bits = rng.choice(256, size=k, replace=False)
+        for b in bits:
+            q[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return q, perm
+
+
+def random_keypoints(n, W=240, H=180, nlevels=4, scale=1.2, seed=6):
+    """Keypoints shaped like extractor output (level-coordinates scaled to the image)."""
+    rng = np.random.default_rng(seed)
+    kp = np.zeros(n, KP_DTYPE)
+    kp["x"] = rng.uniform(10, W - 10, n).astype(np.float32)
+    kp["y"] = rng.uniform(10, H - 10, n).astype(np.float32)
+    kp["octave"] = rng.integers(0, nlevels, n)
+    kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kp["size"] = (31 * scale ** kp["octave"]).astype(np.int32).astype(np.float32)
+    kp["response"] = rng.integers(1, 120, n).astype(np.float32)
+    kp["class_id"] = -1
+    return kp

@@ -1,0 +1,186 @@
+/*
+ * eorb_oracle.h -- CPU ORACLE for the EORB-SLAM event-frame front end.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a strict-IEEE, single-threaded C restatement of the
+ * reference's CPU algorithm for the hot path (event->image accumulation, ORB extraction,
+ * 256-bit Hamming matching).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (eorb_slam_amd/, include/) never includes,
+ * links or calls anything in oracle/.
+ *
+ * PARITY PINNING STATUS (see oracle/README.md):
+ *   - the reference ships no tests / golden vectors / fixtures for this path, and its sources
+ *     cannot be compiled here (they need OpenCV 3.4.1, Eigen, glog, boost ... none present).
+ *   - reference-OWNED arithmetic (event splat, octree, IC_Angle moments, rBRIEF taps,
+ *     DescriptorDistance, matcher control flow, grid) is restated line by line with file:line
+ *     citations and checked against hand-derived known answers from the reference source.
+ *   - OpenCV 3.4.1 arithmetic (resize, GaussianBlur, FAST, fastAtan2, convertTo, copyMakeBorder)
+ *     and libm (expf, sinf, cosf) are restated from their published algorithms:
+ *     "PARITY UNPINNED" at that boundary (no reference-side vectors exist to pin them).
+ *     expf/sinf/cosf are additionally checked exhaustively against the host glibc.
+ *
+ * All citations are file:line relative to the reference repository root.
+ */
+#ifndef EORB_ORACLE_H
+#define EORB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- data types ------------------------------------------------------------------------- */
+
+/* include/Event/EventData.h:36-58 : {double ts; float x; float y; bool p} = 24 B with padding */
+typedef struct {
+    double  ts;
+    float   x, y;
+    uint8_t p;
+    uint8_t pad_[7];
+} orc_event;
+
+/* cv::KeyPoint layout (28 B): pt.x pt.y size angle response octave class_id */
+typedef struct {
+    float   x, y;
+    float   size;
+    float   angle;
+    float   response;
+    int32_t octave;
+    int32_t class_id;
+} orc_keypoint;
+
+/* include/ORBextractor.h:33-47 ORBxParams */
+typedef struct {
+    int   nfeatures;
+    float scaleFactor;
+    int   nlevels;
+    int   iniThFAST;
+    int   minThFAST;
+    int   edgeTh;      /* <0 : adaptive 19*(imWidth/752) rule, src/ORBextractor.cc:481-488 */
+    int   imWidth;     /* only used when edgeTh < 0 */
+} orc_orb_params;
+
+/* ---- math primitives (exposed for tests) ----------------------------------------------- */
+float orc_expf(float x);            /* glibc>=2.28 expf algorithm, strict IEEE double, no FMA   */
+float orc_sinf(float x);            /* glibc>=2.28 sinf algorithm (valid for |x| < 120)         */
+float orc_cosf(float x);
+float orc_fast_atan2(float y, float x);   /* OpenCV 3.4 cv::fastAtan2 polynomial, degrees     */
+int   orc_cvround(double v);              /* cvRound: round-half-to-even                        */
+
+/* ---- event accumulation: src/Event/EventConversion.cc ------------------------------------ */
+
+/* EvImConverter::ev2im (:173-212).  out_f32: W*H floats (accumulated image BEFORE normalisation,
+ * always written).  out_u8: W*H bytes, written only when the reference would normalise.
+ * minmax[0]=minVal, minmax[1]=maxVal (running values).  Returns 1 if the reference returns a
+ * CV_8UC1 image (normalized && max>min), else 0 (CV_32FC1). */
+int orc_ev2im(const orc_event* ev, size_t n, int W, int H, int pol, int normalized,
+              float* out_f32, uint8_t* out_u8, float* minmax);
+
+/* EvImConverter::ev2im_gauss (:215-269).  Same outputs; returns `normalized`. */
+int orc_ev2im_gauss(const orc_event* ev, size_t n, int W, int H, float sigma, int pol,
+                    int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+
+/* normalizeImage (:67-72) == Mat::convertTo(CV_8UC1, alpha, beta) */
+void orc_normalize_u8(const float* src, size_t npix, float maxVal, float minVal, uint8_t* dst);
+
+/* ---- ORB extractor: src/ORBextractor.cc --------------------------------------------------- */
+typedef struct orc_orb orc_orb;
+
+orc_orb* orc_orb_create(const orc_orb_params* p);
+void     orc_orb_destroy(orc_orb* e);
+
+/* ctor tables (:420-489) */
+int          orc_orb_edge_threshold(const orc_orb* e);
+const float* orc_orb_scale_factors(const orc_orb* e);      /* nlevels */
+const float* orc_orb_inv_scale_factors(const orc_orb* e);
+const int*   orc_orb_features_per_level(const orc_orb* e);
+const int*   orc_orb_umax(const orc_orb* e);               /* 16 entries */
+int          orc_orb_max_keypoints(const orc_orb* e);      /* safe output capacity */
+
+/* ORBextractor::operator() (:1092-1176 with descriptors, :1178-1238 detect only).
+ * kps: capacity cap; desc: cap*32 (may be NULL if !want_desc); oob: cap bytes or NULL, set to 1
+ * for keypoints for which at least one of the 512 rBRIEF taps falls outside the blurred level
+ * buffer (the reference reads out of its allocation there: undefined; oracle substitutes 0).
+ * Returns monoIndex (>=0) or -1 for an empty image (:1096), -2 bad config (H14), -3 cap too small. */
+int orc_orb_extract(orc_orb* e, const uint8_t* img, int W, int H, int stride, int lap0, int lap1,
+                    int want_desc, orc_keypoint* kps, uint8_t* desc, uint8_t* oob, int cap,
+                    int* n_out);
+
+/* stage introspection after the last orc_orb_extract() call (for stage-by-stage GPU parity) */
+int            orc_orb_level_size(const orc_orb* e, int level, int* w, int* h);   /* ROI size */
+const uint8_t* orc_orb_level_buffer(const orc_orb* e, int level, int* bw, int* bh);/* bordered */
+const uint8_t* orc_orb_level_blur(const orc_orb* e, int level);                    /* w*h, may be NULL */
+int            orc_orb_level_candidates(const orc_orb* e, int level, const orc_keypoint** out);
+int            orc_orb_level_keypoints(const orc_orb* e, int level, const orc_keypoint** out);
+
+/* pieces exposed for unit tests */
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
+                          uint8_t* dst, int dw, int dh, int dstride);
+void orc_gaussian_blur5_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+void orc_gauss_kernel_q8(int ksize, double sigma, int* out);
+/* cv::FAST(img, kps, threshold, true) TYPE_9_16; returns count, kps as (x,y,score) int triples */
+int  orc_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold, int* xys, int cap);
+/* DistributeOctTree (:558-782); in: candidates, out: selected (capacity cap) */
+int  orc_distribute_octree(const orc_keypoint* in, int n, int minX, int maxX, int minY, int maxY,
+                           int N, orc_keypoint* out, int cap);
+float orc_ic_angle(const uint8_t* center, int step, const int* umax);
+int  orc_orb_descriptor(const uint8_t* img, int w, int h, int step, float kx, float ky, float angle_deg,
+                        uint8_t* desc32);   /* returns 1 if any tap was out of the buffer */
+
+/* ---- matchers: src/ORBmatcher.cc, src/MixedMatcher.cpp, src/Frame.cc ------------------------- */
+
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b);   /* ORBmatcher.cc:2360-2378 */
+void orc_three_maxima(const int* sizes, int L, int* ind1, int* ind2, int* ind3); /* :2314-2355 */
+
+/* Frame grid (src/Frame.cc:431-460, 710-793; include/Frame.h:45-46) */
+typedef struct {
+    float minX, minY, maxX, maxY;     /* mnMinX.. */
+    float invW, invH;                 /* mfGridElementWidthInv/HeightInv */
+} orc_grid_bounds;
+
+typedef struct orc_frame orc_frame;
+/* kps: undistorted keypoints (pt, octave, angle used); desc: N x desc_stride bytes (first 32 used);
+ * is_orb: N flags or NULL (all ORB) -- MixedFrame type gate. */
+orc_frame* orc_frame_create(const orc_keypoint* kps, int N, const uint8_t* desc, int desc_stride,
+                            const uint8_t* is_orb, const orc_grid_bounds* gb);
+void       orc_frame_destroy(orc_frame* f);
+void       orc_grid_bounds_for_image(int W, int H, orc_grid_bounds* gb);  /* Frame.cc:862-866,362-363 */
+int        orc_get_features_in_area(const orc_frame* f, float x, float y, float r,
+                                    int minLevel, int maxLevel, int* out, int cap);
+
+/* ORBmatcher::SearchForInitialization (:714-831) / MixedMatcher (:20-145).
+ * prev_matched: N1 (x,y) pairs in/out; matches12: N1 out. returns nmatches */
+int orc_search_for_initialization(const orc_frame* F1, const orc_frame* F2, float* prev_matched,
+                                  int* matches12, int windowSize, float nnratio, int checkOri);
+
+/* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono) (:1969-2187), mono
+ * branch.  Host-side projection results are inputs: for each last-frame keypoint i:
+ *   valid[i]  : has a map point, not outlier, invzc>=0 and uv inside the image bounds
+ *   uv[2i..]  : projected position;  octave/angle come from `last`;  mp_desc: N_last x 32
+ *   mp_obs[i] : 1 if that map point has Observations()>0
+ * cur_mp (N_cur, in/out): -1 = no map point; k>=0 = holds last-frame point k; -2 = holds a foreign
+ * map point with Observations()>0; -3 = foreign map point without observations.
+ * mode: 0 = [oct-1, oct+1], 1 = forward (>= oct), 2 = backward ([0, oct]).  returns nmatches */
+int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
+                                  const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+                                  int* cur_mp, float th, int mode, int checkOri,
+                                  const float* scale_factors, int nlevels);
+
+/* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (:44-219) mono branch.
+ * Per map point m: in_view, projX, projY, level (mnTrackScaleLevel), viewCos, desc, obs flag,
+ * level_scale[m] = F.getORBScaleFactor(level) (or the AKAZE factor, MixedMatcher.cpp:529-535).
+ * frame_mp (N, in/out) as above with k = map point index. returns nmatches */
+int orc_search_by_projection_map(const orc_frame* F, int M, const uint8_t* in_view, const float* proj_xy,
+                                 const int* level, const float* view_cos, const uint8_t* mp_desc,
+                                 const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
+                                 float th, float nnratio, const float* level_scale);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) (Frame.cc:1228): per query two best (idx, dist)
+ * ascending; ties -> lowest train index.  idx2/dist2: nq*2 (-1 / INT_MAX when nt < k). */
+void orc_bf_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2, int32_t* dist2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

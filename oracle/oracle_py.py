@@ -1,0 +1,320 @@
+"""ctypes binding of the CPU ORACLE (oracle/eorb_oracle.h).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (eorb_slam_amd/) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+EVENT_DTYPE = np.dtype([("ts", "<f8"), ("x", "<f4"), ("y", "<f4"), ("p", "u1"), ("pad", "u1", (7,))])
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert EVENT_DTYPE.itemsize == 24 and KP_DTYPE.itemsize == 28
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scaleFactor", C.c_float), ("nlevels", C.c_int),
+                ("iniThFAST", C.c_int), ("minThFAST", C.c_int), ("edgeTh", C.c_int), ("imWidth", C.c_int)]
+
+
+class GridBounds(C.Structure):
+    _fields_ = [("minX", C.c_float), ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float),
+                ("invW", C.c_float), ("invH", C.c_float)]
+
+
+def build(force=False):
+    """Compile the oracle (both the parity and the timing build)."""
+    out = os.path.join(_HERE, "_build", "liboracle.so")
+    if force or not os.path.exists(out) or not os.path.exists(os.path.join(_HERE, "_build", "liboracle_fast.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return out
+
+
+_libs = {}
+
+
+def lib(fast=False):
+    key = "fast" if fast else "parity"
+    if key in _libs:
+        return _libs[key]
+    build()
+    path = os.path.join(_HERE, "_build", "liboracle_fast.so" if fast else "liboracle.so")
+    L = C.CDLL(path)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.orc_expf.restype = cf; L.orc_expf.argtypes = [cf]
+    L.orc_sinf.restype = cf; L.orc_sinf.argtypes = [cf]
+    L.orc_cosf.restype = cf; L.orc_cosf.argtypes = [cf]
+    L.orc_fast_atan2.restype = cf; L.orc_fast_atan2.argtypes = [cf, cf]
+    L.orc_cvround.restype = ci; L.orc_cvround.argtypes = [C.c_double]
+    L.orc_ev2im.restype = ci
+    L.orc_ev2im.argtypes = [vp, C.c_size_t, ci, ci, ci, ci, vp, vp, vp]
+    L.orc_ev2im_gauss.restype = ci
+    L.orc_ev2im_gauss.argtypes = [vp, C.c_size_t, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.orc_normalize_u8.restype = None
+    L.orc_normalize_u8.argtypes = [vp, C.c_size_t, cf, cf, vp]
+    L.orc_orb_create.restype = vp; L.orc_orb_create.argtypes = [C.POINTER(OrbParams)]
+    L.orc_orb_destroy.restype = None; L.orc_orb_destroy.argtypes = [vp]
+    L.orc_orb_edge_threshold.restype = ci; L.orc_orb_edge_threshold.argtypes = [vp]
+    for f in ("orc_orb_scale_factors", "orc_orb_inv_scale_factors"):
+        getattr(L, f).restype = C.POINTER(cf); getattr(L, f).argtypes = [vp]
+    for f in ("orc_orb_features_per_level", "orc_orb_umax"):
+        getattr(L, f).restype = C.POINTER(ci); getattr(L, f).argtypes = [vp]
+    L.orc_orb_max_keypoints.restype = ci; L.orc_orb_max_keypoints.argtypes = [vp]
+    L.orc_orb_extract.restype = ci
+    L.orc_orb_extract.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, C.POINTER(ci)]
+    L.orc_orb_level_size.restype = ci; L.orc_orb_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.orc_orb_level_buffer.restype = vp; L.orc_orb_level_buffer.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.orc_orb_level_blur.restype = vp; L.orc_orb_level_blur.argtypes = [vp, ci]
+    L.orc_orb_level_candidates.restype = ci; L.orc_orb_level_candidates.argtypes = [vp, ci, C.POINTER(vp)]
+    L.orc_orb_level_keypoints.restype = ci; L.orc_orb_level_keypoints.argtypes = [vp, ci, C.POINTER(vp)]
+    L.orc_resize_linear_u8.restype = None; L.orc_resize_linear_u8.argtypes = [vp, ci, ci, ci, vp, ci, ci, ci]
+    L.orc_gaussian_blur5_u8.restype = None; L.orc_gaussian_blur5_u8.argtypes = [vp, ci, ci, ci, vp, ci]
+    L.orc_gauss_kernel_q8.restype = None; L.orc_gauss_kernel_q8.argtypes = [ci, C.c_double, vp]
+    L.orc_fast9_16.restype = ci; L.orc_fast9_16.argtypes = [vp, ci, ci, ci, ci, vp, ci]
+    L.orc_distribute_octree.restype = ci
+    L.orc_distribute_octree.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci]
+    L.orc_ic_angle.restype = cf; L.orc_ic_angle.argtypes = [vp, ci, vp]
+    L.orc_orb_descriptor.restype = ci; L.orc_orb_descriptor.argtypes = [vp, ci, ci, ci, cf, cf, cf, vp]
+    L.orc_descriptor_distance.restype = ci; L.orc_descriptor_distance.argtypes = [vp, vp]
+    L.orc_three_maxima.restype = None
+    L.orc_three_maxima.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.orc_frame_create.restype = vp; L.orc_frame_create.argtypes = [vp, ci, vp, ci, vp, C.POINTER(GridBounds)]
+    L.orc_frame_destroy.restype = None; L.orc_frame_destroy.argtypes = [vp]
+    L.orc_grid_bounds_for_image.restype = None; L.orc_grid_bounds_for_image.argtypes = [ci, ci, C.POINTER(GridBounds)]
+    L.orc_get_features_in_area.restype = ci; L.orc_get_features_in_area.argtypes = [vp, cf, cf, cf, ci, ci, vp, ci]
+    L.orc_search_for_initialization.restype = ci
+    L.orc_search_for_initialization.argtypes = [vp, vp, vp, vp, ci, cf, ci]
+    L.orc_search_by_projection_last.restype = ci
+    L.orc_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp, ci]
+    L.orc_search_by_projection_map.restype = ci
+    L.orc_search_by_projection_map.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
+    L.orc_bf_knn2.restype = None; L.orc_bf_knn2.argtypes = [vp, ci, vp, ci, vp, vp]
+    _libs[key] = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- events -----------------------------------------------------------------------------------
+def make_events(x, y, ts=None, p=None):
+    n = len(x)
+    ev = np.zeros(n, dtype=EVENT_DTYPE)
+    ev["x"] = x; ev["y"] = y
+    ev["ts"] = np.arange(n, dtype=np.float64) * 1e-6 if ts is None else ts
+    ev["p"] = 1 if p is None else p
+    return ev
+
+
+def ev2im(ev, W, H, pol=False, normalized=True, fast=False):
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    f32 = np.empty((H, W), np.float32); u8 = np.zeros((H, W), np.uint8); mm = np.zeros(2, np.float32)
+    is_u8 = lib(fast).orc_ev2im(_p(ev), len(ev), W, H, int(pol), int(normalized), _p(f32), _p(u8), _p(mm))
+    return f32, (u8 if is_u8 else None), mm
+
+
+def ev2im_gauss(ev, W, H, sigma=1.0, pol=False, normalized=True, fast=False):
+    ev = np.ascontiguousarray(ev, dtype=EVENT_DTYPE)
+    f32 = np.empty((H, W), np.float32); u8 = np.zeros((H, W), np.uint8); mm = np.zeros(2, np.float32)
+    is_u8 = lib(fast).orc_ev2im_gauss(_p(ev), len(ev), W, H, float(sigma), int(pol), int(normalized),
+                                      _p(f32), _p(u8), _p(mm))
+    return f32, (u8 if is_u8 else None), mm
+
+
+# ---- extractor ----------------------------------------------------------------------------------
+class OrbExtractor:
+    """Oracle mirror of ORB_SLAM3::ORBextractor (src/ORBextractor.cc)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0,
+                 edgeTh=19, imWidth=240, fast=False):
+        self.L = lib(fast)
+        self.params = OrbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, edgeTh, imWidth)
+        self.h = self.L.orc_orb_create(C.byref(self.params))
+        if not self.h:
+            raise ValueError("bad ORB params")
+        self.nlevels = nlevels
+        self.cap = self.L.orc_orb_max_keypoints(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_orb_destroy(self.h); self.h = None
+
+    @property
+    def edge(self):
+        return self.L.orc_orb_edge_threshold(self.h)
+
+    @property
+    def scale_factors(self):
+        return np.array(self.L.orc_orb_scale_factors(self.h)[:self.nlevels], np.float32)
+
+    @property
+    def inv_scale_factors(self):
+        return np.array(self.L.orc_orb_inv_scale_factors(self.h)[:self.nlevels], np.float32)
+
+    @property
+    def features_per_level(self):
+        return list(self.L.orc_orb_features_per_level(self.h)[:self.nlevels])
+
+    @property
+    def umax(self):
+        return list(self.L.orc_orb_umax(self.h)[:16])
+
+    def extract(self, img, lap=(0, 1000), want_desc=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W = img.shape
+        kps = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8)
+        oob = np.zeros(self.cap, np.uint8); n = C.c_int(0)
+        mono = self.L.orc_orb_extract(self.h, _p(img), W, H, W, lap[0], lap[1], int(want_desc),
+                                      _p(kps), _p(desc), _p(oob), self.cap, C.byref(n))
+        if mono < 0:
+            return mono, None, None, None
+        return mono, kps[:n.value].copy(), (desc[:n.value].copy() if want_desc else None), oob[:n.value].copy()
+
+    def level_size(self, l):
+        w, h = C.c_int(), C.c_int()
+        self.L.orc_orb_level_size(self.h, l, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_buffer(self, l):
+        bw, bh = C.c_int(), C.c_int()
+        ptr = self.L.orc_orb_level_buffer(self.h, l, C.byref(bw), C.byref(bh))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (bh.value, bw.value)).copy()
+
+    def level_blur(self, l):
+        w, h = self.level_size(l)
+        ptr = self.L.orc_orb_level_blur(self.h, l)
+        if not ptr:
+            return None
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (h, w)).copy()
+
+    def _kparr(self, fn, l):
+        ptr = C.c_void_p()
+        n = fn(self.h, l, C.byref(ptr))
+        if n == 0:
+            return np.zeros(0, KP_DTYPE)
+        buf = (C.c_char * (n * 28)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=KP_DTYPE, count=n).copy()
+
+    def level_candidates(self, l):
+        return self._kparr(self.L.orc_orb_level_candidates, l)
+
+    def level_keypoints(self, l):
+        return self._kparr(self.L.orc_orb_level_keypoints, l)
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8); sh, sw = src.shape
+    dst = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_p(src), sw, sh, sw, _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur5(src):
+    src = np.ascontiguousarray(src, np.uint8); h, w = src.shape
+    dst = np.empty((h, w), np.uint8)
+    lib().orc_gaussian_blur5_u8(_p(src), w, h, w, _p(dst), w)
+    return dst
+
+
+def fast9_16(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+    cap = w * h
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast9_16(_p(img), w, h, w, threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def distribute_octree(cands, minX, maxX, minY, maxY, N):
+    cands = np.ascontiguousarray(cands, KP_DTYPE)
+    cap = max(N + 64, 64)
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().orc_distribute_octree(_p(cands), len(cands), minX, maxX, minY, maxY, N, _p(out), cap)
+    assert 0 <= n <= cap, n
+    return out[:n].copy()
+
+
+# ---- matchers ---------------------------------------------------------------------------------------
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def three_maxima(sizes):
+    s = np.ascontiguousarray(sizes, np.int32)
+    i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    lib().orc_three_maxima(_p(s), len(s), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
+def grid_bounds(W, H):
+    gb = GridBounds()
+    lib().orc_grid_bounds_for_image(W, H, C.byref(gb))
+    return gb
+
+
+class Frame:
+    """Oracle mirror of the Frame grid + descriptors (src/Frame.cc:431-460,710-793)."""
+
+    def __init__(self, kps, desc, W, H, is_orb=None, fast=False):
+        self.L = lib(fast)
+        self.kps = np.ascontiguousarray(kps, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.is_orb = None if is_orb is None else np.ascontiguousarray(is_orb, np.uint8)
+        self.gb = grid_bounds(W, H)
+        self.N = len(self.kps)
+        self.h = self.L.orc_frame_create(_p(self.kps), self.N, _p(self.desc), self.desc.shape[1],
+                                         _p(self.is_orb), C.byref(self.gb))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_frame_destroy(self.h); self.h = None
+
+    def features_in_area(self, x, y, r, minLevel=-1, maxLevel=-1):
+        out = np.zeros(max(self.N, 1), np.int32)
+        n = self.L.orc_get_features_in_area(self.h, x, y, r, minLevel, maxLevel, _p(out), self.N)
+        return out[:n].copy()
+
+
+def search_for_initialization(F1, F2, prev_matched, windowSize=100, nnratio=0.9, checkOri=True):
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.full(F1.N, -1, np.int32)
+    n = F1.L.orc_search_for_initialization(F1.h, F2.h, _p(pm), _p(m12), windowSize, nnratio, int(checkOri))
+    return n, m12, pm
+
+
+def search_by_projection_last(cur, last, valid, uv, mp_desc, mp_obs, cur_mp, th, scale_factors,
+                              mode=0, checkOri=True):
+    valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
+    cm = np.ascontiguousarray(cur_mp, np.int32).copy()
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    n = cur.L.orc_search_by_projection_last(cur.h, last.h, _p(valid), _p(uv), _p(mp_desc), _p(mp_obs),
+                                            _p(cm), th, mode, int(checkOri), _p(sf), len(sf))
+    return n, cm
+
+
+def search_by_projection_map(F, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, frame_mp, th,
+                             nnratio, level_scale, mp_is_orb=None):
+    in_view = np.ascontiguousarray(in_view, np.uint8); proj_xy = np.ascontiguousarray(proj_xy, np.float32)
+    level = np.ascontiguousarray(level, np.int32); view_cos = np.ascontiguousarray(view_cos, np.float32)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
+    level_scale = np.ascontiguousarray(level_scale, np.float32)
+    mio = None if mp_is_orb is None else np.ascontiguousarray(mp_is_orb, np.uint8)
+    fm = np.ascontiguousarray(frame_mp, np.int32).copy()
+    n = F.L.orc_search_by_projection_map(F.h, len(in_view), _p(in_view), _p(proj_xy), _p(level),
+                                         _p(view_cos), _p(mp_desc), _p(mp_obs), _p(mio), _p(fm),
+                                         th, nnratio, _p(level_scale))
+    return n, fm
+
+
+def bf_knn2(q, t, fast=False):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
+    lib(fast).orc_bf_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+    return idx, dist

@@ -1,0 +1,345 @@
+/*
+ * orc_match.c -- ORACLE (test infrastructure only): 256-bit Hamming matchers.
+ * Restates src/ORBmatcher.cc, src/MixedMatcher.cpp (type gate) and the Frame grid
+ * (src/Frame.cc:431-460, 710-793) of the reference.  Everything here is reference-owned
+ * arithmetic (no OpenCV numerics) except cv::BFMatcher::knnMatch semantics (orc_bf_knn2).
+ */
+#include "eorb_oracle.h"
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FRAME_GRID_ROWS 48      /* include/Frame.h:45 */
+#define FRAME_GRID_COLS 64      /* include/Frame.h:46 */
+#define TH_HIGH 100             /* ORBmatcher.cc:36 */
+#define TH_LOW 50               /* :37 */
+#define HISTO_LENGTH 30         /* :38 */
+
+/* ORBmatcher::DescriptorDistance :2360-2378 (reads 8 x int32 whatever the descriptor width) */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4); memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+/* ORBmatcher::ComputeThreeMaxima :2314-2355 */
+void orc_three_maxima(const int* sizes, int L, int* ind1, int* ind2, int* ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* ---- Frame grid ------------------------------------------------------------------------------- */
+struct orc_frame {
+    int N;
+    const orc_keypoint* kps;
+    const uint8_t* desc; int desc_stride;
+    const uint8_t* is_orb;
+    orc_grid_bounds gb;
+    int* cell_start;        /* COLS*ROWS+1, cell id = ix*ROWS + iy */
+    int* cell_items;        /* insertion order inside each cell */
+};
+
+void orc_grid_bounds_for_image(int W, int H, orc_grid_bounds* gb)
+{
+    gb->minX = 0.0f; gb->maxX = (float)W; gb->minY = 0.0f; gb->maxY = (float)H;   /* Frame.cc:862-866 */
+    gb->invW = (float)FRAME_GRID_COLS / (gb->maxX - gb->minX);                  /* :362-363 */
+    gb->invH = (float)FRAME_GRID_ROWS / (gb->maxY - gb->minY);
+}
+
+static int frame_level(const orc_frame* f, int i)
+{   /* Frame::getKPtLevelMono / MixedFrame::getKPtLevelMono (MixedFrame.cpp:438-446) */
+    if (!f->is_orb || f->is_orb[i]) return f->kps[i].octave;
+    return f->kps[i].class_id;
+}
+
+static int pos_in_grid(const orc_frame* f, const orc_keypoint* kp, int* px, int* py)
+{   /* Frame::PosInGrid :783-793 */
+    *px = (int)roundf((kp->x - f->gb.minX) * f->gb.invW);
+    *py = (int)roundf((kp->y - f->gb.minY) * f->gb.invH);
+    if (*px < 0 || *px >= FRAME_GRID_COLS || *py < 0 || *py >= FRAME_GRID_ROWS) return 0;
+    return 1;
+}
+
+orc_frame* orc_frame_create(const orc_keypoint* kps, int N, const uint8_t* desc, int desc_stride,
+                            const uint8_t* is_orb, const orc_grid_bounds* gb)
+{
+    orc_frame* f = (orc_frame*)calloc(1, sizeof(orc_frame));
+    f->N = N; f->kps = kps; f->desc = desc; f->desc_stride = desc_stride; f->is_orb = is_orb; f->gb = *gb;
+    const int ncell = FRAME_GRID_COLS * FRAME_GRID_ROWS;
+    f->cell_start = (int*)calloc(ncell + 1, sizeof(int));
+    f->cell_items = (int*)malloc(sizeof(int) * (N ? N : 1));
+    int* cid = (int*)malloc(sizeof(int) * (N ? N : 1));
+    for (int i = 0; i < N; i++) {                 /* AssignFeaturesToGrid :431-460 */
+        int px, py;
+        cid[i] = pos_in_grid(f, &kps[i], &px, &py) ? px * FRAME_GRID_ROWS + py : -1;
+        if (cid[i] >= 0) f->cell_start[cid[i] + 1]++;
+    }
+    for (int c = 0; c < ncell; c++) f->cell_start[c + 1] += f->cell_start[c];
+    int* fill = (int*)malloc(sizeof(int) * ncell);
+    memcpy(fill, f->cell_start, sizeof(int) * ncell);
+    for (int i = 0; i < N; i++) if (cid[i] >= 0) f->cell_items[fill[cid[i]]++] = i;
+    free(fill); free(cid);
+    return f;
+}
+void orc_frame_destroy(orc_frame* f) { if (f) { free(f->cell_start); free(f->cell_items); free(f); } }
+
+/* Frame::GetFeaturesInArea :710-781 */
+int orc_get_features_in_area(const orc_frame* f, float x, float y, float r, int minLevel, int maxLevel,
+                             int* out, int cap)
+{
+    int n = 0;
+    float factorX = r, factorY = r;
+    int t = (int)floorf((x - f->gb.minX - factorX) * f->gb.invW);
+    const int nMinCellX = t > 0 ? t : 0;
+    if (nMinCellX >= FRAME_GRID_COLS) return 0;
+    t = (int)ceilf((x - f->gb.minX + factorX) * f->gb.invW);
+    const int nMaxCellX = t < FRAME_GRID_COLS - 1 ? t : FRAME_GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    t = (int)floorf((y - f->gb.minY - factorY) * f->gb.invH);
+    const int nMinCellY = t > 0 ? t : 0;
+    if (nMinCellY >= FRAME_GRID_ROWS) return 0;
+    t = (int)ceilf((y - f->gb.minY + factorY) * f->gb.invH);
+    const int nMaxCellY = t < FRAME_GRID_ROWS - 1 ? t : FRAME_GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * FRAME_GRID_ROWS + iy;
+            for (int j = f->cell_start[c]; j < f->cell_start[c + 1]; j++) {
+                const int idx = f->cell_items[j];
+                if (bCheckLevels) {
+                    const int level = frame_level(f, idx);
+                    if (level < minLevel) continue;
+                    if (maxLevel >= 0 && level > maxLevel) continue;
+                }
+                const float distx = f->kps[idx].x - x;
+                const float disty = f->kps[idx].y - y;
+                if (fabsf(distx) < factorX && fabsf(disty) < factorY) {
+                    if (n < cap) out[n] = idx;
+                    n++;
+                }
+            }
+        }
+    }
+    return n;
+}
+
+static int rot_bin(float a1, float a2)
+{   /* ORBmatcher.cc:790-796 / :2082-2087 */
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+/* ORBmatcher::SearchForInitialization :714-831 ; MixedMatcher.cpp:20-145 adds the isORB gate */
+int orc_search_for_initialization(const orc_frame* F1, const orc_frame* F2, float* prev_matched,
+                                  int* matches12, int windowSize, float nnratio, int checkOri)
+{
+    int nmatches = 0;
+    const int N1 = F1->N, N2 = F2->N;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (N1 ? N1 : 1)); rotN[i] = 0; }
+    int* matchedDist = (int*)malloc(sizeof(int) * (N2 ? N2 : 1));
+    int* matches21 = (int*)malloc(sizeof(int) * (N2 ? N2 : 1));
+    int* idxs = (int*)malloc(sizeof(int) * (N2 ? N2 : 1));
+    for (int i = 0; i < N2; i++) { matchedDist[i] = INT_MAX; matches21[i] = -1; }
+    for (int i1 = 0; i1 < N1; i1++) {
+        int level1 = frame_level(F1, i1);
+        if (level1 > 0) continue;
+        int nc = orc_get_features_in_area(F2, prev_matched[2 * i1], prev_matched[2 * i1 + 1],
+                                          (float)windowSize, level1, level1, idxs, N2);
+        if (nc == 0) continue;
+        const int isORB1 = !F1->is_orb || F1->is_orb[i1];
+        const uint8_t* d1 = F1->desc + (size_t)i1 * F1->desc_stride;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            int i2 = idxs[c];
+            const int isORB2 = !F2->is_orb || F2->is_orb[i2];
+            if (isORB1 != isORB2) continue;
+            int dist = orc_descriptor_distance(d1, F2->desc + (size_t)i2 * F2->desc_stride);
+            if (matchedDist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW) {
+            if ((float)bestDist < (float)bestDist2 * nnratio) {
+                if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+                matches12[i1] = bestIdx2;
+                matches21[bestIdx2] = i1;
+                matchedDist[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) {
+                    int bin = rot_bin(F1->kps[i1].angle, F2->kps[bestIdx2].angle);
+                    rotHist[bin][rotN[bin]++] = i1;
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) {
+                int idx1 = rotHist[i][j];
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < N1; i1++)
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = F2->kps[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = F2->kps[matches12[i1]].y;
+        }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(matchedDist); free(matches21); free(idxs);
+    return nmatches;
+}
+
+static int clamp_level(int l, int n) { return l < 0 ? 0 : (l >= n ? n - 1 : l); }  /* checkORBLevel */
+
+/* occupancy rule shared by the projection matchers (:91-93, :2045-2047):
+ * a candidate holding a map point with Observations()>0 is skipped. */
+static int holds_observed(const int* slot_mp, int idx, const uint8_t* mp_obs)
+{
+    int v = slot_mp[idx];
+    if (v == -1 || v == -3) return 0;
+    if (v == -2) return 1;
+    return mp_obs[v] != 0;
+}
+
+/* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono) :1969-2187, mono */
+int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
+                                  const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+                                  int* cur_mp, float th, int mode, int checkOri, const float* sf, int nlev)
+{
+    int nmatches = 0;
+    const int Nc = cur->N;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (last->N ? last->N : 1)); rotN[i] = 0; }
+    int* idxs = (int*)malloc(sizeof(int) * (Nc ? Nc : 1));
+    for (int i = 0; i < last->N; i++) {
+        if (!valid[i]) continue;
+        const float ux = uv[2 * i], uy = uv[2 * i + 1];
+        int nLastOctave = frame_level(last, i);
+        float radius = th * sf[clamp_level(nLastOctave, nlev)];
+        int nc;
+        if (mode == 1) nc = orc_get_features_in_area(cur, ux, uy, radius, nLastOctave, -1, idxs, Nc);
+        else if (mode == 2) nc = orc_get_features_in_area(cur, ux, uy, radius, 0, nLastOctave, idxs, Nc);
+        else nc = orc_get_features_in_area(cur, ux, uy, radius, nLastOctave - 1, nLastOctave + 1, idxs, Nc);
+        if (nc == 0) continue;
+        const uint8_t* dMP = mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = idxs[c];
+            if (holds_observed(cur_mp, i2, mp_obs)) continue;
+            const int dist = orc_descriptor_distance(dMP, cur->desc + (size_t)i2 * cur->desc_stride);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            cur_mp[bestIdx2] = i;
+            nmatches++;
+            if (checkOri) {
+                int bin = rot_bin(last->kps[i].angle, cur->kps[bestIdx2].angle);
+                rotHist[bin][rotN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (int j = 0; j < rotN[i]; j++) { cur_mp[rotHist[i][j]] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(idxs);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) :44-219 mono branch;
+ * MixedMatcher.cpp:500-691 adds the isORB gate (mp_is_orb / frame is_orb). */
+int orc_search_by_projection_map(const orc_frame* F, int M, const uint8_t* in_view, const float* proj_xy,
+                                 const int* level, const float* view_cos, const uint8_t* mp_desc,
+                                 const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
+                                 float th, float nnratio, const float* level_scale)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0;
+    int* idxs = (int*)malloc(sizeof(int) * (F->N ? F->N : 1));
+    for (int m = 0; m < M; m++) {
+        if (!in_view[m]) continue;
+        const int nPredictedLevel = level[m];
+        float r = (view_cos[m] > 0.998) ? 2.5f : 4.0f;          /* RadiusByViewingCos :221-227 */
+        if (bFactor) r *= th;
+        const float rs = r * level_scale[m];
+        int nc = orc_get_features_in_area(F, proj_xy[2 * m], proj_xy[2 * m + 1], rs,
+                                          nPredictedLevel - 1, nPredictedLevel, idxs, F->N);
+        if (nc == 0) continue;
+        const int isORBMP = !mp_is_orb || mp_is_orb[m];
+        const uint8_t* dMP = mp_desc + 32 * (size_t)m;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = idxs[c];
+            if (holds_observed(frame_mp, idx, mp_obs)) continue;
+            const int isORBPt = !F->is_orb || F->is_orb[idx];
+            if (isORBMP != isORBPt) continue;
+            const int dist = orc_descriptor_distance(dMP, F->desc + (size_t)idx * F->desc_stride);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel;
+                bestLevel = frame_level(F, idx); bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = frame_level(F, idx); bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            if (bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2) {
+                frame_mp[bestIdx] = m;
+                nmatches++;
+            }
+        }
+    }
+    free(idxs);
+    return nmatches;
+}
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, matches, 2)  (call site Frame.cc:1228).
+ * OpenCV batchDistance K-NN keeps per query the K smallest distances, inserting a candidate
+ * only when strictly smaller than a kept one => ties resolve to the lowest train index. */
+void orc_bf_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2, int32_t* dist2)
+{
+    for (int i = 0; i < nq; i++) {
+        int b0 = INT_MAX, b1 = INT_MAX, i0 = -1, i1 = -1;
+        for (int j = 0; j < nt; j++) {
+            int d = orc_descriptor_distance(q + 32 * (size_t)i, t + 32 * (size_t)j);
+            if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+            else if (d < b1) { b1 = d; i1 = j; }
+        }
+        idx2[2 * i] = i0; idx2[2 * i + 1] = i1;
+        dist2[2 * i] = b0; dist2[2 * i + 1] = b1;
+    }
+}

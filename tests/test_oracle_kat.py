@@ -1,0 +1,210 @@
+"""Known-answer tests pinning the oracle to values hand-derived from the reference source
+(the reference has no tests or fixtures of its own)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from eorb_slam_amd import synth
+
+
+def test_math_vs_host_libm(oracle):
+    """orc_expf / orc_sinf / orc_cosf restate glibc's algorithms; compare with the host libm."""
+    L = oracle.lib()
+    libm = C.CDLL("libm.so.6")
+    for f in ("expf", "sinf", "cosf"):
+        getattr(libm, f).restype = C.c_float; getattr(libm, f).argtypes = [C.c_float]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([-rng.uniform(0, 32, 20000), -np.linspace(0, 18, 5000)]).astype(np.float32)
+    bad = sum(1 for x in xs if np.float32(L.orc_expf(float(x))).tobytes() != np.float32(libm.expf(float(x))).tobytes())
+    assert bad == 0
+    ang = np.concatenate([rng.uniform(0, 6.3, 20000), np.linspace(0, 6.2832, 5000)]).astype(np.float32)
+    for x in ang:
+        assert L.orc_sinf(float(x)) == libm.sinf(float(x))
+        assert L.orc_cosf(float(x)) == libm.cosf(float(x))
+    # the single known disagreement with glibc's fma variant (oracle = correctly rounded there)
+    assert L.orc_expf(float.fromhex("-0x1.f8cbb2p+5")) == float.fromhex("0x1.f45324p-92")
+
+
+def test_exp2_table_is_exact(oracle):
+    # tab[i] = bits(2^(i/32)) - (i << 47); re-derive each entry with exact rational bracketing
+    from fractions import Fraction
+    import struct
+    L = oracle.lib()
+    # indirect check: orc_expf(x) for x = ln2 * i/32 must be within 1 ulp of 2^(i/32)
+    for i in range(32):
+        x = np.float32(math.log(2.0) * i / 32)
+        ref = math.exp(float(x))
+        got = L.orc_expf(float(x))
+        assert abs(got - ref) <= abs(ref) * 2 ** -23
+
+
+def test_cvround_half_even(oracle):
+    L = oracle.lib()
+    assert [L.orc_cvround(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+
+
+def test_fast_atan2(oracle):
+    L = oracle.lib()
+    assert L.orc_fast_atan2(0.0, 1.0) == 0.0
+    assert abs(L.orc_fast_atan2(1.0, 1.0) - 45.0) < 0.02
+    assert abs(L.orc_fast_atan2(1.0, 0.0) - 90.0) < 0.02
+    assert abs(L.orc_fast_atan2(0.0, -1.0) - 180.0) < 0.02
+    assert abs(L.orc_fast_atan2(-1.0, 0.0) - 270.0) < 0.02
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        y, x = rng.normal(size=2) * 1000
+        a = L.orc_fast_atan2(float(y), float(x))
+        t = math.degrees(math.atan2(y, x)) % 360
+        d = abs(a - t); d = min(d, 360 - d)
+        assert d < 0.3 and 0 <= a <= 360      # OpenCV documents ~0.3 deg accuracy
+
+
+def test_extractor_ctor_tables(oracle):
+    """src/ORBextractor.cc:420-489 — values derived by hand in SURVEY.md §4 / §8(c)."""
+    e = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19, imWidth=240)
+    assert e.features_per_level == [322, 268, 224, 186]
+    assert e.umax == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    sf = e.scale_factors
+    assert sf[0] == 1.0 and sf[1] == np.float32(np.float64(np.float32(1.2)))
+    assert sf[2] == np.float32(np.float64(sf[1]) * np.float64(np.float32(1.2)))
+    # adaptive edge threshold rule :481-488 -> 19*(240/752)=6.06 -> 6 -> made odd: 5
+    e2 = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=-1, imWidth=240)
+    assert e2.edge == 5
+    e3 = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=-1, imWidth=752)
+    assert e3.edge == 19
+    # single level ("FAST mode", EvBaseTracker.cpp:150-164): last level takes everything
+    e4 = oracle.OrbExtractor(400, 1.0, 1, 0, 0, edgeTh=9)
+    assert e4.features_per_level == [400]
+
+
+def test_pyramid_sizes(oracle):
+    img = synth.texture_image(240, 180, seed=3)
+    e = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19)
+    mono, kps, desc, oob = e.extract(img)
+    assert [e.level_size(l) for l in range(4)] == [(240, 180), (200, 150), (167, 125), (139, 104)]
+    e8 = oracle.OrbExtractor(2000, 1.2, 8, 10, 0, edgeTh=15)
+    img2 = synth.texture_image(346, 260, seed=4)
+    e8.extract(img2)
+    sizes = [e8.level_size(l) for l in range(8)]
+    assert sizes[0] == (346, 260) and sizes[7] == (97, 73)
+
+
+def test_gauss_kernel_q8(oracle):
+    k = np.zeros(5, np.int32)
+    oracle.lib().orc_gauss_kernel_q8(5, 2.0, k.ctypes.data_as(C.c_void_p))
+    assert list(k) == [39, 57, 64, 57, 39] and k.sum() == 256
+    flat = np.full((20, 30), 77, np.uint8)
+    assert (oracle.gaussian_blur5(flat) == 77).all()
+
+
+def test_resize_identity_and_constant(oracle):
+    img = synth.texture_image(64, 48, seed=9)
+    assert (oracle.resize_linear(img, 64, 48) == img).all()
+    flat = np.full((48, 64), 200, np.uint8)
+    assert (oracle.resize_linear(flat, 53, 40) == 200).all()
+
+
+def test_descriptor_distance_identities(oracle):
+    z = np.zeros(32, np.uint8); f = np.full(32, 255, np.uint8)
+    assert oracle.descriptor_distance(z, z) == 0
+    assert oracle.descriptor_distance(z, f) == 256
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        a = rng.integers(0, 256, 32, dtype=np.uint8); b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert oracle.descriptor_distance(a, b) == int(np.unpackbits(a ^ b).sum())
+    # AKAZE rows are 61 B wide, only the first 32 B count
+    a = rng.integers(0, 256, 61, dtype=np.uint8); b = a.copy(); b[40] ^= 0xFF
+    assert oracle.descriptor_distance(a, b) == 0
+
+
+def test_three_maxima(oracle):
+    s = [0] * 30
+    s[3], s[7], s[20] = 50, 40, 4            # third < 10 % of first -> dropped
+    assert oracle.three_maxima(s) == (3, 7, -1)
+    s[20] = 5
+    assert oracle.three_maxima(s) == (3, 7, 20)
+    s[7] = 4; s[20] = 3                      # second < 10 % -> both dropped
+    assert oracle.three_maxima(s) == (3, -1, -1)
+
+
+def test_gauss_stamp_centre_value(oracle):
+    """One event at an integer pixel, sigma=1: centre tap = 1/(2*pi) (EventConversion.cc:59-65)."""
+    ev = oracle.make_events([100.0], [90.0])
+    f32, u8, mm = oracle.ev2im_gauss(ev, 240, 180, 1.0, False, True)
+    assert f32[90, 100] == np.float32(1.0) / (np.float32(2.0) * np.float32(math.pi) * np.float32(1.0))
+    assert np.count_nonzero(f32) == 49 and u8[90, 100] == 255 and mm[0] == 0.0 and mm[1] == f32[90, 100]
+    # symmetric stamp
+    assert f32[90, 97] == f32[90, 103] == f32[87, 100] == f32[93, 100]
+
+
+def test_ev2im_count_image(oracle):
+    ev = oracle.make_events([10.4, 10.6, 10.5, 300.0], [5.0, 5.0, 5.0, 5.0], p=[1, 0, 1, 1])
+    f32, u8, mm = oracle.ev2im(ev, 240, 180, pol=False, normalized=False)
+    v = np.float32(0)
+    assert f32[5, 10] == np.float32(0.001)
+    assert f32[5, 11] == np.float32(np.float32(0.001) + np.float32(0.001))   # 10.6->11, 10.5->roundf away: 11
+    assert u8 is None and np.count_nonzero(f32) == 2
+    f32p, _, mmp = oracle.ev2im(ev, 240, 180, pol=True, normalized=False)
+    assert f32p[5, 11] == np.float32(np.float32(-0.001) + np.float32(0.001))
+    assert mmp[0] == np.float32(-0.001)
+
+
+def test_empty_events_normalised_is_zero(oracle):
+    """N=0, normalized: alpha = 255/(-1e6-0) on an all-zero image -> all-zero u8."""
+    ev = np.zeros(0, oracle.EVENT_DTYPE)
+    f32, u8, mm = oracle.ev2im_gauss(ev, 64, 48)
+    assert (f32 == 0).all() and (u8 == 0).all()
+
+
+def test_fast_on_synthetic_corner(oracle):
+    img = np.full((32, 32), 20, np.uint8)
+    img[16, 16] = 200                           # isolated bright pixel: all 16 ring pixels darker
+    k = oracle.fast9_16(img, 10)
+    assert k.tolist() == [[16, 16, 179]]        # score = max t that keeps it a corner = 180 - 1
+    img[16, 17] = 200                           # plateau: equal scores suppress each other (strict >)
+    assert len(oracle.fast9_16(img, 10)) == 0
+    img[16, 17] = 190                           # weaker neighbour loses NMS
+    k = oracle.fast9_16(img, 10)
+    assert k.tolist() == [[16, 16, 179]]
+    # every detection is a strict 3x3 local maximum of the score and >= 3 px from the border
+    assert ((k[:, 0] >= 3) & (k[:, 0] < 29) & (k[:, 1] >= 3) & (k[:, 1] < 29)).all()
+    assert (oracle.fast9_16(np.full((32, 32), 99, np.uint8), 0).shape[0]) == 0
+
+
+def test_octree_simple(oracle):
+    # 4 well separated points, N=4 -> all four kept, output order = final std::list order
+    kp = np.zeros(4, oracle.KP_DTYPE)
+    kp["x"] = [10, 150, 20, 160]; kp["y"] = [10, 20, 120, 130]; kp["response"] = [5, 6, 7, 8]
+    out = oracle.distribute_octree(kp, 0, 200, 0, 150, 4)
+    assert len(out) == 4
+    # one root (round(200/150)=1); children pushed front in order n1,n2,n3,n4 -> list = n4,n3,n2,n1
+    assert list(out["response"]) == [8, 7, 6, 5]
+    # two points in the same leaf region with N=1: best response survives
+    kp2 = np.zeros(2, oracle.KP_DTYPE); kp2["x"] = [10, 11]; kp2["y"] = [10, 10]; kp2["response"] = [3, 9]
+    out2 = oracle.distribute_octree(kp2, 0, 200, 0, 150, 1)
+    assert len(out2) >= 1 and out2["response"].max() == 9
+
+
+def test_extract_output_order_is_reversed(oracle):
+    """SURVEY App.B H12: mono callers pass lapping {0,1000}: every kp takes the back-fill branch."""
+    img = synth.texture_image(240, 180, seed=3)
+    e = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19)
+    mono, kps, desc, oob = e.extract(img, lap=(0, 1000))
+    assert mono == 0 and len(kps) > 300
+    l0 = e.level_keypoints(0)
+    n = len(kps)
+    assert kps[n - 1]["x"] == l0[0]["x"] and kps[n - 1]["y"] == l0[0]["y"]
+    assert (np.diff(kps["octave"]) <= 0).all()          # levels descending after reversal
+    mono2, kps2, desc2, _ = e.extract(img, lap=(0, 0))
+    assert mono2 == len(kps2) - int((kps2["x"] == 0).sum())
+    assert (kps2["octave"][:mono2][:-1] <= kps2["octave"][:mono2][1:]).all()
+    assert not oob.any()                                # edge 19: no tap leaves the level buffer
+
+
+def test_extract_empty_image_returns_minus_one(oracle):
+    e = oracle.OrbExtractor()
+    L = oracle.lib()
+    n = C.c_int()
+    assert L.orc_orb_extract(e.h, None, 0, 0, 0, 0, 1000, 1, None, None, None, 0, C.byref(n)) == -1
