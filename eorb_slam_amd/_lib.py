@@ -1,0 +1,103 @@
+"""ctypes binding of libeorb_fe.so (include/eorb_fe.h).  There is no CPU fallback: if the HIP library
+is missing or fails to load, importing/using the front end raises."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libeorb_fe.so")
+
+EORB_OK, EORB_E_EMPTY, EORB_E_CONFIG, EORB_E_CAPACITY, EORB_E_ARG, EORB_E_HIP, EORB_E_NOTCONF = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/eorb_fe.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "eorb_create", "eorb_destroy", "eorb_sync", "eorb_last_error", "eorb_version",
+    "eorb_prof_enable", "eorb_prof_reset", "eorb_prof_count", "eorb_prof_get",
+    "eorb_ev2im", "eorb_ev2im_gauss",
+    "eorb_orb_configure", "eorb_orb_max_keypoints", "eorb_orb_get_tables", "eorb_orb_extract",
+    "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map",
+    "eorb_hamming_bf_knn2",
+    "eorb_fe_configure", "eorb_fe_run_batch_dev",
+    "eorb_pack_events", "eorb_dev_alloc", "eorb_dev_free", "eorb_dev_upload", "eorb_dev_download",
+]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scaleFactor", C.c_float), ("nlevels", C.c_int),
+                ("iniThFAST", C.c_int), ("minThFAST", C.c_int), ("edgeTh", C.c_int), ("imWidth", C.c_int)]
+
+
+class GridBounds(C.Structure):
+    _fields_ = [("minX", C.c_float), ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float),
+                ("invW", C.c_float), ("invH", C.c_float)]
+
+
+class FeConfig(C.Structure):
+    _fields_ = [("W", C.c_int), ("H", C.c_int), ("sigma", C.c_float), ("pol", C.c_int),
+                ("orb", OrbParams), ("lap0", C.c_int), ("lap1", C.c_int), ("want_desc", C.c_int),
+                ("max_batch", C.c_int), ("max_events", C.c_int), ("match", C.c_int),
+                ("windowSize", C.c_int), ("nnratio", C.c_float), ("checkOri", C.c_int)]
+
+
+def build(force=False):
+    """Compile libeorb_fe.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
+            if f.endswith((".hip", ".h"))] + [os.path.join(_HERE, "..", "include", "eorb_fe.h")]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in srcs)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libeorb_fe.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C eorb_slam_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    pi = C.POINTER(C.c_int)
+    L.eorb_create.restype = ci; L.eorb_create.argtypes = [ci, vp, C.POINTER(vp)]
+    L.eorb_destroy.restype = None; L.eorb_destroy.argtypes = [vp]
+    L.eorb_sync.restype = ci; L.eorb_sync.argtypes = [vp]
+    L.eorb_last_error.restype = C.c_char_p; L.eorb_last_error.argtypes = [vp]
+    L.eorb_version.restype = C.c_char_p; L.eorb_version.argtypes = []
+    L.eorb_prof_enable.restype = ci; L.eorb_prof_enable.argtypes = [vp, ci]
+    L.eorb_prof_reset.restype = ci; L.eorb_prof_reset.argtypes = [vp]
+    L.eorb_prof_count.restype = ci; L.eorb_prof_count.argtypes = [vp]
+    L.eorb_prof_get.restype = ci
+    L.eorb_prof_get.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.eorb_ev2im.restype = ci; L.eorb_ev2im.argtypes = [vp, vp, C.c_size_t, ci, ci, ci, ci, vp, vp, vp, pi]
+    L.eorb_ev2im_gauss.restype = ci; L.eorb_ev2im_gauss.argtypes = [vp, vp, C.c_size_t, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.eorb_orb_configure.restype = ci; L.eorb_orb_configure.argtypes = [vp, C.POINTER(OrbParams), ci, ci]
+    L.eorb_orb_max_keypoints.restype = ci; L.eorb_orb_max_keypoints.argtypes = [vp]
+    L.eorb_orb_get_tables.restype = ci; L.eorb_orb_get_tables.argtypes = [vp, vp, vp, vp, pi]
+    L.eorb_orb_extract.restype = ci
+    L.eorb_orb_extract.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, pi, pi]
+    L.eorb_search_for_initialization.restype = ci
+    L.eorb_search_for_initialization.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci, vp, ci, vp,
+                                                 C.POINTER(GridBounds), vp, vp, ci, cf, ci, pi]
+    L.eorb_search_by_projection_last.restype = ci
+    L.eorb_search_by_projection_last.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp,
+                                                 C.POINTER(GridBounds), vp, cf, ci, ci, pi]
+    L.eorb_search_by_projection_map.restype = ci
+    L.eorb_search_by_projection_map.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                C.POINTER(GridBounds), vp, cf, cf, pi]
+    L.eorb_hamming_bf_knn2.restype = ci; L.eorb_hamming_bf_knn2.argtypes = [vp, vp, ci, vp, ci, vp, vp]
+    L.eorb_fe_configure.restype = ci; L.eorb_fe_configure.argtypes = [vp, C.POINTER(FeConfig)]
+    L.eorb_fe_run_batch_dev.restype = ci
+    L.eorb_fe_run_batch_dev.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
+    L.eorb_pack_events.restype = None; L.eorb_pack_events.argtypes = [vp, C.c_size_t, vp]
+    L.eorb_dev_alloc.restype = vp; L.eorb_dev_alloc.argtypes = [vp, C.c_size_t]
+    L.eorb_dev_free.restype = ci; L.eorb_dev_free.argtypes = [vp, vp]
+    L.eorb_dev_upload.restype = ci; L.eorb_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.eorb_dev_download.restype = ci; L.eorb_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
+    _lib = L
+    return L

@@ -1,0 +1,141 @@
+// dev_math.h -- device-side scalar math with a fixed IEEE-754 operation order (gfx950).
+//
+// The whole library is compiled with -ffp-contract=off: every * + - / below is a single
+// correctly-rounded IEEE operation (f32 denormals on, IEEE f32 division), so results are
+// reproducible bit for bit against any other IEEE machine evaluating the same sequence.
+// expf / sinf / cosf follow the double-precision evaluation schemes glibc (>= 2.28) uses for its
+// single-precision functions, which is what the reference's std::exp/cos/sin calls resolve to
+// (src/Event/EventConversion.cc:59-65, src/ORBextractor.cc:117-118); fastAtan2 follows
+// OpenCV 3.4's cv::fastAtan2 (call site src/ORBextractor.cc:103); cvRound = round-half-even.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eorb {
+
+__device__ __constant__ static const uint64_t kExp2Tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+
+// exp(x) for x <= 0 (the Gaussian stamp only needs the non-positive half-line).
+// tab: the 32-entry table above (constant memory) or an LDS copy of it.
+__device__ __forceinline__ float dev_expf_nonpos(float x, const uint64_t* tab)
+{
+    const double N = 32.0;
+    const double InvLn2N = 0x1.71547652b82fep+0 * N;
+    const double Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / N / N / N;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / N;
+    if (x < -0x1.9fe368p6f) return 0.0f;
+    double xd = (double)x;
+    double z = InvLn2N * xd;
+    double kd = z + Shift;
+    uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd = kd - Shift;
+    double r = z - kd;
+    uint64_t t = tab[ki & 31];
+    t += ki << 47;
+    double s = __longlong_as_double((long long)t);
+    double zz = C0 * r + C1;
+    double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+// sin and cos of an angle in [0, 2*pi] (radians, f32), glibc sincosf fast path.
+__device__ __forceinline__ void dev_sincosf(float yf, float* sn, float* cs)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23;
+    const double hpi = 0x1.921FB54442D18p0;
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5,
+                 c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    double x = (double)yf;
+    const uint32_t top = (__float_as_uint(yf) >> 20) & 0x7ff;
+    int n = 0;
+    double sgn = 1.0;
+    bool small = top < 0x3f4;
+    if (!small) {
+        double r = x * hpi_inv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        x = x - (double)n * hpi;
+        sgn = (n & 1) != ((n >> 1) & 1) ? -1.0 : 1.0;      // sign table {1,-1,-1,1}
+    }
+    const double x2 = x * x;
+    const double cg = (n & 2) ? -1.0 : 1.0;                   // second coefficient table: cos coeffs negated
+    // sine-branch polynomial on (x*sgn) and cosine-branch polynomial (uses x2 only)
+    const double xs = x * sgn;
+    double x3 = xs * x2;
+    double ps1 = s2 + x2 * s3;
+    double x7 = x3 * x2;
+    double ps = xs + x3 * s1;
+    const double sin_poly = ps + x7 * ps1;
+    double x4 = x2 * x2;
+    double pc2 = cg * c3 + x2 * (cg * c4);
+    double pc1 = cg * c0 + x2 * (cg * c1);
+    double x6 = x4 * x2;
+    double pc = pc1 + x4 * (cg * c2);
+    const double cos_poly = pc + x6 * pc2;
+    float s_out, c_out;
+    if (small) {
+        s_out = (top < 0x398) ? yf : (float)sin_poly;
+        c_out = (top < 0x398) ? 1.0f : (float)cos_poly;
+    } else {
+        // sinf: poly index n; cosf: poly index n^1  (odd index = cosine branch)
+        s_out = (float)((n & 1) ? cos_poly : sin_poly);
+        c_out = (float)((n & 1) ? sin_poly : cos_poly);
+    }
+    *sn = s_out; *cs = c_out;
+}
+
+// cv::fastAtan2(y, x) in degrees, [0, 360]
+__device__ __forceinline__ float dev_fast_atan2(float y, float x)
+{
+    const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ int dev_cvround(float v) { return __float2int_rn(v); }
+
+// popcount of a 256-bit XOR: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2360-2378)
+__device__ __forceinline__ int dev_hamming256(const uint64_t a[4], const uint64_t b[4])
+{
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+}  // namespace eorb

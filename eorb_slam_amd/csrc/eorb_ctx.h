@@ -1,0 +1,138 @@
+// eorb_ctx.h -- internal context shared by the translation units of libeorb_fe.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/eorb_fe.h"
+
+namespace eorb {
+
+constexpr int kMaxLevels = 16;
+constexpr int kTile = 8;            // accumulation tile edge (one wavefront = 8x8 pixels)
+constexpr int kChunk = 4096;        // events per binning chunk (one wavefront bins one chunk)
+constexpr int kGridCols = 64;       // FRAME_GRID_COLS include/Frame.h:46
+constexpr int kGridRows = 48;       // FRAME_GRID_ROWS include/Frame.h:45
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfEntry {
+    std::string name;
+    double total_ms = 0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct ChunkDesc {       // one binning chunk = a run of <= kChunk consecutive events of one slice
+    int64_t start;       // index of the first event (into the batch's event array)
+    int32_t n;
+    int32_t slice;
+};
+
+// geometry of one pyramid level (ComputePyramid / ComputeKeyPointsOctTree, ORBextractor.cc:784-808,1240-1265)
+struct LevelGeom {
+    int w, h;            // level (ROI) size
+    int bw, bh;          // bordered buffer size (w+2E, h+2E)
+    int buf_off;         // byte offset of the bordered buffer inside a slice's pyramid block
+    int roi_off;         // byte offset of the un-bordered (w*h) planes (score / blur) inside a slice block
+    int minBX, minBY, maxBX, maxBY;
+    int nCols, nRows, wCell, hCell;
+    int cell_off;        // index of this level's first cell in the per-slice cell arrays
+    int cand_cap;        // candidate capacity of the level
+    int cand_off;        // offset (entries) of the level's candidate array inside a slice block
+    int nfeat;           // mnFeaturesPerLevel
+    int kp_cap;          // nfeat + slack
+    int kp_off;          // offset (entries) of the level's keypoint array inside a slice block
+    int xtab_off, ytab_off;   // resize coefficient tables (int offsets into the table buffer)
+    int xmax;            // first dx whose source column is clamped (HResize)
+    float scale;         // mvScaleFactor[level]
+    int patch_size;      // (int)(31*scale)
+    int node_cap;        // octree node pool capacity
+};
+
+struct OrbState {
+    bool configured = false;
+    eorb_orb_params p{};
+    int W = 0, H = 0, edge = 0, nlevels = 0;
+    float sf[kMaxLevels]{}, inv_sf[kMaxLevels]{};
+    int nfeat[kMaxLevels]{};
+    int umax[16]{};
+    LevelGeom lv[kMaxLevels]{};
+    int pyr_bytes = 0;       // per slice: all bordered level buffers
+    int roi_bytes = 0;       // per slice: all un-bordered level planes
+    int ncells = 0;          // per slice: cells over all levels
+    int cell_cap = 0;        // candidates per cell (capacity)
+    int cand_total = 0;      // per slice: sum of cand_cap
+    int kp_total = 0;        // per slice: sum of kp_cap  (= eorb_orb_max_keypoints)
+    int max_out = 0;
+    int oct_lds = 0;         // dynamic LDS bytes of the octree kernel
+    int oct_scratch = 0;     // per (slice,level) global scratch ints
+    DevBuf tabs;             // resize tables (short/int), level geometry, pattern, umax
+    DevBuf geom;
+};
+
+}  // namespace eorb
+
+struct eorb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool prof = false;
+    std::vector<eorb::ProfEntry> profs;
+
+    // accumulation workspaces
+    eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax;
+    // extractor workspaces
+    eorb::OrbState orb;
+    eorb::DevBuf pyr, score, blur, cell_cnt, cell_cand, lvl_cnt, lvl_kp, kp_angle, out_kp, out_desc, out_oob,
+        out_n, oct_scratch, in_img;
+    // matcher workspaces
+    eorb::DevBuf m_a, m_b, m_c, m_d, m_e, m_f, m_g, m_h, m_i, m_j;
+    // batched front end
+    bool fe_configured = false;
+    eorb_fe_config fe{};
+    eorb::DevBuf fe_prev_kp, fe_prev_desc, fe_prev_n, fe_pm;
+    bool fe_has_prev = false;
+    // pinned staging
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
+namespace eorb {
+
+int  set_err(eorb_ctx* c, int code, const char* fmt, ...);
+int  ensure(eorb_ctx* c, DevBuf& b, size_t bytes);
+void* pinned(eorb_ctx* c, size_t bytes);
+int  hip_check(eorb_ctx* c, hipError_t e, const char* what);
+
+// scoped per-kernel timing (HIP events on the ctx stream) when profiling is enabled
+struct ProfScope {
+    eorb_ctx* c; int idx; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(eorb_ctx* c, const char* name);
+    ~ProfScope();
+};
+
+#define EORB_HIP(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return eorb::hip_check((c), e__, #call); } while (0)
+#define EORB_LAUNCH_CHECK(c, what) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return eorb::hip_check((c), e__, what); } while (0)
+
+// ev_accum.hip
+int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_offsets, int B, int W, int H,
+                      float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
+                      uint32_t* d_minmax_enc);
+// orb_extract.hip
+int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
+                    int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono);
+// match.hip
+int search_init_dev(eorb_ctx* c, int npairs,
+                    const eorb_keypoint* kps1, const int32_t* n1, size_t kp1_stride, const uint8_t* desc1, int dstride1, size_t desc1_slice,
+                    const uint8_t* is_orb1,
+                    const eorb_keypoint* kps2, const int32_t* n2, size_t kp2_stride, const uint8_t* desc2, int dstride2, size_t desc2_slice,
+                    const uint8_t* is_orb2, int cap1, int cap2,
+                    eorb_grid_bounds gb, float* prev_matched, int32_t* matches12, int windowSize, float nnratio,
+                    int checkOri, int32_t* nmatches);
+
+}  // namespace eorb

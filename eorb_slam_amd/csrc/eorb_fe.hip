@@ -1,0 +1,543 @@
+// eorb_fe.hip -- C ABI of libeorb_fe.so (include/eorb_fe.h): context, host-buffer entry points and the
+// batched HBM-resident front end.  No CPU fallback anywhere: every entry point launches HIP kernels.
+#include "eorb_ctx.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+namespace eorb {
+
+int ev_decode_minmax(eorb_ctx* c, const uint32_t* d_enc, float* d_out, int B);
+int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H);
+int orb_err_flag(eorb_ctx* c, int B, int* flag);
+int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2);
+int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride,
+                         const uint8_t* cur_is_orb, const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
+                         const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+                         const float* level_scale, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
+                         int32_t* nmatches);
+int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
+                        int M, const uint8_t* in_view, const float4* mp_f4 /* projX, projY, viewCos, levelScale */,
+                        const int32_t* level, const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb,
+                        eorb_grid_bounds gb, int32_t* frame_mp, float th, float nnratio, int32_t* nmatches);
+
+int set_err(eorb_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+int hip_check(eorb_ctx* c, hipError_t e, const char* what)
+{
+    return set_err(c, EORB_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int ensure(eorb_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return EORB_OK;
+    if (b.p) { hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return hip_check(c, e, "hipFree"); }
+    const size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return hip_check(c, e, "hipMalloc"); }
+    b.cap = want;
+    return EORB_OK;
+}
+
+void* pinned(eorb_ctx* c, size_t bytes)
+{
+    if (c->pinned_cap >= bytes) return c->pinned;
+    if (c->pinned) { hipStreamSynchronize(c->stream); hipHostFree(c->pinned); c->pinned = nullptr; c->pinned_cap = 0; }
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) { c->pinned = nullptr; return nullptr; }
+    c->pinned_cap = want;
+    return c->pinned;
+}
+
+ProfScope::ProfScope(eorb_ctx* cc, const char* name) : c(cc), idx(-1)
+{
+    if (!c->prof) return;
+    for (size_t i = 0; i < c->profs.size(); i++) if (c->profs[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) { c->profs.emplace_back(); c->profs.back().name = name; idx = (int)c->profs.size() - 1; }
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, c->stream);
+}
+ProfScope::~ProfScope()
+{
+    if (idx < 0) return;
+    hipEventRecord(b, c->stream);
+    c->profs[idx].pending.emplace_back(a, b);
+    c->profs[idx].launches++;
+}
+
+static void prof_collect(eorb_ctx* c)
+{
+    for (auto& p : c->profs) {
+        for (auto& ev : p.pending) {
+            hipEventSynchronize(ev.second);
+            float ms = 0; hipEventElapsedTime(&ms, ev.first, ev.second);
+            p.total_ms += ms;
+            hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+        }
+        p.pending.clear();
+    }
+}
+
+static void free_buf(DevBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+}  // namespace eorb
+
+using namespace eorb;
+
+extern "C" {
+
+const char* eorb_version(void) { return "eorb_fe 0.1.0 (gfx950)"; }
+
+int eorb_create(int device, void* hip_stream, eorb_ctx** out)
+{
+    if (!out) return EORB_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EORB_E_HIP;
+    if (device < 0 || device >= ndev) return EORB_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return EORB_E_HIP;
+    eorb_ctx* c = new eorb_ctx();
+    c->device = device;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return EORB_E_HIP; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return EORB_OK;
+}
+
+void eorb_destroy(eorb_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->pyr, &c->score,
+                      &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
+                      &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
+                      &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
+                      &c->orb.tabs, &c->orb.geom};
+    for (DevBuf* b : bufs) free_buf(*b);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int eorb_sync(eorb_ctx* c)
+{
+    if (!c) return EORB_E_ARG;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+const char* eorb_last_error(eorb_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int eorb_prof_enable(eorb_ctx* c, int on) { if (!c) return EORB_E_ARG; c->prof = on != 0; return EORB_OK; }
+int eorb_prof_reset(eorb_ctx* c)
+{
+    if (!c) return EORB_E_ARG;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    c->profs.clear();
+    return EORB_OK;
+}
+int eorb_prof_count(eorb_ctx* c) { if (!c) return EORB_E_ARG; hipStreamSynchronize(c->stream); prof_collect(c); return (int)c->profs.size(); }
+int eorb_prof_get(eorb_ctx* c, int i, const char** name, double* total_ms, int64_t* launches)
+{
+    if (!c || i < 0 || i >= (int)c->profs.size()) return EORB_E_ARG;
+    if (name) *name = c->profs[i].name.c_str();
+    if (total_ms) *total_ms = c->profs[i].total_ms;
+    if (launches) *launches = c->profs[i].launches;
+    return EORB_OK;
+}
+
+void eorb_pack_events(const eorb_event* ev, size_t n, eorb_event16* out)
+{
+    for (size_t i = 0; i < n; i++) {
+        out[i].x = ev[i].x; out[i].y = ev[i].y;
+        double t = ev[i].ts < 0 ? 0.0 : ev[i].ts;
+        uint64_t u; memcpy(&u, &t, 8);
+        if (!ev[i].p) u |= 0x8000000000000000ull;
+        memcpy(&out[i].t, &u, 8);
+    }
+}
+
+void* eorb_dev_alloc(eorb_ctx* c, size_t bytes)
+{
+    if (!c) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { set_err(c, EORB_E_HIP, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+int eorb_dev_free(eorb_ctx* c, void* p) { if (!c) return EORB_E_ARG; hipStreamSynchronize(c->stream); EORB_HIP(c, hipFree(p)); return EORB_OK; }
+int eorb_dev_upload(eorb_ctx* c, void* d, const void* h, size_t bytes)
+{
+    if (!c) return EORB_E_ARG;
+    EORB_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+int eorb_dev_download(eorb_ctx* c, void* h, const void* d, size_t bytes)
+{
+    if (!c) return EORB_E_ARG;
+    EORB_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+// ---- event accumulation, host buffers -------------------------------------------------------------
+static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, int H, float sigma, int pol, int normalized,
+                          int mode_count, float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8)
+{
+    if (!c) return EORB_E_ARG;
+    if (W <= 0 || H <= 0 || (n && !ev)) return set_err(c, EORB_E_ARG, "ev2im: bad arguments");
+    hipSetDevice(c->device);
+    int rc;
+    const size_t npix = (size_t)W * H;
+    if ((rc = ensure(c, c->ev16, sizeof(eorb_event16) * std::max<size_t>(n, 1)))) return rc;
+    if ((rc = ensure(c, c->img_f32, sizeof(float) * npix))) return rc;
+    if ((rc = ensure(c, c->img_u8, npix))) return rc;
+    if ((rc = ensure(c, c->minmax, 64))) return rc;
+    if (n) {
+        std::vector<eorb_event16> packed(n);
+        eorb_pack_events(ev, n, packed.data());
+        EORB_HIP(c, hipMemcpyAsync(c->ev16.p, packed.data(), sizeof(eorb_event16) * n, hipMemcpyHostToDevice, c->stream));
+        EORB_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    int64_t offs[2] = {0, (int64_t)n};
+    uint32_t* mm = (uint32_t*)c->minmax.p;
+    float* mmf = (float*)((char*)c->minmax.p + 16);
+    EORB_HIP(c, hipMemsetAsync(c->img_u8.p, 0, npix, c->stream));
+    rc = ev_accumulate_dev(c, (const eorb_event16*)c->ev16.p, offs, 1, W, H, sigma, pol, mode_count, (float*)c->img_f32.p,
+                           (uint8_t*)c->img_u8.p, normalized, mm);
+    if (rc) return rc;
+    if ((rc = ev_decode_minmax(c, mm, mmf, 1))) return rc;
+    float hmm[2];
+    EORB_HIP(c, hipMemcpyAsync(hmm, mmf, 8, hipMemcpyDeviceToHost, c->stream));
+    if (out_f32) EORB_HIP(c, hipMemcpyAsync(out_f32, c->img_f32.p, sizeof(float) * npix, hipMemcpyDeviceToHost, c->stream));
+    if (out_u8) EORB_HIP(c, hipMemcpyAsync(out_u8, c->img_u8.p, npix, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (minmax) { minmax[0] = hmm[0]; minmax[1] = hmm[1]; }
+    if (is_u8) *is_u8 = mode_count ? (normalized && hmm[1] > hmm[0]) : (normalized != 0);
+    return EORB_OK;
+}
+
+int eorb_ev2im(eorb_ctx* c, const eorb_event* ev, size_t n, int W, int H, int pol, int normalized,
+               float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8)
+{
+    return ev_host_common(c, ev, n, W, H, 0.f, pol, normalized, 1, out_f32, out_u8, minmax, is_u8);
+}
+
+int eorb_ev2im_gauss(eorb_ctx* c, const eorb_event* ev, size_t n, int W, int H, float sigma, int pol,
+                     int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    if (c && !(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev2im_gauss: sigma must be > 0");
+    return ev_host_common(c, ev, n, W, H, sigma, pol, normalized, 0, out_f32, out_u8, minmax, nullptr);
+}
+
+// ---- ORB extractor, host buffers -----------------------------------------------------------------------
+int eorb_orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
+{
+    if (!c) return EORB_E_ARG;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    return orb_configure(c, p, W, H);
+}
+
+int eorb_orb_max_keypoints(eorb_ctx* c) { return (c && c->orb.configured) ? c->orb.max_out : EORB_E_NOTCONF; }
+
+int eorb_orb_get_tables(eorb_ctx* c, float* sf, float* inv_sf, int* nfeat, int* edge)
+{
+    if (!c || !c->orb.configured) return EORB_E_NOTCONF;
+    for (int i = 0; i < c->orb.nlevels; i++) {
+        if (sf) sf[i] = c->orb.sf[i];
+        if (inv_sf) inv_sf[i] = c->orb.inv_sf[i];
+        if (nfeat) nfeat[i] = c->orb.nfeat[i];
+    }
+    if (edge) *edge = c->orb.edge;
+    return EORB_OK;
+}
+
+int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, int lap0, int lap1,
+                     int want_desc, eorb_keypoint* kps, uint8_t* desc, uint8_t* oob, int cap,
+                     int* n_out, int* mono_index)
+{
+    if (!c) return EORB_E_ARG;
+    if (n_out) *n_out = 0;
+    if (!img || W <= 0 || H <= 0) return EORB_E_EMPTY;                 // _image.empty() -> -1 (:1096)
+    OrbState& o = c->orb;
+    if (!o.configured) return set_err(c, EORB_E_NOTCONF, "eorb_orb_extract: not configured");
+    if (W != o.W || H != o.H) return set_err(c, EORB_E_ARG, "image %dx%d does not match the configured %dx%d", W, H, o.W, o.H);
+    if (stride < W) return set_err(c, EORB_E_ARG, "stride < width");
+    hipSetDevice(c->device);
+    int rc;
+    const int mo = o.max_out;
+    if ((rc = ensure(c, c->in_img, (size_t)W * H))) return rc;
+    if ((rc = ensure(c, c->out_kp, sizeof(eorb_keypoint) * (size_t)mo))) return rc;
+    if ((rc = ensure(c, c->m_a, 32 * (size_t)mo))) return rc;
+    if ((rc = ensure(c, c->m_b, (size_t)mo))) return rc;
+    if ((rc = ensure(c, c->out_n, 64))) return rc;
+    EORB_HIP(c, hipMemcpy2DAsync(c->in_img.p, W, img, stride, W, H, hipMemcpyHostToDevice, c->stream));
+    int32_t* dn = (int32_t*)c->out_n.p;
+    rc = orb_extract_dev(c, (const uint8_t*)c->in_img.p, W, (size_t)W * H, 1, lap0, lap1, want_desc, (eorb_keypoint*)c->out_kp.p,
+                         (uint8_t*)c->m_a.p, (uint8_t*)c->m_b.p, dn, dn + 1);
+    if (rc) return rc;
+    int hn[2];
+    EORB_HIP(c, hipMemcpyAsync(hn, dn, 8, hipMemcpyDeviceToHost, c->stream));
+    int flag = 0;
+    if ((rc = orb_err_flag(c, 1, &flag))) return rc;
+    if (flag) return set_err(c, EORB_E_CAPACITY, "orb_extract: internal capacity exceeded (flag %d)", flag);
+    if (hn[0] > cap) return set_err(c, EORB_E_CAPACITY, "orb_extract: %d keypoints > caller capacity %d", hn[0], cap);
+    if (hn[0] > 0) {
+        if (kps) EORB_HIP(c, hipMemcpyAsync(kps, c->out_kp.p, sizeof(eorb_keypoint) * hn[0], hipMemcpyDeviceToHost, c->stream));
+        if (want_desc && desc) EORB_HIP(c, hipMemcpyAsync(desc, c->m_a.p, 32 * (size_t)hn[0], hipMemcpyDeviceToHost, c->stream));
+        if (oob) EORB_HIP(c, hipMemcpyAsync(oob, c->m_b.p, hn[0], hipMemcpyDeviceToHost, c->stream));
+        EORB_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (n_out) *n_out = hn[0];
+    if (mono_index) *mono_index = hn[1];
+    return EORB_OK;
+}
+
+// ---- matchers, host buffers ------------------------------------------------------------------------------
+static int up(eorb_ctx* c, DevBuf& b, const void* h, size_t bytes)
+{
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    if (bytes && h) EORB_HIP(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return EORB_OK;
+}
+
+int eorb_search_for_initialization(eorb_ctx* c,
+        const eorb_keypoint* kps1, int n1, const uint8_t* desc1, int stride1, const uint8_t* is_orb1,
+        const eorb_keypoint* kps2, int n2, const uint8_t* desc2, int stride2, const uint8_t* is_orb2,
+        const eorb_grid_bounds* gb, float* prev_matched, int32_t* matches12,
+        int windowSize, float nnratio, int checkOri, int* nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (n1 < 0 || n2 < 0 || !gb || !matches12 || stride1 < 32 || stride2 < 32) return set_err(c, EORB_E_ARG, "search_for_initialization: bad arguments");
+    hipSetDevice(c->device);
+    if (nmatches) *nmatches = 0;
+    if (n1 == 0) return EORB_OK;
+    int rc;
+    const int c1 = std::max(n1, 1), c2 = std::max(n2, 1);
+    if ((rc = up(c, c->m_a, kps1, sizeof(eorb_keypoint) * n1))) return rc;
+    if ((rc = up(c, c->m_b, desc1, (size_t)stride1 * n1))) return rc;
+    if ((rc = up(c, c->m_c, kps2, sizeof(eorb_keypoint) * n2))) return rc;
+    if ((rc = up(c, c->m_d, desc2, (size_t)stride2 * n2))) return rc;
+    if ((rc = up(c, c->m_e, is_orb1, is_orb1 ? n1 : 0))) return rc;
+    if ((rc = up(c, c->m_f, is_orb2, is_orb2 ? n2 : 0))) return rc;
+    if ((rc = up(c, c->m_g, prev_matched, prev_matched ? sizeof(float) * 2 * n1 : 0))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * c1))) return rc;
+    int32_t hn[2] = {n1, n2};
+    if ((rc = up(c, c->m_i, hn, 8))) return rc;
+    if ((rc = ensure(c, c->m_j, 16))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));       // hn is a stack variable
+    const int32_t* dn = (const int32_t*)c->m_i.p;
+    rc = search_init_dev(c, 1, (const eorb_keypoint*)c->m_a.p, dn, 0, (const uint8_t*)c->m_b.p, stride1, 0,
+                         is_orb1 ? (const uint8_t*)c->m_e.p : nullptr,
+                         (const eorb_keypoint*)c->m_c.p, dn + 1, 0, (const uint8_t*)c->m_d.p, stride2, 0,
+                         is_orb2 ? (const uint8_t*)c->m_f.p : nullptr, c1, c2, *gb,
+                         prev_matched ? (float*)c->m_g.p : nullptr, (int32_t*)c->m_h.p, windowSize, nnratio, checkOri,
+                         (int32_t*)c->m_j.p);
+    if (rc) return rc;
+    int nm = 0;
+    EORB_HIP(c, hipMemcpyAsync(matches12, c->m_h.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, c->stream));
+    if (prev_matched) EORB_HIP(c, hipMemcpyAsync(prev_matched, c->m_g.p, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(&nm, c->m_j.p, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (nmatches) *nmatches = nm;
+    return EORB_OK;
+}
+
+int eorb_search_by_projection_last(eorb_ctx* c,
+        const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
+        const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
+        const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+        const float* level_scale, const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri,
+        int* nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (n_cur < 0 || n_last < 0 || !gb || !cur_mp || cur_stride < 32 || !level_scale)
+        return set_err(c, EORB_E_ARG, "search_by_projection_last: bad arguments");
+    hipSetDevice(c->device);
+    if (nmatches) *nmatches = 0;
+    if (n_last == 0 || n_cur == 0) return EORB_OK;
+    int rc;
+    if ((rc = up(c, c->m_a, cur_kps, sizeof(eorb_keypoint) * n_cur))) return rc;
+    if ((rc = up(c, c->m_b, cur_desc, (size_t)cur_stride * n_cur))) return rc;
+    if ((rc = up(c, c->m_c, last_kps, sizeof(eorb_keypoint) * n_last))) return rc;
+    if ((rc = up(c, c->m_d, mp_desc, 32 * (size_t)n_last))) return rc;
+    if ((rc = up(c, c->m_e, cur_is_orb, cur_is_orb ? n_cur : 0))) return rc;
+    if ((rc = up(c, c->m_f, last_is_orb, last_is_orb ? n_last : 0))) return rc;
+    std::vector<float> f3(3 * (size_t)n_last);
+    for (int i = 0; i < n_last; i++) { f3[3 * i] = uv[2 * i]; f3[3 * i + 1] = uv[2 * i + 1]; f3[3 * i + 2] = level_scale[i]; }
+    if ((rc = up(c, c->m_g, f3.data(), sizeof(float) * f3.size()))) return rc;
+    if ((rc = up(c, c->m_h, cur_mp, sizeof(int32_t) * n_cur))) return rc;
+    // valid | mp_obs packed behind each other
+    std::vector<uint8_t> vo(2 * (size_t)n_last);
+    memcpy(vo.data(), valid, n_last); memcpy(vo.data() + n_last, mp_obs, n_last);
+    if ((rc = up(c, c->m_i, vo.data(), vo.size()))) return rc;
+    if ((rc = ensure(c, c->m_j, 16))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    rc = search_proj_last_dev(c, (const eorb_keypoint*)c->m_a.p, n_cur, (const uint8_t*)c->m_b.p, cur_stride,
+                              cur_is_orb ? (const uint8_t*)c->m_e.p : nullptr, (const eorb_keypoint*)c->m_c.p, n_last,
+                              last_is_orb ? (const uint8_t*)c->m_f.p : nullptr, (const uint8_t*)c->m_i.p, (const float*)c->m_g.p,
+                              (const uint8_t*)c->m_d.p, (const uint8_t*)c->m_i.p + n_last, nullptr, *gb, (int32_t*)c->m_h.p, th,
+                              mode, checkOri, (int32_t*)c->m_j.p);
+    if (rc) return rc;
+    int nm = 0;
+    EORB_HIP(c, hipMemcpyAsync(cur_mp, c->m_h.p, sizeof(int32_t) * n_cur, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(&nm, c->m_j.p, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (nmatches) *nmatches = nm;
+    return EORB_OK;
+}
+
+int eorb_search_by_projection_map(eorb_ctx* c,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
+        int M, const uint8_t* in_view, const float* proj_xy, const int32_t* level, const float* view_cos,
+        const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
+        const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, int* nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (n < 0 || M < 0 || !gb || !frame_mp || stride < 32) return set_err(c, EORB_E_ARG, "search_by_projection_map: bad arguments");
+    hipSetDevice(c->device);
+    if (nmatches) *nmatches = 0;
+    if (M == 0 || n == 0) return EORB_OK;
+    int rc;
+    if ((rc = up(c, c->m_a, kps, sizeof(eorb_keypoint) * n))) return rc;
+    if ((rc = up(c, c->m_b, desc, (size_t)stride * n))) return rc;
+    if ((rc = up(c, c->m_c, is_orb, is_orb ? n : 0))) return rc;
+    if ((rc = up(c, c->m_d, mp_desc, 32 * (size_t)M))) return rc;
+    // per map point record: proj x, proj y, view cos, level scale (floats) | level (int) | in_view, obs, is_orb (bytes)
+    std::vector<float> f4(4 * (size_t)M);
+    for (int m = 0; m < M; m++) { f4[4 * m] = proj_xy[2 * m]; f4[4 * m + 1] = proj_xy[2 * m + 1]; f4[4 * m + 2] = view_cos[m]; f4[4 * m + 3] = level_scale[m]; }
+    if ((rc = up(c, c->m_e, f4.data(), sizeof(float) * f4.size()))) return rc;
+    if ((rc = up(c, c->m_f, level, sizeof(int32_t) * M))) return rc;
+    std::vector<uint8_t> b3(3 * (size_t)M);
+    for (int m = 0; m < M; m++) { b3[m] = in_view[m]; b3[M + m] = mp_obs[m]; b3[2 * M + m] = mp_is_orb ? mp_is_orb[m] : 1; }
+    if ((rc = up(c, c->m_g, b3.data(), b3.size()))) return rc;
+    if ((rc = up(c, c->m_h, frame_mp, sizeof(int32_t) * n))) return rc;
+    if ((rc = ensure(c, c->m_j, 16))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    const float* F = (const float*)c->m_e.p;
+    const uint8_t* Bp = (const uint8_t*)c->m_g.p;
+    rc = search_proj_map_dev(c, (const eorb_keypoint*)c->m_a.p, n, (const uint8_t*)c->m_b.p, stride,
+                             is_orb ? (const uint8_t*)c->m_c.p : nullptr, M, Bp, (const float4*)F, (const int32_t*)c->m_f.p,
+                             (const uint8_t*)c->m_d.p, Bp + M, Bp + 2 * M, *gb, (int32_t*)c->m_h.p, th, nnratio,
+                             (int32_t*)c->m_j.p);
+    if (rc) return rc;
+    int nm = 0;
+    EORB_HIP(c, hipMemcpyAsync(frame_mp, c->m_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(&nm, c->m_j.p, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (nmatches) *nmatches = nm;
+    return EORB_OK;
+}
+
+int eorb_hamming_bf_knn2(eorb_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2, int32_t* dist2)
+{
+    if (!c) return EORB_E_ARG;
+    if (nq < 0 || nt < 0 || !idx2 || !dist2) return set_err(c, EORB_E_ARG, "bf_knn2: bad arguments");
+    if (nq == 0) return EORB_OK;
+    hipSetDevice(c->device);
+    int rc;
+    if ((rc = up(c, c->m_a, q, 32 * (size_t)nq))) return rc;
+    if ((rc = up(c, c->m_b, t, 32 * (size_t)nt))) return rc;
+    if ((rc = ensure(c, c->m_c, sizeof(int32_t) * 2 * (size_t)nq))) return rc;
+    if ((rc = ensure(c, c->m_d, sizeof(int32_t) * 2 * (size_t)nq))) return rc;
+    rc = bf_knn2_dev(c, (const uint8_t*)c->m_a.p, nq, (const uint8_t*)c->m_b.p, nt, (int32_t*)c->m_c.p, (int32_t*)c->m_d.p);
+    if (rc) return rc;
+    EORB_HIP(c, hipMemcpyAsync(idx2, c->m_c.p, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(dist2, c->m_d.p, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+// ---- batched HBM-resident front end --------------------------------------------------------------------
+int eorb_fe_configure(eorb_ctx* c, const eorb_fe_config* cfg)
+{
+    if (!c || !cfg) return EORB_E_ARG;
+    if (cfg->W <= 0 || cfg->H <= 0 || cfg->max_batch < 1 || cfg->max_events < 0 || !(cfg->sigma > 0.f))
+        return set_err(c, EORB_E_ARG, "fe_configure: bad configuration");
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    int rc = orb_configure(c, &cfg->orb, cfg->W, cfg->H);
+    if (rc) return rc;
+    c->fe = *cfg;
+    const size_t B = cfg->max_batch, npix = (size_t)cfg->W * cfg->H, cap = c->orb.max_out;
+    if ((rc = ensure(c, c->img_f32, sizeof(float) * npix * B))) return rc;
+    if ((rc = ensure(c, c->img_u8, npix * B))) return rc;
+    if ((rc = ensure(c, c->minmax, 8 * B + 64))) return rc;
+    if ((rc = ensure(c, c->out_kp, sizeof(eorb_keypoint) * cap * (B + 1)))) return rc;
+    if ((rc = ensure(c, c->m_a, 32 * cap * (B + 1)))) return rc;       // descriptors, slot 0 = previous batch's last slice
+    if ((rc = ensure(c, c->out_n, sizeof(int32_t) * (2 * B + 4)))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * cap * B))) return rc;   // matches12
+    if ((rc = ensure(c, c->m_j, sizeof(int32_t) * (B + 1)))) return rc;    // nmatches
+    EORB_HIP(c, hipMemsetAsync(c->out_n.p, 0, sizeof(int32_t) * (2 * B + 4), c->stream));
+    c->fe_configured = true;
+    c->fe_has_prev = false;
+    return EORB_OK;
+}
+
+int eorb_fe_run_batch_dev(eorb_ctx* c, const eorb_event16* d_events, const int64_t* h_offsets, int B,
+                          uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                          int32_t* d_matches12, int32_t* d_nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (!c->fe_configured) return set_err(c, EORB_E_NOTCONF, "fe_run_batch: eorb_fe_configure not called");
+    const eorb_fe_config& f = c->fe;
+    if (B < 1 || B > f.max_batch || !h_offsets) return set_err(c, EORB_E_ARG, "fe_run_batch: bad batch size %d", B);
+    hipSetDevice(c->device);
+    const size_t npix = (size_t)f.W * f.H, cap = c->orb.max_out;
+    uint8_t* img = d_images ? d_images : (uint8_t*)c->img_u8.p;
+    // working copies: slot 0 of kp/desc/n holds the last slice of the previous batch (frame-to-frame matching)
+    eorb_keypoint* wk = (eorb_keypoint*)c->out_kp.p;
+    uint8_t* wd = (uint8_t*)c->m_a.p;
+    int32_t* wn = (int32_t*)c->out_n.p;                 // [0] prev, [1..B] this batch, then mono index
+    int rc = ev_accumulate_dev(c, d_events, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 1,
+                               (uint32_t*)c->minmax.p);
+    if (rc) return rc;
+    rc = orb_extract_dev(c, img, f.W, npix, B, f.lap0, f.lap1, f.want_desc, wk + cap, wd + 32 * cap, nullptr, wn + 1,
+                         wn + 1 + f.max_batch + 1);
+    if (rc) return rc;
+    if (f.match && f.want_desc) {
+        eorb_grid_bounds gb;
+        gb.minX = 0.f; gb.minY = 0.f; gb.maxX = (float)f.W; gb.maxY = (float)f.H;           // Frame.cc:862-866
+        gb.invW = (float)kGridCols / (gb.maxX - gb.minX); gb.invH = (float)kGridRows / (gb.maxY - gb.minY);
+        const int first = c->fe_has_prev ? 0 : 1;                  // pair p: slice p-1 (slot p) vs slice p (slot p+1)
+        const int npairs = B - first;
+        int32_t* m12 = d_matches12 ? d_matches12 : (int32_t*)c->m_h.p;
+        int32_t* nm = d_nmatches ? d_nmatches : (int32_t*)c->m_j.p;
+        if (!c->fe_has_prev) {
+            EORB_HIP(c, hipMemsetAsync(nm, 0, sizeof(int32_t), c->stream));
+            EORB_HIP(c, hipMemsetAsync(m12, 0xff, sizeof(int32_t) * cap, c->stream));
+        }
+        rc = search_init_dev(c, npairs, wk + cap * first, wn + first, cap, wd + 32 * cap * first, 32, 32 * cap, nullptr,
+                             wk + cap * (first + 1), wn + first + 1, cap, wd + 32 * cap * (first + 1), 32, 32 * cap, nullptr,
+                             (int)cap, (int)cap, gb, nullptr, m12 + cap * first, f.windowSize, f.nnratio, f.checkOri, nm + first);
+        if (rc) return rc;
+    }
+    // user-visible outputs
+    if (d_kps) EORB_HIP(c, hipMemcpyAsync(d_kps, wk + cap, sizeof(eorb_keypoint) * cap * B, hipMemcpyDeviceToDevice, c->stream));
+    if (d_desc) EORB_HIP(c, hipMemcpyAsync(d_desc, wd + 32 * cap, 32 * cap * B, hipMemcpyDeviceToDevice, c->stream));
+    if (d_nkps) EORB_HIP(c, hipMemcpyAsync(d_nkps, wn + 1, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, c->stream));
+    // carry the last slice into slot 0 for the next batch
+    EORB_HIP(c, hipMemcpyAsync(wk, wk + cap * B, sizeof(eorb_keypoint) * cap, hipMemcpyDeviceToDevice, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(wd, wd + 32 * cap * B, 32 * cap, hipMemcpyDeviceToDevice, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(wn, wn + B, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    c->fe_has_prev = true;
+    return EORB_OK;
+}
+
+}  // extern "C"

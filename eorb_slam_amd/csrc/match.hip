@@ -1,0 +1,551 @@
+// match.hip -- 256-bit Hamming matchers on gfx950 (wavefront __popcll), bit-exact w.r.t. the reference's
+// sequential matchers.
+//
+//   bf_knn2_kernel        brute-force 2-NN (cv::BFMatcher::knnMatch(.,.,2) at src/Frame.cc:1228):
+//                         16 lanes share one query and stride over an LDS-staged train tile; the two
+//                         smallest (dist, trainIdx) keys are merged with shuffles.
+//   search_init_kernel    ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:714-831) /
+//                         MixedMatcher (src/MixedMatcher.cpp:20-145).  The reference is a greedy
+//                         sequential loop whose state (vMatchedDistance, vnMatches21) feeds later
+//                         queries, so queries stay sequential; the candidate scan of each query
+//                         (Frame::GetFeaturesInArea, src/Frame.cc:710-781 + DescriptorDistance,
+//                         ORBmatcher.cc:2360-2378) is spread over the 256 threads of a workgroup.
+//                         Tie-breaks follow the reference's candidate order (cell ix, cell iy,
+//                         insertion index) through a composed sort key.
+//   search_proj_*_kernel  the two tracking SearchByProjection variants (ORBmatcher.cc:44-219,
+//                         :1969-2187), same structure.
+// One workgroup per frame pair; batches of pairs run concurrently.
+#include "eorb_ctx.h"
+#include "dev_math.h"
+
+namespace eorb {
+
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;      // ORBmatcher.cc:36-38
+
+// ---------------------------------------------------------------------------------------------------
+// brute force 2-NN
+__global__ __launch_bounds__(256) void bf_knn2_kernel(const uint8_t* __restrict__ q, int nq,
+                                                      const uint8_t* __restrict__ t, int nt,
+                                                      int32_t* __restrict__ idx2, int32_t* __restrict__ dist2)
+{
+    __shared__ uint64_t tile[256 * 4];
+    const int tid = threadIdx.x;
+    const int part = tid & 15;
+    const int qi = blockIdx.x * 16 + (tid >> 4);
+    uint64_t qa[4] = {0, 0, 0, 0};
+    if (qi < nq) {
+        const uint64_t* qp = (const uint64_t*)(q + (size_t)qi * 32);
+        qa[0] = qp[0]; qa[1] = qp[1]; qa[2] = qp[2]; qa[3] = qp[3];
+    }
+    // keys: dist << 32 | trainIdx ; smaller key = better; ties -> lowest train index
+    uint64_t k0 = ~0ull, k1 = ~0ull;
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+        const int nload = min(256, nt - t0);
+        __syncthreads();
+        if (tid < nload) {
+            const uint64_t* tp = (const uint64_t*)(t + (size_t)(t0 + tid) * 32);
+            tile[tid * 4 + 0] = tp[0]; tile[tid * 4 + 1] = tp[1]; tile[tid * 4 + 2] = tp[2]; tile[tid * 4 + 3] = tp[3];
+        }
+        __syncthreads();
+        for (int j = part; j < nload; j += 16) {
+            const uint64_t* tp = &tile[j * 4];
+            const int d = __popcll(qa[0] ^ tp[0]) + __popcll(qa[1] ^ tp[1]) + __popcll(qa[2] ^ tp[2]) + __popcll(qa[3] ^ tp[3]);
+            const uint64_t key = ((uint64_t)d << 32) | (uint32_t)(t0 + j);
+            if (key < k0) { k1 = k0; k0 = key; }
+            else if (key < k1) k1 = key;
+        }
+    }
+    // merge the 16 partial top-2 lists of a query
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
+        // top-2 of {k0,k1,o0,o1}
+        const uint64_t lo = k0 < o0 ? k0 : o0;
+        const uint64_t hi = k0 < o0 ? o0 : k0;
+        const uint64_t s = k1 < o1 ? k1 : o1;
+        k0 = lo; k1 = hi < s ? hi : s;
+    }
+    if (part == 0 && qi < nq) {
+        idx2[2 * qi] = (k0 == ~0ull) ? -1 : (int32_t)(k0 & 0xffffffffu);
+        dist2[2 * qi] = (k0 == ~0ull) ? 0x7fffffff : (int32_t)(k0 >> 32);
+        idx2[2 * qi + 1] = (k1 == ~0ull) ? -1 : (int32_t)(k1 & 0xffffffffu);
+        dist2[2 * qi + 1] = (k1 == ~0ull) ? 0x7fffffff : (int32_t)(k1 >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shared pieces of the greedy window matchers
+struct GridB { float minX, minY, invW, invH; };
+
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{   // ORBmatcher.cc:790-796
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0f) rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// Frame::GetFeaturesInArea cell range (src/Frame.cc:722-745); returns false when the reference returns empty
+__device__ __forceinline__ bool cell_range(const GridB& g, float x, float y, float r, int& cx0, int& cx1, int& cy0, int& cy1)
+{
+    cx0 = max(0, (int)floorf((x - g.minX - r) * g.invW));
+    if (cx0 >= kGridCols) return false;
+    cx1 = min(kGridCols - 1, (int)ceilf((x - g.minX + r) * g.invW));
+    if (cx1 < 0) return false;
+    cy0 = max(0, (int)floorf((y - g.minY - r) * g.invH));
+    if (cy0 >= kGridRows) return false;
+    cy1 = min(kGridRows - 1, (int)ceilf((y - g.minY + r) * g.invH));
+    if (cy1 < 0) return false;
+    return true;
+}
+
+// block-wide top-2 of 64-bit keys (smaller = better). Result valid in all threads.
+__device__ __forceinline__ void block_top2(uint64_t& k0, uint64_t& k1, uint64_t* red /* 2*nwaves */)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
+        const uint64_t lo = k0 < o0 ? k0 : o0;
+        const uint64_t hi = k0 < o0 ? o0 : k0;
+        const uint64_t s = k1 < o1 ? k1 : o1;
+        k0 = lo; k1 = hi < s ? hi : s;
+    }
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[2 * w] = k0; red[2 * w + 1] = k1; }
+    __syncthreads();
+    uint64_t a0 = red[0], a1 = red[1];
+    for (int i = 1; i < nw; i++) {
+        const uint64_t o0 = red[2 * i], o1 = red[2 * i + 1];
+        const uint64_t lo = a0 < o0 ? a0 : o0;
+        const uint64_t hi = a0 < o0 ? o0 : a0;
+        const uint64_t s = a1 < o1 ? a1 : o1;
+        a0 = lo; a1 = hi < s ? hi : s;
+    }
+    k0 = a0; k1 = a1;
+}
+
+// ComputeThreeMaxima (ORBmatcher.cc:2314-2355)
+__device__ __forceinline__ void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// per-keypoint staging of the searched frame in LDS
+struct F2Stage {
+    float*    x;      // N2
+    float*    y;
+    uint16_t* cell;   // ix*48+iy, 0xFFFF = not in grid (PosInGrid false)
+    int8_t*   level;
+    uint8_t*  isorb;
+};
+
+__device__ __forceinline__ int kp_level(const eorb_keypoint& k, bool isorb)
+{   // Frame::getKPtLevelMono / MixedFrame::getKPtLevelMono (MixedFrame.cpp:438-446)
+    return isorb ? k.octave : k.class_id;
+}
+
+struct SearchInitArgs {
+    const eorb_keypoint* kps1; const int32_t* n1; size_t kp1_stride;
+    const uint8_t* desc1; int dstride1; size_t desc1_slice; const uint8_t* is_orb1;
+    const eorb_keypoint* kps2; const int32_t* n2; size_t kp2_stride;
+    const uint8_t* desc2; int dstride2; size_t desc2_slice; const uint8_t* is_orb2;
+    int cap1, cap2;
+    GridB g;
+    float* prev_matched;       // per pair: cap1*2 (may be NULL: initialised from kps1 positions)
+    int32_t* matches12;        // per pair: cap1
+    int32_t* nmatches;         // per pair
+    int windowSize; float nnratio; int checkOri;
+};
+
+__global__ __launch_bounds__(256) void search_init_kernel(SearchInitArgs A)
+{
+    extern __shared__ unsigned char smem[];
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int N1 = A.n1[pair], N2 = A.n2[pair];
+    const eorb_keypoint* K1 = A.kps1 + (size_t)pair * A.kp1_stride;
+    const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
+    const uint8_t* D1 = A.desc1 + (size_t)pair * A.desc1_slice;
+    const uint8_t* D2 = A.desc2 + (size_t)pair * A.desc2_slice;
+    const uint8_t* O1 = A.is_orb1 ? A.is_orb1 + (size_t)pair * A.cap1 : nullptr;
+    const uint8_t* O2 = A.is_orb2 ? A.is_orb2 + (size_t)pair * A.cap2 : nullptr;
+    int32_t* M12 = A.matches12 + (size_t)pair * A.cap1;
+    float* PM = A.prev_matched ? A.prev_matched + (size_t)pair * A.cap1 * 2 : nullptr;
+
+    // LDS carve-up (cap2-sized arrays)
+    const int c2 = A.cap2;
+    uint64_t* red = (uint64_t*)smem;                          // 8 * 8 B
+    int* histo = (int*)(red + 8);                             // 32
+    int* sh_nm = histo + 32;                                  // 4 ints
+    uint64_t* d2 = (uint64_t*)(sh_nm + 4);                    // c2 * 4
+    float* x2 = (float*)(d2 + (size_t)c2 * 4);
+    float* y2 = x2 + c2;
+    int* mdist = (int*)(y2 + c2);
+    int* m21 = mdist + c2;
+    uint16_t* cell2 = (uint16_t*)(m21 + c2);
+    int8_t* lev2 = (int8_t*)(cell2 + c2);
+    uint8_t* orb2 = (uint8_t*)(lev2 + c2);
+    int8_t* bin1 = (int8_t*)(orb2 + c2);                      // cap1 entries
+
+    for (int i = tid; i < N2; i += blockDim.x) {
+        const eorb_keypoint k = K2[i];
+        const bool isorb = O2 ? O2[i] != 0 : true;
+        x2[i] = k.x; y2[i] = k.y;
+        lev2[i] = (int8_t)kp_level(k, isorb);
+        orb2[i] = isorb;
+        // Frame::PosInGrid (Frame.cc:783-793)
+        const int px = (int)roundf((k.x - A.g.minX) * A.g.invW);
+        const int py = (int)roundf((k.y - A.g.minY) * A.g.invH);
+        cell2[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? (uint16_t)0xFFFF : (uint16_t)(px * kGridRows + py);
+        const uint64_t* dp = (const uint64_t*)(D2 + (size_t)i * A.dstride2);
+        d2[(size_t)i * 4 + 0] = dp[0]; d2[(size_t)i * 4 + 1] = dp[1]; d2[(size_t)i * 4 + 2] = dp[2]; d2[(size_t)i * 4 + 3] = dp[3];
+        mdist[i] = 0x7fffffff; m21[i] = -1;
+    }
+    for (int i = tid; i < N1; i += blockDim.x) { M12[i] = -1; bin1[i] = -1; }
+    if (tid < 32) histo[tid] = 0;
+    if (tid == 0) sh_nm[0] = 0;
+    __syncthreads();
+
+    const float r = (float)A.windowSize;
+    for (int i1 = 0; i1 < N1; i1++) {
+        const eorb_keypoint k1 = K1[i1];
+        const bool isorb1 = O1 ? O1[i1] != 0 : true;
+        const int level1 = kp_level(k1, isorb1);
+        if (level1 > 0) continue;
+        const float qx = PM ? PM[2 * i1] : k1.x, qy = PM ? PM[2 * i1 + 1] : k1.y;
+        int cx0, cx1, cy0, cy1;
+        if (!cell_range(A.g, qx, qy, r, cx0, cx1, cy0, cy1)) continue;
+        const uint64_t* dq = (const uint64_t*)(D1 + (size_t)i1 * A.dstride1);
+        const uint64_t q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3];
+        // GetFeaturesInArea(x, y, windowSize, level1, level1): bCheckLevels = true (maxLevel >= 0)
+        uint64_t k0 = ~0ull, k1b = ~0ull;
+        for (int i2 = tid; i2 < N2; i2 += blockDim.x) {
+            const int cell = cell2[i2];
+            if (cell == 0xFFFF) continue;
+            const int cx = cell / kGridRows, cy = cell - cx * kGridRows;
+            if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
+            const int lv = lev2[i2];
+            if (lv < level1 || lv > level1) continue;
+            const float distx = x2[i2] - qx, disty = y2[i2] - qy;
+            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+            if ((orb2[i2] != 0) != isorb1) continue;                 // MixedMatcher.cpp:65-67
+            const uint64_t* tp = &d2[(size_t)i2 * 4];
+            const int dist = __popcll(q0 ^ tp[0]) + __popcll(q1 ^ tp[1]) + __popcll(q2 ^ tp[2]) + __popcll(q3 ^ tp[3]);
+            if (mdist[i2] <= dist) continue;                          // :755
+            // candidate order of the reference = (ix, iy, insertion index): compose a unique key
+            const uint64_t key = ((uint64_t)dist << 40) | ((uint64_t)cell << 24) | (uint32_t)i2;
+            if (key < k0) { k1b = k0; k0 = key; }
+            else if (key < k1b) k1b = key;
+        }
+        block_top2(k0, k1b, red);
+        if (k0 != ~0ull) {
+            const int bestDist = (int)(k0 >> 40);
+            const int bestDist2 = (k1b == ~0ull) ? 0x7fffffff : (int)(k1b >> 40);
+            const int bestIdx2 = (int)(k0 & 0xffffff);
+            if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) {
+                if (tid == 0) {
+                    int nm = sh_nm[0];
+                    if (m21[bestIdx2] >= 0) { M12[m21[bestIdx2]] = -1; nm--; }
+                    M12[i1] = bestIdx2;
+                    m21[bestIdx2] = i1;
+                    mdist[bestIdx2] = bestDist;
+                    nm++;
+                    sh_nm[0] = nm;
+                    if (A.checkOri) {
+                        const int bin = rot_bin(k1.angle, K2[bestIdx2].angle);
+                        histo[bin]++;
+                        bin1[i1] = (int8_t)bin;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (A.checkOri) {
+        int ind1, ind2, ind3;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        __syncthreads();
+        // every i1 appears in at most one bin; clearing is independent per i1
+        int dec = 0;
+        for (int i = tid; i < N1; i += blockDim.x) {
+            const int b = bin1[i];
+            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && M12[i] >= 0) { M12[i] = -1; dec++; }
+        }
+        if (dec) atomicSub(&sh_nm[0], dec);
+        __syncthreads();
+    }
+    if (PM) {
+        for (int i = tid; i < N1; i += blockDim.x) {
+            const int m = M12[i];
+            if (m >= 0) { PM[2 * i] = x2[m]; PM[2 * i + 1] = y2[m]; }
+        }
+    }
+    if (tid == 0) A.nmatches[pair] = sh_nm[0];
+}
+
+static size_t search_init_lds(int cap1, int cap2)
+{
+    size_t b = 8 * 8 + 32 * 4 + 4 * 4;
+    b += (size_t)cap2 * (32 + 4 + 4 + 4 + 4 + 2 + 1 + 1);
+    b += (size_t)cap1;
+    return (b + 15) & ~(size_t)15;
+}
+
+int search_init_dev(eorb_ctx* c, int npairs,
+                    const eorb_keypoint* kps1, const int32_t* n1, size_t kp1_stride, const uint8_t* desc1, int dstride1, size_t desc1_slice,
+                    const uint8_t* is_orb1,
+                    const eorb_keypoint* kps2, const int32_t* n2, size_t kp2_stride, const uint8_t* desc2, int dstride2, size_t desc2_slice,
+                    const uint8_t* is_orb2, int cap1, int cap2,
+                    eorb_grid_bounds gb, float* prev_matched, int32_t* matches12, int windowSize, float nnratio,
+                    int checkOri, int32_t* nmatches)
+{
+    if (npairs <= 0) return EORB_OK;
+    const size_t lds = search_init_lds(cap1, cap2);
+    if (lds > 160 * 1024) return set_err(c, EORB_E_CAPACITY, "search_init: %zu B of LDS needed (cap2=%d)", lds, cap2);
+    if (cap2 >= (1 << 24)) return set_err(c, EORB_E_CAPACITY, "search_init: too many keypoints");
+    SearchInitArgs A{kps1, n1, kp1_stride, desc1, dstride1, desc1_slice, is_orb1,
+                     kps2, n2, kp2_stride, desc2, dstride2, desc2_slice, is_orb2, cap1, cap2,
+                     GridB{gb.minX, gb.minY, gb.invW, gb.invH}, prev_matched, matches12, nmatches,
+                     windowSize, nnratio, checkOri};
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)search_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    ProfScope ps(c, "search_init");
+    search_init_kernel<<<npairs, 256, lds, c->stream>>>(A);
+    EORB_LAUNCH_CHECK(c, "search_init_kernel");
+    return EORB_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// tracking matchers: ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono) (:1969-2187)
+// and ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (:44-219), mono branches, with
+// the MixedMatcher type gate.  One workgroup; queries sequential (setMapPoint feeds later queries).
+struct ProjArgs {
+    const eorb_keypoint* kps; int n; const uint8_t* desc; int stride; const uint8_t* is_orb;     // searched frame
+    int M;                                         // number of queries (last-frame keypoints / map points)
+    const eorb_keypoint* qkps; const uint8_t* q_is_orb;   // LAST variant: last frame keypoints
+    const uint8_t* valid;                          // LAST: valid[i];  MAP: in_view[m]
+    const float* qf;                               // LAST: (u, v, levelScale) x M;  MAP: float4 (x, y, viewCos, levelScale)
+    const int32_t* qlevel;                         // MAP: mnTrackScaleLevel
+    const uint8_t* mp_desc; const uint8_t* mp_obs; const uint8_t* mp_is_orb;
+    GridB g;
+    int32_t* slot_mp;                              // n, in/out
+    float th, nnratio; int mode, checkOri;
+    int32_t* nmatches;
+};
+
+__device__ __forceinline__ bool holds_observed(const int* slot, int idx, const uint8_t* mp_obs)
+{   // "if(F.getMapPoint(idx)) if(F.getMapPoint(idx)->Observations()>0) continue;" (:91-93, :2045-2047)
+    const int v = slot[idx];
+    if (v == -1 || v == -3) return false;
+    if (v == -2) return true;
+    return mp_obs[v] != 0;
+}
+
+template <bool MAP>
+__global__ __launch_bounds__(256) void search_proj_kernel(ProjArgs A)
+{
+    extern __shared__ unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int N = A.n;
+    uint64_t* red = (uint64_t*)smem;
+    int* histo = (int*)(red + 8);
+    int* sh_nm = histo + 32;
+    uint64_t* d2 = (uint64_t*)(sh_nm + 4);
+    float* x2 = (float*)(d2 + (size_t)N * 4);
+    float* y2 = x2 + N;
+    int* slot = (int*)(y2 + N);
+    unsigned int* hbin = (unsigned int*)(slot + N);   // LAST: bitmask of the rotation bins keypoint i was pushed to
+    uint16_t* cell2 = (uint16_t*)(hbin + N);
+    int8_t* lev2 = (int8_t*)(cell2 + N);
+    uint8_t* orb2 = (uint8_t*)(lev2 + N);
+    for (int i = tid; i < N; i += blockDim.x) {
+        const eorb_keypoint k = A.kps[i];
+        const bool isorb = A.is_orb ? A.is_orb[i] != 0 : true;
+        x2[i] = k.x; y2[i] = k.y; lev2[i] = (int8_t)kp_level(k, isorb); orb2[i] = isorb;
+        const int px = (int)roundf((k.x - A.g.minX) * A.g.invW);
+        const int py = (int)roundf((k.y - A.g.minY) * A.g.invH);
+        cell2[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? (uint16_t)0xFFFF : (uint16_t)(px * kGridRows + py);
+        const uint64_t* dp = (const uint64_t*)(A.desc + (size_t)i * A.stride);
+        d2[(size_t)i * 4 + 0] = dp[0]; d2[(size_t)i * 4 + 1] = dp[1]; d2[(size_t)i * 4 + 2] = dp[2]; d2[(size_t)i * 4 + 3] = dp[3];
+        slot[i] = A.slot_mp[i];
+        hbin[i] = 0u;
+    }
+    if (tid < 32) histo[tid] = 0;
+    if (tid == 0) sh_nm[0] = 0;
+    __syncthreads();
+    for (int q = 0; q < A.M; q++) {
+        if (!A.valid[q]) continue;
+        float qx, qy, radius; int minLevel, maxLevel; bool isorbq; int qlev = 0;
+        if (MAP) {
+            const float4 f = ((const float4*)A.qf)[q];
+            qx = f.x; qy = f.y;
+            float r = ((double)f.z > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos (:221-227)
+            if (A.th != 1.0f) r *= A.th;                            // bFactor (:49, :73-74)
+            radius = r * f.w;
+            qlev = A.qlevel[q];
+            minLevel = qlev - 1; maxLevel = qlev;
+            isorbq = A.mp_is_orb ? A.mp_is_orb[q] != 0 : true;
+        } else {
+            qx = A.qf[3 * q]; qy = A.qf[3 * q + 1];
+            isorbq = A.q_is_orb ? A.q_is_orb[q] != 0 : true;
+            qlev = kp_level(A.qkps[q], isorbq);
+            radius = A.th * A.qf[3 * q + 2];
+            if (A.mode == 1) { minLevel = qlev; maxLevel = -1; }
+            else if (A.mode == 2) { minLevel = 0; maxLevel = qlev; }
+            else { minLevel = qlev - 1; maxLevel = qlev + 1; }
+        }
+        int cx0, cx1, cy0, cy1;
+        if (!cell_range(A.g, qx, qy, radius, cx0, cx1, cy0, cy1)) continue;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        const uint64_t* dq = (const uint64_t*)(A.mp_desc + (size_t)q * 32);
+        const uint64_t q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3];
+        uint64_t k0 = ~0ull, k1 = ~0ull;
+        for (int i2 = tid; i2 < N; i2 += blockDim.x) {
+            const int cell = cell2[i2];
+            if (cell == 0xFFFF) continue;
+            const int cx = cell / kGridRows, cy = cell - cx * kGridRows;
+            if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
+            const int lv = lev2[i2];
+            if (bCheckLevels) {
+                if (lv < minLevel) continue;
+                if (maxLevel >= 0 && lv > maxLevel) continue;
+            }
+            const float distx = x2[i2] - qx, disty = y2[i2] - qy;
+            if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
+            if (holds_observed(slot, i2, A.mp_obs)) continue;
+            if ((orb2[i2] != 0) != isorbq) continue;
+            const uint64_t* tp = &d2[(size_t)i2 * 4];
+            const int dist = __popcll(q0 ^ tp[0]) + __popcll(q1 ^ tp[1]) + __popcll(q2 ^ tp[2]) + __popcll(q3 ^ tp[3]);
+            // order = (dist, cell ix*48+iy, insertion index); the level rides in the low byte (payload only)
+            const uint64_t key = ((uint64_t)dist << 44) | ((uint64_t)cell << 32) | ((uint64_t)(uint32_t)i2 << 8) | (uint64_t)((lv + 1) & 0xff);
+            if (key < k0) { k1 = k0; k0 = key; }
+            else if (key < k1) k1 = key;
+        }
+        block_top2(k0, k1, red);
+        if (tid == 0 && k0 != ~0ull && (int)(k0 >> 44) < 256) {
+            // the reference starts from bestDist = bestDist2 = 256 / levels -1 with strict '<' updates
+            const int bestDist = (int)(k0 >> 44), bestIdx = (int)((k0 >> 8) & 0xffffff), bestLevel = (int)(k0 & 0xff) - 1;
+            int bestDist2 = 256, bestLevel2 = -1;
+            if (k1 != ~0ull && (int)(k1 >> 44) < 256) { bestDist2 = (int)(k1 >> 44); bestLevel2 = (int)(k1 & 0xff) - 1; }
+            if (MAP) {
+                if (bestDist <= TH_HIGH) {
+                    const bool reject = (bestLevel == bestLevel2) && ((float)bestDist > A.nnratio * (float)bestDist2);
+                    if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= A.nnratio * (float)bestDist2)) {
+                        slot[bestIdx] = q;
+                        sh_nm[0]++;
+                    }
+                }
+            } else {
+                if (bestDist <= TH_HIGH) {
+                    slot[bestIdx] = q;
+                    sh_nm[0]++;
+                    if (A.checkOri) {
+                        const int bin = rot_bin(A.qkps[q].angle, A.kps[bestIdx].angle);
+                        histo[bin]++;
+                        hbin[bestIdx] |= (1u << bin);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (!MAP && A.checkOri) {
+        // for every push in a losing bin: setMapPoint(idx, NULL); nmatches-- (:2165-2181)
+        int ind1, ind2, ind3;
+        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+        unsigned int keep = 0u;
+        if (ind1 >= 0) keep |= 1u << ind1;
+        if (ind2 >= 0) keep |= 1u << ind2;
+        if (ind3 >= 0) keep |= 1u << ind3;
+        for (int i = tid; i < N; i += blockDim.x)
+            if (hbin[i] & ~keep) slot[i] = -1;
+        __syncthreads();
+        if (tid == 0) {
+            int dec = 0;
+            for (int b = 0; b < HISTO_LENGTH; b++) if (!(keep & (1u << b))) dec += histo[b];
+            sh_nm[0] -= dec;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < N; i += blockDim.x) A.slot_mp[i] = slot[i];
+    if (tid == 0) A.nmatches[0] = sh_nm[0];
+}
+
+static size_t proj_lds(int n)
+{
+    size_t b = 8 * 8 + 32 * 4 + 4 * 4;
+    b += (size_t)n * (32 + 4 + 4 + 4 + 4 + 2 + 1 + 1);
+    return (b + 15) & ~(size_t)15;
+}
+
+template <bool MAP>
+static int launch_proj(eorb_ctx* c, const ProjArgs& A, const char* name)
+{
+    const size_t lds = proj_lds(A.n);
+    if (lds > 160 * 1024) return set_err(c, EORB_E_CAPACITY, "%s: %zu B of LDS needed (n=%d)", name, lds, A.n);
+    hipFuncSetAttribute((const void*)search_proj_kernel<MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ProfScope ps(c, name);
+    search_proj_kernel<MAP><<<1, 256, lds, c->stream>>>(A);
+    EORB_LAUNCH_CHECK(c, name);
+    return EORB_OK;
+}
+
+int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride,
+                         const uint8_t* cur_is_orb, const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
+                         const uint8_t* valid, const float* uvs, const uint8_t* mp_desc, const uint8_t* mp_obs,
+                         const float* unused, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
+                         int32_t* nmatches)
+{
+    (void)unused;
+    ProjArgs A{};
+    A.kps = cur_kps; A.n = n_cur; A.desc = cur_desc; A.stride = cur_stride; A.is_orb = cur_is_orb;
+    A.M = n_last; A.qkps = last_kps; A.q_is_orb = last_is_orb; A.valid = valid; A.qf = uvs; A.qlevel = nullptr;
+    A.mp_desc = mp_desc; A.mp_obs = mp_obs; A.mp_is_orb = nullptr;
+    A.g = GridB{gb.minX, gb.minY, gb.invW, gb.invH};
+    A.slot_mp = cur_mp; A.th = th; A.nnratio = 0.f; A.mode = mode; A.checkOri = checkOri; A.nmatches = nmatches;
+    return launch_proj<false>(c, A, "search_proj_last");
+}
+
+int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
+                        int M, const uint8_t* in_view, const float4* mp_f4, const int32_t* level, const uint8_t* mp_desc,
+                        const uint8_t* mp_obs, const uint8_t* mp_is_orb, eorb_grid_bounds gb, int32_t* frame_mp, float th,
+                        float nnratio, int32_t* nmatches)
+{
+    ProjArgs A{};
+    A.kps = kps; A.n = n; A.desc = desc; A.stride = stride; A.is_orb = is_orb;
+    A.M = M; A.qkps = nullptr; A.q_is_orb = nullptr; A.valid = in_view; A.qf = (const float*)mp_f4; A.qlevel = level;
+    A.mp_desc = mp_desc; A.mp_obs = mp_obs; A.mp_is_orb = mp_is_orb;
+    A.g = GridB{gb.minX, gb.minY, gb.invW, gb.invH};
+    A.slot_mp = frame_mp; A.th = th; A.nnratio = nnratio; A.mode = 0; A.checkOri = 0; A.nmatches = nmatches;
+    return launch_proj<true>(c, A, "search_proj_map");
+}
+
+int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2)
+{
+    if (nq <= 0) return EORB_OK;
+    ProfScope ps(c, "bf_knn2");
+    bf_knn2_kernel<<<(nq + 15) / 16, 256, 0, c->stream>>>(d_q, nq, d_t, nt, d_idx2, d_dist2);
+    EORB_LAUNCH_CHECK(c, "bf_knn2_kernel");
+    return EORB_OK;
+}
+
+}  // namespace eorb

@@ -1,0 +1,939 @@
+// orb_extract.hip -- ORB extraction on gfx950, bit-exact w.r.t. the reference's CPU ORBextractor.
+//
+// Replaces ORBextractor::operator() (src/ORBextractor.cc:1092-1238 of the reference) and everything
+// under it.  All kernels are batched over time-slices (frames); one launch covers every slice and,
+// where the data dependences allow it, every pyramid level.
+//   pyr_level0_kernel   copyMakeBorder(image, REFLECT_101)                       (:1258-1262)
+//   pyr_resize_kernel   cv::resize INTER_LINEAR 8u (fixed-point, 11-bit coefficients) of level l-1 into
+//                       level l + REFLECT_101 border, one launch per level         (:1250-1257)
+//   fast_cells_kernel   one workgroup per (slice, level, cell): FAST-9/16 score of the cell's detection
+//                       domain from an LDS-staged tile, 3x3 NMS, iniThFAST -> minThFAST fallback,
+//                       raster-ordered emission                                    (:784-878, cv::FAST)
+//   octree_kernel       DistributeOctTree (:558-782): the reference's sequential list algorithm, run by
+//                       one wavefront per (slice, level); only DivideNode's key partition is lane-parallel
+//   orient_kernel       IC_Angle (:77-104) + cv::fastAtan2, 16 lanes per keypoint
+//   blur_kernel         GaussianBlur(5x5, sigma 2, REFLECT_101) 8u Q8 separable     (:1141-1142)
+//   brief_kernel        computeOrbDescriptor (:108-157): 32 lanes per keypoint, 16 taps each
+//   assemble_kernel     output ordering of operator() (:1150-1173): scale, lapping-area back-fill
+#include "eorb_ctx.h"
+#include "dev_math.h"
+#include "orb_pattern.h"
+#include <math.h>
+#include <algorithm>
+#include <string.h>
+#include <vector>
+
+namespace eorb {
+
+// device copy of LevelGeom (trivially copyable); kept in constant-like global memory
+struct DevGeom {
+    LevelGeom lv[kMaxLevels];
+    int nlevels, edge, W, H;
+    int pyr_bytes, roi_bytes, ncells, cell_cap, cand_total, kp_total, max_out;
+    int iniTh, minTh;
+    int umax[16];
+    float sf[kMaxLevels];
+    int pts_in_lds;
+    int oct_keys_off, oct_pts_off, oct_nodes_off, oct_vsp_off, oct_lds_bytes;   // per-kernel LDS layout (bytes)
+    int node_cap_max, vsp_cap_max, ncap_max;
+};
+
+__device__ __constant__ signed char c_pattern[1024];
+
+// ---------------------------------------------------------------------------------------------------
+// pyramid
+__global__ void pyr_level0_kernel(const uint8_t* __restrict__ img, int stride, size_t slice_bytes,
+                                  const DevGeom* __restrict__ G, uint8_t* __restrict__ pyr)
+{
+    const LevelGeom& L = G->lv[0];
+    const int slice = blockIdx.y;
+    const int n = L.bw * L.bh;
+    uint8_t* dst = pyr + (size_t)slice * G->pyr_bytes + L.buf_off;
+    const uint8_t* src = img + (size_t)slice * slice_bytes;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / L.bw, x = i - y * L.bw;
+        const int sy = reflect101(y - G->edge, L.h), sx = reflect101(x - G->edge, L.w);
+        dst[i] = src[(size_t)sy * stride + sx];
+    }
+}
+
+// xtab: per destination column {int16 sx, int16 a0, int16 a1, pad}; ytab: per row {sy0, sy1, b0, b1}
+__global__ void pyr_resize_kernel(int level, const DevGeom* __restrict__ G, const short4* __restrict__ tabs,
+                                  uint8_t* __restrict__ pyr)
+{
+    const LevelGeom& L = G->lv[level];
+    const LevelGeom& P = G->lv[level - 1];
+    const int slice = blockIdx.y;
+    uint8_t* base = pyr + (size_t)slice * G->pyr_bytes;
+    const uint8_t* sroi = base + P.buf_off + (size_t)G->edge * P.bw + G->edge;
+    uint8_t* dst = base + L.buf_off;
+    const short4* xt = tabs + L.xtab_off;
+    const short4* yt = tabs + L.ytab_off;
+    const int n = L.bw * L.bh;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / L.bw, x = i - y * L.bw;
+        const int dy = reflect101(y - G->edge, L.h), dx = reflect101(x - G->edge, L.w);
+        const short4 xc = xt[dx], yc = yt[dy];
+        const uint8_t* S0 = sroi + (size_t)yc.x * P.bw;
+        const uint8_t* S1 = sroi + (size_t)yc.y * P.bw;
+        int r0, r1;
+        if (dx < L.xmax) {
+            r0 = S0[xc.x] * xc.y + S0[xc.x + 1] * xc.z;
+            r1 = S1[xc.x] * xc.y + S1[xc.x + 1] * xc.z;
+        } else {
+            r0 = S0[xc.x] * 2048;
+            r1 = S1[xc.x] * 2048;
+        }
+        dst[i] = (uint8_t)((((yc.z * (r0 >> 4)) >> 16) + ((yc.w * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FAST-9/16 score: S = max over the 16 contiguous 9-arcs of min(v - p) (darker) / min(p - v) (brighter).
+// A pixel is a corner at threshold t iff S > t and its cv::FAST score (cornerScore<16>) is S - 1.
+__device__ __forceinline__ int fast_S(const uint8_t* __restrict__ t, int pitch)
+{
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * pitch];          d[1] = v - t[3 * pitch + 1];   d[2] = v - t[2 * pitch + 2];   d[3] = v - t[pitch + 3];
+    d[4] = v - t[3];                  d[5] = v - t[-pitch + 3];      d[6] = v - t[-2 * pitch + 2];  d[7] = v - t[-3 * pitch + 1];
+    d[8] = v - t[-3 * pitch];         d[9] = v - t[-3 * pitch - 1];  d[10] = v - t[-2 * pitch - 2]; d[11] = v - t[-pitch - 3];
+    d[12] = v - t[-3];                d[13] = v - t[pitch - 3];      d[14] = v - t[2 * pitch - 2];  d[15] = v - t[3 * pitch - 1];
+    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+    int A = -256, Bm = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        A = max(A, min(mn8[k], d[(k + 8) & 15]));        // darker arcs: min over 9 of (v - p)
+        Bm = min(Bm, max(mx8[k], d[(k + 8) & 15]));      // brighter arcs: max over 9 of (v - p) -> -min(p - v)
+    }
+    return max(A, -Bm);
+}
+
+constexpr int kCellMax = 48;      // max cell edge (wCell, hCell <= 48 is checked at configure time)
+
+__global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
+                                                         int32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_cand)
+{
+    __shared__ uint8_t tile[(kCellMax + 6) * (kCellMax + 8)];
+    __shared__ uint8_t smap[(kCellMax + 2) * (kCellMax + 2)];
+    __shared__ int s_count, s_wbase[4];
+    const int slice = blockIdx.y;
+    // locate (level, cell)
+    int cid = blockIdx.x, level = 0;
+    while (level + 1 < G->nlevels && cid >= G->lv[level + 1].cell_off) level++;
+    const LevelGeom& L = G->lv[level];
+    const int local = cid - L.cell_off;
+    const int ci = local / L.nCols, cj = local - ci * L.nCols;
+    const int tid = threadIdx.x;
+    int32_t* out_cnt = cell_cnt + (size_t)slice * G->ncells + cid;
+    uint32_t* out = cell_cand + ((size_t)slice * G->ncells + cid) * G->cell_cap;
+    // cell window (ORBextractor.cc:810-827); all quantities are exact small integers
+    const int iniY = L.minBY + ci * L.hCell, iniX = L.minBX + cj * L.wCell;
+    int maxY = iniY + L.hCell + 6, maxX = iniX + L.wCell + 6;
+    if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 3) { if (tid == 0) *out_cnt = 0; return; }
+    maxY = min(maxY, L.maxBY); maxX = min(maxX, L.maxBX);
+    const int cw = maxX - iniX, ch = maxY - iniY;        // sub-image handed to cv::FAST
+    const int dw = cw - 6, dh = ch - 6;                   // detection domain [3, cw-3) x [3, ch-3)
+    if (dw <= 0 || dh <= 0) { if (tid == 0) *out_cnt = 0; return; }
+    const uint8_t* roi = pyr + (size_t)slice * G->pyr_bytes + L.buf_off + (size_t)G->edge * L.bw + G->edge;
+    const int pitch = kCellMax + 8;
+    for (int i = tid; i < cw * ch; i += 256) {
+        const int y = i / cw, x = i - y * cw;
+        tile[y * pitch + x] = roi[(size_t)(iniY + y) * L.bw + iniX + x];
+    }
+    __syncthreads();
+    // score plane with a zero ring: smap[(y+1)*sp + (x+1)] for domain pixel (x,y)
+    const int sp = dw + 2;
+    for (int i = tid; i < (dw + 2) * (dh + 2); i += 256) smap[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < dw * dh; i += 256) {
+        const int y = i / dw, x = i - y * dw;
+        int S = fast_S(&tile[(y + 3) * pitch + x + 3], pitch);
+        smap[(y + 1) * sp + x + 1] = (uint8_t)min(max(S, 0), 255);
+    }
+    __syncthreads();
+    // keypoint test at threshold th: corner (S > th) and score S-1 strictly greater than the 8 neighbours'
+    // scores, a non-corner or out-of-domain neighbour scoring 0 (cv::FAST buffers are zero initialised).
+    int th = G->iniTh;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        int emitted_base = 0;
+        // raster order emission in passes of 256 pixels
+        for (int i0 = 0; i0 < dw * dh; i0 += 256) {
+            const int i = i0 + tid;
+            bool kp = false; int S = 0, x = 0, y = 0;
+            if (i < dw * dh) {
+                y = i / dw; x = i - y * dw;
+                const uint8_t* c = &smap[(y + 1) * sp + x + 1];
+                S = c[0];
+                if (S > th) {
+                    const int sc = S - 1;
+                    kp = true;
+#pragma unroll
+                    for (int oy = -1; oy <= 1; oy++)
+#pragma unroll
+                        for (int ox = -1; ox <= 1; ox++) {
+                            if (ox == 0 && oy == 0) continue;
+                            const int Sn = c[oy * sp + ox];
+                            const int scn = (Sn > th) ? Sn - 1 : 0;
+                            kp = kp && (sc > scn);
+                        }
+                }
+            }
+            const uint64_t bal = __ballot(kp);
+            const int w = tid >> 6, lane = tid & 63;
+            if (lane == 0) s_wbase[w] = __popcll(bal);
+            __syncthreads();
+            int base = emitted_base;
+            for (int k = 0; k < w; k++) base += s_wbase[k];
+            const int tot = s_wbase[0] + s_wbase[1] + s_wbase[2] + s_wbase[3];
+            if (kp) {
+                const int pos = base + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                // keypoint coordinates relative to minBorder (:871-872): (x+3 + j*wCell, y+3 + i*hCell)
+                const uint32_t kx = (uint32_t)(x + 3 + cj * L.wCell), ky = (uint32_t)(y + 3 + ci * L.hCell);
+                if (pos < G->cell_cap) out[pos] = kx | (ky << 12) | ((uint32_t)(S - 1) << 24);
+            }
+            emitted_base += tot;
+            __syncthreads();
+        }
+        if (emitted_base > 0 || th == G->minTh) { if (tid == 0) *out_cnt = min(emitted_base, G->cell_cap); break; }
+        th = G->minTh;        // vKeysCell.empty() -> retry with minThFAST (:849-852)
+        if (attempt == 1 && tid == 0) *out_cnt = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// octree
+struct OctLds {
+    uint16_t* keys[2];
+    uint32_t* pts;        // LDS or global
+    uint16_t *x0, *x1, *y0, *y1, *start, *cnt, *next, *prev, *seq, *freel, *order;
+    uint8_t* flags;       // bit0 nomore, bit1 key buffer select
+    uint64_t* vsp[2];
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// bitonic sort (ascending) of n u64 items in LDS by one wavefront; np2 = next pow2 >= n, padded with ~0
+__device__ void wave_sort_u64(uint64_t* a, int n, int lane)
+{
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    for (int i = n + lane; i < np2; i += 64) a[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < np2; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t ai = a[i], al = a[l];
+                    const bool up = (i & k) == 0;
+                    if ((ai > al) == up) { a[i] = al; a[l] = ai; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ G, const int32_t* __restrict__ cell_cnt,
+                                                    const uint32_t* __restrict__ cell_cand, uint32_t* __restrict__ cand_g,
+                                                    uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_cnt,
+                                                    int32_t* __restrict__ err_flag)
+{
+    extern __shared__ unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int slice = blockIdx.x / G->nlevels, level = blockIdx.x % G->nlevels;
+    const LevelGeom& L = G->lv[level];
+    const int ncap = G->ncap_max, pool = L.node_cap, vcap = G->vsp_cap_max;
+    OctLds S;
+    {
+        unsigned char* p = smem;
+        S.keys[0] = (uint16_t*)p; p += sizeof(uint16_t) * ncap;
+        S.keys[1] = (uint16_t*)p; p += sizeof(uint16_t) * ncap;
+        p = (unsigned char*)(((uintptr_t)p + 7) & ~(uintptr_t)7);
+        S.vsp[0] = (uint64_t*)p; p += sizeof(uint64_t) * vcap;
+        S.vsp[1] = (uint64_t*)p; p += sizeof(uint64_t) * vcap;
+        const int pc = G->node_cap_max;
+        S.x0 = (uint16_t*)p; p += 2 * pc; S.x1 = (uint16_t*)p; p += 2 * pc;
+        S.y0 = (uint16_t*)p; p += 2 * pc; S.y1 = (uint16_t*)p; p += 2 * pc;
+        S.start = (uint16_t*)p; p += 2 * pc; S.cnt = (uint16_t*)p; p += 2 * pc;
+        S.next = (uint16_t*)p; p += 2 * pc; S.prev = (uint16_t*)p; p += 2 * pc;
+        S.seq = (uint16_t*)p; p += 2 * pc; S.freel = (uint16_t*)p; p += 2 * pc;
+        S.order = (uint16_t*)p; p += 2 * pc;
+        S.flags = (uint8_t*)p; p += pc;
+        p = (unsigned char*)(((uintptr_t)p + 3) & ~(uintptr_t)3);
+        if (G->pts_in_lds) S.pts = (uint32_t*)p;
+        else S.pts = cand_g + (size_t)slice * G->cand_total + L.cand_off;
+    }
+    uint32_t* lkp = lvl_kp + (size_t)slice * G->kp_total + L.kp_off;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    constexpr uint16_t NIL = 0xFFFF;
+
+    // ---- gather the level's candidates in cell order (vToDistributeKeys) ----
+    int n = 0;
+    {
+        const int nc = L.nCols * L.nRows;
+        for (int cidx = 0; cidx < nc; cidx++) {
+            const int cc = cell_cnt[(size_t)slice * G->ncells + L.cell_off + cidx];
+            const uint32_t* src = cell_cand + ((size_t)slice * G->ncells + L.cell_off + cidx) * G->cell_cap;
+            for (int i = lane; i < cc; i += 64) {
+                if (n + i < ncap) { S.pts[n + i] = src[i]; S.keys[0][n + i] = (uint16_t)(n + i); }
+            }
+            n += cc;
+        }
+        if (n > ncap) { if (lane == 0) atomicOr(err_flag, 1); n = ncap; }
+    }
+    __syncthreads();
+    if (n == 0) { if (lane == 0) lvl_cnt[slice * G->nlevels + level] = 0; return; }
+
+    const int N = L.nfeat;
+    const int width = L.maxBX - L.minBX, height = L.maxBY - L.minBY;
+    const int nIni = (int)roundf((float)width / (float)height);
+    const float hX = (float)width / (float)nIni;
+    // free list
+    for (int i = lane; i < pool; i += 64) S.freel[i] = (uint16_t)(pool - 1 - i);
+    __syncthreads();
+    int nfree = pool, seqctr = 0, head = NIL, tail = NIL, lsize = 0;
+    bool overflow = false;
+
+    auto alloc_node = [&]() -> int {
+        if (nfree == 0) { overflow = true; return 0; }
+        nfree--;
+        return S.freel[nfree];
+    };
+    // ---- root nodes :562-590 (stable partition of the keys by root index) ----
+    int cur = 0;
+    {
+        int off = 0;
+        for (int r = 0; r < nIni; r++) {
+            int c = 0;
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                const int i = k0 + lane;
+                bool mine = false; uint16_t key = 0;
+                if (i < n) {
+                    key = S.keys[0][i];
+                    const float kx = (float)(S.pts[key] & 0xfff);
+                    int b = (int)(kx / hX);
+                    b = min(max(b, 0), nIni - 1);
+                    mine = (b == r);
+                }
+                const uint64_t bal = __ballot(mine);
+                if (mine) S.keys[1][off + c + __popcll(bal & lt_mask)] = key;
+                c += __popcll(bal);
+            }
+            __syncthreads();
+            if (c > 0) {                           // empty roots are erased (:598-599)
+                const int id = alloc_node();
+                if (lane == 0) {
+                    S.x0[id] = (uint16_t)(int)(hX * (float)r); S.x1[id] = (uint16_t)(int)(hX * (float)(r + 1));
+                    S.y0[id] = 0; S.y1[id] = (uint16_t)height;
+                    S.start[id] = (uint16_t)off; S.cnt[id] = (uint16_t)c;
+                    S.flags[id] = (uint8_t)((c == 1 ? 1 : 0) | 2);
+                    S.seq[id] = (uint16_t)seqctr;
+                    S.next[id] = NIL; S.prev[id] = (uint16_t)tail;      // push_back
+                    if (tail != NIL) S.next[tail] = (uint16_t)id;
+                }
+                if (tail == NIL) head = id;
+                tail = id; lsize++; seqctr++;
+                __syncthreads();
+            }
+            off += c;
+        }
+        cur = 1;
+    }
+    (void)cur;
+
+    // DivideNode :500-556 + push_front of the non-empty children (:633-672).  Returns via refs.
+    int nvsp = 0;                     // entries in S.vsp[vw]
+    int vw = 0;                       // vsp buffer being written
+    auto divide = [&](int id, int& nToExpand) {
+        const int x0 = S.x0[id], x1 = S.x1[id], y0 = S.y0[id], y1 = S.y1[id];
+        const int start = S.start[id], cnt = S.cnt[id];
+        const int fl = S.flags[id];
+        const int sb = (fl >> 1) & 1;
+        const uint16_t* src = S.keys[sb]; uint16_t* dst = S.keys[sb ^ 1];
+        const int halfX = (int)ceilf((float)(x1 - x0) / 2), halfY = (int)ceilf((float)(y1 - y0) / 2);
+        const int midx = x0 + halfX, midy = y0 + halfY;
+        int c[4] = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int i = k0 + lane;
+            int cls = -1;
+            if (i < cnt) {
+                const uint32_t p = S.pts[src[start + i]];
+                const int px = p & 0xfff, py = (p >> 12) & 0xfff;
+                cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[q] += __popcll(__ballot(cls == q));
+        }
+        int sbase[4]; sbase[0] = start; sbase[1] = sbase[0] + c[0]; sbase[2] = sbase[1] + c[1]; sbase[3] = sbase[2] + c[2];
+        int run[4] = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < cnt; k0 += 64) {
+            const int i = k0 + lane;
+            int cls = -1; uint16_t key = 0;
+            if (i < cnt) {
+                key = src[start + i];
+                const uint32_t p = S.pts[key];
+                const int px = p & 0xfff, py = (p >> 12) & 0xfff;
+                cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t bal = __ballot(cls == q);
+                if (cls == q) dst[sbase[q] + run[q] + __popcll(bal & lt_mask)] = key;
+                run[q] += __popcll(bal);
+            }
+        }
+        __syncthreads();
+        // children n1..n4 (x-low/y-low, x-high/y-low, x-low/y-high, x-high/y-high)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (c[q] == 0) continue;
+            const int cid = alloc_node();
+            if (lane == 0) {
+                S.x0[cid] = (uint16_t)((q & 1) ? midx : x0); S.x1[cid] = (uint16_t)((q & 1) ? x1 : midx);
+                S.y0[cid] = (uint16_t)((q & 2) ? midy : y0); S.y1[cid] = (uint16_t)((q & 2) ? y1 : midy);
+                S.start[cid] = (uint16_t)sbase[q]; S.cnt[cid] = (uint16_t)c[q];
+                S.flags[cid] = (uint8_t)((c[q] == 1 ? 1 : 0) | ((sb ^ 1) << 1));
+                S.seq[cid] = (uint16_t)seqctr;
+                S.prev[cid] = NIL; S.next[cid] = (uint16_t)head;                 // push_front
+                if (head != NIL) S.prev[head] = (uint16_t)cid;
+                if (c[q] > 1 && nvsp < vcap)
+                    S.vsp[vw][nvsp] = ((uint64_t)c[q] << 32) | ((uint64_t)seqctr << 16) | (uint64_t)cid;
+            }
+            if (head == NIL) tail = cid;
+            head = cid; lsize++; seqctr++;
+            if (c[q] > 1) { nToExpand++; if (nvsp < vcap) nvsp++; else overflow = true; }
+        }
+        __syncthreads();
+    };
+    auto erase = [&](int id) {
+        const int p = S.prev[id], nx = S.next[id];
+        __syncthreads();
+        if (lane == 0) {
+            if (p != NIL) S.next[p] = (uint16_t)nx;
+            if (nx != NIL) S.prev[nx] = (uint16_t)p;
+            S.freel[nfree] = (uint16_t)id;
+        }
+        if (p == NIL) head = nx;
+        if (nx == NIL) tail = p;
+        nfree++; lsize--;
+        __syncthreads();
+    };
+
+    bool finish = false;
+    int guard = 0;
+    while (!finish && !overflow && guard++ < 64) {
+        const int prevSize = lsize;
+        int nToExpand = 0;
+        nvsp = 0;
+        int lit = head;
+        while (lit != NIL && !overflow) {
+            const int nx = S.next[lit];
+            if (S.flags[lit] & 1) { lit = nx; continue; }
+            divide(lit, nToExpand);
+            erase(lit);
+            lit = nx;
+        }
+        if (lsize >= N || lsize == prevSize) {
+            finish = true;
+        } else if (lsize + nToExpand * 3 > N) {
+            int guard2 = 0;
+            while (!finish && !overflow && guard2++ < 4096) {
+                const int prevSize2 = lsize;
+                const int nprev = nvsp;
+                const int vr = vw;               // read (sort) this buffer, write children into the other
+                vw ^= 1; nvsp = 0;
+                wave_sort_u64(S.vsp[vr], nprev, lane);
+                for (int j = nprev - 1; j >= 0; j--) {
+                    const int id = (int)(S.vsp[vr][j] & 0xffff);
+                    int dummy = 0;
+                    divide(id, dummy);
+                    erase(id);
+                    if (lsize >= N || overflow) break;
+                }
+                if (lsize >= N || lsize == prevSize2) finish = true;
+            }
+        }
+    }
+    if (overflow) { if (lane == 0) atomicOr(err_flag, 2); }
+
+    // ---- retain the best point of each node, in list order (:760-780) ----
+    {
+        int k = 0;
+        for (int lit = head; lit != NIL && k < pool; lit = S.next[lit]) { if (lane == 0) S.order[k] = (uint16_t)lit; k++; }
+        __syncthreads();
+        const int nout = min(k, L.kp_cap);
+        if (k > L.kp_cap && lane == 0) atomicOr(err_flag, 4);
+        for (int i = lane; i < nout; i += 64) {
+            const int id = S.order[i];
+            const uint16_t* ks = S.keys[(S.flags[id] >> 1) & 1] + S.start[id];
+            const int cnt = S.cnt[id];
+            uint32_t best = S.pts[ks[0]];
+            for (int q = 1; q < cnt; q++) {
+                const uint32_t p = S.pts[ks[q]];
+                if ((p >> 24) > (best >> 24)) best = p;
+            }
+            lkp[i] = best;
+        }
+        if (lane == 0) lvl_cnt[slice * G->nlevels + level] = nout;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// orientation: IC_Angle :77-104.  16 lanes per keypoint; lane j sums rows +j and -j of the disc.
+__global__ __launch_bounds__(256) void orient_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
+                                                     const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_cnt,
+                                                     float* __restrict__ kp_angle)
+{
+    const int slice = blockIdx.y;
+    const int gid = blockIdx.x * 16 + (threadIdx.x >> 4);      // keypoint slot in the slice's level arrays
+    const int j = threadIdx.x & 15;
+    if (gid >= G->kp_total) return;
+    int level = 0;
+    while (level + 1 < G->nlevels && gid >= G->lv[level + 1].kp_off) level++;
+    const LevelGeom& L = G->lv[level];
+    const int i = gid - L.kp_off;
+    if (i >= lvl_cnt[slice * G->nlevels + level]) return;     // whole 16-lane group exits together
+    const uint32_t p = lvl_kp[(size_t)slice * G->kp_total + gid];
+    // keypoint in level coordinates: candidate coords are relative to minBorder (:889-893)
+    const int cx = (int)(p & 0xfff) + L.minBX, cy = (int)((p >> 12) & 0xfff) + L.minBY;
+    const uint8_t* center = pyr + (size_t)slice * G->pyr_bytes + L.buf_off + (size_t)(cy + G->edge) * L.bw + (cx + G->edge);
+    const int step = L.bw;
+    int m_01 = 0, m_10 = 0;
+    if (j == 0) {
+        for (int u = -15; u <= 15; ++u) m_10 += u * center[u];
+    } else {
+        const int v = j;
+        int v_sum = 0;
+        const int d = G->umax[v];
+        for (int u = -d; u <= d; ++u) {
+            const int val_plus = center[u + v * step], val_minus = center[u - v * step];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    // v = 15 row pair is handled by lane 15; rows 1..15 -> lanes 1..15 (16 lanes: j = 0..15)
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        m_01 += __shfl_xor(m_01, d, 64);
+        m_10 += __shfl_xor(m_10, d, 64);
+    }
+    if (j == 0) kp_angle[(size_t)slice * G->kp_total + gid] = dev_fast_atan2((float)m_01, (float)m_10);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GaussianBlur 5x5 sigma 2 (Q8 coefficients 39 57 64 57 39), REFLECT_101, on the un-bordered level
+__global__ __launch_bounds__(256) void blur_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
+                                                   uint8_t* __restrict__ blur)
+{
+    __shared__ int rows[(8 + 4) * 32];
+    const int slice = blockIdx.z;
+    // blockIdx.y encodes (level, tile row); blockIdx.x tile column
+    int level = 0, ty = blockIdx.y;
+    while (level < G->nlevels) {
+        const int nty = (G->lv[level].h + 7) / 8;
+        if (ty < nty) break;
+        ty -= nty; level++;
+    }
+    if (level >= G->nlevels) return;
+    const LevelGeom& L = G->lv[level];
+    const int x0 = blockIdx.x * 32, y0 = ty * 8;
+    if (x0 >= L.w) return;
+    const uint8_t* roi = pyr + (size_t)slice * G->pyr_bytes + L.buf_off + (size_t)G->edge * L.bw + G->edge;
+    const int k0 = 39, k1 = 57, k2 = 64;
+    // horizontal pass for 12 source rows x 32 columns
+    for (int i = threadIdx.x; i < 12 * 32; i += 256) {
+        const int r = i / 32, cxi = i - r * 32;
+        const int sy = reflect101(y0 + r - 2, L.h);
+        const int x = x0 + cxi;
+        int acc = 0;
+        if (x < L.w) {
+            const uint8_t* Srow = roi + (size_t)sy * L.bw;
+            acc = k0 * Srow[reflect101(x - 2, L.w)] + k1 * Srow[reflect101(x - 1, L.w)] + k2 * Srow[x] +
+                  k1 * Srow[reflect101(x + 1, L.w)] + k0 * Srow[reflect101(x + 2, L.w)];
+        }
+        rows[i] = acc;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x < L.w && y < L.h) {
+        const int acc = k0 * rows[(ly + 0) * 32 + lx] + k1 * rows[(ly + 1) * 32 + lx] + k2 * rows[(ly + 2) * 32 + lx] +
+                        k1 * rows[(ly + 3) * 32 + lx] + k0 * rows[(ly + 4) * 32 + lx];
+        int v = (acc + (1 << 15)) >> 16;
+        v = min(max(v, 0), 255);
+        blur[(size_t)slice * G->roi_bytes + L.roi_off + (size_t)y * L.w + x] = (uint8_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rBRIEF: 32 lanes per keypoint, lane b computes descriptor byte b (16 taps)
+__global__ __launch_bounds__(256) void brief_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ blur,
+                                                    const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_cnt,
+                                                    const float* __restrict__ kp_angle, uint8_t* __restrict__ lvl_desc,
+                                                    uint8_t* __restrict__ lvl_oob)
+{
+    const int slice = blockIdx.y;
+    const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int b = threadIdx.x & 31;
+    if (gid >= G->kp_total) return;
+    int level = 0;
+    while (level + 1 < G->nlevels && gid >= G->lv[level + 1].kp_off) level++;
+    const LevelGeom& L = G->lv[level];
+    const int i = gid - L.kp_off;
+    if (i >= lvl_cnt[slice * G->nlevels + level]) return;
+    const uint32_t p = lvl_kp[(size_t)slice * G->kp_total + gid];
+    const int cx = (int)(p & 0xfff) + L.minBX, cy = (int)((p >> 12) & 0xfff) + L.minBY;
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float angle = kp_angle[(size_t)slice * G->kp_total + gid] * factorPI;
+    float sb, ca;
+    dev_sincosf(angle, &sb, &ca);
+    const float a = ca, bb = sb;
+    const uint8_t* img = blur + (size_t)slice * G->roi_bytes + L.roi_off;
+    const int step = L.w;
+    const int base = cy * step + cx;
+    const int total = L.w * L.h;
+    const signed char* pat = c_pattern + b * 32;
+    int val = 0; int oob = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int t[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const float px = (float)pat[(2 * k + s) * 2], py = (float)pat[(2 * k + s) * 2 + 1];
+            const float r0 = px * bb, r1 = py * a;
+            const float c0 = px * a, c1 = py * bb;
+            const int dy = dev_cvround(r0 + r1);
+            const int dx = dev_cvround(c0 - c1);
+            const int idx = base + dy * step + dx;
+            if (idx < 0 || idx >= total) { oob = 1; t[s] = 0; }
+            else t[s] = img[idx];
+        }
+        val |= (t[0] < t[1]) << k;
+    }
+    lvl_desc[((size_t)slice * G->kp_total + gid) * 32 + b] = (uint8_t)val;
+    const uint64_t anyoob = __ballot(oob != 0);
+    if (b == 0) {
+        const int half = (threadIdx.x >> 5) & 1;
+        const uint32_t m = half ? (uint32_t)(anyoob >> 32) : (uint32_t)anyoob;
+        lvl_oob[(size_t)slice * G->kp_total + gid] = m ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// output ordering of operator() :1150-1173 / :1207-1236
+__global__ __launch_bounds__(256) void assemble_kernel(const DevGeom* __restrict__ G, const uint32_t* __restrict__ lvl_kp,
+                                                       const int32_t* __restrict__ lvl_cnt, const float* __restrict__ kp_angle,
+                                                       const uint8_t* __restrict__ lvl_desc, const uint8_t* __restrict__ lvl_oob,
+                                                       int lap0, int lap1, int want_desc, int out_cap,
+                                                       eorb_keypoint* __restrict__ out_kp, uint8_t* __restrict__ out_desc,
+                                                       uint8_t* __restrict__ out_oob, int32_t* __restrict__ out_n,
+                                                       int32_t* __restrict__ out_mono)
+{
+    __shared__ int s_w[4];
+    const int slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int nk = 0;
+    for (int l = 0; l < G->nlevels; l++) nk += lvl_cnt[slice * G->nlevels + l];
+    if (tid == 0) out_n[slice] = nk;
+    int mono_run = 0, stereo_run = 0;      // counts of each class before the current pass
+    int e0 = 0;                            // emission index of the first keypoint of the current level
+    for (int l = 0; l < G->nlevels; l++) {
+        const LevelGeom& L = G->lv[l];
+        const int nl = lvl_cnt[slice * G->nlevels + l];
+        const float scale = G->sf[l];
+        for (int i0 = 0; i0 < nl; i0 += 256) {
+            const int i = i0 + tid;
+            bool valid = i < nl, st = false;
+            eorb_keypoint kp{};
+            size_t gi = 0;
+            if (valid) {
+                gi = (size_t)slice * G->kp_total + L.kp_off + i;
+                const uint32_t p = lvl_kp[gi];
+                kp.x = (float)(int)(p & 0xfff) + (float)L.minBX;
+                kp.y = (float)(int)((p >> 12) & 0xfff) + (float)L.minBY;
+                if (l != 0) { kp.x = kp.x * scale; kp.y = kp.y * scale; }       // keypoint.pt *= scale
+                kp.size = (float)L.patch_size;
+                kp.angle = kp_angle[gi];
+                kp.response = (float)(p >> 24);
+                kp.octave = l; kp.class_id = -1;
+                st = kp.x >= (float)lap0 && kp.x <= (float)lap1;
+            }
+            const uint64_t bs = __ballot(valid && st), bm = __ballot(valid && !st);
+            if (lane == 0) s_w[w] = (int)__popcll(bs) | ((int)__popcll(bm) << 16);
+            __syncthreads();
+            int sb = stereo_run, mb = mono_run, ts = 0, tm = 0;
+            for (int k = 0; k < 4; k++) {
+                const int cs = s_w[k] & 0xffff, cm = s_w[k] >> 16;
+                if (k < w) { sb += cs; mb += cm; }
+                ts += cs; tm += cm;
+            }
+            if (valid) {
+                const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                int dst;
+                if (st) dst = nk - 1 - (sb + (int)__popcll(bs & lt));
+                else dst = mb + (int)__popcll(bm & lt);
+                if (dst >= 0 && dst < out_cap) {
+                    out_kp[(size_t)slice * out_cap + dst] = kp;
+                    if (want_desc && out_desc) {
+                        const uint4* s4 = (const uint4*)(lvl_desc + gi * 32);
+                        uint4* d4 = (uint4*)(out_desc + ((size_t)slice * out_cap + dst) * 32);
+                        d4[0] = s4[0]; d4[1] = s4[1];
+                    }
+                    if (out_oob) out_oob[(size_t)slice * out_cap + dst] = want_desc ? lvl_oob[gi] : 0;
+                }
+            }
+            stereo_run += ts; mono_run += tm;
+            __syncthreads();
+        }
+        e0 += nl;
+    }
+    (void)e0;
+    if (tid == 0 && out_mono) out_mono[slice] = mono_run;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side: ORBextractor::ORBextractor (src/ORBextractor.cc:420-489) + per-size geometry
+static int cv_round_d(double v) { return (int)lrint(v); }
+
+int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
+{
+    OrbState& o = c->orb;
+    o.configured = false;
+    if (!p || p->nlevels < 1 || p->nlevels > kMaxLevels || W <= 0 || H <= 0 || p->nfeatures < 0)
+        return set_err(c, EORB_E_ARG, "orb_configure: bad parameters");
+    o.p = *p; o.W = W; o.H = H; o.nlevels = p->nlevels;
+    const int nlevels = p->nlevels;
+    const double scaleFactor = (double)p->scaleFactor;
+    o.sf[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) o.sf[i] = (float)((double)o.sf[i - 1] * scaleFactor);
+    for (int i = 0; i < nlevels; i++) o.inv_sf[i] = 1.0f / o.sf[i];
+    {
+        const float factor = (float)(1.0 / scaleFactor);
+        float nDesired = (float)p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int l = 0; l < nlevels - 1; l++) {
+            o.nfeat[l] = cv_round_d((double)nDesired);
+            sum += o.nfeat[l];
+            nDesired *= factor;
+        }
+        o.nfeat[nlevels - 1] = std::max(p->nfeatures - sum, 0);
+    }
+    {
+        int v, v0, vmax = (int)floor(15 * sqrt(2.f) / 2 + 1);
+        int vmin = (int)ceil(15 * sqrt(2.f) / 2);
+        const double hp2 = 15 * 15;
+        for (v = 0; v <= vmax; ++v) o.umax[v] = cv_round_d(sqrt(hp2 - v * v));
+        for (v = 15, v0 = 0; v >= vmin; --v) {
+            while (o.umax[v0] == o.umax[v0 + 1]) ++v0;
+            o.umax[v] = v0;
+            ++v0;
+        }
+    }
+    if (p->edgeTh < 0) {
+        float ne = 19 * ((float)p->imWidth / (float)752);
+        o.edge = (int)ne;
+        o.edge += (o.edge % 2 - 1);
+    } else o.edge = p->edgeTh;
+    const int E = o.edge;
+    if (E < 8) return set_err(c, EORB_E_CONFIG, "edge threshold %d < 8: the orientation patch would leave the bordered level buffer", E);
+
+    std::vector<short> tabs;     // short4 entries
+    int pyr = 0, roi = 0, cells = 0, cell_cap = 0, cand_total = 0, kp_total = 0;
+    int ncap_max = 0, node_cap_max = 0, vsp_cap_max = 0;
+    for (int l = 0; l < nlevels; l++) {
+        LevelGeom& L = o.lv[l];
+        const float scale = o.inv_sf[l];
+        L.w = cv_round_d((double)((float)W * scale)); L.h = cv_round_d((double)((float)H * scale));
+        if (L.w < 1 || L.h < 1) return set_err(c, EORB_E_CONFIG, "level %d is empty", l);
+        L.bw = L.w + 2 * E; L.bh = L.h + 2 * E;
+        L.buf_off = pyr; pyr += (L.bw * L.bh + 63) & ~63;
+        L.roi_off = roi; roi += (L.w * L.h + 63) & ~63;
+        L.minBX = E - 3; L.minBY = E - 3; L.maxBX = L.w - E + 3; L.maxBY = L.h - E + 3;
+        const float width = (float)(L.maxBX - L.minBX), height = (float)(L.maxBY - L.minBY);
+        L.nCols = (int)(width / 30.0f); L.nRows = (int)(height / 30.0f);
+        if (L.nCols < 1 || L.nRows < 1)          // the reference divides by zero here (SURVEY App.B H14)
+            return set_err(c, EORB_E_CONFIG, "level %d (%dx%d) is smaller than one 30-px cell with edge %d", l, L.w, L.h, E);
+        L.wCell = (int)ceilf(width / (float)L.nCols); L.hCell = (int)ceilf(height / (float)L.nRows);
+        if (L.wCell > kCellMax || L.hCell > kCellMax) return set_err(c, EORB_E_CONFIG, "cell larger than %d px", kCellMax);
+        const int nIni = (int)roundf(width / height);
+        if (nIni < 1) return set_err(c, EORB_E_CONFIG, "level %d: portrait aspect gives zero octree roots", l);
+        if (L.maxBX - L.minBX >= 4096 || L.maxBY - L.minBY >= 4096) return set_err(c, EORB_E_CONFIG, "level too large");
+        L.cell_off = cells; cells += L.nCols * L.nRows;
+        cell_cap = std::max(cell_cap, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
+        L.nfeat = o.nfeat[l];
+        L.kp_cap = L.nfeat + 8;
+        L.kp_off = kp_total; kp_total += L.kp_cap;
+        L.scale = o.sf[l];
+        L.patch_size = (int)(31.0f * o.sf[l]);
+        L.node_cap = L.nfeat + 4 * nIni + 24;
+        node_cap_max = std::max(node_cap_max, L.node_cap);
+        vsp_cap_max = std::max(vsp_cap_max, 2 * (L.nfeat + 16));
+        // resize tables (cv::resize INTER_LINEAR 8u, SURVEY App.B H5)
+        L.xtab_off = (int)tabs.size() / 4;
+        L.xmax = L.w;
+        if (l > 0) {
+            const LevelGeom& P = o.lv[l - 1];
+            const double inv_scale_x = (double)L.w / P.w, inv_scale_y = (double)L.h / P.h;
+            const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+            if (P.w == 2 * L.w && P.h == 2 * L.h)
+                return set_err(c, EORB_E_CONFIG, "exact 2x decimation switches cv::resize to INTER_AREA: unsupported");
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = (int)floor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx + 1 >= P.w) { L.xmax = std::min(L.xmax, dx); if (sx >= P.w - 1) { fx = 0; sx = P.w - 1; } }
+                const int a0 = cv_round_d((double)((1.f - fx) * 2048)), a1 = cv_round_d((double)(fx * 2048));
+                tabs.push_back((short)sx); tabs.push_back((short)a0); tabs.push_back((short)a1); tabs.push_back(0);
+            }
+            L.ytab_off = (int)tabs.size() / 4;
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = (int)floor(fy);
+                fy -= sy;
+                const int b0 = cv_round_d((double)((1.f - fy) * 2048)), b1 = cv_round_d((double)(fy * 2048));
+                const int sy0 = sy < 0 ? 0 : (sy < P.h ? sy : P.h - 1);
+                const int sy1 = sy + 1 < 0 ? 0 : (sy + 1 < P.h ? sy + 1 : P.h - 1);
+                tabs.push_back((short)sy0); tabs.push_back((short)sy1); tabs.push_back((short)b0); tabs.push_back((short)b1);
+            }
+        } else {
+            L.ytab_off = L.xtab_off;
+        }
+    }
+    for (int l = 0; l < nlevels; l++) {
+        LevelGeom& L = o.lv[l];
+        L.cand_cap = L.nCols * L.nRows * cell_cap;
+        L.cand_off = cand_total; cand_total += L.cand_cap;
+        ncap_max = std::max(ncap_max, L.cand_cap);
+    }
+    if (ncap_max >= 65535) return set_err(c, EORB_E_CAPACITY, "image too large for the 16-bit octree keys");
+    o.pyr_bytes = pyr; o.roi_bytes = roi; o.ncells = cells; o.cell_cap = cell_cap;
+    o.cand_total = cand_total; o.kp_total = kp_total; o.max_out = kp_total;
+    // octree LDS layout
+    size_t lds = 2 * sizeof(uint16_t) * (size_t)ncap_max;
+    lds = (lds + 7) & ~(size_t)7;
+    lds += 2 * sizeof(uint64_t) * (size_t)vsp_cap_max;
+    lds += (size_t)node_cap_max * (11 * 2 + 1);
+    lds = (lds + 3) & ~(size_t)3;
+    int pts_in_lds = 0;
+    if (lds + sizeof(uint32_t) * (size_t)ncap_max <= 156 * 1024) { pts_in_lds = 1; lds += sizeof(uint32_t) * (size_t)ncap_max; }
+    if (lds > 156 * 1024)
+        return set_err(c, EORB_E_CAPACITY, "octree working set (%zu B) exceeds the 160 KB LDS: image %dx%d too large for this build", lds, W, H);
+    o.oct_lds = (int)lds;
+
+    DevGeom g{};
+    memcpy(g.lv, o.lv, sizeof(o.lv));
+    g.nlevels = nlevels; g.edge = E; g.W = W; g.H = H;
+    g.pyr_bytes = pyr; g.roi_bytes = roi; g.ncells = cells; g.cell_cap = cell_cap; g.cand_total = cand_total;
+    g.kp_total = kp_total; g.max_out = kp_total; g.iniTh = std::min(std::max(p->iniThFAST, 0), 255);
+    g.minTh = std::min(std::max(p->minThFAST, 0), 255);
+    memcpy(g.umax, o.umax, sizeof(o.umax)); memcpy(g.sf, o.sf, sizeof(o.sf));
+    g.pts_in_lds = pts_in_lds; g.oct_lds_bytes = (int)lds;
+    g.node_cap_max = node_cap_max; g.vsp_cap_max = vsp_cap_max; g.ncap_max = ncap_max;
+    int rc;
+    if ((rc = ensure(c, o.geom, sizeof(DevGeom)))) return rc;
+    if ((rc = ensure(c, o.tabs, std::max<size_t>(tabs.size() * sizeof(short), 8)))) return rc;
+    EORB_HIP(c, hipMemcpy(o.geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
+    if (!tabs.empty()) EORB_HIP(c, hipMemcpy(o.tabs.p, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice));
+    EORB_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_pattern_31, 1024));
+    EORB_HIP(c, hipFuncSetAttribute((const void*)octree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    o.configured = true;
+    return EORB_OK;
+}
+
+int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
+                    int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono)
+{
+    OrbState& o = c->orb;
+    if (!o.configured) return set_err(c, EORB_E_NOTCONF, "orb_extract: eorb_orb_configure not called");
+    if (B <= 0) return EORB_OK;
+    int rc;
+    const size_t nb = (size_t)B;
+    if ((rc = ensure(c, c->pyr, nb * o.pyr_bytes))) return rc;
+    if ((rc = ensure(c, c->blur, nb * o.roi_bytes))) return rc;
+    if ((rc = ensure(c, c->cell_cnt, nb * o.ncells * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(c, c->cell_cand, nb * o.ncells * (size_t)o.cell_cap * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->score, nb * o.cand_total * sizeof(uint32_t)))) return rc;          // compact candidates (global pts)
+    if ((rc = ensure(c, c->lvl_kp, nb * o.kp_total * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, c->lvl_cnt, nb * o.nlevels * sizeof(int32_t) + 64))) return rc;
+    if ((rc = ensure(c, c->kp_angle, nb * o.kp_total * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->out_desc, nb * o.kp_total * 32))) return rc;                        // per-level descriptors
+    if ((rc = ensure(c, c->out_oob, nb * o.kp_total))) return rc;
+    const DevGeom* G = (const DevGeom*)o.geom.p;
+    uint8_t* pyr = (uint8_t*)c->pyr.p;
+    int32_t* err_flag = (int32_t*)((char*)c->lvl_cnt.p + nb * o.nlevels * sizeof(int32_t));
+    {
+        ProfScope ps(c, "orb_pyr");
+        EORB_HIP(c, hipMemsetAsync(err_flag, 0, sizeof(int32_t), c->stream));
+        const int n0 = o.lv[0].bw * o.lv[0].bh;
+        pyr_level0_kernel<<<dim3((n0 + 255) / 256, B), 256, 0, c->stream>>>(d_img, img_stride, img_slice_bytes, G, pyr);
+        for (int l = 1; l < o.nlevels; l++) {
+            const int n = o.lv[l].bw * o.lv[l].bh;
+            pyr_resize_kernel<<<dim3((n + 255) / 256, B), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
+        }
+        EORB_LAUNCH_CHECK(c, "pyramid kernels");
+    }
+    {
+        ProfScope ps(c, "orb_fast_cells");
+        fast_cells_kernel<<<dim3(o.ncells, B), 256, 0, c->stream>>>(G, pyr, (int32_t*)c->cell_cnt.p, (uint32_t*)c->cell_cand.p);
+        EORB_LAUNCH_CHECK(c, "fast_cells_kernel");
+    }
+    {
+        ProfScope ps(c, "orb_octree");
+        octree_kernel<<<B * o.nlevels, 64, o.oct_lds, c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
+                                                                    (uint32_t*)c->score.p, (uint32_t*)c->lvl_kp.p,
+                                                                    (int32_t*)c->lvl_cnt.p, err_flag);
+        EORB_LAUNCH_CHECK(c, "octree_kernel");
+    }
+    {
+        ProfScope ps(c, "orb_orient");
+        orient_kernel<<<dim3((o.kp_total + 15) / 16, B), 256, 0, c->stream>>>(G, pyr, (const uint32_t*)c->lvl_kp.p,
+                                                                              (const int32_t*)c->lvl_cnt.p, (float*)c->kp_angle.p);
+        EORB_LAUNCH_CHECK(c, "orient_kernel");
+    }
+    if (want_desc) {
+        {
+            ProfScope ps(c, "orb_blur");
+            int tyt = 0, wmax = 0;
+            for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + 7) / 8; wmax = std::max(wmax, o.lv[l].w); }
+            blur_kernel<<<dim3((wmax + 31) / 32, tyt, B), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
+            EORB_LAUNCH_CHECK(c, "blur_kernel");
+        }
+        {
+            ProfScope ps(c, "orb_brief");
+            brief_kernel<<<dim3((o.kp_total + 7) / 8, B), 256, 0, c->stream>>>(G, (const uint8_t*)c->blur.p, (const uint32_t*)c->lvl_kp.p,
+                                                                               (const int32_t*)c->lvl_cnt.p, (const float*)c->kp_angle.p,
+                                                                               (uint8_t*)c->out_desc.p, (uint8_t*)c->out_oob.p);
+            EORB_LAUNCH_CHECK(c, "brief_kernel");
+        }
+    }
+    {
+        ProfScope ps(c, "orb_assemble");
+        assemble_kernel<<<B, 256, 0, c->stream>>>(G, (const uint32_t*)c->lvl_kp.p, (const int32_t*)c->lvl_cnt.p,
+                                                  (const float*)c->kp_angle.p, (const uint8_t*)c->out_desc.p,
+                                                  (const uint8_t*)c->out_oob.p, lap0, lap1, want_desc, o.max_out, d_kps, d_desc,
+                                                  d_oob, d_n, d_mono);
+        EORB_LAUNCH_CHECK(c, "assemble_kernel");
+    }
+    return EORB_OK;
+}
+
+int orb_err_flag(eorb_ctx* c, int B, int* flag)
+{
+    OrbState& o = c->orb;
+    int32_t* err_flag = (int32_t*)((char*)c->lvl_cnt.p + (size_t)B * o.nlevels * sizeof(int32_t));
+    EORB_HIP(c, hipMemcpyAsync(flag, err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+}  // namespace eorb

@@ -1,0 +1,285 @@
+"""Python host side of the front end: thin mirrors of the reference's three C++ seams over the C ABI
+(include/eorb_fe.h).  Names and argument meaning follow the reference:
+
+  EvImConverter.ev2im / ev2im_gauss   include/Event/EventConversion.h:52-56
+  ORBextractor.__call__               include/ORBextractor.h:75-81
+  ORBmatcher.SearchForInitialization / SearchByProjection / DescriptorDistance   include/ORBmatcher.h:46-94
+  BFMatcher.knnMatch                  cv::BFMatcher use at src/Frame.cc:1228
+
+Used by tests/ and bench.py; the C++ mirror for the reference's own build is in eorb_slam_amd/host/.
+Every call goes to the HIP library; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .synth import EVENT_DTYPE, KP_DTYPE
+
+EV16_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("t", "<f8")])
+
+
+class EorbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("eorb_fe error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """eorb_ctx: device workspaces + one HIP stream.  Single-threaded; create one per thread."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.eorb_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise EorbError(rc, "eorb_create failed (no usable HIP device?)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.eorb_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise EorbError(rc, self.L.eorb_last_error(self.h).decode())
+
+    def sync(self):
+        self.check(self.L.eorb_sync(self.h))
+
+    # profiling ------------------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self.check(self.L.eorb_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self.check(self.L.eorb_prof_reset(self.h))
+
+    def prof_results(self):
+        out = {}
+        n = self.L.eorb_prof_count(self.h)
+        for i in range(n):
+            name = C.c_char_p(); ms = C.c_double(); cnt = C.c_int64()
+            self.L.eorb_prof_get(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+    # raw device memory (for the HBM-resident batch path without torch) ---------------------------
+    def dev_alloc(self, nbytes):
+        p = self.L.eorb_dev_alloc(self.h, nbytes)
+        if not p:
+            raise EorbError(_lib.EORB_E_HIP, self.L.eorb_last_error(self.h).decode())
+        return p
+
+    def dev_free(self, p):
+        self.check(self.L.eorb_dev_free(self.h, C.c_void_p(p)))
+
+    def upload(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.L.eorb_dev_upload(self.h, C.c_void_p(dptr), _p(arr), arr.nbytes))
+
+    def download(self, arr, dptr):
+        self.check(self.L.eorb_dev_download(self.h, _p(arr), C.c_void_p(dptr), arr.nbytes))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def pack_events(ev):
+    """EventData[] (24 B AoS) -> HBM record (16 B: x, y, t with the polarity in t's sign bit)."""
+    ev = np.ascontiguousarray(ev, EVENT_DTYPE)
+    out = np.zeros(len(ev), EV16_DTYPE)
+    _lib.lib().eorb_pack_events(_p(ev), len(ev), _p(out))
+    return out
+
+
+class EvImConverter:
+    """EORB_SLAM::EvImConverter (include/Event/EventConversion.h:45-75), static-method style."""
+
+    @staticmethod
+    def ev2im(vEvData, imWidth, imHeight, pol=False, normalized=True, ctx=None, return_all=False):
+        ctx = ctx or default_context()
+        ev = np.ascontiguousarray(vEvData, EVENT_DTYPE)
+        f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8)
+        mm = np.zeros(2, np.float32); is_u8 = C.c_int(0)
+        ctx.check(ctx.L.eorb_ev2im(ctx.h, _p(ev), len(ev), imWidth, imHeight, int(pol), int(normalized),
+                                   _p(f32), _p(u8), _p(mm), C.byref(is_u8)))
+        if return_all:
+            return f32, (u8 if is_u8.value else None), mm
+        return u8 if is_u8.value else f32
+
+    @staticmethod
+    def ev2im_gauss(vEvData, imWidth, imHeight, sigma=1.0, pol=False, normalized=True, ctx=None, return_all=False):
+        ctx = ctx or default_context()
+        ev = np.ascontiguousarray(vEvData, EVENT_DTYPE)
+        f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8)
+        mm = np.zeros(2, np.float32)
+        ctx.check(ctx.L.eorb_ev2im_gauss(ctx.h, _p(ev), len(ev), imWidth, imHeight, float(sigma), int(pol),
+                                         int(normalized), _p(f32), _p(u8), _p(mm)))
+        if return_all:
+            return f32, (u8 if normalized else None), mm
+        return u8 if normalized else f32
+
+
+class ORBextractor:
+    """ORB_SLAM3::ORBextractor (include/ORBextractor.h:49-139).  One instance per thread, like the reference."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0, edgeTh=19,
+                 imSize=(240, 180), ctx=None):
+        self.ctx = ctx or Context()
+        self.params = _lib.OrbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, edgeTh, imSize[0])
+        self.W, self.H = imSize
+        self.nlevels = nlevels
+        self.ctx.check(self.ctx.L.eorb_orb_configure(self.ctx.h, C.byref(self.params), self.W, self.H))
+        self.cap = self.ctx.L.eorb_orb_max_keypoints(self.ctx.h)
+        sf = np.zeros(nlevels, np.float32); inv = np.zeros(nlevels, np.float32); nf = np.zeros(nlevels, np.int32)
+        e = C.c_int()
+        self.ctx.check(self.ctx.L.eorb_orb_get_tables(self.ctx.h, _p(sf), _p(inv), _p(nf), C.byref(e)))
+        self.mvScaleFactor, self.mvInvScaleFactor, self.mnFeaturesPerLevel, self.edge = sf, inv, nf, e.value
+
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactors(self):
+        return self.mvScaleFactor
+
+    def __call__(self, image, vLappingArea=(0, 1000), want_desc=True):
+        """Returns (monoIndex, keypoints, descriptors|None, oob_flags).  monoIndex = -1 for an empty image."""
+        if image is None or image.size == 0:
+            return -1, None, None, None
+        image = np.ascontiguousarray(image, np.uint8)
+        H, W = image.shape
+        kps = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8); oob = np.zeros(self.cap, np.uint8)
+        n = C.c_int(); mono = C.c_int()
+        self.ctx.check(self.ctx.L.eorb_orb_extract(self.ctx.h, _p(image), W, H, image.strides[0], vLappingArea[0],
+                                                   vLappingArea[1], int(want_desc), _p(kps), _p(desc), _p(oob),
+                                                   self.cap, C.byref(n), C.byref(mono)))
+        k = n.value
+        return mono.value, kps[:k].copy(), (desc[:k].copy() if want_desc else None), oob[:k].copy()
+
+
+def grid_bounds(W, H):
+    """Frame::ComputeImageBounds for an undistorted image + grid pitch (src/Frame.cc:862-866, 362-363)."""
+    gb = _lib.GridBounds(0.0, 0.0, float(W), float(H), 0.0, 0.0)
+    gb.invW = np.float32(64.0) / (np.float32(gb.maxX) - np.float32(gb.minX))
+    gb.invH = np.float32(48.0) / (np.float32(gb.maxY) - np.float32(gb.minY))
+    return gb
+
+
+class FrameView:
+    """What the matchers read from a Frame: undistorted keypoints, descriptors, (Mixed) type flags, bounds."""
+
+    def __init__(self, kps, desc, W, H, is_orb=None):
+        self.kps = np.ascontiguousarray(kps, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.is_orb = None if is_orb is None else np.ascontiguousarray(is_orb, np.uint8)
+        self.gb = grid_bounds(W, H)
+        self.N = len(self.kps)
+
+
+class ORBmatcher:
+    """ORB_SLAM3::ORBmatcher / EORB_SLAM::MixedMatcher (include/ORBmatcher.h:40-116, include/MixedMatcher.h)."""
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, ctx=None):
+        self.mfNNratio = float(nnratio); self.mbCheckOrientation = bool(checkOri)
+        self.ctx = ctx or default_context()
+
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        pm = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m12 = np.full(F1.N, -1, np.int32); nm = C.c_int(0)
+        c = self.ctx
+        c.check(c.L.eorb_search_for_initialization(c.h, _p(F1.kps), F1.N, _p(F1.desc), F1.desc.shape[1], _p(F1.is_orb),
+                                                   _p(F2.kps), F2.N, _p(F2.desc), F2.desc.shape[1], _p(F2.is_orb),
+                                                   C.byref(F2.gb), _p(pm), _p(m12), int(windowSize), self.mfNNratio,
+                                                   int(self.mbCheckOrientation), C.byref(nm)))
+        return nm.value, m12, pm
+
+    def SearchByProjectionLast(self, Cur, Last, valid, uv, mp_desc, mp_obs, cur_mp, th, level_scale, mode=0):
+        """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) with the projection done
+        by the caller (valid/uv), src/ORBmatcher.cc:1969-2187."""
+        valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        cm = np.ascontiguousarray(cur_mp, np.int32).copy(); nm = C.c_int(0)
+        c = self.ctx
+        c.check(c.L.eorb_search_by_projection_last(c.h, _p(Cur.kps), Cur.N, _p(Cur.desc), Cur.desc.shape[1], _p(Cur.is_orb),
+                                                   _p(Last.kps), Last.N, _p(Last.is_orb), _p(valid), _p(uv), _p(mp_desc),
+                                                   _p(mp_obs), _p(ls), C.byref(Cur.gb), _p(cm), float(th), int(mode),
+                                                   int(self.mbCheckOrientation), C.byref(nm)))
+        return nm.value, cm
+
+    def SearchByProjectionMap(self, F, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, frame_mp, th, level_scale,
+                              mp_is_orb=None):
+        """SearchByProjection(Frame &F, const vector<MapPoint*>&, th) with Frame::isInFrustum's outputs as inputs,
+        src/ORBmatcher.cc:44-219."""
+        in_view = np.ascontiguousarray(in_view, np.uint8); proj_xy = np.ascontiguousarray(proj_xy, np.float32)
+        level = np.ascontiguousarray(level, np.int32); view_cos = np.ascontiguousarray(view_cos, np.float32)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
+        ls = np.ascontiguousarray(level_scale, np.float32)
+        mio = None if mp_is_orb is None else np.ascontiguousarray(mp_is_orb, np.uint8)
+        fm = np.ascontiguousarray(frame_mp, np.int32).copy(); nm = C.c_int(0)
+        c = self.ctx
+        c.check(c.L.eorb_search_by_projection_map(c.h, _p(F.kps), F.N, _p(F.desc), F.desc.shape[1], _p(F.is_orb),
+                                                  len(in_view), _p(in_view), _p(proj_xy), _p(level), _p(view_cos),
+                                                  _p(mp_desc), _p(mp_obs), _p(mio), _p(ls), C.byref(F.gb), _p(fm),
+                                                  float(th), self.mfNNratio, C.byref(nm)))
+        return nm.value, fm
+
+
+class BFMatcher:
+    """cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2) as used at src/Frame.cc:1228."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def knnMatch2(self, query, train):
+        q = np.ascontiguousarray(query, np.uint8); t = np.ascontiguousarray(train, np.uint8)
+        assert q.shape[1] == 32 and t.shape[1] == 32
+        idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
+        c = self.ctx
+        c.check(c.L.eorb_hamming_bf_knn2(c.h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)))
+        return idx, dist
+
+
+class FrontEndBatch:
+    """HBM-resident batched pipeline: accumulate -> extract -> match against the previous slice."""
+
+    def __init__(self, W=240, H=180, sigma=1.0, pol=False, nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10,
+                 minThFAST=0, edgeTh=19, lap=(0, 1000), want_desc=True, max_batch=16, max_events=1000000, match=True,
+                 windowSize=100, nnratio=0.9, checkOri=True, ctx=None):
+        self.ctx = ctx or Context()
+        cfg = _lib.FeConfig()
+        cfg.W, cfg.H, cfg.sigma, cfg.pol = W, H, sigma, int(pol)
+        cfg.orb = _lib.OrbParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, edgeTh, W)
+        cfg.lap0, cfg.lap1, cfg.want_desc = lap[0], lap[1], int(want_desc)
+        cfg.max_batch, cfg.max_events, cfg.match = max_batch, max_events, int(match)
+        cfg.windowSize, cfg.nnratio, cfg.checkOri = windowSize, nnratio, int(checkOri)
+        self.cfg = cfg
+        self.ctx.check(self.ctx.L.eorb_fe_configure(self.ctx.h, C.byref(cfg)))
+        self.cap = self.ctx.L.eorb_orb_max_keypoints(self.ctx.h)
+        self.W, self.H = W, H
+
+    def run_dev(self, d_events, offsets, d_images=None, d_kps=None, d_desc=None, d_nkps=None, d_m12=None, d_nm=None):
+        """d_* are raw device pointers (ints), e.g. torch tensors' data_ptr(); offsets: int64[B+1] on the host."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        B = len(offsets) - 1
+        vp = lambda x: C.c_void_p(x) if x else None
+        self.ctx.check(self.ctx.L.eorb_fe_run_batch_dev(self.ctx.h, vp(d_events), _p(offsets), B, vp(d_images), vp(d_kps),
+                                                        vp(d_desc), vp(d_nkps), vp(d_m12), vp(d_nm)))

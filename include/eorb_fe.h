@@ -1,0 +1,200 @@
+/*
+ * eorb_fe.h -- C ABI of the MI355X-native event-frame front end (libeorb_fe.so).
+ *
+ * Drop-in boundary for the hot path of m-dayani/EORB_SLAM: event->image accumulation, ORB
+ * extraction and 256-bit Hamming matching.  The reference has no FFI for this path: it is reached
+ * through three C++ seams, and every entry point below names the seam (file:line in the
+ * reference repository) it replaces.  INTEGRATION.md shows the adapter a maintainer adds on the
+ * reference side.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every call returns 0 on success, <0 on error (EORB_E_*); never throws, never aborts.
+ *   - an eorb_ctx owns device workspaces and runs on ONE HIP stream; it is single-threaded:
+ *     create one per calling thread (the reference calls ev2im_gauss from 4 transient threads,
+ *     src/Event/EvImBuilder.cpp:1165-1193: give each its own ctx).
+ *   - "host" entry points take host pointers, copy in/out and synchronise before returning.
+ *   - "_dev" entry points take DEVICE pointers (HBM resident), enqueue on the ctx stream and do
+ *     not synchronise: this is the throughput path (batches of slices).
+ *   - results are bit-identical to the strict-IEEE CPU restatement of the reference (oracle/).
+ */
+#ifndef EORB_FE_H
+#define EORB_FE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EORB_OK            0
+#define EORB_E_EMPTY      -1   /* empty image: ORBextractor::operator() returns -1 (ORBextractor.cc:1096) */
+#define EORB_E_CONFIG     -2   /* configuration the reference cannot run (division by zero) */
+#define EORB_E_CAPACITY   -3   /* caller buffer / configured capacity too small */
+#define EORB_E_ARG        -4   /* bad argument */
+#define EORB_E_HIP        -5   /* HIP runtime error (see eorb_last_error) */
+#define EORB_E_NOTCONF    -6   /* call needs a prior eorb_*_configure */
+
+typedef struct eorb_ctx eorb_ctx;
+
+/* include/Event/EventData.h:36-58 : struct EventData {double ts; float x; float y; bool p} (24 B) */
+typedef struct {
+    double  ts;
+    float   x, y;
+    uint8_t p;
+    uint8_t pad_[7];
+} eorb_event;
+
+/* HBM-resident compact event record (16 B = the algorithmic bytes/event of SURVEY §8(d)):
+ * x, y as the loader produced them; t = timestamp with the polarity packed in its sign bit
+ * (t >= 0 always: sign bit SET means p == false). */
+typedef struct {
+    float  x, y;
+    double t;
+} eorb_event16;
+
+/* cv::KeyPoint (28 B): what ORBextractor::operator() fills (_keypoints) */
+typedef struct {
+    float   x, y;
+    float   size;
+    float   angle;
+    float   response;
+    int32_t octave;
+    int32_t class_id;
+} eorb_keypoint;
+
+/* include/ORBextractor.h:33-47 : struct ORBxParams */
+typedef struct {
+    int   nfeatures;
+    float scaleFactor;
+    int   nlevels;
+    int   iniThFAST;
+    int   minThFAST;
+    int   edgeTh;       /* Features.imMargin; <0 = adaptive rule of ORBextractor.cc:481-488 */
+    int   imWidth;      /* used only by the adaptive rule */
+} eorb_orb_params;
+
+/* Frame image bounds + grid pitch: Frame::mnMinX.., mfGridElementWidthInv (Frame.cc:362-363, 855-866) */
+typedef struct {
+    float minX, minY, maxX, maxY;
+    float invW, invH;
+} eorb_grid_bounds;
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* hip_stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a private one */
+int         eorb_create(int device, void* hip_stream, eorb_ctx** out);
+void        eorb_destroy(eorb_ctx* ctx);
+int         eorb_sync(eorb_ctx* ctx);
+const char* eorb_last_error(eorb_ctx* ctx);
+const char* eorb_version(void);
+/* per-kernel HIP-event timing on the ctx stream (off by default; used by bench.py) */
+int         eorb_prof_enable(eorb_ctx* ctx, int on);
+int         eorb_prof_reset(eorb_ctx* ctx);
+int         eorb_prof_count(eorb_ctx* ctx);
+int         eorb_prof_get(eorb_ctx* ctx, int i, const char** name, double* total_ms, int64_t* launches);
+
+/* ---- event accumulation (host buffers) -------------------------------------------------------- */
+/* replaces EvImConverter::ev2im, src/Event/EventConversion.cc:173-212 (include/Event/EventConversion.h:52).
+ * out_f32 (W*H, optional) = accumulated CV_32FC1 image; out_u8 (W*H, optional) = normalised image;
+ * *is_u8 = 1 when the reference would return CV_8UC1 (normalized && max > min). minmax optional [2]. */
+int eorb_ev2im(eorb_ctx* ctx, const eorb_event* ev, size_t n, int W, int H, int pol, int normalized,
+               float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8);
+
+/* replaces EvImConverter::ev2im_gauss, src/Event/EventConversion.cc:215-269
+ * (include/Event/EventConversion.h:54-56; callers EvImBuilder.cpp:1345,1070) */
+int eorb_ev2im_gauss(eorb_ctx* ctx, const eorb_event* ev, size_t n, int W, int H, float sigma, int pol,
+                     int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+
+/* ---- ORB extractor (host buffers) --------------------------------------------------------------- */
+/* replaces ORBextractor::ORBextractor, src/ORBextractor.cc:420-489: scale tables, per-level quotas,
+ * edge threshold (per context, not a process global: SURVEY App.B H3) for images of W x H */
+int eorb_orb_configure(eorb_ctx* ctx, const eorb_orb_params* p, int W, int H);
+int eorb_orb_max_keypoints(eorb_ctx* ctx);               /* output capacity needed */
+int eorb_orb_get_tables(eorb_ctx* ctx, float* scale_factors, float* inv_scale_factors,
+                        int* features_per_level, int* edge_threshold);   /* getters hdr:83-107 */
+
+/* replaces ORBextractor::operator() with descriptors (src/ORBextractor.cc:1092-1176) and the
+ * detect-only overload (:1178-1238); include/ORBextractor.h:75-81.  lap0/lap1 = vLappingArea.
+ * kps[cap], desc[cap*32] (may be NULL when !want_desc), oob[cap] optional (1 = some rBRIEF tap of
+ * that keypoint left the blurred level buffer: the reference reads out of bounds there, H4).
+ * *mono_index = the reference's return value. */
+int eorb_orb_extract(eorb_ctx* ctx, const uint8_t* img, int W, int H, int stride, int lap0, int lap1,
+                     int want_desc, eorb_keypoint* kps, uint8_t* desc, uint8_t* oob, int cap,
+                     int* n_out, int* mono_index);
+
+/* ---- matchers (host buffers) ------------------------------------------------------------------------ */
+/* replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:714-831) and
+ * MixedMatcher::SearchForInitialization (src/MixedMatcher.cpp:20-145; is_orb* = isORBDescValid gate,
+ * NULL = all ORB).  kps*: undistorted keypoints; desc*: n x stride bytes, first 32 compared
+ * (ORBmatcher.cc:2360-2378).  prev_matched: n1 (x,y) in/out; matches12: n1 out. */
+int eorb_search_for_initialization(eorb_ctx* ctx,
+        const eorb_keypoint* kps1, int n1, const uint8_t* desc1, int stride1, const uint8_t* is_orb1,
+        const eorb_keypoint* kps2, int n2, const uint8_t* desc2, int stride2, const uint8_t* is_orb2,
+        const eorb_grid_bounds* gb, float* prev_matched, int32_t* matches12,
+        int windowSize, float nnratio, int checkOri, int* nmatches);
+
+/* replaces the mono branch of ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)
+ * (src/ORBmatcher.cc:1969-2187; MixedMatcher.cpp:693-).  Projection stays on the host:
+ * valid/uv per last-frame keypoint, mp_desc (n_last x 32), mp_obs; cur_mp in/out
+ * (-1 none, k>=0 last-frame point k, -2 foreign observed, -3 foreign unobserved).
+ * mode 0: levels [o-1,o+1]; 1 forward (>= o); 2 backward ([0,o]). */
+int eorb_search_by_projection_last(eorb_ctx* ctx,
+        const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
+        const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
+        const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+        const float* level_scale /* n_last: getORBScaleFactor(octave) or the AKAZE factor */,
+        const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri, int* nmatches);
+
+/* replaces the mono branch of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+ * (src/ORBmatcher.cc:44-219; MixedMatcher.cpp:500-691). */
+int eorb_search_by_projection_map(eorb_ctx* ctx,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
+        int M, const uint8_t* in_view, const float* proj_xy, const int32_t* level, const float* view_cos,
+        const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
+        const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, int* nmatches);
+
+/* replaces cv::BFMatcher(NORM_HAMMING)::knnMatch(q, t, matches, 2) at src/Frame.cc:1228
+ * (+ the ORBmatcher::DescriptorDistance core, ORBmatcher.cc:2360-2378).  idx2/dist2: nq*2. */
+int eorb_hamming_bf_knn2(eorb_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                         int32_t* idx2, int32_t* dist2);
+
+/* ---- batched, HBM-resident front end (throughput path) ------------------------------------------- */
+typedef struct {
+    int   W, H;
+    float sigma;            /* Event.image.l1Sigma */
+    int   pol;
+    eorb_orb_params orb;
+    int   lap0, lap1;       /* vLappingArea (mono: 0, 1000) */
+    int   want_desc;
+    int   max_batch;        /* slices per batch */
+    int   max_events;       /* events per slice (capacity) */
+    int   match;            /* 1: SearchForInitialization of slice b against slice b-1 */
+    int   windowSize;       /* 100 */
+    float nnratio;          /* 0.9 */
+    int   checkOri;
+} eorb_fe_config;
+
+int eorb_fe_configure(eorb_ctx* ctx, const eorb_fe_config* cfg);
+
+/* One pass of the hot path over a batch of B time-slices, everything resident in HBM:
+ *   accumulate (ev2im_gauss, normalised u8) -> ORB extract -> match slice b against slice b-1
+ *   (slice 0 against `prev` state carried in the ctx from the previous batch, if any).
+ * d_events: all slices' events back to back; h_offsets[B+1]: slice boundaries (host array).
+ * Outputs (device pointers, any may be NULL): d_images u8 B*W*H; d_kps B*cap; d_desc B*cap*32;
+ * d_nkps int32 B; d_matches12 int32 B*cap (for slice b: index into slice b, per keypoint of b-1);
+ * d_nmatches int32 B.  cap = eorb_orb_max_keypoints(). */
+int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int64_t* h_offsets, int B,
+                          uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                          int32_t* d_matches12, int32_t* d_nmatches);
+
+/* helpers: convert host AoS events to the compact record; device alloc/copy without a HIP binding */
+void  eorb_pack_events(const eorb_event* ev, size_t n, eorb_event16* out);
+void* eorb_dev_alloc(eorb_ctx* ctx, size_t bytes);
+int   eorb_dev_free(eorb_ctx* ctx, void* p);
+int   eorb_dev_upload(eorb_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int   eorb_dev_download(eorb_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -165,7 +165,7 @@ int orc_search_for_initialization(const orc_frame* F1, const orc_frame* F2, floa
 int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
                                   const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
                                   int* cur_mp, float th, int mode, int checkOri,
-                                  const float* scale_factors, int nlevels);
+                                  const float* level_scale /* per last kp: getORBScaleFactor(octave) */);
 
 /* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (:44-219) mono branch.
  * Per map point m: in_view, projX, projY, level (mnTrackScaleLevel), viewCos, desc, obs flag,

@@ -90,7 +90,7 @@ def lib(fast=False):
     L.orc_search_for_initialization.restype = ci
     L.orc_search_for_initialization.argtypes = [vp, vp, vp, vp, ci, cf, ci]
     L.orc_search_by_projection_last.restype = ci
-    L.orc_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp, ci]
+    L.orc_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     L.orc_search_by_projection_map.restype = ci
     L.orc_search_by_projection_map.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
     L.orc_bf_knn2.restype = None; L.orc_bf_knn2.argtypes = [vp, ci, vp, ci, vp, vp]
@@ -288,14 +288,14 @@ def search_for_initialization(F1, F2, prev_matched, windowSize=100, nnratio=0.9,
     return n, m12, pm
 
 
-def search_by_projection_last(cur, last, valid, uv, mp_desc, mp_obs, cur_mp, th, scale_factors,
+def search_by_projection_last(cur, last, valid, uv, mp_desc, mp_obs, cur_mp, th, level_scale,
                               mode=0, checkOri=True):
     valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
     mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
     cm = np.ascontiguousarray(cur_mp, np.int32).copy()
-    sf = np.ascontiguousarray(scale_factors, np.float32)
+    ls = np.ascontiguousarray(level_scale, np.float32)
     n = cur.L.orc_search_by_projection_last(cur.h, last.h, _p(valid), _p(uv), _p(mp_desc), _p(mp_obs),
-                                            _p(cm), th, mode, int(checkOri), _p(sf), len(sf))
+                                            _p(cm), th, mode, int(checkOri), _p(ls))
     return n, cm
 
 

@@ -217,8 +217,6 @@ int orc_search_for_initialization(const orc_frame* F1, const orc_frame* F2, floa
     return nmatches;
 }
 
-static int clamp_level(int l, int n) { return l < 0 ? 0 : (l >= n ? n - 1 : l); }  /* checkORBLevel */
-
 /* occupancy rule shared by the projection matchers (:91-93, :2045-2047):
  * a candidate holding a map point with Observations()>0 is skipped. */
 static int holds_observed(const int* slot_mp, int idx, const uint8_t* mp_obs)
@@ -232,7 +230,7 @@ static int holds_observed(const int* slot_mp, int idx, const uint8_t* mp_obs)
 /* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono) :1969-2187, mono */
 int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
                                   const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
-                                  int* cur_mp, float th, int mode, int checkOri, const float* sf, int nlev)
+                                  int* cur_mp, float th, int mode, int checkOri, const float* level_scale)
 {
     int nmatches = 0;
     const int Nc = cur->N;
@@ -243,7 +241,8 @@ int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, c
         if (!valid[i]) continue;
         const float ux = uv[2 * i], uy = uv[2 * i + 1];
         int nLastOctave = frame_level(last, i);
-        float radius = th * sf[clamp_level(nLastOctave, nlev)];
+        float radius = th * level_scale[i];                     /* th*getORBScaleFactor(oct) (AKAZE: MixedMatcher.cpp:748-752) */
+        const int isORBMP = !last->is_orb || last->is_orb[i];
         int nc;
         if (mode == 1) nc = orc_get_features_in_area(cur, ux, uy, radius, nLastOctave, -1, idxs, Nc);
         else if (mode == 2) nc = orc_get_features_in_area(cur, ux, uy, radius, 0, nLastOctave, idxs, Nc);
@@ -254,6 +253,8 @@ int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, c
         for (int c = 0; c < nc; c++) {
             const int i2 = idxs[c];
             if (holds_observed(cur_mp, i2, mp_obs)) continue;
+            const int isORBPt = !cur->is_orb || cur->is_orb[i2];
+            if (isORBMP != isORBPt) continue;                     /* MixedMatcher.cpp:787-790 */
             const int dist = orc_descriptor_distance(dMP, cur->desc + (size_t)i2 * cur->desc_stride);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }

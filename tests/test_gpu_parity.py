@@ -1,0 +1,282 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+Run on the GPU box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from eorb_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from eorb_slam_amd import frontend
+    return frontend
+
+
+@pytest.fixture(scope="module")
+def ctx(fe):
+    c = fe.Context()
+    yield c
+    c.close()
+
+
+def _same_bits(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ---- event accumulation ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [
+    dict(n=2000, sigma=1.0, pol=False, frac=True),
+    dict(n=2000, sigma=1.0, pol=True, frac=True),
+    dict(n=6000, sigma=1.0, pol=False, frac=False),
+    dict(n=5000, sigma=0.5, pol=False, frac=True),      # h = 2
+    dict(n=5000, sigma=1.5, pol=False, frac=True),      # h = 5: events span up to 3 tiles per axis
+    dict(n=3000, sigma=2.5, pol=True, frac=True),       # h = 8
+    dict(n=1, sigma=1.0, pol=False, frac=True),
+    dict(n=0, sigma=1.0, pol=False, frac=True),
+    dict(n=20000, sigma=1.0, pol=False, frac=True, W=346, H=260),   # MVSEC shape, partial last tile
+])
+def test_ev2im_gauss_bit_exact(oracle, fe, ctx, case):
+    W, H = case.get("W", 240), case.get("H", 180)
+    ev = synth.random_events(case["n"], W, H, seed=11 + case["n"], frac=case["frac"])
+    for normalized in (True, False):
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized, ctx=ctx, return_all=True)
+        assert _same_bits(of, gf), "f32 image differs: %d px" % int((of.view(np.uint32) != gf.view(np.uint32)).sum())
+        assert _same_bits(omm, gmm)
+        if normalized:
+            assert np.array_equal(ou, gu)
+
+
+def test_ev2im_gauss_shapes_lut(oracle, fe, ctx):
+    """C1 stand-in: LUT-undistorted shapes events, L1 chunk (2000) and L2 window (6000)."""
+    for n in (2000, 6000, 50000):
+        ev = synth.shapes_events(n, seed=1, undistort=True)
+        of, ou, omm = oracle.ev2im_gauss(ev, 240, 180, 1.0, False, True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, 240, 180, 1.0, False, True, ctx=ctx, return_all=True)
+        assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm)
+
+
+def test_ev2im_gauss_hot_pixel_order(oracle, fe, ctx):
+    """Many events on few pixels (long per-pixel chains crossing many chunks): order must be preserved."""
+    rng = np.random.default_rng(5)
+    n = 30000
+    ev = synth.random_events(n, seed=5)
+    ev["x"] = (100 + rng.uniform(0, 3, n)).astype(np.float32); ev["y"] = (60 + rng.uniform(0, 3, n)).astype(np.float32)
+    for pol in (False, True):
+        of, ou, omm = oracle.ev2im_gauss(ev, 240, 180, 1.0, pol, True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, 240, 180, 1.0, pol, True, ctx=ctx, return_all=True)
+        assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm)
+
+
+@pytest.mark.parametrize("pol", [False, True])
+def test_ev2im_count_bit_exact(oracle, fe, ctx, pol):
+    ev = synth.random_events(20000, seed=3, frac=True)
+    for normalized in (True, False):
+        of, ou, omm = oracle.ev2im(ev, 240, 180, pol, normalized)
+        gf, gu, gmm = fe.EvImConverter.ev2im(ev, 240, 180, pol, normalized, ctx=ctx, return_all=True)
+        assert _same_bits(of, gf) and _same_bits(omm, gmm)
+        assert (ou is None) == (gu is None)
+        if ou is not None:
+            assert np.array_equal(ou, gu)
+
+
+# ---- ORB extractor -------------------------------------------------------------------------------------------
+def _event_image(oracle, n=60000, seed=2):
+    ev = synth.shapes_events(n, seed=seed)
+    return oracle.ev2im_gauss(ev, 240, 180, 1.0, False, True)[1]
+
+
+def _check_extract(oracle, fe, img, lap=(0, 1000), want_desc=True, **p):
+    H, W = img.shape
+    oe = oracle.OrbExtractor(imWidth=W, **p)
+    ge = fe.ORBextractor(imSize=(W, H), **p)
+    omono, okp, odesc, ooob = oe.extract(img, lap, want_desc)
+    gmono, gkp, gdesc, goob = ge(img, lap, want_desc)
+    assert list(ge.mnFeaturesPerLevel) == oe.features_per_level and ge.edge == oe.edge
+    assert np.array_equal(ge.mvScaleFactor.view(np.uint32), oe.scale_factors.view(np.uint32))
+    assert omono == gmono
+    assert len(okp) == len(gkp), "keypoint count %d vs %d" % (len(okp), len(gkp))
+    for f in ("x", "y", "size", "angle", "response"):
+        assert np.array_equal(okp[f].view(np.uint32), gkp[f].view(np.uint32)), f
+    assert np.array_equal(okp["octave"], gkp["octave"]) and np.array_equal(okp["class_id"], gkp["class_id"])
+    if want_desc:
+        assert np.array_equal(odesc, gdesc)
+        assert np.array_equal(ooob, goob)
+    ge.ctx.close()
+    return okp, odesc
+
+
+@pytest.mark.parametrize("edge", [19, 21, 9])
+def test_orb_extract_texture(oracle, fe, edge):
+    img = synth.texture_image(240, 180, seed=3)
+    kp, _ = _check_extract(oracle, fe, img, nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0, edgeTh=edge)
+    assert len(kp) > 300
+
+
+def test_orb_extract_event_image(oracle, fe):
+    img = _event_image(oracle)
+    _check_extract(oracle, fe, img, nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0, edgeTh=19)
+
+
+def test_orb_extract_detect_only_fast_mode(oracle, fe):
+    """Event path: 'FAST = ORB with 1 level', thresholds 0/0, edge 9, 400 and 800 points."""
+    img = _event_image(oracle, n=6000, seed=7)
+    for nf in (400, 800):
+        _check_extract(oracle, fe, img, want_desc=False, nfeatures=nf, scaleFactor=1.0, nlevels=1, iniThFAST=0, minThFAST=0, edgeTh=9)
+
+
+def test_orb_extract_mvsec_shape(oracle, fe):
+    img = synth.texture_image(346, 260, seed=4)
+    _check_extract(oracle, fe, img, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=10, minThFAST=1, edgeTh=15)
+
+
+def test_orb_extract_stereo_lapping_and_flat(oracle, fe):
+    img = synth.texture_image(240, 180, seed=8)
+    _check_extract(oracle, fe, img, lap=(0, 0), nfeatures=500, scaleFactor=1.2, nlevels=3, iniThFAST=20, minThFAST=7, edgeTh=19)
+    _check_extract(oracle, fe, img, lap=(60, 120), nfeatures=500, scaleFactor=1.2, nlevels=3, iniThFAST=20, minThFAST=7, edgeTh=19)
+    flat = np.full((180, 240), 128, np.uint8)           # no corners at all: zero keypoints, descriptors released
+    ge = fe.ORBextractor(imSize=(240, 180))
+    mono, kp, desc, oob = ge(flat)
+    assert mono == 0 and len(kp) == 0
+    assert ge(np.zeros((0, 0), np.uint8))[0] == -1      # empty image -> -1 (ORBextractor.cc:1096)
+    ge.ctx.close()
+
+
+def test_orb_extract_bad_config_is_error_not_crash(fe):
+    with pytest.raises(fe.EorbError) as ei:
+        fe.ORBextractor(nfeatures=1000, scaleFactor=1.2, nlevels=8, edgeTh=19, imSize=(240, 180))   # level 7 < one 30-px cell
+    assert ei.value.code == -2
+
+
+# ---- matchers ----------------------------------------------------------------------------------------------------
+def test_bf_knn2(oracle, fe, ctx):
+    bf = fe.BFMatcher(ctx)
+    t = synth.random_descriptors(2000, seed=4)
+    for q in (synth.random_descriptors(2000, seed=14), synth.planted_descriptors(t, seed=5)[0], t[:37]):
+        oi, od = oracle.bf_knn2(q, t)
+        gi, gd = bf.knnMatch2(q, t)
+        assert np.array_equal(oi, gi) and np.array_equal(od, gd)
+    # heavy ties: many identical train rows -> lowest train index wins
+    t2 = np.repeat(synth.random_descriptors(8, seed=1), 50, axis=0)
+    oi, od = oracle.bf_knn2(t2[::7], t2)
+    gi, gd = bf.knnMatch2(t2[::7], t2)
+    assert np.array_equal(oi, gi) and np.array_equal(od, gd)
+    # a single train row: second neighbour absent
+    oi, od = oracle.bf_knn2(t[:5], t[:1])
+    gi, gd = bf.knnMatch2(t[:5], t[:1])
+    assert np.array_equal(oi, gi) and np.array_equal(od, gd)
+
+
+def _two_frames(oracle, seed=3, shift=3):
+    img1 = synth.texture_image(240, 180, seed=seed)
+    img2 = np.roll(img1, (shift, -shift), axis=(0, 1))
+    e = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19)
+    _, k1, d1, _ = e.extract(img1)
+    _, k2, d2, _ = e.extract(img2)
+    return k1, d1, k2, d2
+
+
+@pytest.mark.parametrize("window,ratio,ori", [(100, 0.9, True), (30, 0.6, True), (100, 0.9, False)])
+def test_search_for_initialization(oracle, fe, ctx, window, ratio, ori):
+    k1, d1, k2, d2 = _two_frames(oracle)
+    pm = np.stack([k1["x"], k1["y"]], axis=1)
+    on, om, opm = oracle.search_for_initialization(oracle.Frame(k1, d1, 240, 180), oracle.Frame(k2, d2, 240, 180), pm, window, ratio, ori)
+    gn, gm, gpm = fe.ORBmatcher(ratio, ori, ctx).SearchForInitialization(fe.FrameView(k1, d1, 240, 180), fe.FrameView(k2, d2, 240, 180), pm, window)
+    assert on == gn and np.array_equal(om, gm) and np.array_equal(opm.view(np.uint32), gpm.view(np.uint32))
+    assert on > 20
+
+
+def test_search_for_initialization_mixed_gate(oracle, fe, ctx):
+    """MixedMatcher: ORB rows + 61-byte AKAZE-like rows; only same-type pairs, first 32 bytes compared."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=13)
+    rng = np.random.default_rng(1)
+
+    def mix(k, d, seed):
+        n = len(k)
+        d61 = np.zeros((n, 61), np.uint8); d61[:, :32] = d; d61[:, 32:] = rng.integers(0, 256, (n, 29))
+        is_orb = (np.arange(n) < n * 2 // 3).astype(np.uint8)
+        k = k.copy(); k["class_id"] = np.where(is_orb == 1, -1, 0); k["octave"] = np.where(is_orb == 1, k["octave"], 2)
+        return k, d61, is_orb
+    k1, d1, o1 = mix(k1, d1, 1); k2, d2, o2 = mix(k2, d2, 2)
+    pm = np.stack([k1["x"], k1["y"]], axis=1)
+    on, om, opm = oracle.search_for_initialization(oracle.Frame(k1, d1, 240, 180, o1), oracle.Frame(k2, d2, 240, 180, o2), pm, 100, 0.9, True)
+    gn, gm, gpm = fe.ORBmatcher(0.9, True, ctx).SearchForInitialization(fe.FrameView(k1, d1, 240, 180, o1), fe.FrameView(k2, d2, 240, 180, o2), pm, 100)
+    assert on == gn and np.array_equal(om, gm) and np.array_equal(opm.view(np.uint32), gpm.view(np.uint32))
+
+
+def test_search_by_projection_last(oracle, fe, ctx):
+    k1, d1, k2, d2 = _two_frames(oracle, seed=21, shift=2)
+    rng = np.random.default_rng(2)
+    n1 = len(k1)
+    valid = (rng.uniform(size=n1) < 0.8).astype(np.uint8)
+    uv = np.stack([k1["x"] - 2 + rng.normal(0, 1, n1), k1["y"] + 2 + rng.normal(0, 1, n1)], axis=1).astype(np.float32)
+    mp_obs = (rng.uniform(size=n1) < 0.7).astype(np.uint8)
+    sf = oracle.OrbExtractor(1000, 1.2, 4).scale_factors
+    ls = sf[np.clip(k1["octave"], 0, 3)]
+    cur_mp = np.full(len(k2), -1, np.int32); cur_mp[::17] = -2; cur_mp[5::23] = -3
+    for mode in (0, 1, 2):
+        for ori in (True, False):
+            on, ocm = oracle.search_by_projection_last(oracle.Frame(k2, d2, 240, 180), oracle.Frame(k1, d1, 240, 180), valid, uv, d1, mp_obs, cur_mp, 15.0, ls, mode, ori)
+            gn, gcm = fe.ORBmatcher(0.9, ori, ctx).SearchByProjectionLast(fe.FrameView(k2, d2, 240, 180), fe.FrameView(k1, d1, 240, 180), valid, uv, d1, mp_obs, cur_mp, 15.0, ls, mode)
+            assert on == gn and np.array_equal(ocm, gcm)
+    assert on > 10
+
+
+def test_search_by_projection_map(oracle, fe, ctx):
+    k1, d1, k2, d2 = _two_frames(oracle, seed=22, shift=1)
+    rng = np.random.default_rng(3)
+    M = len(k1)
+    in_view = (rng.uniform(size=M) < 0.9).astype(np.uint8)
+    proj = np.stack([k1["x"] - 1 + rng.normal(0, 0.7, M), k1["y"] + 1 + rng.normal(0, 0.7, M)], axis=1).astype(np.float32)
+    level = k1["octave"].astype(np.int32)
+    vc = rng.uniform(0.99, 1.0, M).astype(np.float32)
+    mp_obs = (rng.uniform(size=M) < 0.6).astype(np.uint8)
+    sf = oracle.OrbExtractor(1000, 1.2, 4).scale_factors
+    ls = sf[np.clip(level, 0, 3)]
+    fm = np.full(len(k2), -1, np.int32); fm[::19] = -2
+    for th in (1.0, 3.0):
+        on, ofm = oracle.search_by_projection_map(oracle.Frame(k2, d2, 240, 180), in_view, proj, level, vc, d1, mp_obs, fm, th, 0.8, ls)
+        gn, gfm = fe.ORBmatcher(0.8, True, ctx).SearchByProjectionMap(fe.FrameView(k2, d2, 240, 180), in_view, proj, level, vc, d1, mp_obs, fm, th, ls)
+        assert on == gn and np.array_equal(ofm, gfm)
+    assert on > 10
+
+
+# ---- the batched HBM-resident pipeline -------------------------------------------------------------------------------
+def test_frontend_batch_matches_oracle_pipeline(oracle, fe):
+    W, H, B, n = 240, 180, 3, 40000
+    slices = [synth.shapes_events(n, seed=40 + b, motion=0.3) for b in range(B)]
+    fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=n, windowSize=100, nnratio=0.9)
+    c = fb.ctx
+    ev16 = np.concatenate([fe.pack_events(s) for s in slices])
+    cap = fb.cap
+    d_ev = c.dev_alloc(ev16.nbytes); c.upload(d_ev, ev16)
+    d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32)
+    d_n = c.dev_alloc(B * 4); d_m = c.dev_alloc(B * cap * 4); d_nm = c.dev_alloc(B * 4)
+    offs = np.arange(B + 1, dtype=np.int64) * n
+    fb.run_dev(d_ev, offs, d_img, d_kp, d_desc, d_n, d_m, d_nm)
+    c.sync()
+    imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
+    kps = np.zeros((B, cap), synth.KP_DTYPE); c.download(kps, d_kp)
+    desc = np.zeros((B, cap, 32), np.uint8); c.download(desc, d_desc)
+    nk = np.zeros(B, np.int32); c.download(nk, d_n)
+    m12 = np.zeros((B, cap), np.int32); c.download(m12, d_m)
+    nm = np.zeros(B, np.int32); c.download(nm, d_nm)
+    oe = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19)
+    prev = None
+    for b in range(B):
+        _, ou, _ = oracle.ev2im_gauss(slices[b], W, H, 1.0, False, True)
+        assert np.array_equal(ou, imgs[b])
+        _, okp, odesc, _ = oe.extract(ou)
+        assert nk[b] == len(okp)
+        assert np.array_equal(okp.view(np.uint8), kps[b, :nk[b]].view(np.uint8)) and np.array_equal(odesc, desc[b, :nk[b]])
+        if prev is not None:
+            pk, pd = prev
+            pm = np.stack([pk["x"], pk["y"]], axis=1)
+            on, om, _ = oracle.search_for_initialization(oracle.Frame(pk, pd, W, H), oracle.Frame(okp, odesc, W, H), pm, 100, 0.9, True)
+            assert on == nm[b] and np.array_equal(om, m12[b, :len(pk)])
+        prev = (okp, odesc)
+    for p in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
+        c.dev_free(p)
+    c.close()
