@@ -73,6 +73,27 @@ __global__ __launch_bounds__(256) void bf_knn2_kernel(const uint8_t* __restrict_
     }
 }
 
+
+// 32 descriptor bytes -> 4 x u64 (little endian).  AKAZE rows are 61 B apart (src/MixedFrame.cpp:20-21), so a
+// row may start at any byte: assemble bytewise unless 8-byte aligned.
+__device__ __forceinline__ void load_desc32(const uint8_t* __restrict__ p, uint64_t& a, uint64_t& b, uint64_t& c, uint64_t& d)
+{
+    if ((((uintptr_t)p) & 7) == 0) {
+        const uint64_t* q = (const uint64_t*)p;
+        a = q[0]; b = q[1]; c = q[2]; d = q[3];
+    } else {
+        uint64_t v[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint64_t x = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) x |= (uint64_t)p[w * 8 + k] << (8 * k);
+            v[w] = x;
+        }
+        a = v[0]; b = v[1]; c = v[2]; d = v[3];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // shared pieces of the greedy window matchers
 struct GridB { float minX, minY, invW, invH; };
@@ -209,8 +230,7 @@ __global__ __launch_bounds__(256) void search_init_kernel(SearchInitArgs A)
         const int px = (int)roundf((k.x - A.g.minX) * A.g.invW);
         const int py = (int)roundf((k.y - A.g.minY) * A.g.invH);
         cell2[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? (uint16_t)0xFFFF : (uint16_t)(px * kGridRows + py);
-        const uint64_t* dp = (const uint64_t*)(D2 + (size_t)i * A.dstride2);
-        d2[(size_t)i * 4 + 0] = dp[0]; d2[(size_t)i * 4 + 1] = dp[1]; d2[(size_t)i * 4 + 2] = dp[2]; d2[(size_t)i * 4 + 3] = dp[3];
+        load_desc32(D2 + (size_t)i * A.dstride2, d2[(size_t)i * 4 + 0], d2[(size_t)i * 4 + 1], d2[(size_t)i * 4 + 2], d2[(size_t)i * 4 + 3]);
         mdist[i] = 0x7fffffff; m21[i] = -1;
     }
     for (int i = tid; i < N1; i += blockDim.x) { M12[i] = -1; bin1[i] = -1; }
@@ -227,8 +247,8 @@ __global__ __launch_bounds__(256) void search_init_kernel(SearchInitArgs A)
         const float qx = PM ? PM[2 * i1] : k1.x, qy = PM ? PM[2 * i1 + 1] : k1.y;
         int cx0, cx1, cy0, cy1;
         if (!cell_range(A.g, qx, qy, r, cx0, cx1, cy0, cy1)) continue;
-        const uint64_t* dq = (const uint64_t*)(D1 + (size_t)i1 * A.dstride1);
-        const uint64_t q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3];
+        uint64_t q0, q1, q2, q3;
+        load_desc32(D1 + (size_t)i1 * A.dstride1, q0, q1, q2, q3);
         // GetFeaturesInArea(x, y, windowSize, level1, level1): bCheckLevels = true (maxLevel >= 0)
         uint64_t k0 = ~0ull, k1b = ~0ull;
         for (int i2 = tid; i2 < N2; i2 += blockDim.x) {
@@ -383,8 +403,7 @@ __global__ __launch_bounds__(256) void search_proj_kernel(ProjArgs A)
         const int px = (int)roundf((k.x - A.g.minX) * A.g.invW);
         const int py = (int)roundf((k.y - A.g.minY) * A.g.invH);
         cell2[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? (uint16_t)0xFFFF : (uint16_t)(px * kGridRows + py);
-        const uint64_t* dp = (const uint64_t*)(A.desc + (size_t)i * A.stride);
-        d2[(size_t)i * 4 + 0] = dp[0]; d2[(size_t)i * 4 + 1] = dp[1]; d2[(size_t)i * 4 + 2] = dp[2]; d2[(size_t)i * 4 + 3] = dp[3];
+        load_desc32(A.desc + (size_t)i * A.stride, d2[(size_t)i * 4 + 0], d2[(size_t)i * 4 + 1], d2[(size_t)i * 4 + 2], d2[(size_t)i * 4 + 3]);
         slot[i] = A.slot_mp[i];
         hbin[i] = 0u;
     }

@@ -115,14 +115,14 @@ __device__ __forceinline__ int fast_S(const uint8_t* __restrict__ t, int pitch)
     return max(A, -Bm);
 }
 
-constexpr int kCellMax = 48;      // max cell edge (wCell, hCell <= 48 is checked at configure time)
+constexpr int kCellMax = 60;      // max cell edge: nCols = int(width/30) gives cells of 30..59 px (checked at configure time)
 
 __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
                                                          int32_t* __restrict__ cell_cnt, uint32_t* __restrict__ cell_cand)
 {
     __shared__ uint8_t tile[(kCellMax + 6) * (kCellMax + 8)];
     __shared__ uint8_t smap[(kCellMax + 2) * (kCellMax + 2)];
-    __shared__ int s_count, s_wbase[4];
+    __shared__ int s_wbase[4];
     const int slice = blockIdx.y;
     // locate (level, cell)
     int cid = blockIdx.x, level = 0;
@@ -162,8 +162,6 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restri
     // scores, a non-corner or out-of-domain neighbour scoring 0 (cv::FAST buffers are zero initialised).
     int th = G->iniTh;
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (tid == 0) s_count = 0;
-        __syncthreads();
         int emitted_base = 0;
         // raster order emission in passes of 256 pixels
         for (int i0 = 0; i0 < dw * dh; i0 += 256) {
