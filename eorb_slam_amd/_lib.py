@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libeorb_fe.so")
+LIB_PATH = os.environ.get("EORB_FE_LIB") or os.path.join(_HERE, "csrc", "libeorb_fe.so")   # override: kernel experiments
 
 EORB_OK, EORB_E_EMPTY, EORB_E_CONFIG, EORB_E_CAPACITY, EORB_E_ARG, EORB_E_HIP, EORB_E_NOTCONF = 0, -1, -2, -3, -4, -5, -6
 
@@ -18,6 +18,7 @@ EXPORTS = [
     "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map",
     "eorb_hamming_bf_knn2",
     "eorb_fe_configure", "eorb_fe_run_batch_dev",
+    "eorb_selfcheck_division",
     "eorb_pack_events", "eorb_dev_alloc", "eorb_dev_free", "eorb_dev_upload", "eorb_dev_download",
 ]
 
@@ -94,6 +95,7 @@ def lib():
     L.eorb_fe_configure.restype = ci; L.eorb_fe_configure.argtypes = [vp, C.POINTER(FeConfig)]
     L.eorb_fe_run_batch_dev.restype = ci
     L.eorb_fe_run_batch_dev.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
+    L.eorb_selfcheck_division.restype = ci; L.eorb_selfcheck_division.argtypes = [vp, cf, cf, cf, C.POINTER(C.c_uint64)]
     L.eorb_pack_events.restype = None; L.eorb_pack_events.argtypes = [vp, C.c_size_t, vp]
     L.eorb_dev_alloc.restype = vp; L.eorb_dev_alloc.argtypes = [vp, C.c_size_t]
     L.eorb_dev_free.restype = ci; L.eorb_dev_free.argtypes = [vp, vp]

@@ -9,6 +9,8 @@
 namespace eorb {
 
 int ev_decode_minmax(eorb_ctx* c, const uint32_t* d_enc, float* d_out, int B);
+int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long* bad_out);
+int ev_diag_read(unsigned long long* out16);
 int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H);
 int orb_err_flag(eorb_ctx* c, int B, int* flag);
 int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2);
@@ -243,6 +245,20 @@ int eorb_ev2im_gauss(eorb_ctx* c, const eorb_event* ev, size_t n, int W, int H, 
     if (c && !(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev2im_gauss: sigma must be > 0");
     return ev_host_common(c, ev, n, W, H, sigma, pol, normalized, 0, out_f32, out_u8, minmax, nullptr);
 }
+
+int eorb_selfcheck_division(eorb_ctx* c, float lo, float hi, float sigma, uint64_t* mismatches)
+{
+    if (!c || !mismatches || !(lo > 0.f) || !(hi >= lo) || !(sigma > 0.f)) return c ? set_err(c, EORB_E_ARG, "selfcheck_division: bad arguments") : EORB_E_ARG;
+    hipSetDevice(c->device);
+    unsigned long long bad = 0;
+    int rc = ev_divcheck(c, lo, hi, sigma, &bad);
+    *mismatches = bad;
+    return rc;
+}
+
+#ifdef EORB_DIAG
+int eorb_diag_read(unsigned long long* out16) { return ev_diag_read(out16); }
+#endif
 
 // ---- ORB extractor, host buffers -----------------------------------------------------------------------
 int eorb_orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)

@@ -18,6 +18,7 @@
 #include "dev_math.h"
 #include <math.h>
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -142,82 +143,248 @@ struct GatherParams {
     int total;           // number of (slice, tile) work items
     float two_sig2;      // 2.0f * sig2
     float norm;          // 2.0f*float(CV_PI)*sig2
+    float inv_two_sig2;  // exact reciprocal when two_sig2 is a power of two
+    float rcp_norm;      // RN(1/norm)
+    int div_is_pow2, fast_norm;
 };
 
+// K2: one 512-thread workgroup per 8x8 tile (EORB_GATHER_THREADS overrides: 256..1024 measured, 512 fastest); the tile's entries are consumed in batches of 64 (event order)
+// through a 3-stage software pipeline with ONE barrier per batch:
+//   wave 1, set-up(t)   lane = entry (loaded one batch ahead): floor/frac (breakFloatCoords :51-57) and the 8-bit
+//                       column / row masks of the stamp taps that land on this tile; 16 ballots turn them into
+//                       colsel[x] / rowsel[y] (bit e set = entry e touches that column / row), so pixel (x,y) is
+//                       touched by exactly the entries colsel[x] & rowsel[y] -- in event order by bit index.
+//   waves 2-7, values(t-1)  lane = pixel: for every set bit e of its mask (each wave takes 1/6 of the bits) the stamp
+//                       value exp_XY2f (:59-65) goes to the pixel's list slot rank = popcount(mask below e): a
+//                       per-pixel list already in event order.  No divergence on the tap window, no search.
+//   wave 0, adds(t-2)   lane = pixel: acc += list[k], k = 0..popcount(mask)-1 (newVal = image + polSign*val,
+//                       :251-254): the only sequential part; lists are read four ranks at a time (ds_read_b128).
+// With pol == false every increment is >= 0, so the running max is the final value and the running min stays 0.
+struct EvEntryInfo { uint32_t xy; float xr, yr, sg; };      // xi | yi << 16 (int16 each)
+#ifndef EORB_GATHER_THREADS
+#define EORB_GATHER_THREADS 512
+#endif
+constexpr int kGatherThreads = EORB_GATHER_THREADS;
+
+#ifdef EORB_DIAG
+__device__ unsigned long long g_diag[16];
+#endif
+
 template <bool POL>
-__global__ __launch_bounds__(64) void ev_gather_kernel(const int* __restrict__ slice_chunk0,   // B+1
-                                                       GatherParams P, const uint16_t* __restrict__ segoff,
-                                                       const float* __restrict__ entries,
-                                                       float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
+__global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__ slice_chunk0,   // B+1
+                                                                  GatherParams P, const uint16_t* __restrict__ segoff,
+                                                                  const float* __restrict__ entries,
+                                                                  float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
 {
     __shared__ uint64_t tab[32];
-    const int lane = threadIdx.x;
-    if (lane < 32) tab[lane] = kExp2Tab[lane];
-    __syncthreads();
-    // XCD-aware mapping: blocks b and b+8 share an XCD/L2; give each XCD a contiguous run of tiles so
-    // neighbouring tiles (adjacent segments of the same chunks) hit the same L2.
-    const int nb = gridDim.x;
-    const int per = (nb + 7) / 8;
-    int logical = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    if (logical >= P.total) return;     // grid is padded to a multiple of 8 by the launcher
+    __shared__ EvEntryInfo einfo[2][64];
+    __shared__ uint64_t sel[3][16];                 // [0..7] colsel, [8..15] rowsel
+    __shared__ float4 vals[2][16 * 64];             // [rank / 4][pixel] . (rank % 4)
+    __shared__ int s_nb;
+    extern __shared__ uint32_t segs[];              // per chunk of the slice: o0 | o1 << 16 for this tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwaves = (int)(blockDim.x >> 6), nprod = nwaves - 2;      // wave 0 adds, wave 1 set-up, the rest values
+    if (tid < 32) tab[tid] = kExp2Tab[tid];
+    if (tid == 0) s_nb = 0;
+    for (int i = tid; i < 2 * 16 * 64; i += blockDim.x) (&vals[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nbk = gridDim.x;
+    const int per = (nbk + 7) / 8;
+    const int logical = (blockIdx.x % 8) * per + blockIdx.x / 8;     // XCD-aware: neighbouring tiles share an L2
+    if (logical >= P.total) return;
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
     const int c0 = slice_chunk0[slice], c1 = slice_chunk0[slice + 1];
-    const int px = (tile % P.TX) * kTile + (lane & 7);
-    const int py = (tile / P.TX) * kTile + (lane >> 3);
+    const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int px = tx0 + lx, py = ty0 + ly;
     const bool inimg = px < P.W && py < P.H;
+    const int xhi = min(tx0 + kTile - 1, P.W - 1), yhi = min(ty0 + kTile - 1, P.H - 1);
     constexpr int ESZ = POL ? 4 : 2;
+    const int h = P.h;
+    __syncthreads();
+    {   // this tile's segment of every chunk -> LDS; number of 64-entry batches
+        int nb = 0;
+        for (int c = c0 + tid; c < c1; c += blockDim.x) {
+            const uint16_t* so = segoff + (size_t)c * (P.NT + 1) + tile;
+            const uint32_t o0 = so[0], o1 = so[1];
+            segs[c - c0] = o0 | (o1 << 16);
+            nb += ((int)o1 - (int)o0 + 63) >> 6;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nb += __shfl_xor(nb, d, 64);
+        if (lane == 0 && nb) atomicAdd(&s_nb, nb);
+    }
+    __syncthreads();
+    const int nbatch = s_nb;
+    const int nch = c1 - c0;
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
-    for (int c = c0; c < c1; c++) {
-        const uint16_t* so = segoff + (size_t)c * (P.NT + 1) + tile;
-        const int o0 = so[0], o1 = so[1];
-        const float* base = entries + (size_t)c * P.cap * ESZ;
-        for (int j0 = o0; j0 < o1; j0 += 64) {
-            const int j = j0 + lane;
-            int exi = 0, eyi = 0; float exr = 0.f, eyr = 0.f, esg = 1.f;
-            if (j < o1) {
-                float ex, ey;
-                if (POL) { float4 v = *(const float4*)(base + (size_t)j * 4); ex = v.x; ey = v.y; esg = v.z; }
-                else { float2 v = *(const float2*)(base + (size_t)j * 2); ex = v.x; ey = v.y; }
-                if (P.mode_count) {                    // roundFloatCoord (:46-49)
-                    exi = (int)roundf(ex); eyi = (int)roundf(ey);
-                } else {                               // breakFloatCoords (:51-57)
-                    const float fx = floorf(ex), fy = floorf(ey);
-                    exi = (int)fx; eyi = (int)fy;
-                    exr = ex - (float)exi; eyr = ey - (float)eyi;
+    bool touched = false;
+    // wave-1 cursor over the tile's segments + one-batch-ahead entry registers
+    int ci = 0, jcur = 0, jend = 0;
+    float ex = 0.f, ey = 0.f, esg = 1.f; bool valid = false;
+    auto load_batch = [&]() {              // loads the batch at the cursor (if any) and advances the cursor
+        valid = false;
+        while (ci < nch) {
+            const uint32_t sg = segs[ci];
+            if (jend == 0) { jcur = (int)(sg & 0xffff); jend = (int)(sg >> 16); }
+            if (jcur < jend) break;
+            ci++; jend = 0;
+        }
+        if (ci >= nch) return;
+        const float* base = entries + (size_t)(c0 + ci) * P.cap * ESZ;
+        const int j = jcur + lane;
+        valid = j < jend;
+        if (valid) {
+            if (POL) { float4 v = *(const float4*)(base + (size_t)j * 4); ex = v.x; ey = v.y; esg = v.z; }
+            else { float2 v = *(const float2*)(base + (size_t)j * 2); ex = v.x; ey = v.y; }
+        }
+        jcur += 64;
+        if (jcur >= jend) { ci++; jend = 0; }
+    };
+    if (wave == 1 && nbatch > 0) load_batch();
+#ifdef EORB_DIAG
+    unsigned long long d_work = 0, d_t0 = __builtin_readcyclecounter(), d_setup = 0;
+#endif
+    for (int t = 0; t < nbatch + 2; t++) {
+#ifdef EORB_DIAG
+        const unsigned long long d_s = __builtin_readcyclecounter();
+#endif
+        if (wave == 0) {
+            // ---- adds(t-2) ----
+            if (t >= 2) {
+                const int bs3 = (t - 2) % 3, bs2 = t & 1;
+                const uint64_t m = sel[bs3][lx] & sel[bs3][8 + ly];
+                const int cnt = __popcll(m);
+                int mx = cnt;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+                float4* vb = vals[bs2] + lane;
+                touched = touched || (cnt > 0);
+                const int ng = (mx + 3) >> 2;
+                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!POL) {
+                    // list slots beyond a pixel's count hold +0.0f (the buffers are cleared after use), and adding
+                    // +0.0f leaves acc unchanged bit for bit (acc is never -0.0): no per-add predicate needed
+                    int g = 0;
+                    for (; g + 4 <= ng; g += 4) {
+                        const float4 v0 = vb[g * 64], v1 = vb[(g + 1) * 64], v2 = vb[(g + 2) * 64], v3 = vb[(g + 3) * 64];
+                        vb[g * 64] = zero4; vb[(g + 1) * 64] = zero4; vb[(g + 2) * 64] = zero4; vb[(g + 3) * 64] = zero4;
+                        acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
+                        acc = acc + v1.x; acc = acc + v1.y; acc = acc + v1.z; acc = acc + v1.w;
+                        acc = acc + v2.x; acc = acc + v2.y; acc = acc + v2.z; acc = acc + v2.w;
+                        acc = acc + v3.x; acc = acc + v3.y; acc = acc + v3.z; acc = acc + v3.w;
+                    }
+                    for (; g < ng; g++) {
+                        const float4 v0 = vb[g * 64];
+                        vb[g * 64] = zero4;
+                        acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
+                    }
+                } else {
+                    for (int g = 0; g < ng; g++) {
+                        const float4 v0 = vb[g * 64];
+                        vb[g * 64] = zero4;
+                        const int k = 4 * g;
+#define EORB_ADD(val, kk) { if ((kk) < cnt) { acc = acc + (val); vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); } }
+                        EORB_ADD(v0.x, k + 0) EORB_ADD(v0.y, k + 1) EORB_ADD(v0.z, k + 2) EORB_ADD(v0.w, k + 3)
+#undef EORB_ADD
+                    }
                 }
             }
-            const int cnt = min(64, o1 - j0);
-            for (int q = 0; q < cnt; q++) {
-                const int xi = __builtin_amdgcn_readlane(exi, q);
-                const int yi = __builtin_amdgcn_readlane(eyi, q);
-                const int dx = px - xi, dy = py - yi;
-                if ((unsigned)(dx + P.h) <= (unsigned)(2 * P.h) && (unsigned)(dy + P.h) <= (unsigned)(2 * P.h)) {
+        } else {
+            if (wave == 1 && t < nbatch) {
+                // ---- set-up(t) from the registers loaded one iteration ago ----
+                const int bs3 = t % 3, bs2 = t & 1;
+                int xi = 0, yi = 0; float xr = 0.f, yr = 0.f;
+                uint32_t xm = 0, ym = 0;
+                if (valid) {
+                    if (P.mode_count) { xi = (int)roundf(ex); yi = (int)roundf(ey); }       // roundFloatCoord :46-49
+                    else {                                                                   // breakFloatCoords :51-57
+                        xi = (int)floorf(ex); yi = (int)floorf(ey);
+                        xr = ex - (float)xi; yr = ey - (float)yi;
+                    }
+                    const int a0 = max(xi - h, tx0) - tx0, a1 = min(xi + h, xhi) - tx0;
+                    const int b0 = max(yi - h, ty0) - ty0, b1 = min(yi + h, yhi) - ty0;
+                    if (a1 >= a0 && b1 >= b0) {
+                        xm = ((2u << a1) - 1u) & ~((1u << a0) - 1u);
+                        ym = ((2u << b1) - 1u) & ~((1u << b0) - 1u);
+                    }
+                }
+                EvEntryInfo ei; ei.xy = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16); ei.xr = xr; ei.yr = yr; ei.sg = esg;
+                einfo[bs2][lane] = ei;
+                uint64_t mine = 0;
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const uint64_t cb = __ballot((xm >> b) & 1u), rb = __ballot((ym >> b) & 1u);
+                    mine = (lane == b) ? cb : mine;
+                    mine = (lane == 8 + b) ? rb : mine;
+                }
+                if (lane < 16) sel[bs3][lane] = mine;
+                if (t + 1 < nbatch) load_batch();       // prefetch batch t+1
+#ifdef EORB_DIAG
+                d_setup += __builtin_readcyclecounter() - d_s;
+#endif
+            }
+            // ---- values(t-1): waves 2.. split the 64 entry bits ----
+            if (wave >= 2 && t >= 1 && t <= nbatch) {
+                const int bs3 = (t - 1) % 3, bs2 = (t - 1) & 1;
+                const uint64_t m = sel[bs3][lx] & sel[bs3][8 + ly];
+                const int lo = ((wave - 2) * 64) / nprod, hi = ((wave - 1) * 64) / nprod;
+                const uint64_t lowmask = (lo == 0) ? 0ull : (~0ull >> (64 - lo));
+                const uint64_t himask = (hi == 64) ? ~0ull : (~0ull >> (64 - hi));
+                uint64_t sub = m & himask & ~lowmask;
+                int rank = __popcll(m & lowmask);
+                float* vb = (float*)(vals[bs2] + lane);
+                while (sub) {
+                    const int e = __ffsll((long long)sub) - 1;
+                    sub &= sub - 1;
+                    const EvEntryInfo ei = einfo[bs2][e];
                     float val;
-                    if (P.mode_count) {
-                        val = 0.001f;
-                    } else {
-                        const float xr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(exr), q));
-                        const float yr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(eyr), q));
-                        const float fx = (float)dx - xr, fy = (float)dy - yr;      // exp_XY2f(i-xRes, j-yRes) :59-65
+#ifdef EORB_EXPERIMENT_NOEXP
+                    if (true) val = 0.001f;
+#else
+                    if (P.mode_count) val = 0.001f;
+#endif
+                    else {
+                        const int dx = px - (int)(int16_t)(ei.xy & 0xffff), dy = py - (int)(int16_t)(ei.xy >> 16);
+                        const float fx = (float)dx - ei.xr, fy = (float)dy - ei.yr;        // exp_XY2f(i-xRes, j-yRes) :59-65
                         const float xx = fx * fx, yy = fy * fy;
                         float dd = xx + yy;
-                        dd = dd / P.two_sig2;
-                        val = dev_expf_nonpos(-dd, tab) / P.norm;
+                        // dd /= 2*sig2: when the divisor is a power of two the product with its (exact) reciprocal is
+                        // the same real number, hence the same rounding
+                        dd = P.div_is_pow2 ? dd * P.inv_two_sig2 : dd / P.two_sig2;
+                        const float ev = dev_expf_nonpos(-dd, tab);
+                        if (P.fast_norm) {
+                            // correctly rounded ev / norm from the correctly rounded reciprocal (Markstein): valid while the
+                            // residual is a normal float; checked exhaustively against IEEE division by tests/test_gpu_math.py
+                            const float q0 = ev * P.rcp_norm;
+                            const float r0 = fmaf(-P.norm, q0, ev);
+                            val = fmaf(r0, P.rcp_norm, q0);
+                        } else val = ev / P.norm;
                     }
-                    float sgn = 1.0f;
-                    if (POL) sgn = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(esg), q));
-                    const float nv = acc + sgn * val;
-                    acc = nv;
-                    vmax = fmaxf(vmax, nv);
-                    vmin = fminf(vmin, nv);
+                    vb[(rank >> 2) * 256 + (rank & 3)] = POL ? ei.sg * val : val;
+                    rank++;
                 }
             }
         }
+#ifdef EORB_DIAG
+        d_work += __builtin_readcyclecounter() - d_s;
+#endif
+        __syncthreads();
     }
+#ifdef EORB_DIAG
+    if (nbatch > 1000 && lane == 0) {
+        const unsigned long long tot = __builtin_readcyclecounter() - d_t0;
+        const int role = wave == 0 ? 0 : (wave == 1 ? 1 : 2);
+        atomicAdd(&g_diag[role * 4 + 0], d_work);
+        atomicAdd(&g_diag[role * 4 + 1], tot);
+        atomicAdd(&g_diag[role * 4 + 2], (unsigned long long)nbatch);
+        atomicAdd(&g_diag[role * 4 + 3], d_setup);
+    }
+#endif
+    if (wave != 0) return;
+    if (!POL && touched) vmax = fmaxf(vmax, acc);
     if (inimg) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = acc;
     else { vmax = -1000000.0f; vmin = 0.0f; }
-    // wave reduce min/max
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
@@ -227,6 +394,22 @@ __global__ __launch_bounds__(64) void ev_gather_kernel(const int* __restrict__ s
         atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
         atomicMax(&minmax_enc[slice * 2 + 1], enc_f32(vmax));
     }
+}
+
+// exhaustive self-check helper: IEEE quotient vs the reciprocal/fma sequence used above
+__global__ void ev_divcheck_kernel(uint32_t lo_bits, uint32_t hi_bits, float norm, float rcp, unsigned long long* bad)
+{
+    unsigned long long local = 0;
+    for (uint64_t u = (uint64_t)lo_bits + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u <= hi_bits;
+         u += (uint64_t)gridDim.x * blockDim.x) {
+        const float ev = __uint_as_float((uint32_t)u);
+        const float q0 = ev * rcp;
+        const float r0 = fmaf(-norm, q0, ev);
+        const float q = fmaf(r0, rcp, q0);
+        const float ref = ev / norm;
+        if (__float_as_uint(q) != __float_as_uint(ref)) local++;
+    }
+    if (local) atomicAdd(bad, local);
 }
 
 __global__ void ev_minmax_init_kernel(uint32_t* mm, int B)
@@ -324,16 +507,36 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
     {
         const float sig2 = sigma * sigma;
         GatherParams G{W, H, h, TX, TY, NT, cap, mode_count, B * NT, 2.0f * sig2,
-                       2.0f * (float)3.1415926535897932384626433832795 * sig2};
+                       2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0};
+        {
+            int ex2 = 0;
+            const float mant = frexpf(G.two_sig2, &ex2);
+            G.div_is_pow2 = (mant == 0.5f) && ex2 > -100 && ex2 < 100;
+            G.inv_two_sig2 = G.div_is_pow2 ? 1.0f / G.two_sig2 : 0.f;
+            G.rcp_norm = (float)(1.0 / (double)G.norm);
+            // the residual ev*2^-24 must stay a normal float: exp(-dd_max) > 1e-27, dd_max = (h+1)^2 / sig2
+            const double ddmax = (double)(h + 1) * (h + 1) / (double)sig2;
+            G.fast_norm = (ddmax < 60.0) && (G.norm < 1e3f) && (G.norm > 1e-3f);
+        }
         const int nb = B * NT;
         const int grid = ((nb + 7) / 8) * 8;
         // the kernel derives `per` from gridDim; pass the padded grid and let surplus blocks exit
         GatherParams G2 = G;
         ProfScope ps(c, "ev_gather");
-        if (pol) ev_gather_kernel<true><<<grid, 64, 0, c->stream>>>(d_slice_c0, G2, (const uint16_t*)c->segoff.p,
-                                                                   (const float*)c->entries.p, d_f32, d_minmax_enc);
-        else ev_gather_kernel<false><<<grid, 64, 0, c->stream>>>(d_slice_c0, G2, (const uint16_t*)c->segoff.p,
-                                                                 (const float*)c->entries.p, d_f32, d_minmax_enc);
+        int maxch = 1;
+        for (int b = 0; b < B; b++) maxch = std::max(maxch, slice_c0[b + 1] - slice_c0[b]);
+        const size_t lds = sizeof(uint32_t) * (size_t)maxch;
+        if (lds > 100 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d chunks per slice exceed the LDS segment table", maxch);
+        if (lds > 16 * 1024) {
+            hipFuncSetAttribute((const void*)ev_gather_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024);
+            hipFuncSetAttribute((const void*)ev_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024);
+        }
+        static const int gthreads = [] { const char* e = getenv("EORB_GATHER_THREADS"); int v = e ? atoi(e) : kGatherThreads;
+                                         return (v >= 192 && v <= 1024 && v % 64 == 0) ? v : kGatherThreads; }();
+        if (pol) ev_gather_kernel<true><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, G2, (const uint16_t*)c->segoff.p,
+                                                                                 (const float*)c->entries.p, d_f32, d_minmax_enc);
+        else ev_gather_kernel<false><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, G2, (const uint16_t*)c->segoff.p,
+                                                                               (const float*)c->entries.p, d_f32, d_minmax_enc);
         EORB_LAUNCH_CHECK(c, "ev_gather_kernel");
     }
     if (normalized && d_u8) {
@@ -343,6 +546,36 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
         EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
     }
     return EORB_OK;
+}
+
+// counts floats in [lo, hi] (positive, by bit pattern) for which the reciprocal/fma quotient differs from IEEE ev / norm
+int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long* bad_out)
+{
+    const float sig2 = sigma * sigma;
+    const float norm = 2.0f * (float)3.1415926535897932384626433832795 * sig2;
+    const float rcp = (float)(1.0 / (double)norm);
+    int rc;
+    if ((rc = ensure(c, c->minmax, 64))) return rc;
+    EORB_HIP(c, hipMemsetAsync(c->minmax.p, 0, 8, c->stream));
+    uint32_t lb, hb; memcpy(&lb, &lo, 4); memcpy(&hb, &hi, 4);
+    ev_divcheck_kernel<<<2048, 256, 0, c->stream>>>(lb, hb, norm, rcp, (unsigned long long*)c->minmax.p);
+    EORB_LAUNCH_CHECK(c, "ev_divcheck_kernel");
+    EORB_HIP(c, hipMemcpyAsync(bad_out, c->minmax.p, 8, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+int ev_diag_read(unsigned long long* out16)
+{
+#ifdef EORB_DIAG
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 16);
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof(z));
+    return 1;
+#else
+    (void)out16; return 0;
+#endif
 }
 
 int ev_decode_minmax(eorb_ctx* c, const uint32_t* d_enc, float* d_out, int B)

@@ -187,6 +187,10 @@ int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int
                           uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                           int32_t* d_matches12, int32_t* d_nmatches);
 
+/* self-check used by tests: number of floats v in [lo, hi] (0 < lo <= hi) for which the reciprocal+fma quotient the
+ * accumulation kernel uses for v / (2*pi*sigma^2) differs from the IEEE-754 quotient (must be 0). */
+int eorb_selfcheck_division(eorb_ctx* ctx, float lo, float hi, float sigma, uint64_t* mismatches);
+
 /* helpers: convert host AoS events to the compact record; device alloc/copy without a HIP binding */
 void  eorb_pack_events(const eorb_event* ev, size_t n, eorb_event16* out);
 void* eorb_dev_alloc(eorb_ctx* ctx, size_t bytes);
