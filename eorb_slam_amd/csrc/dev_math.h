@@ -26,6 +26,8 @@ __device__ __constant__ static const uint64_t kExp2Tab[32] = {
 
 // exp(x) for x <= 0 (the Gaussian stamp only needs the non-positive half-line).
 // tab: the 32-entry table above (constant memory) or an LDS copy of it.
+// CHECK = false: the caller guarantees x > -104 (no underflow test on the hot path).
+template <bool CHECK = true>
 __device__ __forceinline__ float dev_expf_nonpos(float x, const uint64_t* tab)
 {
     const double N = 32.0;
@@ -34,7 +36,7 @@ __device__ __forceinline__ float dev_expf_nonpos(float x, const uint64_t* tab)
     const double C0 = 0x1.c6af84b912394p-5 / N / N / N;
     const double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
     const double C2 = 0x1.62e42ff0c52d6p-1 / N;
-    if (x < -0x1.9fe368p6f) return 0.0f;
+    if (CHECK && x < -0x1.9fe368p6f) return 0.0f;
     double xd = (double)x;
     double z = InvLn2N * xd;
     double kd = z + Shift;

@@ -170,7 +170,9 @@ constexpr int kGatherThreads = EORB_GATHER_THREADS;
 __device__ unsigned long long g_diag[16];
 #endif
 
-template <bool POL>
+// MODE 0: general sigma (IEEE divisions); 1: 2*sig2 a power of two and reciprocal+fma normalisation (sigma = 1, 0.5, 2 ...);
+// 2: count image (ev2im)
+template <bool POL, int MODE>
 __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__ slice_chunk0,   // B+1
                                                                   GatherParams P, const uint16_t* __restrict__ segoff,
                                                                   const float* __restrict__ entries,
@@ -178,7 +180,9 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
 {
     __shared__ uint64_t tab[32];
     __shared__ EvEntryInfo einfo[2][64];
-    __shared__ uint64_t sel[3][16];                 // [0..7] colsel, [8..15] rowsel
+    __shared__ uint2 rinfo[2][64];                  // x: a0 | b0 << 4 | w << 8 | h << 12 (tile-local tap rectangle); y: 65536/h + 1
+    __shared__ uint16_t offs[2][66];                // exclusive prefix of the rectangle sizes; [64] = number of pairs
+    __shared__ uint64_t pm[3][64];                  // per pixel: bit e set = entry e of the batch touches it
     __shared__ float4 vals[2][16 * 64];             // [rank / 4][pixel] . (rank % 4)
     __shared__ int s_nb;
     extern __shared__ uint32_t segs[];              // per chunk of the slice: o0 | o1 << 16 for this tile
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
             // ---- adds(t-2) ----
             if (t >= 2) {
                 const int bs3 = (t - 2) % 3, bs2 = t & 1;
-                const uint64_t m = sel[bs3][lx] & sel[bs3][8 + ly];
+                const uint64_t m = pm[bs3][lane];
                 const int cnt = __popcll(m);
                 int mx = cnt;
 #pragma unroll
@@ -296,8 +300,9 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
                 const int bs3 = t % 3, bs2 = t & 1;
                 int xi = 0, yi = 0; float xr = 0.f, yr = 0.f;
                 uint32_t xm = 0, ym = 0;
+                int ra0 = 0, rb0 = 0, rw = 0, rh = 0;
                 if (valid) {
-                    if (P.mode_count) { xi = (int)roundf(ex); yi = (int)roundf(ey); }       // roundFloatCoord :46-49
+                    if (MODE == 2) { xi = (int)roundf(ex); yi = (int)roundf(ey); }          // roundFloatCoord :46-49
                     else {                                                                   // breakFloatCoords :51-57
                         xi = (int)floorf(ex); yi = (int)floorf(ey);
                         xr = ex - (float)xi; yr = ey - (float)yi;
@@ -307,10 +312,19 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
                     if (a1 >= a0 && b1 >= b0) {
                         xm = ((2u << a1) - 1u) & ~((1u << a0) - 1u);
                         ym = ((2u << b1) - 1u) & ~((1u << b0) - 1u);
+                        ra0 = a0; rb0 = b0; rw = a1 - a0 + 1; rh = b1 - b0 + 1;
                     }
                 }
                 EvEntryInfo ei; ei.xy = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16); ei.xr = xr; ei.yr = yr; ei.sg = esg;
                 einfo[bs2][lane] = ei;
+                rinfo[bs2][lane] = make_uint2((uint32_t)ra0 | ((uint32_t)rb0 << 4) | ((uint32_t)rw << 8) | ((uint32_t)rh << 12),
+                                              rh > 0 ? 65536u / (uint32_t)rh + 1u : 0u);
+                const int np = rw * rh;
+                int incl = np;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+                offs[bs2][lane] = (uint16_t)(incl - np);
+                if (lane == 63) offs[bs2][64] = (uint16_t)incl;
                 uint64_t mine = 0;
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
@@ -318,51 +332,125 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
                     mine = (lane == b) ? cb : mine;
                     mine = (lane == 8 + b) ? rb : mine;
                 }
-                if (lane < 16) sel[bs3][lane] = mine;
+                const uint64_t cs = (uint64_t)__shfl((unsigned long long)mine, lx, 64);
+                const uint64_t rs = (uint64_t)__shfl((unsigned long long)mine, 8 + ly, 64);
+                pm[bs3][lane] = cs & rs;
                 if (t + 1 < nbatch) load_batch();       // prefetch batch t+1
 #ifdef EORB_DIAG
                 d_setup += __builtin_readcyclecounter() - d_s;
 #endif
             }
-            // ---- values(t-1): waves 2.. split the 64 entry bits ----
+            // ---- values(t-1): the (entry, tap) pairs of the batch are dealt evenly to the lanes of waves 2.. ----
             if (wave >= 2 && t >= 1 && t <= nbatch) {
                 const int bs3 = (t - 1) % 3, bs2 = (t - 1) & 1;
-                const uint64_t m = sel[bs3][lx] & sel[bs3][8 + ly];
-                const int lo = ((wave - 2) * 64) / nprod, hi = ((wave - 1) * 64) / nprod;
-                const uint64_t lowmask = (lo == 0) ? 0ull : (~0ull >> (64 - lo));
-                const uint64_t himask = (hi == 64) ? ~0ull : (~0ull >> (64 - hi));
-                uint64_t sub = m & himask & ~lowmask;
-                int rank = __popcll(m & lowmask);
-                float* vb = (float*)(vals[bs2] + lane);
-                while (sub) {
-                    const int e = __ffsll((long long)sub) - 1;
-                    sub &= sub - 1;
-                    const EvEntryInfo ei = einfo[bs2][e];
-                    float val;
-#ifdef EORB_EXPERIMENT_NOEXP
-                    if (true) val = 0.001f;
-#else
-                    if (P.mode_count) val = 0.001f;
-#endif
-                    else {
-                        const int dx = px - (int)(int16_t)(ei.xy & 0xffff), dy = py - (int)(int16_t)(ei.xy >> 16);
-                        const float fx = (float)dx - ei.xr, fy = (float)dy - ei.yr;        // exp_XY2f(i-xRes, j-yRes) :59-65
-                        const float xx = fx * fx, yy = fy * fy;
-                        float dd = xx + yy;
-                        // dd /= 2*sig2: when the divisor is a power of two the product with its (exact) reciprocal is
-                        // the same real number, hence the same rounding
-                        dd = P.div_is_pow2 ? dd * P.inv_two_sig2 : dd / P.two_sig2;
-                        const float ev = dev_expf_nonpos(-dd, tab);
-                        if (P.fast_norm) {
-                            // correctly rounded ev / norm from the correctly rounded reciprocal (Markstein): valid while the
-                            // residual is a normal float; checked exhaustively against IEEE division by tests/test_gpu_math.py
-                            const float q0 = ev * P.rcp_norm;
-                            const float r0 = fmaf(-P.norm, q0, ev);
-                            val = fmaf(r0, P.rcp_norm, q0);
-                        } else val = ev / P.norm;
+                const int T = offs[bs2][64];
+                const int G = nprod * 64, g = (wave - 2) * 64 + lane;
+                const int K = (T + G - 1) / G;
+                const int p0 = g * K, p1 = min(p0 + K, T);
+                float* vbase = (float*)vals[bs2];
+                if (p0 < p1) {
+                    // owner of the first pair: last e with offs[e] <= p0 (empty entries share an offset with their successor)
+                    int e = 0;
+                    {
+                        int lo = 0, hi = 63;
+#pragma unroll
+                        for (int it = 0; it < 6; it++) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if ((int)offs[bs2][mid] <= p0) lo = mid; else hi = mid - 1;
+                        }
+                        e = lo;
                     }
-                    vb[(rank >> 2) * 256 + (rank & 3)] = POL ? ei.sg * val : val;
-                    rank++;
+                    int ebeg = offs[bs2][e], eend = offs[bs2][e + 1];
+                    EvEntryInfo cei = einfo[bs2][e];                     // current entry, re-read only when it changes
+                    uint2 cri = rinfo[bs2][e];
+                    constexpr int U = 4;                                // taps in flight per lane
+                    for (int k0 = p0; k0 < p1; k0 += U) {
+                        EvEntryInfo ei[U]; int pix[U], rank[U], ppx[U], ppy[U]; bool on[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const int p = k0 + u;
+                            on[u] = p < p1;
+                            if (on[u]) {
+                                if (p >= eend) {
+                                    do { e++; ebeg = eend; eend = offs[bs2][e + 1]; } while (p >= eend);
+                                    cei = einfo[bs2][e]; cri = rinfo[bs2][e];
+                                }
+                                const uint2 ri = cri;
+                                const int r = p - ebeg;
+                                const int rhh = (int)((ri.x >> 12) & 15u);
+                                const int ii = (int)(((uint32_t)r * ri.y) >> 16);          // r / h  (r < 64, h <= 8)
+                                const int jj = r - ii * rhh;
+                                const int qx = (int)(ri.x & 15u) + ii, qy = (int)((ri.x >> 4) & 15u) + jj;
+                                pix[u] = qy * 8 + qx; ppx[u] = tx0 + qx; ppy[u] = ty0 + qy;
+                                ei[u] = cei;
+                                const uint64_t mk = pm[bs3][pix[u]];
+                                rank[u] = __popcll(mk & ((1ull << e) - 1ull));
+                            } else { pix[u] = 0; rank[u] = 0; ppx[u] = 0; ppy[u] = 0; ei[u] = EvEntryInfo{0u, 0.f, 0.f, 1.f}; }
+                        }
+                        float v[U];
+                        if (MODE == 1) {
+                            // exp_XY2f (:59-65) for four taps, written stage by stage so the dependent f64 chains interleave.
+                            // dd /= 2*sig2 with a power-of-two divisor == product with its exact reciprocal (same real number,
+                            // same rounding); ev / norm = correctly rounded quotient from the correctly rounded reciprocal
+                            // (Markstein), valid while the residual is a normal float: the host selects MODE 1 only when
+                            // exp(-dd) > 1e-27 for every tap; proven against IEEE division by tests/test_gpu_math.py.
+                            float nd[U]; double z[U], kd[U], r[U], sc[U]; uint64_t ki[U];
+                            const double N = 32.0, InvLn2N = 0x1.71547652b82fep+0 * N, Shift = 0x1.8p+52;
+                            const double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                const int dx = ppx[u] - (int)(int16_t)(ei[u].xy & 0xffff), dy = ppy[u] - (int)(int16_t)(ei[u].xy >> 16);
+                                const float fx = (float)dx - ei[u].xr, fy = (float)dy - ei[u].yr;
+                                const float xx = fx * fx, yy = fy * fy;
+                                float dd = xx + yy;
+                                dd = dd * P.inv_two_sig2;
+                                nd[u] = -dd;
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; u++) { z[u] = InvLn2N * (double)nd[u]; kd[u] = z[u] + Shift; }
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                ki[u] = (uint64_t)__double_as_longlong(kd[u]);
+                                uint64_t tt = tab[ki[u] & 31];
+                                tt += ki[u] << 47;
+                                sc[u] = __longlong_as_double((long long)tt);
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; u++) { kd[u] = kd[u] - Shift; r[u] = z[u] - kd[u]; }
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                const double zz = C0 * r[u] + C1;
+                                const double r2 = r[u] * r[u];
+                                double y = C2 * r[u] + 1.0;
+                                y = zz * r2 + y;
+                                y = y * sc[u];
+                                const float ev = (float)y;
+                                const float q0 = ev * P.rcp_norm;
+                                const float r0 = fmaf(-P.norm, q0, ev);
+                                v[u] = fmaf(r0, P.rcp_norm, q0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+#ifdef EORB_EXPERIMENT_NOEXP
+                                v[u] = 0.001f;
+#else
+                                if (MODE == 2) v[u] = 0.001f;
+                                else {
+                                    const int dx = ppx[u] - (int)(int16_t)(ei[u].xy & 0xffff), dy = ppy[u] - (int)(int16_t)(ei[u].xy >> 16);
+                                    const float fx = (float)dx - ei[u].xr, fy = (float)dy - ei[u].yr;   // exp_XY2f(i-xRes, j-yRes) :59-65
+                                    const float xx = fx * fx, yy = fy * fy;
+                                    float dd = xx + yy;
+                                    dd = dd / P.two_sig2;
+                                    v[u] = dev_expf_nonpos<true>(-dd, tab) / P.norm;
+                                }
+#endif
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++)
+                            if (on[u]) vbase[((rank[u] >> 2) * 64 + pix[u]) * 4 + (rank[u] & 3)] = POL ? ei[u].sg * v[u] : v[u];
+                    }
                 }
             }
         }
@@ -526,17 +614,16 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
         int maxch = 1;
         for (int b = 0; b < B; b++) maxch = std::max(maxch, slice_c0[b + 1] - slice_c0[b]);
         const size_t lds = sizeof(uint32_t) * (size_t)maxch;
-        if (lds > 100 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d chunks per slice exceed the LDS segment table", maxch);
-        if (lds > 16 * 1024) {
-            hipFuncSetAttribute((const void*)ev_gather_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024);
-            hipFuncSetAttribute((const void*)ev_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024);
-        }
+        if (lds > 16 * 1024)
+            return set_err(c, EORB_E_CAPACITY, "ev_accumulate: more than %d chunks (%d events) per slice", 4096, 4096 * kChunk);
         static const int gthreads = [] { const char* e = getenv("EORB_GATHER_THREADS"); int v = e ? atoi(e) : kGatherThreads;
                                          return (v >= 192 && v <= 1024 && v % 64 == 0) ? v : kGatherThreads; }();
-        if (pol) ev_gather_kernel<true><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, G2, (const uint16_t*)c->segoff.p,
-                                                                                 (const float*)c->entries.p, d_f32, d_minmax_enc);
-        else ev_gather_kernel<false><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, G2, (const uint16_t*)c->segoff.p,
-                                                                               (const float*)c->entries.p, d_f32, d_minmax_enc);
+        const int mode = mode_count ? 2 : ((G2.div_is_pow2 && G2.fast_norm) ? 1 : 0);
+        const uint16_t* so = (const uint16_t*)c->segoff.p; const float* en = (const float*)c->entries.p;
+#define LAUNCH_G(PP, MM) ev_gather_kernel<PP, MM><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, G2, so, en, d_f32, d_minmax_enc)
+        if (pol) { if (mode == 2) LAUNCH_G(true, 2); else if (mode == 1) LAUNCH_G(true, 1); else LAUNCH_G(true, 0); }
+        else { if (mode == 2) LAUNCH_G(false, 2); else if (mode == 1) LAUNCH_G(false, 1); else LAUNCH_G(false, 0); }
+#undef LAUNCH_G
         EORB_LAUNCH_CHECK(c, "ev_gather_kernel");
     }
     if (normalized && d_u8) {
