@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="time-slices per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="time-slices per step per GPU")
     ap.add_argument("--events", type=int, default=1000000, help="events per slice")
     ap.add_argument("--cpu-slices", type=int, default=16, help="slices timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
@@ -63,7 +63,7 @@ def main():
     W, H, B, NEV = 240, 180, a.batch, a.events
     orb = dict(nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0, edgeTh=19)
     # ---- synthetic input: B independent slices per rank (seeded), packed to the 16 B HBM record ----
-    slices = [synth.shapes_events(NEV, W, H, seed=2 + 1000 * rank + b, motion=0.5) for b in range(B)]
+    slices = [synth.shapes_events(NEV, W, H, seed=2 + 1000 * rank + b, motion=0.5, undistort=True) for b in range(B)]
     ev16 = np.concatenate([frontend.pack_events(s) for s in slices])
     offsets = np.arange(B + 1, dtype=np.int64) * NEV
 
@@ -124,8 +124,8 @@ def main():
             "metric": METRIC, "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: synthetic %d events/slice on %dx%d (shapes generator, "
-                                   "integer DAVIS pixels), ev2im_gauss sigma=1 -> ORB-1000 (1.2, 4 levels, FAST 10/0, "
+            "config": {"workload": "BASELINE.json configs[1]: synthetic %d events/slice on %dx%d (shapes generator, DAVIS "
+                                   "pixels LUT-undistorted with the EvETHZ intrinsics like the reference loader), ev2im_gauss sigma=1 -> ORB-1000 (1.2, 4 levels, FAST 10/0, "
                                    "edge 19) -> SearchForInitialization vs previous slice" % (NEV, W, H),
                        "slices_per_step_per_gpu": B, "events_per_slice": NEV, "image": [W, H],
                        "parallelism": "1 process/GPU, independent slices, RCCL gather of keypoints" if world > 1 else "1 GPU",
