@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 
 namespace eorb {
 
@@ -23,6 +24,15 @@ int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint
                         int M, const uint8_t* in_view, const float4* mp_f4 /* projX, projY, viewCos, levelScale */,
                         const int32_t* level, const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb,
                         eorb_grid_bounds gb, int32_t* frame_mp, float th, float nnratio, int32_t* nmatches);
+
+int orb_pyramid_blur_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride);
+int orb_tracked_dev(eorb_ctx* c, eorb_keypoint* d_kps, int n, int mode, const uint8_t* d_ref, uint8_t* d_desc, uint8_t* d_oob);
+int search_bow_dev(eorb_ctx* c, const eorb_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
+                   const uint32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx, int kf_nn,
+                   const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc, const uint32_t* f_nodes, const int32_t* f_off,
+                   const int32_t* f_idx, int f_nn, int32_t* match_f, int8_t* bin_f, int32_t* histo, int32_t* nmatches,
+                   float nnratio, int checkOri);
+int sort_response_dev(eorb_ctx* c, const eorb_keypoint* d_kps, int n, int32_t* d_perm);
 
 int set_err(eorb_ctx* c, int code, const char* fmt, ...)
 {
@@ -324,6 +334,51 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     return EORB_OK;
 }
 
+static int tracked_common(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, eorb_keypoint* kps_io, const eorb_keypoint* kps_in,
+                          int n, int mode, const uint8_t* ref, uint8_t* desc, uint8_t* oob)
+{
+    if (!c) return EORB_E_ARG;
+    if (!img || W <= 0 || H <= 0) return EORB_E_EMPTY;                 // trackedImage.empty() -> return (:1270, :1319)
+    OrbState& o = c->orb;
+    if (!o.configured) return set_err(c, EORB_E_NOTCONF, "tracked descriptors: not configured");
+    if (W != o.W || H != o.H || stride < W || n < 0) return set_err(c, EORB_E_ARG, "tracked descriptors: bad image/arguments");
+    if (n == 0) return EORB_OK;
+    hipSetDevice(c->device);
+    int rc;
+    if ((rc = ensure(c, c->in_img, (size_t)W * H))) return rc;
+    if ((rc = ensure(c, c->out_kp, sizeof(eorb_keypoint) * (size_t)std::max(n, o.max_out)))) return rc;
+    if ((rc = ensure(c, c->m_a, 32 * (size_t)std::max(n, o.max_out)))) return rc;
+    if ((rc = ensure(c, c->m_b, (size_t)std::max(n, o.max_out)))) return rc;
+    if ((rc = ensure(c, c->m_c, 32 * (size_t)n))) return rc;
+    EORB_HIP(c, hipMemcpy2DAsync(c->in_img.p, W, img, stride, W, H, hipMemcpyHostToDevice, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(c->out_kp.p, kps_in, sizeof(eorb_keypoint) * n, hipMemcpyHostToDevice, c->stream));
+    if (ref) EORB_HIP(c, hipMemcpyAsync(c->m_c.p, ref, 32 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = orb_pyramid_blur_dev(c, (const uint8_t*)c->in_img.p, W))) return rc;
+    if ((rc = orb_tracked_dev(c, (eorb_keypoint*)c->out_kp.p, n, mode, (const uint8_t*)c->m_c.p, (uint8_t*)c->m_a.p, (uint8_t*)c->m_b.p))) return rc;
+    if (mode == 0) {
+        EORB_HIP(c, hipMemcpyAsync(desc, c->m_a.p, 32 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        if (oob) EORB_HIP(c, hipMemcpyAsync(oob, c->m_b.p, n, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        EORB_HIP(c, hipMemcpyAsync(kps_io, c->out_kp.p, sizeof(eorb_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+int eorb_orb_tracked_descriptors(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, const eorb_keypoint* kps, int n,
+                                 uint8_t* desc, uint8_t* oob)
+{
+    if (c && (!kps || !desc) && n > 0) return set_err(c, EORB_E_ARG, "tracked descriptors: null buffers");
+    return tracked_common(c, img, W, H, stride, nullptr, kps, n, 0, nullptr, desc, oob);
+}
+
+int eorb_orb_assign_level_by_best_desc(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, const uint8_t* ref_desc,
+                                       eorb_keypoint* kps, int n)
+{
+    if (c && (!kps || !ref_desc) && n > 0) return set_err(c, EORB_E_ARG, "assign level: null buffers");
+    return tracked_common(c, img, W, H, stride, kps, kps, n, 1, ref_desc, nullptr, nullptr);
+}
+
 // ---- matchers, host buffers ------------------------------------------------------------------------------
 static int up(eorb_ctx* c, DevBuf& b, const void* h, size_t bytes)
 {
@@ -459,6 +514,85 @@ int eorb_search_by_projection_map(eorb_ctx* c,
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     if (nmatches) *nmatches = nm;
     return EORB_OK;
+}
+
+int eorb_search_by_bow(eorb_ctx* c,
+        const eorb_keypoint* kf_kps, int n_kf, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
+        const uint32_t* kf_nodes, const int32_t* kf_node_off, const int32_t* kf_idx, int kf_nn,
+        const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc,
+        const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
+        int32_t* match_f, float nnratio, int checkOri, int* nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (n_kf < 0 || n_f < 0 || kf_nn < 0 || f_nn < 0 || !match_f) return set_err(c, EORB_E_ARG, "search_by_bow: bad arguments");
+    hipSetDevice(c->device);
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n_f; i++) match_f[i] = -1;
+    if (n_kf == 0 || n_f == 0 || kf_nn == 0 || f_nn == 0) return EORB_OK;
+    const int nki = kf_node_off[kf_nn], nfi = f_node_off[f_nn];
+    for (int i = 0; i < nki; i++) if (kf_idx[i] < 0 || kf_idx[i] >= n_kf) return set_err(c, EORB_E_ARG, "search_by_bow: KeyFrame index out of range");
+    for (int i = 0; i < nfi; i++) if (f_idx[i] < 0 || f_idx[i] >= n_f) return set_err(c, EORB_E_ARG, "search_by_bow: frame index out of range");
+    int rc;
+    if ((rc = up(c, c->m_a, kf_kps, sizeof(eorb_keypoint) * n_kf))) return rc;
+    if ((rc = up(c, c->m_b, kf_desc, 32 * (size_t)n_kf))) return rc;
+    if ((rc = up(c, c->m_c, f_kps, sizeof(eorb_keypoint) * n_f))) return rc;
+    if ((rc = up(c, c->m_d, f_desc, 32 * (size_t)n_f))) return rc;
+    if ((rc = up(c, c->m_e, kf_has_mp, n_kf))) return rc;
+    // CSR blocks: [kf_nodes | kf_off | kf_idx] and [f_nodes | f_off | f_idx]
+    std::vector<int32_t> blk;
+    blk.insert(blk.end(), (const int32_t*)kf_nodes, (const int32_t*)kf_nodes + kf_nn);
+    blk.insert(blk.end(), kf_node_off, kf_node_off + kf_nn + 1);
+    blk.insert(blk.end(), kf_idx, kf_idx + nki);
+    const size_t fbase = blk.size();
+    blk.insert(blk.end(), (const int32_t*)f_nodes, (const int32_t*)f_nodes + f_nn);
+    blk.insert(blk.end(), f_node_off, f_node_off + f_nn + 1);
+    blk.insert(blk.end(), f_idx, f_idx + nfi);
+    if ((rc = up(c, c->m_f, blk.data(), sizeof(int32_t) * blk.size()))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * n_f))) return rc;
+    if ((rc = ensure(c, c->m_g, (size_t)n_f))) return rc;
+    if ((rc = ensure(c, c->m_j, sizeof(int32_t) * 40))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    const int32_t* B = (const int32_t*)c->m_f.p;
+    int32_t* hist = (int32_t*)c->m_j.p;
+    rc = search_bow_dev(c, (const eorb_keypoint*)c->m_a.p, (const uint8_t*)c->m_b.p, (const uint8_t*)c->m_e.p,
+                        (const uint32_t*)B, B + kf_nn, B + kf_nn + kf_nn + 1, kf_nn,
+                        (const eorb_keypoint*)c->m_c.p, n_f, (const uint8_t*)c->m_d.p,
+                        (const uint32_t*)(B + fbase), B + fbase + f_nn, B + fbase + f_nn + f_nn + 1, f_nn,
+                        (int32_t*)c->m_h.p, (int8_t*)c->m_g.p, hist, hist + 32, nnratio, checkOri);
+    if (rc) return rc;
+    int nm = 0;
+    EORB_HIP(c, hipMemcpyAsync(match_f, c->m_h.p, sizeof(int32_t) * n_f, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(&nm, hist + 32, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (nmatches) *nmatches = nm;
+    return EORB_OK;
+}
+
+int eorb_sort_by_response(eorb_ctx* c, const eorb_keypoint* kps, int n, int32_t* perm)
+{
+    if (!c) return EORB_E_ARG;
+    if (n < 0 || (n > 0 && (!kps || !perm))) return set_err(c, EORB_E_ARG, "sort_by_response: bad arguments");
+    if (n == 0) return EORB_OK;
+    hipSetDevice(c->device);
+    int rc;
+    if ((rc = up(c, c->m_a, kps, sizeof(eorb_keypoint) * n))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * n))) return rc;
+    if ((rc = sort_response_dev(c, (const eorb_keypoint*)c->m_a.p, n, (int32_t*)c->m_h.p))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(perm, c->m_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+void eorb_resolve_num_mixed(int nDetectedORB, int nDetectedAK, int nDesired, int nDesiredAK, int* nORB, int* nAK)
+{   // MixedFrame::resolveNumMixedPts (src/MixedFrame.cpp:281-317): pure count bookkeeping of the container
+    const int nDetected = nDetectedORB + nDetectedAK;
+    const int nDesiredORB = nDesired - nDesiredAK;
+    if (nDetected > nDesired) {
+        const int nDiff = nDetected - nDesired;
+        if (nDetectedORB > nDesiredORB && nDetectedAK > nDesiredAK) { *nORB = nDesiredORB; *nAK = nDesiredAK; }
+        else if (nDetectedORB > nDesiredORB) { *nORB = nDetectedORB - nDiff; *nAK = std::min(nDetectedAK, nDesiredAK); }
+        else if (nDetectedAK > nDesiredAK) { *nORB = std::min(nDetectedORB, nDesiredORB); *nAK = nDetectedAK - nDiff; }
+    } else { *nORB = nDetectedORB; *nAK = nDetectedAK; }
 }
 
 int eorb_hamming_bf_knn2(eorb_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2, int32_t* dist2)

@@ -366,28 +366,54 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
                     constexpr int U = 4;                                // taps in flight per lane
                     for (int k0 = p0; k0 < p1; k0 += U) {
                         EvEntryInfo ei[U]; int pix[U], rank[U], ppx[U], ppy[U]; bool on[U];
+                        if (k0 + U <= p1 && k0 + U <= eend) {
+                            // common case: the U pairs belong to the current entry -> straight-line code, no LDS walk
+                            const int rhh = (int)((cri.x >> 12) & 15u);
+                            const int r0 = k0 - ebeg;
+                            int ii = (int)(((uint32_t)r0 * cri.y) >> 16);                  // r / h  (r < 64, h <= 8)
+                            int jj = r0 - ii * rhh;
+                            const int ax = (int)(cri.x & 15u), by = (int)((cri.x >> 4) & 15u);
+                            const uint64_t below = (1ull << e) - 1ull;
 #pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            const int p = k0 + u;
-                            on[u] = p < p1;
-                            if (on[u]) {
-                                if (p >= eend) {
-                                    do { e++; ebeg = eend; eend = offs[bs2][e + 1]; } while (p >= eend);
-                                    cei = einfo[bs2][e]; cri = rinfo[bs2][e];
-                                }
-                                const uint2 ri = cri;
-                                const int r = p - ebeg;
-                                const int rhh = (int)((ri.x >> 12) & 15u);
-                                const int ii = (int)(((uint32_t)r * ri.y) >> 16);          // r / h  (r < 64, h <= 8)
-                                const int jj = r - ii * rhh;
-                                const int qx = (int)(ri.x & 15u) + ii, qy = (int)((ri.x >> 4) & 15u) + jj;
+                            for (int u = 0; u < U; u++) {
+                                const int qx = ax + ii, qy = by + jj;
                                 pix[u] = qy * 8 + qx; ppx[u] = tx0 + qx; ppy[u] = ty0 + qy;
-                                ei[u] = cei;
-                                const uint64_t mk = pm[bs3][pix[u]];
-                                rank[u] = __popcll(mk & ((1ull << e) - 1ull));
-                            } else { pix[u] = 0; rank[u] = 0; ppx[u] = 0; ppy[u] = 0; ei[u] = EvEntryInfo{0u, 0.f, 0.f, 1.f}; }
+                                ei[u] = cei; on[u] = true;
+#ifdef EORB_EXPERIMENT_NOPM
+                                rank[u] = (k0 - p0 + u) & 63;
+#else
+                                rank[u] = __popcll(pm[bs3][pix[u]] & below);
+#endif
+                                jj++;
+                                if (jj == rhh) { jj = 0; ii++; }
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                const int p = k0 + u;
+                                on[u] = p < p1;
+                                if (on[u]) {
+                                    if (p >= eend) {
+                                        do { e++; ebeg = eend; eend = offs[bs2][e + 1]; } while (p >= eend);
+                                        cei = einfo[bs2][e]; cri = rinfo[bs2][e];
+                                    }
+                                    const uint2 ri = cri;
+                                    const int r = p - ebeg;
+                                    const int rhh = (int)((ri.x >> 12) & 15u);
+                                    const int ii = (int)(((uint32_t)r * ri.y) >> 16);      // r / h  (r < 64, h <= 8)
+                                    const int jj = r - ii * rhh;
+                                    const int qx = (int)(ri.x & 15u) + ii, qy = (int)((ri.x >> 4) & 15u) + jj;
+                                    pix[u] = qy * 8 + qx; ppx[u] = tx0 + qx; ppy[u] = ty0 + qy;
+                                    ei[u] = cei;
+                                    const uint64_t mk = pm[bs3][pix[u]];
+                                    rank[u] = __popcll(mk & ((1ull << e) - 1ull));
+                                } else { pix[u] = 0; rank[u] = 0; ppx[u] = 0; ppy[u] = 0; ei[u] = EvEntryInfo{0u, 0.f, 0.f, 1.f}; }
+                            }
                         }
                         float v[U];
+#ifdef EORB_EXPERIMENT_NOEXP
+                        if (true) { for (int u = 0; u < U; u++) v[u] = 0.001f; } else
+#endif
                         if (MODE == 1) {
                             // exp_XY2f (:59-65) for four taps, written stage by stage so the dependent f64 chains interleave.
                             // dd /= 2*sig2 with a power-of-two divisor == product with its exact reciprocal (same real number,

@@ -17,6 +17,7 @@
 // One workgroup per frame pair; batches of pairs run concurrently.
 #include "eorb_ctx.h"
 #include "dev_math.h"
+#include <algorithm>
 
 namespace eorb {
 
@@ -556,6 +557,146 @@ int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint
     A.g = GridB{gb.minX, gb.minY, gb.invW, gb.invH};
     A.slot_mp = frame_mp; A.th = th; A.nnratio = nnratio; A.mode = 0; A.checkOri = 0; A.nmatches = nmatches;
     return launch_proj<true>(c, A, "search_proj_map");
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:276-478), mono branch.  A frame feature belongs to
+// exactly one vocabulary node, so the greedy state (vpMapPointMatches) never crosses nodes: shared nodes are matched
+// concurrently (one wavefront each), KeyFrame features of a node sequentially, the node's frame features over the lanes.
+struct BowArgs {
+    const eorb_keypoint* kf_kps; const uint8_t* kf_desc; const uint8_t* kf_has_mp;
+    const uint32_t* kf_nodes; const int32_t* kf_off; const int32_t* kf_idx; int kf_nn;
+    const eorb_keypoint* f_kps; int n_f; const uint8_t* f_desc;
+    const uint32_t* f_nodes; const int32_t* f_off; const int32_t* f_idx; int f_nn;
+    int32_t* match_f; int8_t* bin_f; int32_t* histo; int32_t* nmatches;
+    float nnratio; int checkOri;
+};
+
+__global__ __launch_bounds__(256) void search_bow_kernel(BowArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int a = gw; a < A.kf_nn; a += nw) {
+        // the frame node with the same id (both lists ascending): binary search = the reference's lower_bound walk
+        const uint32_t node = A.kf_nodes[a];
+        int lo = 0, hi = A.f_nn;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (A.f_nodes[mid] < node) lo = mid + 1; else hi = mid; }
+        if (lo >= A.f_nn || A.f_nodes[lo] != node) continue;
+        const int f0 = A.f_off[lo], f1 = A.f_off[lo + 1];
+        for (int iKF = A.kf_off[a]; iKF < A.kf_off[a + 1]; iKF++) {
+            const int realIdxKF = A.kf_idx[iKF];
+            if (!A.kf_has_mp[realIdxKF]) continue;
+            const uint64_t* dq = (const uint64_t*)(A.kf_desc + (size_t)realIdxKF * 32);
+            const uint64_t q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3];
+            // candidate order = vector order (iF): key = dist << 32 | iF keeps the reference's first-wins tie rule
+            uint64_t k0 = ~0ull, k1 = ~0ull;
+            for (int iF = f0 + lane; iF < f1; iF += 64) {
+                const int realIdxF = A.f_idx[iF];
+                if (__hip_atomic_load(&A.match_f[realIdxF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;   // vpMapPointMatches[realIdxF]
+                const uint64_t* tp = (const uint64_t*)(A.f_desc + (size_t)realIdxF * 32);
+                const int dist = __popcll(q0 ^ tp[0]) + __popcll(q1 ^ tp[1]) + __popcll(q2 ^ tp[2]) + __popcll(q3 ^ tp[3]);
+                const uint64_t key = ((uint64_t)dist << 32) | (uint32_t)iF;
+                if (key < k0) { k1 = k0; k0 = key; }
+                else if (key < k1) k1 = key;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
+                const uint64_t l0 = k0 < o0 ? k0 : o0, h0 = k0 < o0 ? o0 : k0, s1 = k1 < o1 ? k1 : o1;
+                k0 = l0; k1 = h0 < s1 ? h0 : s1;
+            }
+            if (k0 != ~0ull && (int)(k0 >> 32) < 256) {
+                const int bestDist1 = (int)(k0 >> 32);
+                const int bestDist2 = (k1 != ~0ull && (int)(k1 >> 32) < 256) ? (int)(k1 >> 32) : 256;
+                if (bestDist1 <= TH_LOW && (float)bestDist1 < A.nnratio * (float)bestDist2) {
+                    if (lane == 0) {
+                        const int bestIdxF = A.f_idx[(int)(k0 & 0xffffffffu)];
+                        __hip_atomic_store(&A.match_f[bestIdxF], realIdxKF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicAdd(A.nmatches, 1);
+                        if (A.checkOri) {
+                            const int bin = rot_bin(A.kf_kps[realIdxKF].angle, A.f_kps[bestIdxF].angle);
+                            A.bin_f[bestIdxF] = (int8_t)bin;
+                            atomicAdd(&A.histo[bin], 1);
+                        }
+                    }
+                    __threadfence();          // the next KeyFrame feature of this node must see match_f
+                }
+            }
+        }
+    }
+}
+
+__global__ void search_bow_finish_kernel(BowArgs A)
+{
+    __shared__ int keep;
+    if (threadIdx.x == 0) {
+        int h[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) h[i] = A.histo[i];
+        int i1, i2, i3;
+        three_maxima(h, HISTO_LENGTH, i1, i2, i3);
+        int k = 0;
+        if (i1 >= 0) k |= 1 << i1; if (i2 >= 0) k |= 1 << i2; if (i3 >= 0) k |= 1 << i3;
+        keep = k;
+    }
+    __syncthreads();
+    int dec = 0;
+    for (int i = threadIdx.x; i < A.n_f; i += blockDim.x) {
+        const int b = A.bin_f[i];
+        if (b >= 0 && !(keep & (1 << b)) && A.match_f[i] >= 0) { A.match_f[i] = -1; dec++; }
+    }
+    if (dec) atomicSub(A.nmatches, dec);
+}
+
+__global__ void bow_init_kernel(int32_t* match_f, int8_t* bin_f, int n_f, int32_t* histo, int32_t* nmatches)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_f) { match_f[i] = -1; bin_f[i] = -1; }
+    if (i < 32) histo[i] = 0;
+    if (i == 0) *nmatches = 0;
+}
+
+int search_bow_dev(eorb_ctx* c, const eorb_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
+                   const uint32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx, int kf_nn,
+                   const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc, const uint32_t* f_nodes, const int32_t* f_off,
+                   const int32_t* f_idx, int f_nn, int32_t* match_f, int8_t* bin_f, int32_t* histo, int32_t* nmatches,
+                   float nnratio, int checkOri)
+{
+    BowArgs A{kf_kps, kf_desc, kf_has_mp, kf_nodes, kf_off, kf_idx, kf_nn, f_kps, n_f, f_desc, f_nodes, f_off, f_idx, f_nn,
+              match_f, bin_f, histo, nmatches, nnratio, checkOri};
+    ProfScope ps(c, "search_bow");
+    bow_init_kernel<<<(std::max(n_f, 32) + 255) / 256, 256, 0, c->stream>>>(match_f, bin_f, n_f, histo, nmatches);
+    if (kf_nn > 0 && f_nn > 0) {
+        const int blocks = std::min((kf_nn + 3) / 4, 1024);
+        search_bow_kernel<<<blocks, 256, 0, c->stream>>>(A);
+        if (checkOri) search_bow_finish_kernel<<<1, 256, 0, c->stream>>>(A);
+    }
+    EORB_LAUNCH_CHECK(c, "search_bow kernels");
+    return EORB_OK;
+}
+
+// MixedFrame::sortFeaturesResponse (MixedFrame.cpp:211-225): stable descending order by response.
+// rank(i) = #{j : r_j > r_i} + #{j < i : r_j == r_i}; perm[rank(i)] = i.  n is a few thousand at most.
+__global__ void sort_response_kernel(const eorb_keypoint* __restrict__ kps, int n, int32_t* __restrict__ perm)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r = kps[i].response;
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+        const float q = kps[j].response;
+        rank += (q > r) || (q == r && j < i);
+    }
+    perm[rank] = i;
+}
+
+int sort_response_dev(eorb_ctx* c, const eorb_keypoint* d_kps, int n, int32_t* d_perm)
+{
+    if (n <= 0) return EORB_OK;
+    ProfScope ps(c, "sort_response");
+    sort_response_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d_kps, n, d_perm);
+    EORB_LAUNCH_CHECK(c, "sort_response_kernel");
+    return EORB_OK;
 }
 
 int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2)

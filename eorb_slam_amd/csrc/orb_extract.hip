@@ -575,33 +575,19 @@ __global__ __launch_bounds__(256) void blur_kernel(const DevGeom* __restrict__ G
 
 // ---------------------------------------------------------------------------------------------------
 // rBRIEF: 32 lanes per keypoint, lane b computes descriptor byte b (16 taps)
-__global__ __launch_bounds__(256) void brief_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ blur,
-                                                    const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_cnt,
-                                                    const float* __restrict__ kp_angle, uint8_t* __restrict__ lvl_desc,
-                                                    uint8_t* __restrict__ lvl_oob)
+// computeOrbDescriptor (:108-157) for one descriptor byte; img = blurred level (w x h, step = w, no border)
+__device__ __forceinline__ int brief_byte(const uint8_t* __restrict__ img, int w, int h, int cx, int cy, float angle_deg, int b, int& oob)
 {
-    const int slice = blockIdx.y;
-    const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int b = threadIdx.x & 31;
-    if (gid >= G->kp_total) return;
-    int level = 0;
-    while (level + 1 < G->nlevels && gid >= G->lv[level + 1].kp_off) level++;
-    const LevelGeom& L = G->lv[level];
-    const int i = gid - L.kp_off;
-    if (i >= lvl_cnt[slice * G->nlevels + level]) return;
-    const uint32_t p = lvl_kp[(size_t)slice * G->kp_total + gid];
-    const int cx = (int)(p & 0xfff) + L.minBX, cy = (int)((p >> 12) & 0xfff) + L.minBY;
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float angle = kp_angle[(size_t)slice * G->kp_total + gid] * factorPI;
+    const float angle = angle_deg * factorPI;
     float sb, ca;
     dev_sincosf(angle, &sb, &ca);
     const float a = ca, bb = sb;
-    const uint8_t* img = blur + (size_t)slice * G->roi_bytes + L.roi_off;
-    const int step = L.w;
+    const int step = w;
     const int base = cy * step + cx;
-    const int total = L.w * L.h;
+    const int total = w * h;
     const signed char* pat = c_pattern + b * 32;
-    int val = 0; int oob = 0;
+    int val = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         int t[2];
@@ -618,12 +604,77 @@ __global__ __launch_bounds__(256) void brief_kernel(const DevGeom* __restrict__ 
         }
         val |= (t[0] < t[1]) << k;
     }
+    return val;
+}
+
+__global__ __launch_bounds__(256) void brief_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ blur,
+                                                    const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_cnt,
+                                                    const float* __restrict__ kp_angle, uint8_t* __restrict__ lvl_desc,
+                                                    uint8_t* __restrict__ lvl_oob)
+{
+    const int slice = blockIdx.y;
+    const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int b = threadIdx.x & 31;
+    if (gid >= G->kp_total) return;
+    int level = 0;
+    while (level + 1 < G->nlevels && gid >= G->lv[level + 1].kp_off) level++;
+    const LevelGeom& L = G->lv[level];
+    const int i = gid - L.kp_off;
+    if (i >= lvl_cnt[slice * G->nlevels + level]) return;
+    const uint32_t p = lvl_kp[(size_t)slice * G->kp_total + gid];
+    const int cx = (int)(p & 0xfff) + L.minBX, cy = (int)((p >> 12) & 0xfff) + L.minBY;
+    const uint8_t* img = blur + (size_t)slice * G->roi_bytes + L.roi_off;
+    int oob = 0;
+    const int val = brief_byte(img, L.w, L.h, cx, cy, kp_angle[(size_t)slice * G->kp_total + gid], b, oob);
     lvl_desc[((size_t)slice * G->kp_total + gid) * 32 + b] = (uint8_t)val;
     const uint64_t anyoob = __ballot(oob != 0);
     if (b == 0) {
         const int half = (threadIdx.x >> 5) & 1;
         const uint32_t m = half ? (uint32_t)(anyoob >> 32) : (uint32_t)anyoob;
         lvl_oob[(size_t)slice * G->kp_total + gid] = m ? 1 : 0;
+    }
+}
+
+// ORBextractor::ComputeTrackedKPtsDesc (:1316-1363) [mode 0] and AssignKPtLevelByBestDesc (:1267-1314) [mode 1]:
+// 32 lanes per tracked keypoint.  mode 0: descriptor at the keypoint's octave; mode 1: descriptor at every level, the
+// level with the smallest Hamming distance to ref_desc (first minimum, strict <) becomes the octave.
+__global__ __launch_bounds__(256) void tracked_desc_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ blur,
+                                                           eorb_keypoint* __restrict__ kps, int n, int mode,
+                                                           const uint8_t* __restrict__ ref_desc, uint8_t* __restrict__ desc,
+                                                           uint8_t* __restrict__ oobf)
+{
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int b = threadIdx.x & 31;
+    if (i >= n) return;
+    const eorb_keypoint kp = kps[i];
+    const int half = (threadIdx.x >> 5) & 1;
+    if (mode == 0) {
+        const int level = kp.octave;
+        int val = 0, oob = 0;
+        if (level >= 0 && level < G->nlevels) {
+            const LevelGeom& L = G->lv[level];
+            const float scale = 1.0f / G->sf[level];                                  // mvInvScaleFactor[level] (:436)
+            const int cx = dev_cvround(kp.x * scale), cy = dev_cvround(kp.y * scale);
+            val = brief_byte(blur + L.roi_off, L.w, L.h, cx, cy, kp.angle, b, oob);
+        }
+        desc[(size_t)i * 32 + b] = (uint8_t)val;
+        const uint64_t anyoob = __ballot(oob != 0);
+        if (b == 0 && oobf) oobf[i] = (half ? (uint32_t)(anyoob >> 32) : (uint32_t)anyoob) ? 1 : 0;
+    } else {
+        const int refb = ref_desc[(size_t)i * 32 + b];
+        int minDist = 0x7fffffff, best = kp.octave;
+        for (int level = 0; level < G->nlevels; level++) {
+            const LevelGeom& L = G->lv[level];
+            const float scale = 1.0f / G->sf[level];
+            const int cx = dev_cvround(kp.x * scale), cy = dev_cvround(kp.y * scale);
+            int oob = 0;
+            const int val = brief_byte(blur + L.roi_off, L.w, L.h, cx, cy, kp.angle, b, oob);
+            int d = __popc((unsigned)(val ^ refb));
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) d += __shfl_xor(d, sft, 64);   // sum over the 32 lanes of this keypoint
+            if (d < minDist) { minDist = d; best = level; }
+        }
+        if (b == 0) kps[i].octave = best;
     }
 }
 
@@ -922,6 +973,41 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
                                                   d_oob, d_n, d_mono);
         EORB_LAUNCH_CHECK(c, "assemble_kernel");
     }
+    return EORB_OK;
+}
+
+// pyramid + blurred planes of ONE image (the front half of operator(), shared by the tracked-keypoint helpers)
+int orb_pyramid_blur_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride)
+{
+    OrbState& o = c->orb;
+    if (!o.configured) return set_err(c, EORB_E_NOTCONF, "orb: eorb_orb_configure not called");
+    int rc;
+    if ((rc = ensure(c, c->pyr, (size_t)o.pyr_bytes))) return rc;
+    if ((rc = ensure(c, c->blur, (size_t)o.roi_bytes))) return rc;
+    const DevGeom* G = (const DevGeom*)o.geom.p;
+    uint8_t* pyr = (uint8_t*)c->pyr.p;
+    ProfScope ps(c, "orb_pyr_blur");
+    const int n0 = o.lv[0].bw * o.lv[0].bh;
+    pyr_level0_kernel<<<dim3((n0 + 255) / 256, 1), 256, 0, c->stream>>>(d_img, img_stride, 0, G, pyr);
+    for (int l = 1; l < o.nlevels; l++) {
+        const int n = o.lv[l].bw * o.lv[l].bh;
+        pyr_resize_kernel<<<dim3((n + 255) / 256, 1), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
+    }
+    int tyt = 0, wmax = 0;
+    for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + 7) / 8; wmax = std::max(wmax, o.lv[l].w); }
+    blur_kernel<<<dim3((wmax + 31) / 32, tyt, 1), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
+    EORB_LAUNCH_CHECK(c, "pyramid/blur kernels");
+    return EORB_OK;
+}
+
+int orb_tracked_dev(eorb_ctx* c, eorb_keypoint* d_kps, int n, int mode, const uint8_t* d_ref, uint8_t* d_desc, uint8_t* d_oob)
+{
+    if (n <= 0) return EORB_OK;
+    OrbState& o = c->orb;
+    ProfScope ps(c, "orb_tracked_desc");
+    tracked_desc_kernel<<<(n + 7) / 8, 256, 0, c->stream>>>((const DevGeom*)o.geom.p, (const uint8_t*)c->blur.p, d_kps, n, mode,
+                                                           d_ref, d_desc, d_oob);
+    EORB_LAUNCH_CHECK(c, "tracked_desc_kernel");
     return EORB_OK;
 }
 

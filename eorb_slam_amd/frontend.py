@@ -174,6 +174,22 @@ class ORBextractor:
         return mono.value, kps[:k].copy(), (desc[:k].copy() if want_desc else None), oob[:k].copy()
 
 
+    def ComputeTrackedKPtsDesc(self, trackedImage, trackedKPts):
+        """src/ORBextractor.cc:1316-1363 -> (refDescs n x 32, oob flags)"""
+        img = np.ascontiguousarray(trackedImage, np.uint8); H, W = img.shape
+        kps = np.ascontiguousarray(trackedKPts, KP_DTYPE); n = len(kps)
+        desc = np.zeros((n, 32), np.uint8); oob = np.zeros(n, np.uint8)
+        self.ctx.check(self.ctx.L.eorb_orb_tracked_descriptors(self.ctx.h, _p(img), W, H, img.strides[0], _p(kps), n, _p(desc), _p(oob)))
+        return desc, oob
+
+    def AssignKPtLevelByBestDesc(self, refDescs, trackedImage, trackedKPts):
+        """src/ORBextractor.cc:1267-1314 -> keypoints with the octave field reassigned"""
+        img = np.ascontiguousarray(trackedImage, np.uint8); H, W = img.shape
+        kps = np.ascontiguousarray(trackedKPts, KP_DTYPE).copy(); ref = np.ascontiguousarray(refDescs, np.uint8)
+        self.ctx.check(self.ctx.L.eorb_orb_assign_level_by_best_desc(self.ctx.h, _p(img), W, H, img.strides[0], _p(ref), _p(kps), len(kps)))
+        return kps
+
+
 def grid_bounds(W, H):
     """Frame::ComputeImageBounds for an undistorted image + grid pitch (src/Frame.cc:862-866, 362-363)."""
     gb = _lib.GridBounds(0.0, 0.0, float(W), float(H), 0.0, 0.0)
@@ -241,6 +257,36 @@ class ORBmatcher:
                                                   _p(mp_desc), _p(mp_obs), _p(mio), _p(ls), C.byref(F.gb), _p(fm),
                                                   float(th), self.mfNNratio, C.byref(nm)))
         return nm.value, fm
+
+
+def SearchByBoW(kf_kps, kf_desc, kf_has_mp, kf_fv, f_kps, f_desc, f_fv, nnratio=0.7, checkOri=True, ctx=None):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:276-478); feature vectors as CSR triples
+    (nodes uint32 ascending, node_off int32[nn+1], idx int32[]).  Returns (nmatches, match_f)."""
+    c = ctx or default_context()
+    kf_kps = np.ascontiguousarray(kf_kps, KP_DTYPE); f_kps = np.ascontiguousarray(f_kps, KP_DTYPE)
+    kf_desc = np.ascontiguousarray(kf_desc, np.uint8); f_desc = np.ascontiguousarray(f_desc, np.uint8)
+    hm = np.ascontiguousarray(kf_has_mp, np.uint8)
+    kn, ko, ki = [np.ascontiguousarray(a, t) for a, t in zip(kf_fv, (np.uint32, np.int32, np.int32))]
+    fn, fo, fi = [np.ascontiguousarray(a, t) for a, t in zip(f_fv, (np.uint32, np.int32, np.int32))]
+    m = np.full(len(f_kps), -1, np.int32); nm = C.c_int(0)
+    c.check(c.L.eorb_search_by_bow(c.h, _p(kf_kps), len(kf_kps), _p(kf_desc), _p(hm), _p(kn), _p(ko), _p(ki), len(kn),
+                                   _p(f_kps), len(f_kps), _p(f_desc), _p(fn), _p(fo), _p(fi), len(fn), _p(m), float(nnratio),
+                                   int(checkOri), C.byref(nm)))
+    return nm.value, m
+
+
+def sortFeaturesResponse(kps, ctx=None):
+    """MixedFrame::sortFeaturesResponse (src/MixedFrame.cpp:211-225): permutation (descending response, stable)."""
+    c = ctx or default_context()
+    kps = np.ascontiguousarray(kps, KP_DTYPE); perm = np.zeros(len(kps), np.int32)
+    c.check(c.L.eorb_sort_by_response(c.h, _p(kps), len(kps), _p(perm)))
+    return perm
+
+
+def resolveNumMixedPts(nDetectedORB, nDetectedAK, nDesired, nDesiredAK):
+    a, b = C.c_int(-1), C.c_int(-1)
+    _lib.lib().eorb_resolve_num_mixed(nDetectedORB, nDetectedAK, nDesired, nDesiredAK, C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 class BFMatcher:

@@ -122,6 +122,17 @@ int eorb_orb_extract(eorb_ctx* ctx, const uint8_t* img, int W, int H, int stride
                      int want_desc, eorb_keypoint* kps, uint8_t* desc, uint8_t* oob, int cap,
                      int* n_out, int* mono_index);
 
+/* replaces ORBextractor::ComputeTrackedKPtsDesc (src/ORBextractor.cc:1316-1363; callers EvAsynchTrackerU.cpp:794,812):
+ * descriptor of every tracked keypoint at the pyramid level of its octave (pt * mvInvScaleFactor[octave], kp.angle).
+ * desc: n x 32; rows whose octave is outside [0, nlevels) are zero (uninitialised in the reference). oob optional. */
+int eorb_orb_tracked_descriptors(eorb_ctx* ctx, const uint8_t* img, int W, int H, int stride,
+                                 const eorb_keypoint* kps, int n, uint8_t* desc, uint8_t* oob);
+
+/* replaces ORBextractor::AssignKPtLevelByBestDesc (src/ORBextractor.cc:1267-1314; caller EvSynchTracker.cpp:790):
+ * kps[i].octave <- the level whose descriptor at pt * invScale[level] is closest (Hamming) to ref_desc row i. */
+int eorb_orb_assign_level_by_best_desc(eorb_ctx* ctx, const uint8_t* img, int W, int H, int stride,
+                                       const uint8_t* ref_desc, eorb_keypoint* kps, int n);
+
 /* ---- matchers (host buffers) ------------------------------------------------------------------------ */
 /* replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:714-831) and
  * MixedMatcher::SearchForInitialization (src/MixedMatcher.cpp:20-145; is_orb* = isORBDescValid gate,
@@ -152,6 +163,22 @@ int eorb_search_by_projection_map(eorb_ctx* ctx,
         int M, const uint8_t* in_view, const float* proj_xy, const int32_t* level, const float* view_cos,
         const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
         const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, int* nmatches);
+
+/* replaces the mono branch of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:276-478;
+ * MixedMatcher.cpp:148-356).  DBoW2::FeatureVector as CSR (node ids ascending, offsets, feature indices in vector
+ * order).  kf_has_mp[i] = map point present and !isBad().  match_f[n_f] out = KeyFrame feature index or -1. */
+int eorb_search_by_bow(eorb_ctx* ctx,
+        const eorb_keypoint* kf_kps, int n_kf, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
+        const uint32_t* kf_nodes, const int32_t* kf_node_off, const int32_t* kf_idx, int kf_nn,
+        const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc,
+        const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
+        int32_t* match_f, float nnratio, int checkOri, int* nmatches);
+
+/* replaces MixedFrame::sortFeaturesResponse (src/MixedFrame.cpp:211-225): perm[k] = index of the k-th keypoint in
+ * descending-response order, equal responses in insertion order (std::multimap semantics). */
+int eorb_sort_by_response(eorb_ctx* ctx, const eorb_keypoint* kps, int n, int32_t* perm);
+/* MixedFrame::resolveNumMixedPts (src/MixedFrame.cpp:281-317): how many ORB / AKAZE features the mixed frame keeps */
+void eorb_resolve_num_mixed(int nDetectedORB, int nDetectedAK, int nDesired, int nDesiredAK, int* nORB, int* nAK);
 
 /* replaces cv::BFMatcher(NORM_HAMMING)::knnMatch(q, t, matches, 2) at src/Frame.cc:1228
  * (+ the ORBmatcher::DescriptorDistance core, ORBmatcher.cc:2360-2378).  idx2/dist2: nq*2. */

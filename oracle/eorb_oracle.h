@@ -114,6 +114,16 @@ const uint8_t* orc_orb_level_blur(const orc_orb* e, int level);                 
 int            orc_orb_level_candidates(const orc_orb* e, int level, const orc_keypoint** out);
 int            orc_orb_level_keypoints(const orc_orb* e, int level, const orc_keypoint** out);
 
+/* ORBextractor::ComputeTrackedKPtsDesc (:1316-1363): descriptor of each tracked keypoint at the pyramid level given by
+ * its octave (pt * mvInvScaleFactor[octave], kp.angle).  desc: n x 32 (rows of keypoints whose octave is outside
+ * [0, nlevels) are left zero; the reference leaves them uninitialised).  oob: n flags or NULL. */
+int orc_orb_tracked_descriptors(orc_orb* e, const uint8_t* img, int W, int H, int stride, const orc_keypoint* kps, int n,
+                                uint8_t* desc, uint8_t* oob);
+/* ORBextractor::AssignKPtLevelByBestDesc (:1267-1314): kps[i].octave = level with the smallest Hamming distance between
+ * ref_desc row i and the descriptor computed at that level (first minimum wins). */
+int orc_orb_assign_level_by_best_desc(orc_orb* e, const uint8_t* img, int W, int H, int stride, const uint8_t* ref_desc,
+                                      orc_keypoint* kps, int n);
+
 /* pieces exposed for unit tests */
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
                           uint8_t* dst, int dw, int dh, int dstride);
@@ -175,6 +185,21 @@ int orc_search_by_projection_map(const orc_frame* F, int M, const uint8_t* in_vi
                                  const int* level, const float* view_cos, const uint8_t* mp_desc,
                                  const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
                                  float th, float nnratio, const float* level_scale);
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:276-478), mono branch.  The DBoW2 feature vectors
+ * are CSR: node ids ascending, node_off[nn+1], idx[] = feature indices in vector order.  kf_has_mp[i] = map point present
+ * and not bad.  match_f[N_F] out: KeyFrame feature index matched to each frame feature, or -1.  returns nmatches */
+int orc_search_by_bow(const orc_keypoint* kf_kps, int n_kf, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
+                      const uint32_t* kf_nodes, const int32_t* kf_node_off, const int32_t* kf_idx, int kf_nn,
+                      const orc_keypoint* f_kps, int n_f, const uint8_t* f_desc,
+                      const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
+                      int32_t* match_f, float nnratio, int checkOri);
+
+/* MixedFrame::sortFeaturesResponse (MixedFrame.cpp:211-225): order = descending response, equal responses keep their
+ * insertion order (multimap).  perm[k] = source index of the k-th output element. */
+void orc_sort_by_response(const orc_keypoint* kps, int n, int32_t* perm);
+/* MixedFrame::resolveNumMixedPts (MixedFrame.cpp:281-317) */
+void orc_resolve_num_mixed(int nDetectedORB, int nDetectedAK, int nDesired, int nDesiredAK, int* nORB, int* nAK);
 
 /* cv::BFMatcher(NORM_HAMMING).knnMatch(q, t, 2) (Frame.cc:1228): per query two best (idx, dist)
  * ascending; ties -> lowest train index.  idx2/dist2: nq*2 (-1 / INT_MAX when nt < k). */

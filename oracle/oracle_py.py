@@ -93,6 +93,14 @@ def lib(fast=False):
     L.orc_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     L.orc_search_by_projection_map.restype = ci
     L.orc_search_by_projection_map.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
+    L.orc_orb_tracked_descriptors.restype = ci; L.orc_orb_tracked_descriptors.argtypes = [vp, vp, ci, ci, ci, vp, ci, vp, vp]
+    L.orc_orb_assign_level_by_best_desc.restype = ci
+    L.orc_orb_assign_level_by_best_desc.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci]
+    L.orc_search_by_bow.restype = ci
+    L.orc_search_by_bow.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci]
+    L.orc_sort_by_response.restype = None; L.orc_sort_by_response.argtypes = [vp, ci, vp]
+    L.orc_resolve_num_mixed.restype = None
+    L.orc_resolve_num_mixed.argtypes = [ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
     L.orc_bf_knn2.restype = None; L.orc_bf_knn2.argtypes = [vp, ci, vp, ci, vp, vp]
     _libs[key] = L
     return L
@@ -175,6 +183,21 @@ class OrbExtractor:
         if mono < 0:
             return mono, None, None, None
         return mono, kps[:n.value].copy(), (desc[:n.value].copy() if want_desc else None), oob[:n.value].copy()
+
+    def tracked_descriptors(self, img, kps):
+        img = np.ascontiguousarray(img, np.uint8); H, W = img.shape
+        kps = np.ascontiguousarray(kps, KP_DTYPE); n = len(kps)
+        desc = np.zeros((n, 32), np.uint8); oob = np.zeros(n, np.uint8)
+        rc = self.L.orc_orb_tracked_descriptors(self.h, _p(img), W, H, W, _p(kps), n, _p(desc), _p(oob))
+        assert rc == 0, rc
+        return desc, oob
+
+    def assign_level_by_best_desc(self, img, ref_desc, kps):
+        img = np.ascontiguousarray(img, np.uint8); H, W = img.shape
+        kps = np.ascontiguousarray(kps, KP_DTYPE).copy(); ref = np.ascontiguousarray(ref_desc, np.uint8)
+        rc = self.L.orc_orb_assign_level_by_best_desc(self.h, _p(img), W, H, W, _p(ref), _p(kps), len(kps))
+        assert rc == 0, rc
+        return kps
 
     def level_size(self, l):
         w, h = C.c_int(), C.c_int()
@@ -318,3 +341,29 @@ def bf_knn2(q, t, fast=False):
     idx = np.zeros((len(q), 2), np.int32); dist = np.zeros((len(q), 2), np.int32)
     lib(fast).orc_bf_knn2(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
     return idx, dist
+
+
+def search_by_bow(kf_kps, kf_desc, kf_has_mp, kf_fv, f_kps, f_desc, f_fv, nnratio=0.7, checkOri=True):
+    """kf_fv / f_fv: (nodes uint32[nn] ascending, node_off int32[nn+1], idx int32[])."""
+    kf_kps = np.ascontiguousarray(kf_kps, KP_DTYPE); f_kps = np.ascontiguousarray(f_kps, KP_DTYPE)
+    kf_desc = np.ascontiguousarray(kf_desc, np.uint8); f_desc = np.ascontiguousarray(f_desc, np.uint8)
+    hm = np.ascontiguousarray(kf_has_mp, np.uint8)
+    kn, ko, ki = [np.ascontiguousarray(a, t) for a, t in zip(kf_fv, (np.uint32, np.int32, np.int32))]
+    fn, fo, fi = [np.ascontiguousarray(a, t) for a, t in zip(f_fv, (np.uint32, np.int32, np.int32))]
+    m = np.full(len(f_kps), -1, np.int32)
+    n = lib().orc_search_by_bow(_p(kf_kps), len(kf_kps), _p(kf_desc), _p(hm), _p(kn), _p(ko), _p(ki), len(kn),
+                                _p(f_kps), len(f_kps), _p(f_desc), _p(fn), _p(fo), _p(fi), len(fn), _p(m), nnratio, int(checkOri))
+    return n, m
+
+
+def sort_by_response(kps):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    perm = np.zeros(len(kps), np.int32)
+    lib().orc_sort_by_response(_p(kps), len(kps), _p(perm))
+    return perm
+
+
+def resolve_num_mixed(nDetORB, nDetAK, nDesired, nDesiredAK):
+    a, b = C.c_int(-1), C.c_int(-1)
+    lib().orc_resolve_num_mixed(nDetORB, nDetAK, nDesired, nDesiredAK, C.byref(a), C.byref(b))
+    return a.value, b.value

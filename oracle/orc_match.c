@@ -344,3 +344,84 @@ void orc_bf_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* id
         dist2[2 * i] = b0; dist2[2 * i + 1] = b1;
     }
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>&) :276-478, mono branch */
+int orc_search_by_bow(const orc_keypoint* kf_kps, int n_kf, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
+                      const uint32_t* kf_nodes, const int32_t* kf_node_off, const int32_t* kf_idx, int kf_nn,
+                      const orc_keypoint* f_kps, int n_f, const uint8_t* f_desc,
+                      const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
+                      int32_t* match_f, float nnratio, int checkOri)
+{
+    (void)n_kf;
+    int nmatches = 0;
+    for (int i = 0; i < n_f; i++) match_f[i] = -1;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n_f ? n_f : 1)); rotN[i] = 0; }
+    int a = 0, b = 0;
+    while (a < kf_nn && b < f_nn) {
+        if (kf_nodes[a] == f_nodes[b]) {
+            for (int iKF = kf_node_off[a]; iKF < kf_node_off[a + 1]; iKF++) {
+                const int realIdxKF = kf_idx[iKF];
+                if (!kf_has_mp[realIdxKF]) continue;                          /* !pMP || pMP->isBad() */
+                const uint8_t* dKF = kf_desc + 32 * (size_t)realIdxKF;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int iF = f_node_off[b]; iF < f_node_off[b + 1]; iF++) {
+                    const int realIdxF = f_idx[iF];
+                    if (match_f[realIdxF] >= 0) continue;                     /* vpMapPointMatches[realIdxF] */
+                    const int dist = orc_descriptor_distance(dKF, f_desc + 32 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        match_f[bestIdxF] = realIdxKF;
+                        if (checkOri) {
+                            int bin = rot_bin(kf_kps[realIdxKF].angle, f_kps[bestIdxF].angle);
+                            rotHist[bin][rotN[bin]++] = bestIdxF;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (kf_nodes[a] < f_nodes[b]) {
+            while (a < kf_nn && kf_nodes[a] < f_nodes[b]) a++;                /* lower_bound */
+        } else {
+            while (b < f_nn && f_nodes[b] < kf_nodes[a]) b++;
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) { match_f[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    return nmatches;
+}
+
+/* MixedFrame::sortFeaturesResponse: multimap<float, ..., greater<float>> keeps insertion order among equal keys */
+void orc_sort_by_response(const orc_keypoint* kps, int n, int32_t* perm)
+{
+    for (int i = 0; i < n; i++) {           /* stable insertion into a descending sequence */
+        int k = i;
+        while (k > 0 && kps[perm[k - 1]].response < kps[i].response) { perm[k] = perm[k - 1]; k--; }
+        perm[k] = i;
+    }
+}
+
+/* MixedFrame::resolveNumMixedPts (MixedFrame.cpp:281-317) */
+void orc_resolve_num_mixed(int nDetectedORB, int nDetectedAK, int nDesired, int nDesiredAK, int* nORB, int* nAK)
+{
+    const int nDetected = nDetectedORB + nDetectedAK;
+    const int nDesiredORB = nDesired - nDesiredAK;
+    if (nDetected > nDesired) {
+        const int nDiff = nDetected - nDesired;
+        if (nDetectedORB > nDesiredORB && nDetectedAK > nDesiredAK) { *nORB = nDesiredORB; *nAK = nDesiredAK; }
+        else if (nDetectedORB > nDesiredORB) { *nORB = nDetectedORB - nDiff; *nAK = nDetectedAK < nDesiredAK ? nDetectedAK : nDesiredAK; }
+        else if (nDetectedAK > nDesiredAK) { *nORB = nDetectedORB < nDesiredORB ? nDetectedORB : nDesiredORB; *nAK = nDetectedAK - nDiff; }
+        else { /* the reference only prints an error and leaves the counts untouched */ }
+    } else { *nORB = nDetectedORB; *nAK = nDetectedAK; }
+}

@@ -724,3 +724,69 @@ int orc_orb_level_candidates(const orc_orb* e, int level, const orc_keypoint** o
 { *out = e->cand[level]; return e->ncand[level]; }
 int orc_orb_level_keypoints(const orc_orb* e, int level, const orc_keypoint** out)
 { *out = e->kps[level]; return e->nkps[level]; }
+
+/* ---- tracked keypoints: ComputeTrackedKPtsDesc :1316-1363, AssignKPtLevelByBestDesc :1267-1314 ------------------- */
+static int pyramid_and_blur(orc_orb* e, const uint8_t* img, int W, int H, int stride)
+{
+    free_state(e);
+    int rc = compute_pyramid(e, img, W, H, stride);
+    if (rc) return rc;
+    const int E = e->edge;
+    for (int l = 0; l < e->p.nlevels; l++) {
+        const int w = e->lw[l], h = e->lh[l], bw = w + 2 * E;
+        const uint8_t* roi = e->buf[l] + (size_t)E * bw + E;
+        e->blur[l] = (uint8_t*)malloc((size_t)w * h);
+        orc_gaussian_blur5_u8(roi, w, h, bw, e->blur[l], w);
+    }
+    return 0;
+}
+
+int orc_orb_tracked_descriptors(orc_orb* e, const uint8_t* img, int W, int H, int stride, const orc_keypoint* kps, int n,
+                                uint8_t* desc, uint8_t* oob)
+{
+    if (!img || W <= 0 || H <= 0) return -1;                     /* trackedImage.empty() -> return */
+    int rc = pyramid_and_blur(e, img, W, H, stride);
+    if (rc) return rc;
+    memset(desc, 0, 32 * (size_t)n);
+    if (oob) memset(oob, 0, n);
+    for (int level = 0; level < e->p.nlevels; level++) {
+        const float scale = e->inv_sf[level];
+        for (int i = 0; i < n; i++) {
+            if (kps[i].octave != level) continue;
+            const float x = kps[i].x * scale, y = kps[i].y * scale;      /* currKPt.pt = currKPt.pt * scale */
+            int o = orc_orb_descriptor(e->blur[level], e->lw[level], e->lh[level], e->lw[level], x, y, kps[i].angle,
+                                       desc + 32 * (size_t)i);
+            if (oob) oob[i] = (uint8_t)o;
+        }
+    }
+    return 0;
+}
+
+static int hamming32(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int i = 0; i < 32; i++) { unsigned v = a[i] ^ b[i]; while (v) { d += v & 1; v >>= 1; } }
+    return d;
+}
+
+int orc_orb_assign_level_by_best_desc(orc_orb* e, const uint8_t* img, int W, int H, int stride, const uint8_t* ref_desc,
+                                      orc_keypoint* kps, int n)
+{
+    if (!img || W <= 0 || H <= 0) return -1;
+    int rc = pyramid_and_blur(e, img, W, H, stride);
+    if (rc) return rc;
+    int* minDist = (int*)malloc(sizeof(int) * (n ? n : 1));
+    for (int i = 0; i < n; i++) minDist[i] = 0x7fffffff;
+    for (int level = 0; level < e->p.nlevels; level++) {
+        const float scale = e->inv_sf[level];
+        for (int i = 0; i < n; i++) {
+            uint8_t d[32];
+            const float x = kps[i].x * scale, y = kps[i].y * scale;
+            orc_orb_descriptor(e->blur[level], e->lw[level], e->lh[level], e->lw[level], x, y, kps[i].angle, d);
+            const int dist = hamming32(ref_desc + 32 * (size_t)i, d);    /* ORBmatcher::DescriptorDistance */
+            if (dist < minDist[i]) { minDist[i] = dist; kps[i].octave = level; }
+        }
+    }
+    free(minDist);
+    return 0;
+}

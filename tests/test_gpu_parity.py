@@ -280,3 +280,72 @@ def test_frontend_batch_matches_oracle_pipeline(oracle, fe):
     for p in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
         c.dev_free(p)
     c.close()
+
+
+# ---- tracked keypoints (a14), SearchByBoW (a20), MixedFrame container ops (a23) ----------------------------------------
+def test_tracked_descriptors_and_level_assignment(oracle, fe):
+    img = synth.texture_image(240, 180, seed=31)
+    oe = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19)
+    ge = fe.ORBextractor(1000, 1.2, 4, 10, 0, 19, (240, 180))
+    _, kps, desc, _ = oe.extract(img)
+    rng = np.random.default_rng(7)
+    # tracked points: extractor keypoints moved by a KLT-like sub-pixel displacement, some with bogus octaves / near borders
+    tk = kps.copy()
+    tk["x"] += rng.normal(0, 1.5, len(tk)).astype(np.float32); tk["y"] += rng.normal(0, 1.5, len(tk)).astype(np.float32)
+    tk["octave"][::37] = 9; tk["octave"][5::41] = -1
+    tk["x"][::53] = 3.5; tk["y"][7::59] = 177.25
+    od, oo = oe.tracked_descriptors(img, tk)
+    gd, go = ge.ComputeTrackedKPtsDesc(img, tk)
+    assert np.array_equal(od, gd) and np.array_equal(oo, go)
+    ok = oe.assign_level_by_best_desc(img, desc, tk)
+    gk = ge.AssignKPtLevelByBestDesc(desc, img, tk)
+    assert np.array_equal(ok.view(np.uint8), gk.view(np.uint8))
+    assert (gk["octave"] != tk["octave"]).any()
+    assert ge.ctx.L.eorb_orb_tracked_descriptors(ge.ctx.h, None, 0, 0, 0, None, 0, None, None) == -1      # empty image
+    ge.ctx.close()
+
+
+def _feature_vector(nfeat, nnodes, rng):
+    """A DBoW2::FeatureVector stand-in: every feature falls into exactly one node (node ids ascending)."""
+    node_of = rng.integers(0, nnodes, nfeat)
+    ids = np.unique(node_of)
+    off = [0]; idx = []
+    for nid in ids:
+        members = np.nonzero(node_of == nid)[0]
+        rng.shuffle(members)                       # vector order inside a node is the insertion order, not sorted
+        idx.extend(members.tolist()); off.append(len(idx))
+    return (ids.astype(np.uint32) * 7 + 3), np.array(off, np.int32), np.array(idx, np.int32)
+
+
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_by_bow(oracle, fe, ctx, ori):
+    k1, d1, k2, d2 = _two_frames(oracle, seed=41, shift=2)
+    rng = np.random.default_rng(11)
+    # correlated node assignment: matching features mostly share a node, as a vocabulary tree would give
+    nn = 60
+    kfv = _feature_vector(len(k1), nn, rng)
+    # frame features inherit the node of their spatially nearest KeyFrame feature most of the time
+    node_kf = np.zeros(len(k1), np.int64)
+    for a in range(len(kfv[0])):
+        node_kf[kfv[2][kfv[1][a]:kfv[1][a + 1]]] = kfv[0][a]
+    dx = k2["x"][:, None] - (k1["x"][None, :] - 2); dy = k2["y"][:, None] - (k1["y"][None, :] + 2)
+    near = np.argmin(dx * dx + dy * dy, axis=1)
+    node_f = np.where(rng.uniform(size=len(k2)) < 0.85, node_kf[near], rng.integers(0, nn, len(k2)) * 7 + 3)
+    ids = np.unique(node_f); off = [0]; idx = []
+    for nid in ids:
+        m = np.nonzero(node_f == nid)[0]; rng.shuffle(m); idx.extend(m.tolist()); off.append(len(idx))
+    ffv = (ids.astype(np.uint32), np.array(off, np.int32), np.array(idx, np.int32))
+    has_mp = (rng.uniform(size=len(k1)) < 0.8).astype(np.uint8)
+    for ratio in (0.7, 0.95):
+        on, om = oracle.search_by_bow(k1, d1, has_mp, kfv, k2, d2, ffv, ratio, ori)
+        gn, gm = fe.SearchByBoW(k1, d1, has_mp, kfv, k2, d2, ffv, ratio, ori, ctx=ctx)
+        assert on == gn and np.array_equal(om, gm)
+    assert on > 20
+
+
+def test_mixed_frame_container_ops(oracle, fe, ctx):
+    kps = synth.random_keypoints(1500, seed=12)
+    kps["response"] = np.random.default_rng(3).integers(1, 40, 1500).astype(np.float32)      # many equal responses
+    assert np.array_equal(oracle.sort_by_response(kps), fe.sortFeaturesResponse(kps, ctx))
+    for args in ((1200, 600, 1500, 500), (1200, 300, 1500, 500), (800, 900, 1500, 500), (800, 300, 1500, 500), (0, 0, 1500, 500)):
+        assert oracle.resolve_num_mixed(*args) == fe.resolveNumMixedPts(*args)
