@@ -349,3 +349,56 @@ def test_mixed_frame_container_ops(oracle, fe, ctx):
     assert np.array_equal(oracle.sort_by_response(kps), fe.sortFeaturesResponse(kps, ctx))
     for args in ((1200, 600, 1500, 500), (1200, 300, 1500, 500), (800, 900, 1500, 500), (800, 300, 1500, 500), (0, 0, 1500, 500)):
         assert oracle.resolve_num_mixed(*args) == fe.resolveNumMixedPts(*args)
+
+
+def test_frontend_batch_ragged_and_empty_slices(oracle, fe):
+    """Slices of different lengths, including an empty one and one that is not a multiple of the 4096-event chunk."""
+    W, H = 240, 180
+    counts = [5000, 0, 12345, 1, 4096]
+    slices = [synth.shapes_events(n, seed=60 + i, undistort=True) if n else np.zeros(0, synth.EVENT_DTYPE) for i, n in enumerate(counts)]
+    B = len(counts)
+    fb = fe.FrontEndBatch(W, H, 1.0, False, 500, 1.2, 3, 10, 0, 19, max_batch=B, max_events=max(counts), match=True)
+    c, cap = fb.ctx, fb.cap
+    ev16 = np.concatenate([fe.pack_events(s) for s in slices])
+    d_ev = c.dev_alloc(max(ev16.nbytes, 16)); c.upload(d_ev, ev16)
+    d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32); d_n = c.dev_alloc(B * 4)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    fb.run_dev(d_ev, offs, d_img, d_kp, d_desc, d_n)
+    c.sync()
+    imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
+    kps = np.zeros((B, cap), synth.KP_DTYPE); c.download(kps, d_kp)
+    nk = np.zeros(B, np.int32); c.download(nk, d_n)
+    oe = oracle.OrbExtractor(500, 1.2, 3, 10, 0, edgeTh=19)
+    for b in range(B):
+        _, ou, _ = oracle.ev2im_gauss(slices[b], W, H, 1.0, False, True)
+        assert np.array_equal(ou, imgs[b]), b
+        _, okp, _, _ = oe.extract(ou)
+        assert nk[b] == len(okp) and np.array_equal(okp.view(np.uint8), kps[b, :nk[b]].view(np.uint8))
+    assert (imgs[1] == 0).all()
+    for p in (d_ev, d_img, d_kp, d_desc, d_n):
+        c.dev_free(p)
+    c.close()
+
+
+def test_large_slice_many_chunks(oracle, fe, ctx):
+    """3 M events in one slice: 733 chunks per tile list; order must survive every chunk boundary."""
+    ev = synth.shapes_events(3000000, seed=77, undistort=True)
+    of, ou, omm = oracle.ev2im_gauss(ev, 240, 180, 1.0, False, True, fast=True)
+    gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, 240, 180, 1.0, False, True, ctx=ctx, return_all=True)
+    assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm)
+
+
+def test_error_paths_return_codes(fe, ctx):
+    ev = synth.random_events(10, seed=1)
+    L = ctx.L
+    import ctypes as C
+    f32 = np.zeros((180, 240), np.float32)
+    assert L.eorb_ev2im_gauss(ctx.h, ev.ctypes.data_as(C.c_void_p), 10, 240, 180, C.c_float(0.0), 0, 1, f32.ctypes.data_as(C.c_void_p), None, None) == -4
+    assert L.eorb_ev2im_gauss(ctx.h, ev.ctypes.data_as(C.c_void_p), 10, 240, 180, C.c_float(4.0), 0, 1, f32.ctypes.data_as(C.c_void_p), None, None) == -2   # h = 12 > 8
+    assert b"sigma" in L.eorb_last_error(ctx.h)
+    assert L.eorb_ev2im_gauss(ctx.h, None, 10, 240, 180, C.c_float(1.0), 0, 1, None, None, None) == -4
+    c2 = fe.Context()
+    n = C.c_int(); m = C.c_int()
+    img = np.zeros((180, 240), np.uint8)
+    assert c2.L.eorb_orb_extract(c2.h, img.ctypes.data_as(C.c_void_p), 240, 180, 240, 0, 1000, 1, None, None, None, 0, C.byref(n), C.byref(m)) == -6   # not configured
+    c2.close()
