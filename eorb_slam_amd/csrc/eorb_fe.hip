@@ -12,6 +12,7 @@ namespace eorb {
 int ev_decode_minmax(eorb_ctx* c, const uint32_t* d_enc, float* d_out, int B);
 int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long* bad_out);
 int ev_diag_read(unsigned long long* out16);
+int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out);
 int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H);
 int orb_err_flag(eorb_ctx* c, int B, int* flag);
 int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2);
@@ -263,6 +264,16 @@ int eorb_selfcheck_division(eorb_ctx* c, float lo, float hi, float sigma, uint64
     unsigned long long bad = 0;
     int rc = ev_divcheck(c, lo, hi, sigma, &bad);
     *mismatches = bad;
+    return rc;
+}
+
+int eorb_selfcheck_math(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, uint64_t* hash)
+{
+    if (!c || !hash || which < 0 || which > 2 || hi_bits < lo_bits) return c ? set_err(c, EORB_E_ARG, "selfcheck_math: bad arguments") : EORB_E_ARG;
+    hipSetDevice(c->device);
+    unsigned long long h = 0;
+    int rc = ev_mathhash(c, which, lo_bits, hi_bits, &h);
+    *hash = h;
     return rc;
 }
 

@@ -661,6 +661,36 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
     return EORB_OK;
 }
 
+__global__ void ev_mathhash_kernel(int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out)
+{
+    __shared__ uint64_t tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    __syncthreads();
+    unsigned long long h = 0;
+    for (uint64_t u = (uint64_t)lo_bits + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; u <= hi_bits;
+         u += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ub = (uint32_t)u;
+        const float x = __uint_as_float(ub);
+        float y;
+        if (which == 0) y = dev_expf_nonpos<true>(-x, tab);
+        else { float sn, cs; dev_sincosf(x, &sn, &cs); y = (which == 1) ? sn : cs; }
+        h += (((unsigned long long)ub * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)__float_as_uint(y)) * 0xC2B2AE3D27D4EB4Full;
+    }
+    atomicAdd(out, h);
+}
+
+int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out)
+{
+    int rc;
+    if ((rc = ensure(c, c->minmax, 64))) return rc;
+    EORB_HIP(c, hipMemsetAsync(c->minmax.p, 0, 8, c->stream));
+    ev_mathhash_kernel<<<2048, 256, 0, c->stream>>>(which, lo_bits, hi_bits, (unsigned long long*)c->minmax.p);
+    EORB_LAUNCH_CHECK(c, "ev_mathhash_kernel");
+    EORB_HIP(c, hipMemcpyAsync(out, c->minmax.p, 8, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
 // counts floats in [lo, hi] (positive, by bit pattern) for which the reciprocal/fma quotient differs from IEEE ev / norm
 int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long* bad_out)
 {

@@ -218,6 +218,11 @@ int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int
  * accumulation kernel uses for v / (2*pi*sigma^2) differs from the IEEE-754 quotient (must be 0). */
 int eorb_selfcheck_division(eorb_ctx* ctx, float lo, float hi, float sigma, uint64_t* mismatches);
 
+/* self-check used by tests: order-independent 64-bit hash of a device math function over every float whose bit pattern
+ * lies in [lo_bits, hi_bits]: which = 0 exp(-x) as used by exp_XY2f, 1 sin(x), 2 cos(x) as used by computeOrbDescriptor.
+ * The CPU oracle computes the same hash of its own functions: equality proves the two agree on every input. */
+int eorb_selfcheck_math(eorb_ctx* ctx, int which, uint32_t lo_bits, uint32_t hi_bits, uint64_t* hash);
+
 /* helpers: convert host AoS events to the compact record; device alloc/copy without a HIP binding */
 void  eorb_pack_events(const eorb_event* ev, size_t n, eorb_event16* out);
 void* eorb_dev_alloc(eorb_ctx* ctx, size_t bytes);

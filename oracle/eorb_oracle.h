@@ -67,6 +67,9 @@ float orc_sinf(float x);            /* glibc>=2.28 sinf algorithm (valid for |x|
 float orc_cosf(float x);
 float orc_fast_atan2(float y, float x);   /* OpenCV 3.4 cv::fastAtan2 polynomial, degrees     */
 int   orc_cvround(double v);              /* cvRound: round-half-to-even                        */
+/* order-independent 64-bit hash of f over every float whose bit pattern is in [lo_bits, hi_bits] (which: 0 expf(-x),
+ * 1 sinf(x), 2 cosf(x)); the device computes the same hash of its own functions (eorb_selfcheck_math). */
+uint64_t orc_math_hash(int which, uint32_t lo_bits, uint32_t hi_bits);
 
 /* ---- event accumulation: src/Event/EventConversion.cc ------------------------------------ */
 

@@ -51,6 +51,7 @@ def lib(fast=False):
     L.orc_cosf.restype = cf; L.orc_cosf.argtypes = [cf]
     L.orc_fast_atan2.restype = cf; L.orc_fast_atan2.argtypes = [cf, cf]
     L.orc_cvround.restype = ci; L.orc_cvround.argtypes = [C.c_double]
+    L.orc_math_hash.restype = C.c_uint64; L.orc_math_hash.argtypes = [ci, C.c_uint32, C.c_uint32]
     L.orc_ev2im.restype = ci
     L.orc_ev2im.argtypes = [vp, C.c_size_t, ci, ci, ci, ci, vp, vp, vp]
     L.orc_ev2im_gauss.restype = ci

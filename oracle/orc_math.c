@@ -159,3 +159,15 @@ float orc_fast_atan2(float y, float x)
     if (y < 0) a = 360.f - a;
     return a;
 }
+
+uint64_t orc_math_hash(int which, uint32_t lo_bits, uint32_t hi_bits)
+{
+    uint64_t h = 0;
+    for (uint64_t u = lo_bits; u <= hi_bits; u++) {
+        uint32_t ub = (uint32_t)u; float x; memcpy(&x, &ub, 4);
+        float y = which == 0 ? orc_expf(-x) : (which == 1 ? orc_sinf(x) : orc_cosf(x));
+        uint32_t yb; memcpy(&yb, &y, 4);
+        h += (((uint64_t)ub * 0x9E3779B97F4A7C15ull) ^ (uint64_t)yb) * 0xC2B2AE3D27D4EB4Full;
+    }
+    return h;
+}

@@ -16,3 +16,20 @@ def test_reciprocal_fma_quotient_is_ieee_exact(sigma):
     ctx.check(ctx.L.eorb_selfcheck_division(ctx.h, 1e-27, 1.0, sigma, C.byref(bad)))
     assert bad.value == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("which,lo,hi", [
+    (0, 2.0 ** -30, 104.0),      # exp(-x) for every float x in [2^-30, 104]: 307 232 769 inputs
+    (1, 2.0 ** -20, 6.5),        # sin(x), every float in [2^-20, 6.5]: 189 792 257 inputs
+    (2, 2.0 ** -20, 6.5),        # cos(x)
+])
+def test_device_math_equals_oracle_on_every_input(oracle, which, lo, hi):
+    import numpy as np
+    from eorb_slam_amd import frontend
+    lob = int(np.float32(lo).view(np.uint32)); hib = int(np.float32(hi).view(np.uint32))
+    want = oracle.lib(fast=True).orc_math_hash(which, lob, hib)
+    ctx = frontend.Context()
+    got = C.c_uint64(0)
+    ctx.check(ctx.L.eorb_selfcheck_math(ctx.h, which, lob, hib, C.byref(got)))
+    ctx.close()
+    assert got.value == want
