@@ -13,7 +13,7 @@ EORB_OK, EORB_E_EMPTY, EORB_E_CONFIG, EORB_E_CAPACITY, EORB_E_ARG, EORB_E_HIP, E
 EXPORTS = [
     "eorb_create", "eorb_destroy", "eorb_sync", "eorb_last_error", "eorb_version",
     "eorb_prof_enable", "eorb_prof_reset", "eorb_prof_count", "eorb_prof_get",
-    "eorb_ev2im", "eorb_ev2im_gauss",
+    "eorb_ev2im", "eorb_ev2im_gauss", "eorb_ev2mci_se3", "eorb_ev2mci_se2", "eorb_measure_image_focus", "eorb_normalize_minmax_u8",
     "eorb_orb_configure", "eorb_orb_max_keypoints", "eorb_orb_get_tables", "eorb_orb_extract",
     "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map",
     "eorb_hamming_bf_knn2", "eorb_search_by_bow", "eorb_sort_by_response", "eorb_resolve_num_mixed",
@@ -27,6 +27,10 @@ EXPORTS = [
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int), ("scaleFactor", C.c_float), ("nlevels", C.c_int),
                 ("iniThFAST", C.c_int), ("minThFAST", C.c_int), ("edgeTh", C.c_int), ("imWidth", C.c_int)]
+
+
+class Pinhole(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
 
 
 class GridBounds(C.Structure):
@@ -78,6 +82,13 @@ def lib():
     L.eorb_prof_get.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.eorb_ev2im.restype = ci; L.eorb_ev2im.argtypes = [vp, vp, C.c_size_t, ci, ci, ci, ci, vp, vp, vp, pi]
     L.eorb_ev2im_gauss.restype = ci; L.eorb_ev2im_gauss.argtypes = [vp, vp, C.c_size_t, ci, ci, cf, ci, ci, vp, vp, vp]
+    cd = C.c_double
+    L.eorb_ev2mci_se3.restype = ci
+    L.eorb_ev2mci_se3.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pinhole), cd, vp, vp, cf, vp, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.eorb_ev2mci_se2.restype = ci
+    L.eorb_ev2mci_se2.argtypes = [vp, vp, C.c_size_t, C.POINTER(Pinhole), vp, ci, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.eorb_measure_image_focus.restype = ci; L.eorb_measure_image_focus.argtypes = [vp, vp, ci, ci, C.POINTER(cf)]
+    L.eorb_normalize_minmax_u8.restype = ci; L.eorb_normalize_minmax_u8.argtypes = [vp, vp, ci, ci, vp]
     L.eorb_orb_configure.restype = ci; L.eorb_orb_configure.argtypes = [vp, C.POINTER(OrbParams), ci, ci]
     L.eorb_orb_max_keypoints.restype = ci; L.eorb_orb_max_keypoints.argtypes = [vp]
     L.eorb_orb_get_tables.restype = ci; L.eorb_orb_get_tables.argtypes = [vp, vp, vp, vp, pi]

@@ -125,6 +125,56 @@ __device__ __forceinline__ float dev_fast_atan2(float y, float x)
     return a;
 }
 
+// double-precision sin/cos for the per-event Eigen::AngleAxisd -> rotation matrix of ev2mci_gg_f
+// (src/Event/EventConversion.cc:317-320): fdlibm k_sin / k_cos with the two-term pi/2 reduction, |x| < 100.
+__device__ __forceinline__ double dev_ksin(double x, double y, int iy)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x;
+    const double v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    if (iy == 0) return x + v * (S1 + z * r);
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+__device__ __forceinline__ double dev_kcos(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ax = fabs(x);
+    if (ax < 0.3) return 1.0 - (0.5 * z - (z * r - x * y));
+    double qx = 0.28125;
+    if (!(ax > 0.78125)) {
+        const double q = 0.25 * ax;
+        qx = __longlong_as_double(__double_as_longlong(q) & (long long)0xffffffff00000000ull);
+    }
+    const double hz = 0.5 * z - qx;
+    const double a = 1.0 - qx;
+    return a - (hz - (z * r - x * y));
+}
+__device__ __forceinline__ void dev_dsincos(double x, double* sn, double* cs)
+{
+    if (fabs(x) <= 0.78539816339744830962) { *sn = dev_ksin(x, 0.0, 0); *cs = dev_kcos(x, 0.0); return; }
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    const double t = fabs(x);
+    int n = (int)(t * invpio2 + 0.5);
+    const double fn = (double)n;
+    const double r = t - fn * pio2_1;
+    const double w = fn * pio2_1t;
+    double a = r - w;
+    double b = (r - a) - w;
+    if (x < 0) { a = -a; b = -b; n = -n; }
+    const double ks = dev_ksin(a, b, 1), kc = dev_kcos(a, b);
+    switch (n & 3) {
+        case 0: *sn = ks; *cs = kc; break;
+        case 1: *sn = kc; *cs = -ks; break;
+        case 2: *sn = -ks; *cs = -kc; break;
+        default: *sn = -kc; *cs = ks; break;
+    }
+}
+
 __device__ __forceinline__ int dev_cvround(float v) { return __float2int_rn(v); }
 
 // popcount of a 256-bit XOR: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2360-2378)

@@ -12,6 +12,11 @@ namespace eorb {
 int ev_decode_minmax(eorb_ctx* c, const uint32_t* d_enc, float* d_out, int B);
 int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long* bad_out);
 int ev_diag_read(unsigned long long* out16);
+int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], double angle,
+                    const double axis[3], const double tt[3], float medDepth, const float* d_depth);
+int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], const float* params, int nparams);
+int ev_focus_dev(eorb_ctx* c, const float* d_img, int W, int H, float* d_out);
+int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm, uint8_t* d_out);
 int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out);
 int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H);
 int orb_err_flag(eorb_ctx* c, int B, int* flag);
@@ -255,6 +260,104 @@ int eorb_ev2im_gauss(eorb_ctx* c, const eorb_event* ev, size_t n, int W, int H, 
 {
     if (c && !(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev2im_gauss: sigma must be > 0");
     return ev_host_common(c, ev, n, W, H, sigma, pol, normalized, 0, out_f32, out_u8, minmax, nullptr);
+}
+
+static int up(eorb_ctx* c, DevBuf& b, const void* h, size_t bytes);
+
+// ---- motion-compensated accumulation (f1) ----
+static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, int se3, double angle, const double* axis,
+                      const double* t, float medDepth, const float* depth, const float* params, int nparams, int W, int H,
+                      float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    if (!c) return EORB_E_ARG;
+    if (W <= 0 || H <= 0 || (n && !ev) || !cam || !(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev2mci: bad arguments");
+    hipSetDevice(c->device);
+    const size_t npix = (size_t)W * H;
+    if (n == 0) {                         // "no events" -> zero CV_32FC1 image (:292-295)
+        if (out_f32) memset(out_f32, 0, sizeof(float) * npix);
+        if (out_u8) memset(out_u8, 0, npix);
+        if (minmax) { minmax[0] = 0.f; minmax[1] = -1000000.0f; }
+        return EORB_OK;
+    }
+    if (n > 0x7fffffff) return set_err(c, EORB_E_CAPACITY, "ev2mci: too many events");
+    int rc;
+    if ((rc = ensure(c, c->ev16, sizeof(eorb_event16) * n))) return rc;
+    if ((rc = ensure(c, c->m_a, sizeof(eorb_event16) * n))) return rc;
+    if ((rc = ensure(c, c->img_f32, sizeof(float) * npix))) return rc;
+    if ((rc = ensure(c, c->img_u8, npix))) return rc;
+    if ((rc = ensure(c, c->minmax, 64))) return rc;
+    std::vector<eorb_event16> packed(n);
+    eorb_pack_events(ev, n, packed.data());
+    EORB_HIP(c, hipMemcpyAsync(c->m_a.p, packed.data(), sizeof(eorb_event16) * n, hipMemcpyHostToDevice, c->stream));
+    const float* d_depth = nullptr;
+    if (depth) {
+        if ((rc = up(c, c->m_b, depth, sizeof(float) * n))) return rc;
+        d_depth = (const float*)c->m_b.p;
+    }
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    const float camv[4] = {cam->fx, cam->fy, cam->cx, cam->cy};
+    if (se3) rc = ev_warp_se3_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, camv, angle, axis, t, medDepth, d_depth);
+    else rc = ev_warp_se2_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, camv, params, nparams);
+    if (rc) return rc;
+    int64_t offs[2] = {0, (int64_t)n};
+    uint32_t* mm = (uint32_t*)c->minmax.p;
+    float* mmf = (float*)((char*)c->minmax.p + 16);
+    rc = ev_accumulate_dev(c, (const eorb_event16*)c->ev16.p, offs, 1, W, H, sigma, pol, 0, (float*)c->img_f32.p, (uint8_t*)c->img_u8.p,
+                           normalized, mm);
+    if (rc) return rc;
+    if ((rc = ev_decode_minmax(c, mm, mmf, 1))) return rc;
+    float hmm[2];
+    EORB_HIP(c, hipMemcpyAsync(hmm, mmf, 8, hipMemcpyDeviceToHost, c->stream));
+    if (out_f32) EORB_HIP(c, hipMemcpyAsync(out_f32, c->img_f32.p, sizeof(float) * npix, hipMemcpyDeviceToHost, c->stream));
+    if (out_u8 && normalized) EORB_HIP(c, hipMemcpyAsync(out_u8, c->img_u8.p, npix, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (minmax) { minmax[0] = hmm[0]; minmax[1] = hmm[1]; }
+    return EORB_OK;
+}
+
+int eorb_ev2mci_se3(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, double angle, const double axis[3],
+                    const double t[3], float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol,
+                    int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    if (c && (!axis || !t)) return set_err(c, EORB_E_ARG, "ev2mci_se3: null pose");
+    return mci_common(c, ev, n, cam, 1, angle, axis, t, medDepth, depth_per_event, nullptr, 0, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+}
+
+int eorb_ev2mci_se2(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, const float* params2D, int nparams,
+                    int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    if (c && (!params2D || nparams < 3)) return set_err(c, EORB_E_ARG, "ev2mci_se2: need at least 3 parameters");
+    return mci_common(c, ev, n, cam, 0, 0.0, nullptr, nullptr, 0.f, nullptr, params2D, nparams, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+}
+
+int eorb_measure_image_focus(eorb_ctx* c, const float* img, int W, int H, float* focus)
+{
+    if (!c) return EORB_E_ARG;
+    if (!img || !focus || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "measure_image_focus: bad arguments");
+    hipSetDevice(c->device);
+    int rc;
+    if ((rc = up(c, c->img_f32, img, sizeof(float) * (size_t)W * H))) return rc;
+    if ((rc = ensure(c, c->minmax, 64))) return rc;
+    if ((rc = ev_focus_dev(c, (const float*)c->img_f32.p, W, H, (float*)c->minmax.p))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(focus, c->minmax.p, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+int eorb_normalize_minmax_u8(eorb_ctx* c, const float* img, int W, int H, uint8_t* out)
+{
+    if (!c) return EORB_E_ARG;
+    if (!img || !out || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "normalize_minmax_u8: bad arguments");
+    hipSetDevice(c->device);
+    const size_t npix = (size_t)W * H;
+    int rc;
+    if ((rc = up(c, c->img_f32, img, sizeof(float) * npix))) return rc;
+    if ((rc = ensure(c, c->img_u8, npix))) return rc;
+    if ((rc = ensure(c, c->minmax, 64))) return rc;
+    if ((rc = ev_cvnormalize_dev(c, (const float*)c->img_f32.p, (int)npix, (uint32_t*)c->minmax.p, (uint8_t*)c->img_u8.p))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(out, c->img_u8.p, npix, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
 }
 
 int eorb_selfcheck_division(eorb_ctx* c, float lo, float hi, float sigma, uint64_t* mismatches)

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(64) void ev_bin_kernel(const eorb_event16* __restri
     // ---- pass A: count ----
     for (int s = 0; s < cd.n; s += 64) {
         const int k = s + lane;
-        if (k < cd.n) {
-            const float x = e[k].x, y = e[k].y;
+        if (k < cd.n && e[k].x == e[k].x && e[k].y == e[k].y) {      // NaN coordinates (e.g. a one-event MCI window: 0 * inf)
+            const float x = e[k].x, y = e[k].y;                       // convert to INT_MIN on the reference's x86: never in the image
             const int xi = P.mode_count ? (int)roundf(x) : (int)floorf(x);
             const int yi = P.mode_count ? (int)roundf(y) : (int)floorf(y);
             int tx0 = (xi - P.h) >> 3, tx1 = (xi + P.h) >> 3, ty0 = (yi - P.h) >> 3, ty1 = (yi + P.h) >> 3;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void ev_bin_kernel(const eorb_event16* __restri
         const bool valid = k < cd.n;
         float x = 0.f, y = 0.f, sg = 1.f;
         int tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0;
-        if (valid) {
+        if (valid && e[k].x == e[k].x && e[k].y == e[k].y) {
             x = e[k].x; y = e[k].y;
             if (POL) sg = (__double_as_longlong(e[k].t) < 0) ? -1.0f : 1.0f;
             const int xi = P.mode_count ? (int)roundf(x) : (int)floorf(x);
@@ -557,6 +557,175 @@ __global__ void ev_decode_minmax_kernel(const uint32_t* mm, float* out, int B)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 2 * B) out[i] = dec_f32(mm[i]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Motion-compensated accumulation: ev2mci_gg_f (src/Event/EventConversion.cc:280-531) = a per-event warp
+// followed by exactly the ev2im_gauss splat.  The warp kernels rewrite (x, y) of the 16-byte records; the splat is the
+// pipeline above.
+struct WarpSE3 {
+    float fx, fy, cx, cy;
+    double angle, ax, ay, az, tx, ty, tz;
+    float medDepth;
+};
+
+__global__ void ev_warp_se3_kernel(const eorb_event16* __restrict__ in, eorb_event16* __restrict__ out, int n, WarpSE3 P,
+                                   const float* __restrict__ depth)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double t1 = fabs(in[n - 1].t), t0 = fabs(in[0].t);
+    const double DT = t1 - t0;
+    const double invDT = 1.0 / DT;
+    const eorb_event16 e = in[k];
+    const double etRate = (t1 - fabs(e.t)) * invDT;
+    const float X = (e.x - P.cx) / P.fx, Y = (e.y - P.cy) / P.fy;          // Pinhole::unproject (float)
+    const double Pv[3] = {(double)X, (double)Y, 1.0};
+    const double a = P.angle * etRate;
+    double sn, c;
+    dev_dsincos(a, &sn, &c);
+    // Eigen::AngleAxisd::toRotationMatrix()
+    const double sax = sn * P.ax, say = sn * P.ay, saz = sn * P.az;
+    const double c1x = (1.0 - c) * P.ax, c1y = (1.0 - c) * P.ay, c1z = (1.0 - c) * P.az;
+    double R[3][3];
+    double tmp;
+    tmp = c1x * P.ay; R[0][1] = tmp - saz; R[1][0] = tmp + saz;
+    tmp = c1x * P.az; R[0][2] = tmp + say; R[2][0] = tmp - say;
+    tmp = c1y * P.az; R[1][2] = tmp - sax; R[2][1] = tmp + sax;
+    R[0][0] = c1x * P.ax + c; R[1][1] = c1y * P.ay + c; R[2][2] = c1z * P.az + c;
+    const double d = (double)(depth ? depth[k] : P.medDepth);
+    const double tt[3] = {P.tx, P.ty, P.tz};
+    double np[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double acc = (d * R[i][0]) * Pv[0];
+        acc = acc + (d * R[i][1]) * Pv[1];
+        acc = acc + (d * R[i][2]) * Pv[2];
+        np[i] = acc + tt[i] * etRate;
+    }
+    const double u = (double)P.fx * np[0] / np[2] + (double)P.cx;            // Pinhole::project(Eigen::Vector3d)
+    const double v = (double)P.fy * np[1] / np[2] + (double)P.cy;
+    eorb_event16 o = e;
+    o.x = (float)u; o.y = (float)v;
+    out[k] = o;
+}
+
+struct WarpSE2 { float fx, fy, cx, cy, p0, p1, p2, sc; };
+
+__global__ void ev_warp_se2_kernel(const eorb_event16* __restrict__ in, eorb_event16* __restrict__ out, int n, WarpSE2 P)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double t1 = fabs(in[n - 1].t), t0 = fabs(in[0].t);
+    const float DT = (float)(t1 - t0);
+    const float invDT = 1.f / DT;
+    const float omega0 = P.p0 * invDT, vx0 = P.p1 * invDT, vy0 = P.p2 * invDT;
+    const float scDiff = 1.f - P.sc;
+    const eorb_event16 e = in[k];
+    const float tk = (float)(t1 - fabs(e.t));
+    const float X = (e.x - P.cx) / P.fx, Y = (e.y - P.cy) / P.fy;
+    const float theta_k = tk * omega0;
+    const float currSc = scDiff * (1 - tk * invDT) + P.sc;
+    float sn, cs;
+    dev_sincosf(theta_k, &sn, &cs);
+    const float xp = currSc * (X * cs - Y * sn) + vx0 * tk;
+    const float yp = currSc * (X * sn + Y * cs) + vy0 * tk;
+    eorb_event16 o = e;
+    o.x = P.fx * xp / 1.f + P.cx;                                            // Pinhole::project(cv::Point3f)
+    o.y = P.fy * yp / 1.f + P.cy;
+    out[k] = o;
+}
+
+int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], double angle,
+                    const double axis[3], const double tt[3], float medDepth, const float* d_depth)
+{
+    if (n <= 0) return EORB_OK;
+    WarpSE3 P{cam[0], cam[1], cam[2], cam[3], angle, axis[0], axis[1], axis[2], tt[0], tt[1], tt[2], medDepth};
+    ProfScope ps(c, "ev_warp_se3");
+    ev_warp_se3_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d_in, d_out, n, P, d_depth);
+    EORB_LAUNCH_CHECK(c, "ev_warp_se3_kernel");
+    return EORB_OK;
+}
+
+int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], const float* params, int nparams)
+{
+    if (n <= 0) return EORB_OK;
+    WarpSE2 P{cam[0], cam[1], cam[2], cam[3], params[0], params[1], params[2], nparams > 3 ? params[3] : 1.f};
+    ProfScope ps(c, "ev_warp_se2");
+    ev_warp_se2_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d_in, d_out, n, P);
+    EORB_LAUNCH_CHECK(c, "ev_warp_se2_kernel");
+    return EORB_OK;
+}
+
+// EvImConverter::measureImageFocus (:74-111): one thread per 30x30 patch (raster-order double accumulation like
+// cv::meanStdDev), then the patch deviations are summed in patch order.
+__global__ void ev_focus_kernel(const float* __restrict__ img, int W, int H, float* __restrict__ out)
+{
+    __shared__ float sd[1024];
+    const int patch = 30;
+    const int pc = (W + patch - 1) / patch, pr = (H + patch - 1) / patch, np = pc * pr;
+    for (int p = threadIdx.x; p < np; p += blockDim.x) {
+        const int i = (p / pc) * patch, j = (p % pc) * patch;
+        const int maxRow = min(i + patch, H), maxCol = min(j + patch, W);
+        double s = 0, sq = 0;
+        for (int y = i; y < maxRow; y++)
+            for (int x = j; x < maxCol; x++) { const double v = (double)img[(size_t)y * W + x]; s += v; sq += v * v; }
+        const double N = (double)(maxRow - i) * (double)(maxCol - j);
+        const double scale = 1.0 / N;
+        const double mean = s * scale;
+        double var = sq * scale - mean * mean;
+        if (var < 0) var = 0;
+        sd[p] = (float)sqrt(var);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float localStd = 0.f;
+        for (int p = 0; p < np; p++) localStd += sd[p];
+        out[0] = localStd / (float)np;
+    }
+}
+
+int ev_focus_dev(eorb_ctx* c, const float* d_img, int W, int H, float* d_out)
+{
+    const int np = ((W + 29) / 30) * ((H + 29) / 30);
+    if (np > 1024) return set_err(c, EORB_E_CAPACITY, "measure_image_focus: more than 1024 patches");
+    ProfScope ps(c, "ev_focus");
+    ev_focus_kernel<<<1, 256, 0, c->stream>>>(d_img, W, H, d_out);
+    EORB_LAUNCH_CHECK(c, "ev_focus_kernel");
+    return EORB_OK;
+}
+
+// cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) (EvImBuilder.cpp:1076): min/max of the final image
+__global__ void ev_minmax_final_kernel(const float* __restrict__ img, int npix, uint32_t* __restrict__ mm)
+{
+    float lo = img[0], hi = img[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) { lo = fminf(lo, img[i]); hi = fmaxf(hi, img[i]); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], enc_f32(lo)); atomicMax(&mm[1], enc_f32(hi)); }
+}
+__global__ void ev_cvnormalize_kernel(const float* __restrict__ img, int npix, const uint32_t* __restrict__ mm, uint8_t* __restrict__ out)
+{
+    const double smin = (double)dec_f32(mm[0]), smax = (double)dec_f32(mm[1]);
+    const double scale = 255.0 * (smax - smin > 2.2204460492503131e-16 ? 1. / (smax - smin) : 0);
+    const double shift = 0.0 - smin * scale;
+    const float fs = (float)scale, fh = (float)shift;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const float m = img[i] * fs;
+        const float v = m + fh;
+        out[i] = (uint8_t)min(max(__float2int_rn(v), 0), 255);
+    }
+}
+__global__ void ev_mm_reset_kernel(uint32_t* mm) { mm[0] = 0xffffffffu; mm[1] = 0u; }
+
+int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm, uint8_t* d_out)
+{
+    ProfScope ps(c, "ev_cvnormalize");
+    ev_mm_reset_kernel<<<1, 1, 0, c->stream>>>(d_mm);
+    ev_minmax_final_kernel<<<64, 256, 0, c->stream>>>(d_img, npix, d_mm);
+    ev_cvnormalize_kernel<<<64, 256, 0, c->stream>>>(d_img, npix, d_mm, d_out);
+    EORB_LAUNCH_CHECK(c, "cv::normalize kernels");
+    return EORB_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------

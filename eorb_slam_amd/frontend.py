@@ -137,6 +137,52 @@ class EvImConverter:
         return u8 if normalized else f32
 
 
+    @staticmethod
+    def ev2mci_gg_f_se3(vEvData, cam, angle, axis, t, medDepth, imWidth, imHeight, sigma=1.0, pol=False, normalized=False,
+                        depth_per_event=None, ctx=None):
+        """ev2mci_gg_f(evs, pCamera, Tcw, medDepth | depth map, ...) (src/Event/EventConversion.cc:280-360, 451-531); cam =
+        (fx, fy, cx, cy); angle/axis = AngleAxisd(R(Tcw)), t = translation.  Returns (f32 image, u8 image|None, minmax)."""
+        ctx = ctx or default_context()
+        ev = np.ascontiguousarray(vEvData, EVENT_DTYPE)
+        ax = np.ascontiguousarray(axis, np.float64); tt = np.ascontiguousarray(t, np.float64)
+        dp = None if depth_per_event is None else np.ascontiguousarray(depth_per_event, np.float32)
+        f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8); mm = np.zeros(2, np.float32)
+        pc = _lib.Pinhole(*cam)
+        ctx.check(ctx.L.eorb_ev2mci_se3(ctx.h, _p(ev), len(ev), C.byref(pc), float(angle), _p(ax), _p(tt), float(medDepth), _p(dp),
+                                        imWidth, imHeight, float(sigma), int(pol), int(normalized), _p(f32), _p(u8), _p(mm)))
+        return f32, (u8 if (normalized and len(ev)) else None), mm
+
+    @staticmethod
+    def ev2mci_gg_f_se2(vEvData, cam, params2D, imWidth, imHeight, sigma=1.0, pol=False, normalized=False, ctx=None):
+        """ev2mci_gg_f(evs, pCamera, params2D, ...) (src/Event/EventConversion.cc:363-448)"""
+        ctx = ctx or default_context()
+        ev = np.ascontiguousarray(vEvData, EVENT_DTYPE)
+        pr = np.ascontiguousarray(params2D, np.float32)
+        f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8); mm = np.zeros(2, np.float32)
+        pc = _lib.Pinhole(*cam)
+        ctx.check(ctx.L.eorb_ev2mci_se2(ctx.h, _p(ev), len(ev), C.byref(pc), _p(pr), len(pr), imWidth, imHeight, float(sigma),
+                                        int(pol), int(normalized), _p(f32), _p(u8), _p(mm)))
+        return f32, (u8 if (normalized and len(ev)) else None), mm
+
+    @staticmethod
+    def measureImageFocus(image, ctx=None):
+        """src/Event/EventConversion.cc:74-111"""
+        ctx = ctx or default_context()
+        img = np.ascontiguousarray(image, np.float32); H, W = img.shape
+        f = C.c_float(0)
+        ctx.check(ctx.L.eorb_measure_image_focus(ctx.h, _p(img), W, H, C.byref(f)))
+        return f.value
+
+
+def cv_normalize_minmax_u8(image, ctx=None):
+    """cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) as called at src/Event/EvImBuilder.cpp:1076"""
+    ctx = ctx or default_context()
+    img = np.ascontiguousarray(image, np.float32); H, W = img.shape
+    out = np.zeros((H, W), np.uint8)
+    ctx.check(ctx.L.eorb_normalize_minmax_u8(ctx.h, _p(img), W, H, _p(out)))
+    return out
+
+
 class ORBextractor:
     """ORB_SLAM3::ORBextractor (include/ORBextractor.h:49-139).  One instance per thread, like the reference."""
 

@@ -105,6 +105,24 @@ int eorb_ev2im(eorb_ctx* ctx, const eorb_event* ev, size_t n, int W, int H, int 
 int eorb_ev2im_gauss(eorb_ctx* ctx, const eorb_event* ev, size_t n, int W, int H, float sigma, int pol,
                      int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
 
+/* ---- motion-compensated accumulation (host buffers) ------------------------------------------------ */
+typedef struct { float fx, fy, cx, cy; } eorb_pinhole;     /* Pinhole::mvParameters (CameraModels/Pinhole.cpp:30-62) */
+
+/* replaces EvImConverter::ev2mci_gg_f(evs, pCamera, Tcw, medDepth, W, H, sigma, pol, normalized)
+ * (src/Event/EventConversion.cc:280-360) and the depth-map overload (:451-531, pass depth_per_event[n] =
+ * depthMapObj.getDepthLinInterp(ex, ey)).  angle / axis = Eigen::AngleAxisd(R of Tcw), t = translation of Tcw (the
+ * adapter computes them once per call with Eigen, as the reference does at :297-301).  n == 0 -> zero image. */
+int eorb_ev2mci_se3(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eorb_pinhole* cam, double angle,
+                    const double axis[3], const double t[3], float medDepth, const float* depth_per_event,
+                    int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+/* replaces the SE2 overload (params2D = {omega, vx, vy[, scale]}), src/Event/EventConversion.cc:363-448 */
+int eorb_ev2mci_se2(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eorb_pinhole* cam, const float* params2D, int nparams,
+                    int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+/* replaces EvImConverter::measureImageFocus (src/Event/EventConversion.cc:74-111) */
+int eorb_measure_image_focus(eorb_ctx* ctx, const float* img, int W, int H, float* focus);
+/* replaces cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) at src/Event/EvImBuilder.cpp:976,1055,1076,1140 */
+int eorb_normalize_minmax_u8(eorb_ctx* ctx, const float* img, int W, int H, uint8_t* out);
+
 /* ---- ORB extractor (host buffers) --------------------------------------------------------------- */
 /* replaces ORBextractor::ORBextractor, src/ORBextractor.cc:420-489: scale tables, per-level quotas,
  * edge threshold (per context, not a process global: SURVEY App.B H3) for images of W x H */

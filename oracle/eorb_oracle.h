@@ -84,6 +84,33 @@ int orc_ev2im(const orc_event* ev, size_t n, int W, int H, int pol, int normaliz
 int orc_ev2im_gauss(const orc_event* ev, size_t n, int W, int H, float sigma, int pol,
                     int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
 
+/* ---- motion-compensated accumulation: src/Event/EventConversion.cc:280-531 -------------------- */
+/* double-precision sin/cos used by the per-event AngleAxisd -> rotation matrix (Eigen): fdlibm kernels + two-term pi/2
+ * reduction, strict IEEE double, valid for |x| < 100 (parity unpinned against glibc's double sin/cos; agrees to 1 ulp) */
+double orc_dsin(double x);
+double orc_dcos(double x);
+
+typedef struct { float fx, fy, cx, cy; } orc_pinhole;          /* Pinhole::mvParameters (float), CameraModels/Pinhole.cpp */
+
+/* per-event warp of ev2mci_gg_f(evs, cam, Tcw, medDepth, ...) (:304-335): angle/axis = Eigen::AngleAxisd(R) and tt = t of
+ * Tcw, computed by the caller (host, once per call).  depth_per_event != NULL replaces medDepth per event (depth-map
+ * variant :451-531).  uv_out: n x 2 floats (the arguments of breakFloatCoords). */
+void orc_mci_warp_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, double angle, const double axis[3],
+                      const double tt[3], float medDepth, const float* depth_per_event, float* uv_out);
+/* per-event warp of the SE2 variant (:363-412): params2D = {omega, vx, vy[, scale]} (nparams 3 or 4) */
+void orc_mci_warp_se2(const orc_event* ev, size_t n, const orc_pinhole* cam, const float* params2D, int nparams, float* uv_out);
+/* full ev2mci_gg_f: warp + the ev2im_gauss splat on the warped coordinates; n == 0 -> zeros, returns 0 (:292-295) */
+int orc_ev2mci_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, double angle, const double axis[3], const double tt[3],
+                   float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol, int normalized,
+                   float* out_f32, uint8_t* out_u8, float* minmax);
+int orc_ev2mci_se2(const orc_event* ev, size_t n, const orc_pinhole* cam, const float* params2D, int nparams,
+                   int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+/* EvImConverter::measureImageFocus (:74-111): mean over 30x30 patches of the patch standard deviation (cv::meanStdDev,
+ * double accumulation in raster order) */
+float orc_measure_image_focus(const float* img, int W, int H);
+/* cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) (EvImBuilder.cpp:1076) */
+void orc_cv_normalize_minmax_u8(const float* img, size_t npix, uint8_t* dst);
+
 /* normalizeImage (:67-72) == Mat::convertTo(CV_8UC1, alpha, beta) */
 void orc_normalize_u8(const float* src, size_t npix, float maxVal, float minVal, uint8_t* dst);
 

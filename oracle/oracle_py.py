@@ -22,6 +22,10 @@ class OrbParams(C.Structure):
                 ("iniThFAST", C.c_int), ("minThFAST", C.c_int), ("edgeTh", C.c_int), ("imWidth", C.c_int)]
 
 
+class Pinhole(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
 class GridBounds(C.Structure):
     _fields_ = [("minX", C.c_float), ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float),
                 ("invW", C.c_float), ("invH", C.c_float)]
@@ -56,6 +60,18 @@ def lib(fast=False):
     L.orc_ev2im.argtypes = [vp, C.c_size_t, ci, ci, ci, ci, vp, vp, vp]
     L.orc_ev2im_gauss.restype = ci
     L.orc_ev2im_gauss.argtypes = [vp, C.c_size_t, ci, ci, cf, ci, ci, vp, vp, vp]
+    cd = C.c_double
+    L.orc_dsin.restype = cd; L.orc_dsin.argtypes = [cd]
+    L.orc_dcos.restype = cd; L.orc_dcos.argtypes = [cd]
+    L.orc_mci_warp_se3.restype = None
+    L.orc_mci_warp_se3.argtypes = [vp, C.c_size_t, C.POINTER(Pinhole), cd, vp, vp, cf, vp, vp]
+    L.orc_mci_warp_se2.restype = None; L.orc_mci_warp_se2.argtypes = [vp, C.c_size_t, C.POINTER(Pinhole), vp, ci, vp]
+    L.orc_ev2mci_se3.restype = ci
+    L.orc_ev2mci_se3.argtypes = [vp, C.c_size_t, C.POINTER(Pinhole), cd, vp, vp, cf, vp, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.orc_ev2mci_se2.restype = ci
+    L.orc_ev2mci_se2.argtypes = [vp, C.c_size_t, C.POINTER(Pinhole), vp, ci, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.orc_measure_image_focus.restype = cf; L.orc_measure_image_focus.argtypes = [vp, ci, ci]
+    L.orc_cv_normalize_minmax_u8.restype = None; L.orc_cv_normalize_minmax_u8.argtypes = [vp, C.c_size_t, vp]
     L.orc_normalize_u8.restype = None
     L.orc_normalize_u8.argtypes = [vp, C.c_size_t, cf, cf, vp]
     L.orc_orb_create.restype = vp; L.orc_orb_create.argtypes = [C.POINTER(OrbParams)]
@@ -368,3 +384,37 @@ def resolve_num_mixed(nDetORB, nDetAK, nDesired, nDesiredAK):
     a, b = C.c_int(-1), C.c_int(-1)
     lib().orc_resolve_num_mixed(nDetORB, nDetAK, nDesired, nDesiredAK, C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+# ---- motion-compensated accumulation (f1) --------------------------------------------------------------------------------
+def ev2mci_se3(ev, cam, angle, axis, tt, medDepth, W, H, sigma=1.0, pol=False, normalized=False, depth=None):
+    ev = np.ascontiguousarray(ev, EVENT_DTYPE)
+    ax = np.ascontiguousarray(axis, np.float64); t = np.ascontiguousarray(tt, np.float64)
+    dp = None if depth is None else np.ascontiguousarray(depth, np.float32)
+    f32 = np.empty((H, W), np.float32); u8 = np.zeros((H, W), np.uint8); mm = np.zeros(2, np.float32)
+    pc = Pinhole(*cam)
+    r = lib().orc_ev2mci_se3(_p(ev), len(ev), C.byref(pc), float(angle), _p(ax), _p(t), float(medDepth), _p(dp), W, H,
+                             float(sigma), int(pol), int(normalized), _p(f32), _p(u8), _p(mm))
+    return f32, (u8 if r else None), mm
+
+
+def ev2mci_se2(ev, cam, params2D, W, H, sigma=1.0, pol=False, normalized=False):
+    ev = np.ascontiguousarray(ev, EVENT_DTYPE)
+    pr = np.ascontiguousarray(params2D, np.float32)
+    f32 = np.empty((H, W), np.float32); u8 = np.zeros((H, W), np.uint8); mm = np.zeros(2, np.float32)
+    pc = Pinhole(*cam)
+    r = lib().orc_ev2mci_se2(_p(ev), len(ev), C.byref(pc), _p(pr), len(pr), W, H, float(sigma), int(pol), int(normalized),
+                             _p(f32), _p(u8), _p(mm))
+    return f32, (u8 if r else None), mm
+
+
+def measure_image_focus(img):
+    img = np.ascontiguousarray(img, np.float32); H, W = img.shape
+    return lib().orc_measure_image_focus(_p(img), W, H)
+
+
+def cv_normalize_minmax_u8(img):
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.zeros(img.shape, np.uint8)
+    lib().orc_cv_normalize_minmax_u8(_p(img), img.size, _p(out))
+    return out

@@ -5,6 +5,7 @@
  */
 #include "eorb_oracle.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* MyCalibrator::isInImage, src/Utils/MyCalibrator.cpp:36-39 */
@@ -93,4 +94,161 @@ int orc_ev2im_gauss(const orc_event* ev, size_t n, int W, int H, float sigma, in
         return 1;
     }
     return 0;
+}
+
+/* ---- motion-compensated accumulation: EventConversion.cc:280-531 ------------------------------------------------- */
+/* Pinhole::unproject (CameraModels/Pinhole.cpp:59-62), float */
+static inline void pin_unproject(const orc_pinhole* c, float x, float y, float* X, float* Y)
+{
+    *X = (x - c->cx) / c->fx;
+    *Y = (y - c->cy) / c->fy;
+}
+
+void orc_mci_warp_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, double angle, const double axis[3],
+                      const double tt[3], float medDepth, const float* depth_per_event, float* uv)
+{
+    if (n == 0) return;
+    const double t1 = ev[n - 1].ts;
+    const double DT = t1 - ev[0].ts;
+    const double invDT = 1.0 / DT;
+    for (size_t k = 0; k < n; k++) {
+        const double etRate = (t1 - ev[k].ts) * invDT;
+        float X, Y;
+        pin_unproject(cam, ev[k].x, ev[k].y, &X, &Y);
+        const double P[3] = { (double)X, (double)Y, (double)1.f };
+        /* Eigen::AngleAxisd(omega.angle()*etRate, omega.axis()).toRotationMatrix() */
+        const double a = angle * etRate;
+        const double sn = orc_dsin(a), c = orc_dcos(a);
+        const double sax = sn * axis[0], say = sn * axis[1], saz = sn * axis[2];
+        const double c1x = (1.0 - c) * axis[0], c1y = (1.0 - c) * axis[1], c1z = (1.0 - c) * axis[2];
+        double R[3][3];
+        double tmp;
+        tmp = c1x * axis[1]; R[0][1] = tmp - saz; R[1][0] = tmp + saz;
+        tmp = c1x * axis[2]; R[0][2] = tmp + say; R[2][0] = tmp - say;
+        tmp = c1y * axis[2]; R[1][2] = tmp - sax; R[2][1] = tmp + sax;
+        R[0][0] = c1x * axis[0] + c; R[1][1] = c1y * axis[1] + c; R[2][2] = c1z * axis[2] + c;
+        const double d = (double)(depth_per_event ? depth_per_event[k] : medDepth);
+        double np[3];
+        for (int i = 0; i < 3; i++) {
+            /* (medDepth * newR) * P3D + newT : coefficient-based 3x3 product, left to right */
+            double acc = (d * R[i][0]) * P[0];
+            acc = acc + (d * R[i][1]) * P[1];
+            acc = acc + (d * R[i][2]) * P[2];
+            np[i] = acc + tt[i] * etRate;
+        }
+        /* Pinhole::project(Eigen::Vector3d) :41-47 */
+        const double u = (double)cam->fx * np[0] / np[2] + (double)cam->cx;
+        const double v = (double)cam->fy * np[1] / np[2] + (double)cam->cy;
+        uv[2 * k] = (float)u; uv[2 * k + 1] = (float)v;
+    }
+}
+
+void orc_mci_warp_se2(const orc_event* ev, size_t n, const orc_pinhole* cam, const float* params2D, int nparams, float* uv)
+{
+    if (n == 0) return;
+    const double t1 = ev[n - 1].ts;
+    const float DT = (float)(t1 - ev[0].ts);
+    const float invDT = 1.f / DT;
+    const float omega0 = params2D[0] * invDT, vx0 = params2D[1] * invDT, vy0 = params2D[2] * invDT;
+    float sc = 1.f;
+    if (nparams > 3) sc = params2D[3];
+    const float scDiff = 1.f - sc;
+    for (size_t k = 0; k < n; k++) {
+        const float tk = (float)(t1 - ev[k].ts);
+        float X, Y;
+        pin_unproject(cam, ev[k].x, ev[k].y, &X, &Y);
+        const float Z = 1.f;
+        const float theta_k = tk * omega0;
+        const float currSc = scDiff * (1 - tk * invDT) + sc;
+        const float cs = orc_cosf(theta_k), sn = orc_sinf(theta_k);
+        const float xp = currSc * (X * cs - Y * sn) + vx0 * tk;
+        const float yp = currSc * (X * sn + Y * cs) + vy0 * tk;
+        /* Pinhole::project(cv::Point3f) :30-33 */
+        uv[2 * k] = cam->fx * xp / Z + cam->cx;
+        uv[2 * k + 1] = cam->fy * yp / Z + cam->cy;
+    }
+}
+
+static int mci_splat(const orc_event* ev, size_t n, const float* uv, int W, int H, float sigma, int pol, int normalized,
+                     float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    orc_event* w = (orc_event*)malloc(sizeof(orc_event) * (n ? n : 1));
+    for (size_t k = 0; k < n; k++) { w[k] = ev[k]; w[k].x = uv[2 * k]; w[k].y = uv[2 * k + 1]; }
+    int r = orc_ev2im_gauss(w, n, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+    free(w);
+    return r;
+}
+
+int orc_ev2mci_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, double angle, const double axis[3], const double tt[3],
+                   float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol, int normalized,
+                   float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    if (n == 0) {                       /* "no events": returns the zero CV_32FC1 image (:292-295) */
+        memset(out_f32, 0, sizeof(float) * (size_t)W * H);
+        if (minmax) { minmax[0] = 0.f; minmax[1] = -1000000.0f; }
+        return 0;
+    }
+    float* uv = (float*)malloc(sizeof(float) * 2 * n);
+    orc_mci_warp_se3(ev, n, cam, angle, axis, tt, medDepth, depth_per_event, uv);
+    int r = mci_splat(ev, n, uv, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+    free(uv);
+    return r;
+}
+
+int orc_ev2mci_se2(const orc_event* ev, size_t n, const orc_pinhole* cam, const float* params2D, int nparams,
+                   int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    if (n == 0) {
+        memset(out_f32, 0, sizeof(float) * (size_t)W * H);
+        if (minmax) { minmax[0] = 0.f; minmax[1] = -1000000.0f; }
+        return 0;
+    }
+    float* uv = (float*)malloc(sizeof(float) * 2 * n);
+    orc_mci_warp_se2(ev, n, cam, params2D, nparams, uv);
+    int r = mci_splat(ev, n, uv, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+    free(uv);
+    return r;
+}
+
+/* EvImConverter::measureImageFocus :74-111 ; cv::meanStdDev on a CV_32FC1 patch: sum and sum of squares accumulated in
+ * double in raster order, stddev = sqrt(max(sqsum/N - mean^2, 0)) */
+float orc_measure_image_focus(const float* img, int W, int H)
+{
+    const int patch = 30;
+    float localStd = 0.f;
+    int cnt = 0;
+    for (int i = 0; i < H; i += patch) {
+        for (int j = 0; j < W; j += patch) {
+            const int maxRow = i + patch < H ? i + patch : H, maxCol = j + patch < W ? j + patch : W;
+            double s = 0, sq = 0;
+            for (int y = i; y < maxRow; y++)
+                for (int x = j; x < maxCol; x++) { const double v = (double)img[(size_t)y * W + x]; s += v; sq += v * v; }
+            const double N = (double)(maxRow - i) * (double)(maxCol - j);
+            const double scale = 1.0 / N;
+            const double mean = s * scale;
+            double var = sq * scale - mean * mean;
+            if (var < 0) var = 0;
+            const float currStd = (float)sqrt(var);
+            localStd += currStd;
+            cnt++;
+        }
+    }
+    return localStd / (float)cnt;
+}
+
+/* cv::normalize(src, dst, 255, 0, NORM_MINMAX, CV_8UC1): scale = 255 * (1/(max-min)) in double (0 when max-min <=
+ * DBL_EPSILON), shift = -min*scale; convertTo works with float(scale), float(shift) */
+void orc_cv_normalize_minmax_u8(const float* img, size_t npix, uint8_t* dst)
+{
+    double smin = img[0], smax = img[0];
+    for (size_t i = 1; i < npix; i++) { if (img[i] < smin) smin = img[i]; if (img[i] > smax) smax = img[i]; }
+    const double scale = (255.0 - 0.0) * (smax - smin > 2.2204460492503131e-16 ? 1. / (smax - smin) : 0);
+    const double shift = 0.0 - smin * scale;
+    const float fs = (float)scale, fh = (float)shift;
+    for (size_t i = 0; i < npix; i++) {
+        const float m = img[i] * fs;
+        const float v = m + fh;
+        int iv = orc_cvround((double)v);
+        dst[i] = (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
+    }
 }

@@ -171,3 +171,68 @@ uint64_t orc_math_hash(int which, uint32_t lo_bits, uint32_t hi_bits)
     }
     return h;
 }
+
+/* ---- double sin/cos (fdlibm k_sin / k_cos + medium-range pi/2 reduction) ------------------------------------------- */
+static double k_sin(double x, double y, int iy)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = x * x;
+    double v = z * x;
+    double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    if (iy == 0) return x + v * (S1 + z * r);
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+static double k_cos(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = x * x;
+    double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    double ax = fabs(x);
+    if (ax < 0.3) return 1.0 - (0.5 * z - (z * r - x * y));
+    double qx = (ax > 0.78125) ? 0.28125 : 0.25 * ax;      /* fdlibm takes x/4 with the low word cleared */
+    {
+        uint64_t u = asu64(qx); u &= 0xffffffff00000000ull; qx = (ax > 0.78125) ? 0.28125 : asf64(u);
+    }
+    double hz = 0.5 * z - qx;
+    double a = 1.0 - qx;
+    return a - (hz - (z * r - x * y));
+}
+static int rem_pio2_medium(double x, double* y0, double* y1)
+{
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    double t = fabs(x);
+    int n = (int)(t * invpio2 + 0.5);
+    double fn = (double)n;
+    double r = t - fn * pio2_1;
+    double w = fn * pio2_1t;
+    double a = r - w;
+    double b = (r - a) - w;
+    if (x < 0) { *y0 = -a; *y1 = -b; return -n; }
+    *y0 = a; *y1 = b; return n;
+}
+double orc_dsin(double x)
+{
+    if (fabs(x) <= 0.78539816339744830962) return k_sin(x, 0.0, 0);
+    double y0, y1;
+    int n = rem_pio2_medium(x, &y0, &y1);
+    switch (n & 3) {
+        case 0: return k_sin(y0, y1, 1);
+        case 1: return k_cos(y0, y1);
+        case 2: return -k_sin(y0, y1, 1);
+        default: return -k_cos(y0, y1);
+    }
+}
+double orc_dcos(double x)
+{
+    if (fabs(x) <= 0.78539816339744830962) return k_cos(x, 0.0);
+    double y0, y1;
+    int n = rem_pio2_medium(x, &y0, &y1);
+    switch (n & 3) {
+        case 0: return k_cos(y0, y1);
+        case 1: return -k_sin(y0, y1, 1);
+        case 2: return -k_cos(y0, y1);
+        default: return k_sin(y0, y1, 1);
+    }
+}

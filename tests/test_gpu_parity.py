@@ -402,3 +402,54 @@ def test_error_paths_return_codes(fe, ctx):
     img = np.zeros((180, 240), np.uint8)
     assert c2.L.eorb_orb_extract(c2.h, img.ctypes.data_as(C.c_void_p), 240, 180, 240, 0, 1000, 1, None, None, None, 0, C.byref(n), C.byref(m)) == -6   # not configured
     c2.close()
+
+
+# ---- motion-compensated accumulation + focus -----------------------------------------------------------
+EVETHZ_CAM = (199.092366542, 198.82882047, 132.192071378, 110.712660011)
+
+
+@pytest.mark.parametrize("n,pol", [(6000, False), (6000, True), (1, False), (0, False)])
+def test_ev2mci_se3(oracle, fe, ctx, n, pol):
+    ev = synth.shapes_events(n, seed=81, undistort=True) if n else np.zeros(0, synth.EVENT_DTYPE)
+    axis = np.array([0.12, -0.3, 0.946484], np.float64); axis /= np.linalg.norm(axis)
+    t = np.array([0.013, -0.007, 0.002])
+    depth = np.random.default_rng(1).uniform(0.8, 2.5, max(n, 1)).astype(np.float32)[:n]
+    for kw in (dict(medDepth=1.7, depth=None), dict(medDepth=1.0, depth=depth)):
+        for normalized in (False, True):
+            of, ou, omm = oracle.ev2mci_se3(ev, EVETHZ_CAM, 0.031, axis, t, kw["medDepth"], 240, 180, 1.0, pol, normalized, depth=kw["depth"])
+            gf, gu, gmm = fe.EvImConverter.ev2mci_gg_f_se3(ev, EVETHZ_CAM, 0.031, axis, t, kw["medDepth"], 240, 180, 1.0, pol, normalized,
+                                                          depth_per_event=kw["depth"], ctx=ctx)
+            assert _same_bits(of, gf)
+            if n:
+                assert _same_bits(omm, gmm)
+            if normalized and n:
+                assert np.array_equal(ou, gu)
+
+
+def test_ev2mci_se2_and_focus_contest(oracle, fe, ctx):
+    """The reconstruction contest of EvImBuilder::generateMCImage (EvImBuilder.cpp:1146-1247): event histogram vs SE3 vs SE2
+    reconstructions, each scored by measureImageFocus and normalised with cv::normalize; best focus wins."""
+    ev = synth.shapes_events(6000, seed=82, undistort=True, motion=1.5)
+    axis = np.array([0.0, 0.0, 1.0]); t = np.array([0.01, 0.0, 0.0])
+    cands = {}
+    of, _, _ = oracle.ev2im_gauss(ev, 240, 180, 1.0, False, False)
+    gf, _, _ = fe.EvImConverter.ev2im_gauss(ev, 240, 180, 1.0, False, False, ctx=ctx, return_all=True)
+    cands["EH"] = (of, gf)
+    of, _, _ = oracle.ev2mci_se3(ev, EVETHZ_CAM, 0.02, axis, t, 1.3, 240, 180)
+    gf, _, _ = fe.EvImConverter.ev2mci_gg_f_se3(ev, EVETHZ_CAM, 0.02, axis, t, 1.3, 240, 180, ctx=ctx)
+    cands["DP"] = (of, gf)
+    for params in ([0.02, 0.004, -0.003], [-0.015, 0.002, 0.001, 0.97]):
+        of, _, _ = oracle.ev2mci_se2(ev, EVETHZ_CAM, params, 240, 180)
+        gf, _, _ = fe.EvImConverter.ev2mci_gg_f_se2(ev, EVETHZ_CAM, params, 240, 180, ctx=ctx)
+        cands["A%d" % len(params)] = (of, gf)
+    scores = {}
+    for k, (of, gf) in cands.items():
+        assert _same_bits(of, gf), k
+        fo, fg = oracle.measure_image_focus(of), fe.EvImConverter.measureImageFocus(gf, ctx=ctx)
+        assert np.float32(fo).tobytes() == np.float32(fg).tobytes(), k
+        assert np.array_equal(oracle.cv_normalize_minmax_u8(of), fe.cv_normalize_minmax_u8(gf, ctx=ctx)), k
+        scores[k] = fo
+    assert len(set(scores.values())) == len(scores)
+    flat = np.zeros((180, 240), np.float32)
+    assert np.array_equal(oracle.cv_normalize_minmax_u8(flat), fe.cv_normalize_minmax_u8(flat, ctx=ctx))
+    assert oracle.measure_image_focus(flat) == fe.EvImConverter.measureImageFocus(flat, ctx=ctx) == 0.0
