@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="time-slices per step per GPU")
     ap.add_argument("--events", type=int, default=1000000, help="events per slice")
-    ap.add_argument("--cpu-slices", type=int, default=16, help="slices timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-slices", type=int, default=64, help="slices timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
     return ap.parse_args()
 
@@ -144,11 +144,16 @@ def main():
             ext_bytes = 7.0 * P + 1321.0 * float(nk.mean())
             unit_bytes = acc_bytes if dom.startswith("ev_") else ext_bytes
             achieved = unit_bytes * B / (avg_ms * 1e-3) / 1e9
+            # HBM traffic of the dominant kernel per launch: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload
+            # (profiles/r01_pmc_traffic.txt: ev_gather 25.6 MB per 1 Mev slice with the gfx950 x2 FETCH correction), scaled to
+            # this launch; bench.py cannot collect PMC counters itself
+            traffic = 25.6e6 * (NEV / 1e6) * B if dom == "ev_gather" else None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": "profiles/r01_pmc_traffic.txt",
                                "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": unit_bytes * B,
-                               "note": "ev_gather is VALU-bound by construction: 49 IEEE expf taps per 16 B event "
-                                       "(see DESIGN.md); the HBM fraction is reported as the contract asks"}
+                               "note": "ev_gather is VALU/latency-bound by construction: 49 ordered IEEE expf taps per 16 B event "
+                                       "(DESIGN.md section 4); the HBM fraction is reported as the contract asks"}
             out["kernels_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items())}
         # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same workload ----
         if a.cpu_slices > 0:
