@@ -37,7 +37,8 @@ int search_bow_dev(eorb_ctx* c, const eorb_keypoint* kf_kps, const uint8_t* kf_d
                    const uint32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx, int kf_nn,
                    const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc, const uint32_t* f_nodes, const int32_t* f_off,
                    const int32_t* f_idx, int f_nn, int32_t* match_f, int8_t* bin_f, int32_t* histo, int32_t* nmatches,
-                   float nnratio, int checkOri);
+                   float nnratio, int checkOri, int kf_kf, const uint8_t* f_has_mp, int32_t* match12, int n_kf);
+int distinctive_dev(eorb_ctx* c, const uint8_t* d_desc, const int32_t* d_offsets, int M, int32_t* d_best);
 int sort_response_dev(eorb_ctx* c, const eorb_keypoint* d_kps, int n, int32_t* d_perm);
 
 int set_err(eorb_ctx* c, int code, const char* fmt, ...)
@@ -630,18 +631,19 @@ int eorb_search_by_projection_map(eorb_ctx* c,
     return EORB_OK;
 }
 
-int eorb_search_by_bow(eorb_ctx* c,
+static int bow_common(eorb_ctx* c, int kf_kf,
         const eorb_keypoint* kf_kps, int n_kf, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
         const uint32_t* kf_nodes, const int32_t* kf_node_off, const int32_t* kf_idx, int kf_nn,
-        const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc,
+        const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc, const uint8_t* f_has_mp,
         const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
-        int32_t* match_f, float nnratio, int checkOri, int* nmatches)
+        int32_t* match_out, float nnratio, int checkOri, int* nmatches)
 {
     if (!c) return EORB_E_ARG;
-    if (n_kf < 0 || n_f < 0 || kf_nn < 0 || f_nn < 0 || !match_f) return set_err(c, EORB_E_ARG, "search_by_bow: bad arguments");
+    if (n_kf < 0 || n_f < 0 || kf_nn < 0 || f_nn < 0 || !match_out) return set_err(c, EORB_E_ARG, "search_by_bow: bad arguments");
     hipSetDevice(c->device);
     if (nmatches) *nmatches = 0;
-    for (int i = 0; i < n_f; i++) match_f[i] = -1;
+    const int nout = kf_kf ? n_kf : n_f;
+    for (int i = 0; i < nout; i++) match_out[i] = -1;
     if (n_kf == 0 || n_f == 0 || kf_nn == 0 || f_nn == 0) return EORB_OK;
     const int nki = kf_node_off[kf_nn], nfi = f_node_off[f_nn];
     for (int i = 0; i < nki; i++) if (kf_idx[i] < 0 || kf_idx[i] >= n_kf) return set_err(c, EORB_E_ARG, "search_by_bow: KeyFrame index out of range");
@@ -651,7 +653,10 @@ int eorb_search_by_bow(eorb_ctx* c,
     if ((rc = up(c, c->m_b, kf_desc, 32 * (size_t)n_kf))) return rc;
     if ((rc = up(c, c->m_c, f_kps, sizeof(eorb_keypoint) * n_f))) return rc;
     if ((rc = up(c, c->m_d, f_desc, 32 * (size_t)n_f))) return rc;
-    if ((rc = up(c, c->m_e, kf_has_mp, n_kf))) return rc;
+    std::vector<uint8_t> flags((size_t)n_kf + n_f, 1);
+    memcpy(flags.data(), kf_has_mp, n_kf);
+    if (f_has_mp) memcpy(flags.data() + n_kf, f_has_mp, n_f);
+    if ((rc = up(c, c->m_e, flags.data(), flags.size()))) return rc;
     // CSR blocks: [kf_nodes | kf_off | kf_idx] and [f_nodes | f_off | f_idx]
     std::vector<int32_t> blk;
     blk.insert(blk.end(), (const int32_t*)kf_nodes, (const int32_t*)kf_nodes + kf_nn);
@@ -662,23 +667,67 @@ int eorb_search_by_bow(eorb_ctx* c,
     blk.insert(blk.end(), f_node_off, f_node_off + f_nn + 1);
     blk.insert(blk.end(), f_idx, f_idx + nfi);
     if ((rc = up(c, c->m_f, blk.data(), sizeof(int32_t) * blk.size()))) return rc;
-    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * n_f))) return rc;
-    if ((rc = ensure(c, c->m_g, (size_t)n_f))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * (size_t)(n_f + n_kf)))) return rc;
+    if ((rc = ensure(c, c->m_g, (size_t)std::max(n_f, n_kf)))) return rc;
     if ((rc = ensure(c, c->m_j, sizeof(int32_t) * 40))) return rc;
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     const int32_t* B = (const int32_t*)c->m_f.p;
     int32_t* hist = (int32_t*)c->m_j.p;
+    int32_t* d_match_f = (int32_t*)c->m_h.p;
+    int32_t* d_match12 = d_match_f + n_f;
     rc = search_bow_dev(c, (const eorb_keypoint*)c->m_a.p, (const uint8_t*)c->m_b.p, (const uint8_t*)c->m_e.p,
                         (const uint32_t*)B, B + kf_nn, B + kf_nn + kf_nn + 1, kf_nn,
                         (const eorb_keypoint*)c->m_c.p, n_f, (const uint8_t*)c->m_d.p,
                         (const uint32_t*)(B + fbase), B + fbase + f_nn, B + fbase + f_nn + f_nn + 1, f_nn,
-                        (int32_t*)c->m_h.p, (int8_t*)c->m_g.p, hist, hist + 32, nnratio, checkOri);
+                        d_match_f, (int8_t*)c->m_g.p, hist, hist + 32, nnratio, checkOri, kf_kf,
+                        (const uint8_t*)c->m_e.p + n_kf, d_match12, n_kf);
     if (rc) return rc;
     int nm = 0;
-    EORB_HIP(c, hipMemcpyAsync(match_f, c->m_h.p, sizeof(int32_t) * n_f, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(match_out, kf_kf ? d_match12 : d_match_f, sizeof(int32_t) * nout, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipMemcpyAsync(&nm, hist + 32, 4, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     if (nmatches) *nmatches = nm;
+    return EORB_OK;
+}
+
+int eorb_search_by_bow(eorb_ctx* c,
+        const eorb_keypoint* kf_kps, int n_kf, const uint8_t* kf_desc, const uint8_t* kf_has_mp,
+        const uint32_t* kf_nodes, const int32_t* kf_node_off, const int32_t* kf_idx, int kf_nn,
+        const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc,
+        const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
+        int32_t* match_f, float nnratio, int checkOri, int* nmatches)
+{
+    return bow_common(c, 0, kf_kps, n_kf, kf_desc, kf_has_mp, kf_nodes, kf_node_off, kf_idx, kf_nn, f_kps, n_f, f_desc, nullptr,
+                      f_nodes, f_node_off, f_idx, f_nn, match_f, nnratio, checkOri, nmatches);
+}
+
+int eorb_search_by_bow_kf(eorb_ctx* c,
+        const eorb_keypoint* kps1, int n1, const uint8_t* desc1, const uint8_t* has_mp1,
+        const uint32_t* nodes1, const int32_t* node_off1, const int32_t* idx1, int nn1,
+        const eorb_keypoint* kps2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
+        const uint32_t* nodes2, const int32_t* node_off2, const int32_t* idx2, int nn2,
+        int32_t* match12, float nnratio, int checkOri, int* nmatches)
+{
+    if (c && !has_mp2 && n2 > 0) return set_err(c, EORB_E_ARG, "search_by_bow_kf: has_mp2 is required");
+    return bow_common(c, 1, kps1, n1, desc1, has_mp1, nodes1, node_off1, idx1, nn1, kps2, n2, desc2, has_mp2,
+                      nodes2, node_off2, idx2, nn2, match12, nnratio, checkOri, nmatches);
+}
+
+int eorb_distinctive_descriptors(eorb_ctx* c, const uint8_t* desc, const int32_t* offsets, int M, int32_t* best)
+{
+    if (!c) return EORB_E_ARG;
+    if (M < 0 || (M > 0 && (!offsets || !best))) return set_err(c, EORB_E_ARG, "distinctive_descriptors: bad arguments");
+    if (M == 0) return EORB_OK;
+    for (int m = 0; m < M; m++) if (offsets[m + 1] < offsets[m]) return set_err(c, EORB_E_ARG, "distinctive_descriptors: offsets not monotone");
+    hipSetDevice(c->device);
+    const int n = offsets[M];
+    int rc;
+    if ((rc = up(c, c->m_a, desc, 32 * (size_t)std::max(n, 1)))) return rc;
+    if ((rc = up(c, c->m_b, offsets, sizeof(int32_t) * (size_t)(M + 1)))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * (size_t)M))) return rc;
+    if ((rc = distinctive_dev(c, (const uint8_t*)c->m_a.p, (const int32_t*)c->m_b.p, M, (int32_t*)c->m_h.p))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(best, c->m_h.p, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
     return EORB_OK;
 }
 

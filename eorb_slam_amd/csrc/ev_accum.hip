@@ -363,6 +363,10 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
                     int ebeg = offs[bs2][e], eend = offs[bs2][e + 1];
                     EvEntryInfo cei = einfo[bs2][e];                     // current entry, re-read only when it changes
                     uint2 cri = rinfo[bs2][e];
+#ifdef EORB_DIAG
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    d_setup += __builtin_readcyclecounter() - d_s;
+#endif
                     constexpr int U = 4;                                // taps in flight per lane
                     for (int k0 = p0; k0 < p1; k0 += U) {
                         EvEntryInfo ei[U]; int pix[U], rank[U], ppx[U], ppy[U]; bool on[U];

@@ -571,6 +571,8 @@ struct BowArgs {
     const uint32_t* f_nodes; const int32_t* f_off; const int32_t* f_idx; int f_nn;
     int32_t* match_f; int8_t* bin_f; int32_t* histo; int32_t* nmatches;
     float nnratio; int checkOri;
+    int kf_kf;                       // 1: SearchByBoW(KF, KF) (:833-973): output per idx1, vbMatched2 flags, strict TH_LOW
+    const uint8_t* f_has_mp; int32_t* match12; int n_kf;
 };
 
 __global__ __launch_bounds__(256) void search_bow_kernel(BowArgs A)
@@ -593,7 +595,8 @@ __global__ __launch_bounds__(256) void search_bow_kernel(BowArgs A)
             uint64_t k0 = ~0ull, k1 = ~0ull;
             for (int iF = f0 + lane; iF < f1; iF += 64) {
                 const int realIdxF = A.f_idx[iF];
-                if (__hip_atomic_load(&A.match_f[realIdxF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;   // vpMapPointMatches[realIdxF]
+                if (__hip_atomic_load(&A.match_f[realIdxF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) continue;   // vpMapPointMatches[realIdxF] / vbMatched2
+                if (A.kf_kf && !A.f_has_mp[realIdxF]) continue;                      // !pMP2 || pMP2->isBad()
                 const uint64_t* tp = (const uint64_t*)(A.f_desc + (size_t)realIdxF * 32);
                 const int dist = __popcll(q0 ^ tp[0]) + __popcll(q1 ^ tp[1]) + __popcll(q2 ^ tp[2]) + __popcll(q3 ^ tp[3]);
                 const uint64_t key = ((uint64_t)dist << 32) | (uint32_t)iF;
@@ -609,14 +612,15 @@ __global__ __launch_bounds__(256) void search_bow_kernel(BowArgs A)
             if (k0 != ~0ull && (int)(k0 >> 32) < 256) {
                 const int bestDist1 = (int)(k0 >> 32);
                 const int bestDist2 = (k1 != ~0ull && (int)(k1 >> 32) < 256) ? (int)(k1 >> 32) : 256;
-                if (bestDist1 <= TH_LOW && (float)bestDist1 < A.nnratio * (float)bestDist2) {
+                if ((A.kf_kf ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) && (float)bestDist1 < A.nnratio * (float)bestDist2) {
                     if (lane == 0) {
                         const int bestIdxF = A.f_idx[(int)(k0 & 0xffffffffu)];
                         __hip_atomic_store(&A.match_f[bestIdxF], realIdxKF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         atomicAdd(A.nmatches, 1);
+                        if (A.kf_kf) A.match12[realIdxKF] = bestIdxF;
                         if (A.checkOri) {
                             const int bin = rot_bin(A.kf_kps[realIdxKF].angle, A.f_kps[bestIdxF].angle);
-                            A.bin_f[bestIdxF] = (int8_t)bin;
+                            A.bin_f[A.kf_kf ? realIdxKF : bestIdxF] = (int8_t)bin;      // rotHist holds idx1 (KF,KF) or bestIdxF (KF,F)
                             atomicAdd(&A.histo[bin], 1);
                         }
                     }
@@ -641,17 +645,21 @@ __global__ void search_bow_finish_kernel(BowArgs A)
     }
     __syncthreads();
     int dec = 0;
-    for (int i = threadIdx.x; i < A.n_f; i += blockDim.x) {
+    const int nout = A.kf_kf ? A.n_kf : A.n_f;
+    int32_t* out = A.kf_kf ? A.match12 : A.match_f;
+    for (int i = threadIdx.x; i < nout; i += blockDim.x) {
         const int b = A.bin_f[i];
-        if (b >= 0 && !(keep & (1 << b)) && A.match_f[i] >= 0) { A.match_f[i] = -1; dec++; }
+        if (b >= 0 && !(keep & (1 << b)) && out[i] >= 0) { out[i] = -1; dec++; }
     }
     if (dec) atomicSub(A.nmatches, dec);
 }
 
-__global__ void bow_init_kernel(int32_t* match_f, int8_t* bin_f, int n_f, int32_t* histo, int32_t* nmatches)
+__global__ void bow_init_kernel(int32_t* match_f, int8_t* bin_f, int n_f, int32_t* histo, int32_t* nmatches, int32_t* match12, int n_kf)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_f) { match_f[i] = -1; bin_f[i] = -1; }
+    if (i < n_f) match_f[i] = -1;
+    if (i < max(n_f, n_kf)) bin_f[i] = -1;
+    if (match12 && i < n_kf) match12[i] = -1;
     if (i < 32) histo[i] = 0;
     if (i == 0) *nmatches = 0;
 }
@@ -660,12 +668,13 @@ int search_bow_dev(eorb_ctx* c, const eorb_keypoint* kf_kps, const uint8_t* kf_d
                    const uint32_t* kf_nodes, const int32_t* kf_off, const int32_t* kf_idx, int kf_nn,
                    const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc, const uint32_t* f_nodes, const int32_t* f_off,
                    const int32_t* f_idx, int f_nn, int32_t* match_f, int8_t* bin_f, int32_t* histo, int32_t* nmatches,
-                   float nnratio, int checkOri)
+                   float nnratio, int checkOri, int kf_kf, const uint8_t* f_has_mp, int32_t* match12, int n_kf)
 {
     BowArgs A{kf_kps, kf_desc, kf_has_mp, kf_nodes, kf_off, kf_idx, kf_nn, f_kps, n_f, f_desc, f_nodes, f_off, f_idx, f_nn,
-              match_f, bin_f, histo, nmatches, nnratio, checkOri};
+              match_f, bin_f, histo, nmatches, nnratio, checkOri, kf_kf, f_has_mp, match12, n_kf};
     ProfScope ps(c, "search_bow");
-    bow_init_kernel<<<(std::max(n_f, 32) + 255) / 256, 256, 0, c->stream>>>(match_f, bin_f, n_f, histo, nmatches);
+    bow_init_kernel<<<(std::max(std::max(n_f, n_kf), 32) + 255) / 256, 256, 0, c->stream>>>(match_f, bin_f, n_f, histo, nmatches,
+                                                                                          kf_kf ? match12 : nullptr, n_kf);
     if (kf_nn > 0 && f_nn > 0) {
         const int blocks = std::min((kf_nn + 3) / 4, 1024);
         search_bow_kernel<<<blocks, 256, 0, c->stream>>>(A);
@@ -696,6 +705,58 @@ int sort_response_dev(eorb_ctx* c, const eorb_keypoint* d_kps, int n, int32_t* d
     ProfScope ps(c, "sort_response");
     sort_response_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d_kps, n, d_perm);
     EORB_LAUNCH_CHECK(c, "sort_response_kernel");
+    return EORB_OK;
+}
+
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423), batched over map points: one workgroup per map point,
+// thread i owns row i of the N x N distance matrix; its median is read off a 257-bin counting histogram (distances are
+// integers in [0, 256]); the first row with the smallest median wins.
+__global__ __launch_bounds__(256) void distinctive_kernel(const uint8_t* __restrict__ desc, const int32_t* __restrict__ offsets,
+                                                          int32_t* __restrict__ best)
+{
+    __shared__ uint16_t hist[64 * 260];
+    __shared__ unsigned long long s_best;
+    const int m = blockIdx.x;
+    const int o0 = offsets[m], N = offsets[m + 1] - o0;
+    if (N <= 0) { if (threadIdx.x == 0) best[m] = -1; return; }
+    if (threadIdx.x == 0) s_best = ~0ull;
+    __syncthreads();
+    const uint8_t* D = desc + 32 * (size_t)o0;
+    const int k = (int)(0.5 * (double)(N - 1));          // vDists[0.5*(N-1)]
+    for (int r0 = 0; r0 < N; r0 += 64) {                  // 64 rows at a time; 4 threads per row split the columns
+        const int row = r0 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+        uint16_t* h = hist + (threadIdx.x >> 2) * 260;
+        for (int b = part; b < 257; b += 4) h[b] = 0;
+        __syncthreads();
+        if (row < N) {
+            uint64_t q[4];
+            load_desc32(D + 32 * (size_t)row, q[0], q[1], q[2], q[3]);
+            for (int j = part; j < N; j += 4) {
+                uint64_t t0, t1, t2, t3;
+                load_desc32(D + 32 * (size_t)j, t0, t1, t2, t3);
+                const int d = (j == row) ? 0 : (__popcll(q[0] ^ t0) + __popcll(q[1] ^ t1) + __popcll(q[2] ^ t2) + __popcll(q[3] ^ t3));
+                atomicAdd((unsigned int*)(h + (d & ~1)), (d & 1) ? 0x10000u : 1u);     // 16-bit counter inside its 32-bit word
+            }
+        }
+        __syncthreads();
+        if (row < N && part == 0) {
+            int acc = 0, median = 256;
+            for (int b = 0; b < 257; b++) { acc += h[b]; if (acc > k) { median = b; break; } }
+            const unsigned long long key = ((unsigned long long)median << 32) | (unsigned int)row;   // first minimum wins
+            atomicMin(&s_best, key);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) best[m] = (int32_t)(s_best & 0xffffffffu);
+}
+
+int distinctive_dev(eorb_ctx* c, const uint8_t* d_desc, const int32_t* d_offsets, int M, int32_t* d_best)
+{
+    if (M <= 0) return EORB_OK;
+    ProfScope ps(c, "distinctive_descriptors");
+    distinctive_kernel<<<M, 256, 0, c->stream>>>(d_desc, d_offsets, d_best);
+    EORB_LAUNCH_CHECK(c, "distinctive_kernel");
     return EORB_OK;
 }
 

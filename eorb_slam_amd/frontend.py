@@ -321,6 +321,30 @@ def SearchByBoW(kf_kps, kf_desc, kf_has_mp, kf_fv, f_kps, f_desc, f_fv, nnratio=
     return nm.value, m
 
 
+def SearchByBoW_KF(kps1, desc1, has_mp1, fv1, kps2, desc2, has_mp2, fv2, nnratio=0.8, checkOri=True, ctx=None):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:833-973). Returns (nmatches, match12)."""
+    c = ctx or default_context()
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE); kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+    n1, o1, i1 = [np.ascontiguousarray(a, t) for a, t in zip(fv1, (np.uint32, np.int32, np.int32))]
+    n2, o2, i2 = [np.ascontiguousarray(a, t) for a, t in zip(fv2, (np.uint32, np.int32, np.int32))]
+    m = np.full(len(kps1), -1, np.int32); nm = C.c_int(0)
+    c.check(c.L.eorb_search_by_bow_kf(c.h, _p(kps1), len(kps1), _p(desc1), _p(h1), _p(n1), _p(o1), _p(i1), len(n1),
+                                      _p(kps2), len(kps2), _p(desc2), _p(h2), _p(n2), _p(o2), _p(i2), len(n2), _p(m),
+                                      float(nnratio), int(checkOri), C.byref(nm)))
+    return nm.value, m
+
+
+def ComputeDistinctiveDescriptors(desc, offsets, ctx=None):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for a batch of map points (CSR offsets)."""
+    c = ctx or default_context()
+    desc = np.ascontiguousarray(desc, np.uint8); offsets = np.ascontiguousarray(offsets, np.int32)
+    best = np.zeros(len(offsets) - 1, np.int32)
+    c.check(c.L.eorb_distinctive_descriptors(c.h, _p(desc), _p(offsets), len(offsets) - 1, _p(best)))
+    return best
+
+
 def sortFeaturesResponse(kps, ctx=None):
     """MixedFrame::sortFeaturesResponse (src/MixedFrame.cpp:211-225): permutation (descending response, stable)."""
     c = ctx or default_context()

@@ -192,6 +192,20 @@ int eorb_search_by_bow(eorb_ctx* ctx,
         const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
         int32_t* match_f, float nnratio, int checkOri, int* nmatches);
 
+/* replaces the mono branch of ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:833-973; loop
+ * closing / place recognition).  match12[n1] out = index of the pKF2 feature, or -1. */
+int eorb_search_by_bow_kf(eorb_ctx* ctx,
+        const eorb_keypoint* kps1, int n1, const uint8_t* desc1, const uint8_t* has_mp1,
+        const uint32_t* nodes1, const int32_t* node_off1, const int32_t* idx1, int nn1,
+        const eorb_keypoint* kps2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
+        const uint32_t* nodes2, const int32_t* node_off2, const int32_t* idx2, int nn2,
+        int32_t* match12, float nnratio, int checkOri, int* nmatches);
+
+/* replaces MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423; f3), batched over M map points: the
+ * descriptors observed for map point m are rows offsets[m] .. offsets[m+1]-1 of desc (n x 32); best[m] = the row (relative
+ * to offsets[m]) with the least median Hamming distance to the others, -1 when there is none. */
+int eorb_distinctive_descriptors(eorb_ctx* ctx, const uint8_t* desc, const int32_t* offsets, int M, int32_t* best);
+
 /* replaces MixedFrame::sortFeaturesResponse (src/MixedFrame.cpp:211-225): perm[k] = index of the k-th keypoint in
  * descending-response order, equal responses in insertion order (std::multimap semantics). */
 int eorb_sort_by_response(eorb_ctx* ctx, const eorb_keypoint* kps, int n, int32_t* perm);

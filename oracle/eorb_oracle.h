@@ -225,6 +225,19 @@ int orc_search_by_bow(const orc_keypoint* kf_kps, int n_kf, const uint8_t* kf_de
                       const uint32_t* f_nodes, const int32_t* f_node_off, const int32_t* f_idx, int f_nn,
                       int32_t* match_f, float nnratio, int checkOri);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (:833-973), mono.  has_mp1 / has_mp2: map point present
+ * and not bad.  match12[n1] out: index of the pKF2 feature whose map point is assigned to feature idx1, or -1. */
+int orc_search_by_bow_kf(const orc_keypoint* kps1, int n1, const uint8_t* desc1, const uint8_t* has_mp1,
+                         const uint32_t* nodes1, const int32_t* off1, const int32_t* idx1, int nn1,
+                         const orc_keypoint* kps2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
+                         const uint32_t* nodes2, const int32_t* off2, const int32_t* idx2, int nn2,
+                         int32_t* match12, float nnratio, int checkOri);
+
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for M map points: descriptors of map point m are rows
+ * offsets[m]..offsets[m+1]-1 of desc (n x 32); best[m] = row (relative to offsets[m]) with the least median distance to
+ * the others (first minimum), or -1 when the map point has no descriptor. */
+void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int M, int32_t* best);
+
 /* MixedFrame::sortFeaturesResponse (MixedFrame.cpp:211-225): order = descending response, equal responses keep their
  * insertion order (multimap).  perm[k] = source index of the k-th output element. */
 void orc_sort_by_response(const orc_keypoint* kps, int n, int32_t* perm);

@@ -115,6 +115,9 @@ def lib(fast=False):
     L.orc_orb_assign_level_by_best_desc.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci]
     L.orc_search_by_bow.restype = ci
     L.orc_search_by_bow.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci]
+    L.orc_search_by_bow_kf.restype = ci
+    L.orc_search_by_bow_kf.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, cf, ci]
+    L.orc_distinctive_descriptors.restype = None; L.orc_distinctive_descriptors.argtypes = [vp, vp, ci, vp]
     L.orc_sort_by_response.restype = None; L.orc_sort_by_response.argtypes = [vp, ci, vp]
     L.orc_resolve_num_mixed.restype = None
     L.orc_resolve_num_mixed.argtypes = [ci, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
@@ -418,3 +421,22 @@ def cv_normalize_minmax_u8(img):
     out = np.zeros(img.shape, np.uint8)
     lib().orc_cv_normalize_minmax_u8(_p(img), img.size, _p(out))
     return out
+
+
+def search_by_bow_kf(kps1, desc1, has_mp1, fv1, kps2, desc2, has_mp2, fv2, nnratio=0.8, checkOri=True):
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE); kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+    n1, o1, i1 = [np.ascontiguousarray(a, t) for a, t in zip(fv1, (np.uint32, np.int32, np.int32))]
+    n2, o2, i2 = [np.ascontiguousarray(a, t) for a, t in zip(fv2, (np.uint32, np.int32, np.int32))]
+    m = np.full(len(kps1), -1, np.int32)
+    n = lib().orc_search_by_bow_kf(_p(kps1), len(kps1), _p(desc1), _p(h1), _p(n1), _p(o1), _p(i1), len(n1),
+                                   _p(kps2), len(kps2), _p(desc2), _p(h2), _p(n2), _p(o2), _p(i2), len(n2), _p(m), nnratio, int(checkOri))
+    return n, m
+
+
+def distinctive_descriptors(desc, offsets):
+    desc = np.ascontiguousarray(desc, np.uint8); offsets = np.ascontiguousarray(offsets, np.int32)
+    best = np.zeros(len(offsets) - 1, np.int32)
+    lib().orc_distinctive_descriptors(_p(desc), _p(offsets), len(offsets) - 1, _p(best))
+    return best

@@ -425,3 +425,84 @@ void orc_resolve_num_mixed(int nDetectedORB, int nDetectedAK, int nDesired, int 
         else { /* the reference only prints an error and leaves the counts untouched */ }
     } else { *nORB = nDetectedORB; *nAK = nDetectedAK; }
 }
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) :833-973, mono */
+int orc_search_by_bow_kf(const orc_keypoint* kps1, int n1, const uint8_t* desc1, const uint8_t* has_mp1,
+                         const uint32_t* nodes1, const int32_t* off1, const int32_t* idx1, int nn1,
+                         const orc_keypoint* kps2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
+                         const uint32_t* nodes2, const int32_t* off2, const int32_t* idx2, int nn2,
+                         int32_t* match12, float nnratio, int checkOri)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    uint8_t* matched2 = (uint8_t*)calloc(n2 ? n2 : 1, 1);
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n1 ? n1 : 1)); rotN[i] = 0; }
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const int id1 = idx1[i1];
+                if (!has_mp1[id1]) continue;
+                const uint8_t* d1 = desc1 + 32 * (size_t)id1;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const int id2 = idx2[i2];
+                    if (matched2[id2] || !has_mp2[id2]) continue;
+                    const int dist = orc_descriptor_distance(d1, desc2 + 32 * (size_t)id2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = id2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        match12[id1] = bestIdx2;
+                        matched2[bestIdx2] = 1;
+                        if (checkOri) {
+                            int bin = rot_bin(kps1[id1].angle, kps2[bestIdx2].angle);
+                            rotHist[bin][rotN[bin]++] = id1;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) a++;
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) b++;
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(matched2);
+    return nmatches;
+}
+
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+
+/* MapPoint::ComputeDistinctiveDescriptors src/MapPoint.cc:349-423 */
+void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int M, int32_t* best)
+{
+    for (int m = 0; m < M; m++) {
+        const int N = offsets[m + 1] - offsets[m];
+        if (N <= 0) { best[m] = -1; continue; }
+        const uint8_t* D = desc + 32 * (size_t)offsets[m];
+        int* row = (int*)malloc(sizeof(int) * N);
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (int i = 0; i < N; i++) {
+            for (int j = 0; j < N; j++) row[j] = (i == j) ? 0 : orc_descriptor_distance(D + 32 * (size_t)i, D + 32 * (size_t)j);
+            qsort(row, N, sizeof(int), cmp_int);
+            const int median = row[(int)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        free(row);
+        best[m] = BestIdx;
+    }
+}

@@ -343,6 +343,56 @@ def test_search_by_bow(oracle, fe, ctx, ori):
     assert on > 20
 
 
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_by_bow_keyframes(oracle, fe, ctx, ori):
+    """f3: ORBmatcher::SearchByBoW(KF, KF) (:833-973): strict TH_LOW, vbMatched2, output per idx1."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=43, shift=3)
+    rng = np.random.default_rng(12)
+    nn = 50
+    fv1 = _feature_vector(len(k1), nn, rng)
+    node1 = np.zeros(len(k1), np.int64)
+    for a in range(len(fv1[0])):
+        node1[fv1[2][fv1[1][a]:fv1[1][a + 1]]] = fv1[0][a]
+    dx = k2["x"][:, None] - (k1["x"][None, :] - 3); dy = k2["y"][:, None] - (k1["y"][None, :] + 3)
+    near = np.argmin(dx * dx + dy * dy, axis=1)
+    node2 = np.where(rng.uniform(size=len(k2)) < 0.85, node1[near], rng.integers(0, nn, len(k2)) * 7 + 3)
+    ids = np.unique(node2); off = [0]; idx = []
+    for nid in ids:
+        m = np.nonzero(node2 == nid)[0]; rng.shuffle(m); idx.extend(m.tolist()); off.append(len(idx))
+    fv2 = (ids.astype(np.uint32), np.array(off, np.int32), np.array(idx, np.int32))
+    h1 = (rng.uniform(size=len(k1)) < 0.8).astype(np.uint8)
+    h2 = (rng.uniform(size=len(k2)) < 0.8).astype(np.uint8)
+    for ratio in (0.7, 0.95):
+        on, om = oracle.search_by_bow_kf(k1, d1, h1, fv1, k2, d2, h2, fv2, ratio, ori)
+        gn, gm = fe.SearchByBoW_KF(k1, d1, h1, fv1, k2, d2, h2, fv2, ratio, ori, ctx=ctx)
+        assert on == gn and np.array_equal(om, gm)
+        assert np.all(h1[om >= 0] == 1) and np.all(h2[om[om >= 0]] == 1)
+    assert on > 20
+    # empty sides
+    e = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    gn, gm = fe.SearchByBoW_KF(k1, d1, h1, fv1, k2[:0], d2[:0], h2[:0], e, 0.8, ori, ctx=ctx)
+    assert gn == 0 and np.all(gm == -1)
+
+
+def test_distinctive_descriptors(oracle, fe, ctx):
+    """f3: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:349-423), batched; sizes 0, 1, 2, even/odd, > 64 rows."""
+    rng = np.random.default_rng(5)
+    sizes = [0, 1, 2, 3, 4, 7, 8, 33, 64, 65, 130, 301] + rng.integers(1, 40, 200).tolist()
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    desc = np.zeros((offs[-1], 32), np.uint8)
+    for m, n in enumerate(sizes):
+        if n == 0: continue
+        base = rng.integers(0, 256, 32, dtype=np.uint8)
+        noise = rng.uniform(size=(n, 256)) < rng.uniform(0.02, 0.3, size=(n, 1))       # per-observation noise level
+        desc[offs[m]:offs[m + 1]] = base[None, :] ^ np.packbits(noise, axis=1)
+    desc[offs[5]:offs[6]] = desc[offs[5]]                                                # all equal: ties -> first row
+    ob = oracle.distinctive_descriptors(desc, offs)
+    gb = fe.ComputeDistinctiveDescriptors(desc, offs, ctx=ctx)
+    assert np.array_equal(ob, gb)
+    assert ob[0] == -1 and ob[5] == 0
+    assert len(np.unique(ob[12:])) > 5
+
+
 def test_mixed_frame_container_ops(oracle, fe, ctx):
     kps = synth.random_keypoints(1500, seed=12)
     kps["response"] = np.random.default_rng(3).integers(1, 40, 1500).astype(np.float32)      # many equal responses
