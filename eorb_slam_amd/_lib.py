@@ -15,8 +15,8 @@ EXPORTS = [
     "eorb_prof_enable", "eorb_prof_reset", "eorb_prof_count", "eorb_prof_get",
     "eorb_ev2im", "eorb_ev2im_gauss", "eorb_ev2mci_se3", "eorb_ev2mci_se2", "eorb_measure_image_focus", "eorb_normalize_minmax_u8",
     "eorb_orb_configure", "eorb_orb_max_keypoints", "eorb_orb_get_tables", "eorb_orb_extract",
-    "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map",
-    "eorb_hamming_bf_knn2", "eorb_search_by_bow", "eorb_search_by_bow_kf", "eorb_distinctive_descriptors", "eorb_sort_by_response", "eorb_resolve_num_mixed",
+    "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map", "eorb_search_by_projection_kf",
+    "eorb_hamming_bf_knn2", "eorb_search_by_bow", "eorb_search_by_bow_kf", "eorb_distinctive_descriptors", "eorb_search_for_triangulation", "eorb_kf_radius_match", "eorb_sort_by_response", "eorb_resolve_num_mixed",
     "eorb_orb_tracked_descriptors", "eorb_orb_assign_level_by_best_desc",
     "eorb_fe_configure", "eorb_fe_run_batch_dev",
     "eorb_selfcheck_division", "eorb_selfcheck_math",
@@ -110,6 +110,11 @@ def lib():
     L.eorb_search_by_bow.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci, pi]
     L.eorb_search_by_bow_kf.restype = ci
     L.eorb_search_by_bow_kf.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, cf, ci, pi]
+    L.eorb_search_for_triangulation.restype = ci
+    L.eorb_search_for_triangulation.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci,
+                                                vp, vp, vp, vp, ci, ci, ci, vp, pi]
+    L.eorb_kf_radius_match.restype = ci
+    L.eorb_kf_radius_match.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, cf, vp, vp]
     L.eorb_distinctive_descriptors.restype = ci; L.eorb_distinctive_descriptors.argtypes = [vp, vp, vp, ci, vp]
     L.eorb_sort_by_response.restype = ci; L.eorb_sort_by_response.argtypes = [vp, vp, ci, vp]
     L.eorb_resolve_num_mixed.restype = None; L.eorb_resolve_num_mixed.argtypes = [ci, ci, ci, ci, pi, pi]

@@ -1,6 +1,7 @@
 // eorb_fe.hip -- C ABI of libeorb_fe.so (include/eorb_fe.h): context, host-buffer entry points and the
 // batched HBM-resident front end.  No CPU fallback anywhere: every entry point launches HIP kernels.
 #include "eorb_ctx.h"
+#include "match_args.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -24,7 +25,7 @@ int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int
 int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride,
                          const uint8_t* cur_is_orb, const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
                          const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
-                         const float* level_scale, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
+                         int dist_th, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
                          int32_t* nmatches);
 int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
                         int M, const uint8_t* in_view, const float4* mp_f4 /* projX, projY, viewCos, levelScale */,
@@ -38,6 +39,8 @@ int search_bow_dev(eorb_ctx* c, const eorb_keypoint* kf_kps, const uint8_t* kf_d
                    const eorb_keypoint* f_kps, int n_f, const uint8_t* f_desc, const uint32_t* f_nodes, const int32_t* f_off,
                    const int32_t* f_idx, int f_nn, int32_t* match_f, int8_t* bin_f, int32_t* histo, int32_t* nmatches,
                    float nnratio, int checkOri, int kf_kf, const uint8_t* f_has_mp, int32_t* match12, int n_kf);
+int search_tri_dev(eorb_ctx* c, const TriArgs& A);
+int kf_radius_dev(eorb_ctx* c, const RadArgs& A, uint16_t* d_cell);
 int distinctive_dev(eorb_ctx* c, const uint8_t* d_desc, const int32_t* d_offsets, int M, int32_t* d_best);
 int sort_response_dev(eorb_ctx* c, const eorb_keypoint* d_kps, int n, int32_t* d_perm);
 
@@ -545,12 +548,12 @@ int eorb_search_for_initialization(eorb_ctx* c,
     return EORB_OK;
 }
 
-int eorb_search_by_projection_last(eorb_ctx* c,
+static int proj_last_common(eorb_ctx* c,
         const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
         const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
         const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
         const float* level_scale, const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri,
-        int* nmatches)
+        int dist_th, int* nmatches)
 {
     if (!c) return EORB_E_ARG;
     if (n_cur < 0 || n_last < 0 || !gb || !cur_mp || cur_stride < 32 || !level_scale)
@@ -578,7 +581,7 @@ int eorb_search_by_projection_last(eorb_ctx* c,
     rc = search_proj_last_dev(c, (const eorb_keypoint*)c->m_a.p, n_cur, (const uint8_t*)c->m_b.p, cur_stride,
                               cur_is_orb ? (const uint8_t*)c->m_e.p : nullptr, (const eorb_keypoint*)c->m_c.p, n_last,
                               last_is_orb ? (const uint8_t*)c->m_f.p : nullptr, (const uint8_t*)c->m_i.p, (const float*)c->m_g.p,
-                              (const uint8_t*)c->m_d.p, (const uint8_t*)c->m_i.p + n_last, nullptr, *gb, (int32_t*)c->m_h.p, th,
+                              (const uint8_t*)c->m_d.p, (const uint8_t*)c->m_i.p + n_last, dist_th, *gb, (int32_t*)c->m_h.p, th,
                               mode, checkOri, (int32_t*)c->m_j.p);
     if (rc) return rc;
     int nm = 0;
@@ -586,6 +589,39 @@ int eorb_search_by_projection_last(eorb_ctx* c,
     EORB_HIP(c, hipMemcpyAsync(&nm, c->m_j.p, 4, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     if (nmatches) *nmatches = nm;
+    return EORB_OK;
+}
+
+int eorb_search_by_projection_last(eorb_ctx* c,
+        const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
+        const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
+        const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+        const float* level_scale, const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri,
+        int* nmatches)
+{
+    return proj_last_common(c, cur_kps, n_cur, cur_desc, cur_stride, cur_is_orb, last_kps, n_last, last_is_orb, valid, uv, mp_desc,
+                            mp_obs, level_scale, gb, cur_mp, th, mode, checkOri, 100 /* TH_HIGH */, nmatches);
+}
+
+int eorb_search_by_projection_kf(eorb_ctx* c,
+        const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
+        const eorb_keypoint* kf_kps, int n_kf, const uint8_t* kf_is_orb,
+        const uint8_t* valid, const float* uv, const int32_t* pred_level, const float* level_scale, const uint8_t* mp_desc,
+        const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int ORBdist, int checkOri, int* nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (n_kf < 0 || (n_kf > 0 && (!kf_kps || !pred_level || !valid))) return set_err(c, EORB_E_ARG, "search_by_projection_kf: bad arguments");
+    // the last-frame kernel with: query level = nPredictedLevel (:2236), window [L-1, L+1] (:2241), every occupied slot of the
+    // current frame skipped (:2255-2256) and ORBdist in place of TH_HIGH (:2271)
+    std::vector<eorb_keypoint> q(kf_kps, kf_kps + n_kf);
+    for (int i = 0; i < n_kf; i++) { q[i].octave = pred_level[i]; q[i].class_id = pred_level[i]; }
+    std::vector<uint8_t> obs((size_t)n_kf, 1);
+    std::vector<int32_t> slots(cur_mp, cur_mp + (n_cur > 0 ? n_cur : 0));
+    for (int i = 0; i < n_cur; i++) if (slots[i] != -1) slots[i] = -2;
+    const int rc = proj_last_common(c, cur_kps, n_cur, cur_desc, cur_stride, cur_is_orb, q.data(), n_kf, kf_is_orb, valid, uv, mp_desc,
+                                    obs.data(), level_scale, gb, slots.data(), th, 0, checkOri, ORBdist, nmatches);
+    if (rc) return rc;
+    for (int i = 0; i < n_cur; i++) if (slots[i] >= 0) cur_mp[i] = slots[i];
     return EORB_OK;
 }
 
@@ -711,6 +747,120 @@ int eorb_search_by_bow_kf(eorb_ctx* c,
     if (c && !has_mp2 && n2 > 0) return set_err(c, EORB_E_ARG, "search_by_bow_kf: has_mp2 is required");
     return bow_common(c, 1, kps1, n1, desc1, has_mp1, nodes1, node_off1, idx1, nn1, kps2, n2, desc2, has_mp2,
                       nodes2, node_off2, idx2, nn2, match12, nnratio, checkOri, nmatches);
+}
+
+int eorb_search_for_triangulation(eorb_ctx* c,
+        const eorb_keypoint* kps1, int n1, const uint8_t* desc1, int stride1, const uint8_t* elig1,
+        const uint32_t* nodes1, const int32_t* node_off1, const int32_t* idx1, int nn1,
+        const eorb_keypoint* kps2, int n2, const uint8_t* desc2, int stride2, const uint8_t* elig2,
+        const uint32_t* nodes2, const int32_t* node_off2, const int32_t* idx2, int nn2,
+        const float* ep, const float* F12, const float* scale2, const float* sigma2_2, int nlevels,
+        int bCoarse, int checkOri, int32_t* match12, int* nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || !match12 || stride1 < 32 || stride2 < 32 || !ep || !F12 || !scale2 || !sigma2_2 ||
+        nlevels <= 0 || nlevels > 64)
+        return set_err(c, EORB_E_ARG, "search_for_triangulation: bad arguments");
+    hipSetDevice(c->device);
+    if (nmatches) *nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    if (n1 == 0 || n2 == 0 || nn1 == 0 || nn2 == 0) return EORB_OK;
+    const int nki = node_off1[nn1], nfi = node_off2[nn2];
+    for (int i = 0; i < nki; i++) if (idx1[i] < 0 || idx1[i] >= n1) return set_err(c, EORB_E_ARG, "search_for_triangulation: pKF1 index out of range");
+    for (int i = 0; i < nfi; i++) if (idx2[i] < 0 || idx2[i] >= n2) return set_err(c, EORB_E_ARG, "search_for_triangulation: pKF2 index out of range");
+    for (int i = 0; i < n2; i++)
+        if (elig2[i] && (kps2[i].octave < 0 || kps2[i].octave >= nlevels))
+            return set_err(c, EORB_E_ARG, "search_for_triangulation: pKF2 keypoint %d has octave %d outside [0,%d)", i, kps2[i].octave, nlevels);
+    int rc;
+    if ((rc = up(c, c->m_a, kps1, sizeof(eorb_keypoint) * n1))) return rc;
+    if ((rc = up(c, c->m_b, desc1, (size_t)stride1 * n1))) return rc;
+    if ((rc = up(c, c->m_c, kps2, sizeof(eorb_keypoint) * n2))) return rc;
+    if ((rc = up(c, c->m_d, desc2, (size_t)stride2 * n2))) return rc;
+    std::vector<uint8_t> flags((size_t)n1 + n2);
+    memcpy(flags.data(), elig1, n1); memcpy(flags.data() + n1, elig2, n2);
+    if ((rc = up(c, c->m_e, flags.data(), flags.size()))) return rc;
+    std::vector<int32_t> blk;
+    blk.insert(blk.end(), (const int32_t*)nodes1, (const int32_t*)nodes1 + nn1);
+    blk.insert(blk.end(), node_off1, node_off1 + nn1 + 1);
+    blk.insert(blk.end(), idx1, idx1 + nki);
+    const size_t fbase = blk.size();
+    blk.insert(blk.end(), (const int32_t*)nodes2, (const int32_t*)nodes2 + nn2);
+    blk.insert(blk.end(), node_off2, node_off2 + nn2 + 1);
+    blk.insert(blk.end(), idx2, idx2 + nfi);
+    if ((rc = up(c, c->m_f, blk.data(), sizeof(int32_t) * blk.size()))) return rc;
+    std::vector<float> lv(2 * (size_t)nlevels);
+    memcpy(lv.data(), scale2, sizeof(float) * nlevels); memcpy(lv.data() + nlevels, sigma2_2, sizeof(float) * nlevels);
+    if ((rc = up(c, c->m_i, lv.data(), sizeof(float) * lv.size()))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * (size_t)n1))) return rc;
+    if ((rc = ensure(c, c->m_g, (size_t)n1))) return rc;
+    if ((rc = ensure(c, c->m_j, sizeof(int32_t) * 40))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    const int32_t* B = (const int32_t*)c->m_f.p;
+    int32_t* hist = (int32_t*)c->m_j.p;
+    TriArgs A{};
+    A.kps1 = (const eorb_keypoint*)c->m_a.p; A.n1 = n1; A.desc1 = (const uint8_t*)c->m_b.p; A.stride1 = stride1;
+    A.elig1 = (const uint8_t*)c->m_e.p;
+    A.nodes1 = (const uint32_t*)B; A.off1 = B + nn1; A.idx1 = B + nn1 + nn1 + 1; A.nn1 = nn1;
+    A.kps2 = (const eorb_keypoint*)c->m_c.p; A.n2 = n2; A.desc2 = (const uint8_t*)c->m_d.p; A.stride2 = stride2;
+    A.elig2 = (const uint8_t*)c->m_e.p + n1;
+    A.nodes2 = (const uint32_t*)(B + fbase); A.off2 = B + fbase + nn2; A.idx2 = B + fbase + nn2 + nn2 + 1; A.nn2 = nn2;
+    A.epx = ep[0]; A.epy = ep[1];
+    for (int i = 0; i < 9; i++) A.F[i] = F12[i];
+    A.scale2 = (const float*)c->m_i.p; A.sigma2_2 = (const float*)c->m_i.p + nlevels; A.nlevels = nlevels;
+    A.bCoarse = bCoarse; A.checkOri = checkOri;
+    A.match12 = (int32_t*)c->m_h.p; A.bin1 = (int8_t*)c->m_g.p; A.histo = hist; A.nmatches = hist + 32;
+    if ((rc = search_tri_dev(c, A))) return rc;
+    int nm = 0;
+    EORB_HIP(c, hipMemcpyAsync(match12, c->m_h.p, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(&nm, hist + 32, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (nmatches) *nmatches = nm;
+    return EORB_OK;
+}
+
+int eorb_kf_radius_match(eorb_ctx* c,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const eorb_grid_bounds* gb,
+        int M, const uint8_t* valid, const float* uv, const float* radius, const int32_t* level, const uint8_t* q_desc,
+        const float* inv_sigma2, int nlevels, uint8_t* taken, float accept_thr, int32_t* best_idx, int32_t* best_dist)
+{
+    if (!c) return EORB_E_ARG;
+    if (n < 0 || M < 0 || stride < 32 || !gb || (M > 0 && (!valid || !uv || !radius || !level || !q_desc || !best_idx || !best_dist)) ||
+        (inv_sigma2 && (nlevels <= 0 || nlevels > 64)))
+        return set_err(c, EORB_E_ARG, "kf_radius_match: bad arguments");
+    hipSetDevice(c->device);
+    for (int m = 0; m < M; m++) { best_idx[m] = -1; best_dist[m] = 256; }
+    if (M == 0 || n == 0) return EORB_OK;
+    int rc;
+    if ((rc = up(c, c->m_a, kps, sizeof(eorb_keypoint) * n))) return rc;
+    if ((rc = up(c, c->m_b, desc, (size_t)stride * n))) return rc;
+    if ((rc = up(c, c->m_c, uv, sizeof(float) * 2 * (size_t)M))) return rc;
+    std::vector<int32_t> qi(2 * (size_t)M);
+    memcpy(qi.data(), radius, sizeof(float) * M); memcpy(qi.data() + M, level, sizeof(int32_t) * M);
+    if ((rc = up(c, c->m_d, qi.data(), sizeof(int32_t) * qi.size()))) return rc;
+    std::vector<uint8_t> fl((size_t)M + n, 0);
+    memcpy(fl.data(), valid, M);
+    if (taken) memcpy(fl.data() + M, taken, n);
+    if ((rc = up(c, c->m_e, fl.data(), fl.size()))) return rc;
+    if ((rc = up(c, c->m_f, q_desc, 32 * (size_t)M))) return rc;
+    if (inv_sigma2 && (rc = up(c, c->m_i, inv_sigma2, sizeof(float) * nlevels))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * 2 * (size_t)M))) return rc;
+    if ((rc = ensure(c, c->m_g, sizeof(uint16_t) * (size_t)n))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    RadArgs A{};
+    A.kps = (const eorb_keypoint*)c->m_a.p; A.n = n; A.desc = (const uint8_t*)c->m_b.p; A.stride = stride;
+    A.g = GridB{gb->minX, gb->minY, gb->invW, gb->invH};
+    A.cell = (const uint16_t*)c->m_g.p;
+    A.M = M; A.valid = (const uint8_t*)c->m_e.p; A.uv = (const float*)c->m_c.p;
+    A.radius = (const float*)c->m_d.p; A.level = (const int32_t*)c->m_d.p + M; A.q_desc = (const uint8_t*)c->m_f.p;
+    A.inv_sigma2 = inv_sigma2 ? (const float*)c->m_i.p : nullptr; A.nlevels = nlevels;
+    A.taken = taken ? (uint8_t*)c->m_e.p + M : nullptr; A.accept_thr = accept_thr;
+    A.best_idx = (int32_t*)c->m_h.p; A.best_dist = (int32_t*)c->m_h.p + M;
+    if ((rc = kf_radius_dev(c, A, (uint16_t*)c->m_g.p))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(best_idx, c->m_h.p, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(best_dist, (int32_t*)c->m_h.p + M, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    if (taken) EORB_HIP(c, hipMemcpyAsync(taken, (uint8_t*)c->m_e.p + M, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
 }
 
 int eorb_distinctive_descriptors(eorb_ctx* c, const uint8_t* desc, const int32_t* offsets, int M, int32_t* best)

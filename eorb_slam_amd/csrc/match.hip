@@ -16,6 +16,7 @@
 //                         :1969-2187), same structure.
 // One workgroup per frame pair; batches of pairs run concurrently.
 #include "eorb_ctx.h"
+#include "match_args.h"
 #include "dev_math.h"
 #include <algorithm>
 
@@ -97,7 +98,6 @@ __device__ __forceinline__ void load_desc32(const uint8_t* __restrict__ p, uint6
 
 // ---------------------------------------------------------------------------------------------------
 // shared pieces of the greedy window matchers
-struct GridB { float minX, minY, invW, invH; };
 
 __device__ __forceinline__ int rot_bin(float a1, float a2)
 {   // ORBmatcher.cc:790-796
@@ -369,6 +369,7 @@ struct ProjArgs {
     GridB g;
     int32_t* slot_mp;                              // n, in/out
     float th, nnratio; int mode, checkOri;
+    int dist_th;                                   // LAST: TH_HIGH (:2140) or ORBdist of the KeyFrame variant (:2271)
     int32_t* nmatches;
 };
 
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256) void search_proj_kernel(ProjArgs A)
                     }
                 }
             } else {
-                if (bestDist <= TH_HIGH) {
+                if (bestDist <= A.dist_th) {
                     slot[bestIdx] = q;
                     sh_nm[0]++;
                     if (A.checkOri) {
@@ -532,11 +533,11 @@ static int launch_proj(eorb_ctx* c, const ProjArgs& A, const char* name)
 int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride,
                          const uint8_t* cur_is_orb, const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
                          const uint8_t* valid, const float* uvs, const uint8_t* mp_desc, const uint8_t* mp_obs,
-                         const float* unused, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
+                         int dist_th, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
                          int32_t* nmatches)
 {
-    (void)unused;
     ProjArgs A{};
+    A.dist_th = dist_th;
     A.kps = cur_kps; A.n = n_cur; A.desc = cur_desc; A.stride = cur_stride; A.is_orb = cur_is_orb;
     A.M = n_last; A.qkps = last_kps; A.q_is_orb = last_is_orb; A.valid = valid; A.qf = uvs; A.qlevel = nullptr;
     A.mp_desc = mp_desc; A.mp_obs = mp_obs; A.mp_is_orb = nullptr;
@@ -681,6 +682,192 @@ int search_bow_dev(eorb_ctx* c, const eorb_keypoint* kf_kps, const uint8_t* kf_d
         if (checkOri) search_bow_finish_kernel<<<1, 256, 0, c->stream>>>(A);
     }
     EORB_LAUNCH_CHECK(c, "search_bow kernels");
+    return EORB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// local-mapping matcher: mono branch of ORBmatcher::SearchForTriangulation (:975-1214; MixedMatcher.cpp:1326-1573).
+// vbMatched2 is never written in the reference, so every pKF1 feature is independent: one wave per feature-vector entry of
+// pKF1, lanes over the pKF2 features of the same vocabulary node.  The sequential update rule (skip dist > bestDist, replace
+// on pass) keeps the passing candidate with the least distance, the LAST one among equals: key = dist << 32 | ~position.
+
+__device__ __forceinline__ bool epipolar_ok(float x1, float y1, float x2, float y2, const float* F, float unc)
+{   // Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:142-156) with F12 given
+    const float a = x1 * F[0] + y1 * F[3] + F[6];
+    const float b = x1 * F[1] + y1 * F[4] + F[7];
+    const float c = x1 * F[2] + y1 * F[5] + F[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84f * unc;
+}
+
+__global__ __launch_bounds__(256) void search_tri_kernel(TriArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int total = A.off1[A.nn1];
+    for (int p = gw; p < total; p += nw) {
+        const int id1 = A.idx1[p];
+        if (!A.elig1[id1]) continue;
+        int lo = 0, hi = A.nn1;                         // node a with off1[a] <= p < off1[a+1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.off1[mid] <= p) lo = mid; else hi = mid; }
+        const uint32_t node = A.nodes1[lo];
+        int l2 = 0, h2 = A.nn2;
+        while (l2 < h2) { const int mid = (l2 + h2) >> 1; if (A.nodes2[mid] < node) l2 = mid + 1; else h2 = mid; }
+        if (l2 >= A.nn2 || A.nodes2[l2] != node) continue;
+        const eorb_keypoint kp1 = A.kps1[id1];
+        uint64_t q0, q1, q2, q3;
+        load_desc32(A.desc1 + (size_t)id1 * A.stride1, q0, q1, q2, q3);
+        uint64_t k0 = ~0ull;
+        for (int i2 = A.off2[l2] + lane; i2 < A.off2[l2 + 1]; i2 += 64) {
+            const int id2 = A.idx2[i2];
+            if (!A.elig2[id2]) continue;
+            uint64_t t0, t1, t2, t3;
+            load_desc32(A.desc2 + (size_t)id2 * A.stride2, t0, t1, t2, t3);
+            const int dist = __popcll(q0 ^ t0) + __popcll(q1 ^ t1) + __popcll(q2 ^ t2) + __popcll(q3 ^ t3);
+            if (dist > TH_LOW) continue;
+            const eorb_keypoint kp2 = A.kps2[id2];
+            if (kp2.octave < 0 || kp2.octave >= A.nlevels) continue;            // rejected on the host already
+            const float distex = A.epx - kp2.x, distey = A.epy - kp2.y;
+            if (distex * distex + distey * distey < 100 * A.scale2[kp2.octave]) continue;
+            if (!(A.bCoarse || epipolar_ok(kp1.x, kp1.y, kp2.x, kp2.y, A.F, A.sigma2_2[kp2.octave]))) continue;
+            const uint64_t key = ((uint64_t)dist << 32) | (uint32_t)(~(uint32_t)i2);
+            if (key < k0) k0 = key;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(k0, d, 64); k0 = o < k0 ? o : k0; }
+        if (lane == 0 && k0 != ~0ull) {
+            const int bestIdx2 = A.idx2[(int)(~(uint32_t)(k0 & 0xffffffffu))];
+            A.match12[id1] = bestIdx2;
+            atomicAdd(A.nmatches, 1);
+            if (A.checkOri) {
+                const int bin = rot_bin(kp1.angle, A.kps2[bestIdx2].angle);
+                A.bin1[id1] = (int8_t)bin;
+                atomicAdd(&A.histo[bin], 1);
+            }
+        }
+    }
+}
+
+int search_tri_dev(eorb_ctx* c, const TriArgs& A)
+{
+    ProfScope ps(c, "search_for_triangulation");
+    bow_init_kernel<<<(std::max(A.n1, 32) + 255) / 256, 256, 0, c->stream>>>(A.match12, A.bin1, A.n1, A.histo, A.nmatches, nullptr, 0);
+    search_tri_kernel<<<std::min((A.n1 + 3) / 4 + 1, 2048), 256, 0, c->stream>>>(A);
+    if (A.checkOri) {
+        BowArgs B{};
+        B.kf_kf = 1; B.n_kf = A.n1; B.match12 = A.match12; B.bin_f = A.bin1; B.histo = A.histo; B.nmatches = A.nmatches;
+        search_bow_finish_kernel<<<1, 256, 0, c->stream>>>(B);
+    }
+    EORB_LAUNCH_CHECK(c, "search_for_triangulation kernels");
+    return EORB_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// search core of ORBmatcher::Fuse (:1512-1578, :1700-1720), SearchBySim3 (:1829-1860, :1909-1940) and
+// SearchByProjection(KeyFrame*, Scw, ...) (:548-588): best keypoint (least distance, first in GetFeaturesInArea order) with
+// octave in [L-1, L] inside the radius.  SEQ = false: queries independent, one wave each.  SEQ = true (vpMatched feeds later
+// queries): one workgroup walks the queries in order.
+
+__global__ void kf_cells_kernel(const eorb_keypoint* __restrict__ kps, int n, GridB g, uint16_t* __restrict__ cell)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int px = (int)roundf((kps[i].x - g.minX) * g.invW);
+    const int py = (int)roundf((kps[i].y - g.minY) * g.invH);
+    cell[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? (uint16_t)0xFFFF : (uint16_t)(px * kGridRows + py);
+}
+
+template <bool SEQ>
+__device__ __forceinline__ uint64_t radius_scan(const RadArgs& A, int m, int first, int step, const uint8_t* taken)
+{
+    const float u = A.uv[2 * m], v = A.uv[2 * m + 1], r = A.radius[m];
+    int cx0, cx1, cy0, cy1;
+    uint64_t k0 = ~0ull;
+    if (!cell_range(A.g, u, v, r, cx0, cx1, cy0, cy1)) return k0;
+    const int L = A.level[m];
+    uint64_t q0, q1, q2, q3;
+    load_desc32(A.q_desc + (size_t)m * 32, q0, q1, q2, q3);
+    for (int i = first; i < A.n; i += step) {
+        const int cell = A.cell[i];
+        if (cell == 0xFFFF) continue;
+        const int cx = cell / kGridRows, cy = cell - cx * kGridRows;
+        if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
+        const eorb_keypoint k = A.kps[i];
+        const float distx = k.x - u, disty = k.y - v;
+        if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
+        if (SEQ && taken[i]) continue;
+        if (k.octave < L - 1 || k.octave > L) continue;
+        if (A.inv_sigma2) {
+            if (k.octave < 0 || k.octave >= A.nlevels) continue;
+            const float ex = u - k.x, ey = v - k.y;
+            const float e2 = ex * ex + ey * ey;
+            if ((double)(e2 * A.inv_sigma2[k.octave]) > 5.99) continue;
+        }
+        uint64_t t0, t1, t2, t3;
+        load_desc32(A.desc + (size_t)i * A.stride, t0, t1, t2, t3);
+        const int dist = __popcll(q0 ^ t0) + __popcll(q1 ^ t1) + __popcll(q2 ^ t2) + __popcll(q3 ^ t3);
+        const uint64_t key = ((uint64_t)dist << 44) | ((uint64_t)cell << 32) | (uint32_t)i;
+        if (key < k0) k0 = key;
+    }
+    return k0;
+}
+
+__global__ __launch_bounds__(256) void kf_radius_kernel(RadArgs A)
+{
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    for (int m = gw; m < A.M; m += nw) {
+        uint64_t k0 = ~0ull;
+        if (A.valid[m]) k0 = radius_scan<false>(A, m, lane, 64, nullptr);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(k0, d, 64); k0 = o < k0 ? o : k0; }
+        if (lane == 0) {
+            const bool ok = k0 != ~0ull && (int)(k0 >> 44) < 256;
+            A.best_idx[m] = ok ? (int)(k0 & 0xffffffffu) : -1;
+            A.best_dist[m] = ok ? (int)(k0 >> 44) : 256;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void kf_radius_seq_kernel(RadArgs A)
+{
+    extern __shared__ unsigned char smem[];
+    uint64_t* red = (uint64_t*)smem;
+    uint8_t* taken = (uint8_t*)(red + 8);
+    for (int i = threadIdx.x; i < A.n; i += blockDim.x) taken[i] = A.taken[i];
+    __syncthreads();
+    for (int m = 0; m < A.M; m++) {
+        uint64_t k0 = ~0ull, k1 = ~0ull;
+        if (A.valid[m]) k0 = radius_scan<true>(A, m, threadIdx.x, blockDim.x, taken);
+        block_top2(k0, k1, red);
+        if (threadIdx.x == 0) {
+            const bool ok = k0 != ~0ull && (int)(k0 >> 44) < 256;
+            const int bi = ok ? (int)(k0 & 0xffffffffu) : -1, bd = ok ? (int)(k0 >> 44) : 256;
+            A.best_idx[m] = bi; A.best_dist[m] = bd;
+            if (ok && (float)bd <= A.accept_thr) taken[bi] = 1;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < A.n; i += blockDim.x) A.taken[i] = taken[i];
+}
+
+int kf_radius_dev(eorb_ctx* c, const RadArgs& A, uint16_t* d_cell)
+{
+    if (A.M <= 0) return EORB_OK;
+    ProfScope ps(c, "kf_radius_match");
+    if (A.n > 0) kf_cells_kernel<<<(A.n + 255) / 256, 256, 0, c->stream>>>(A.kps, A.n, A.g, d_cell);
+    if (A.taken) {
+        const size_t lds = 64 + (((size_t)A.n + 15) & ~(size_t)15);
+        if (lds > 160 * 1024) return set_err(c, EORB_E_CAPACITY, "kf_radius_match: %d keypoints exceed the LDS flags", A.n);
+        hipFuncSetAttribute((const void*)kf_radius_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        kf_radius_seq_kernel<<<1, 256, lds, c->stream>>>(A);
+    } else {
+        kf_radius_kernel<<<std::min((A.M + 3) / 4, 4096), 256, 0, c->stream>>>(A);
+    }
+    EORB_LAUNCH_CHECK(c, "kf_radius_match kernels");
     return EORB_OK;
 }
 

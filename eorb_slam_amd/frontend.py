@@ -336,6 +336,70 @@ def SearchByBoW_KF(kps1, desc1, has_mp1, fv1, kps2, desc2, has_mp2, fv2, nnratio
     return nm.value, m
 
 
+def SearchForTriangulation(kps1, desc1, elig1, fv1, kps2, desc2, elig2, fv2, ep, F12, scale2, sigma2_2,
+                           bCoarse=False, checkOri=True, ctx=None):
+    """Mono ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:975-1214). Returns (nmatches, vMatchedPairs as (k,2) int32)."""
+    c = ctx or default_context()
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE); kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    e1 = np.ascontiguousarray(elig1, np.uint8); e2 = np.ascontiguousarray(elig2, np.uint8)
+    n1, o1, i1 = [np.ascontiguousarray(a, t) for a, t in zip(fv1, (np.uint32, np.int32, np.int32))]
+    n2, o2, i2 = [np.ascontiguousarray(a, t) for a, t in zip(fv2, (np.uint32, np.int32, np.int32))]
+    ep = np.ascontiguousarray(ep, np.float32); F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
+    m = np.full(len(kps1), -1, np.int32); nm = C.c_int(0)
+    c.check(c.L.eorb_search_for_triangulation(c.h, _p(kps1), len(kps1), _p(desc1), desc1.shape[1], _p(e1), _p(n1), _p(o1), _p(i1), len(n1),
+                                              _p(kps2), len(kps2), _p(desc2), desc2.shape[1], _p(e2), _p(n2), _p(o2), _p(i2), len(n2),
+                                              _p(ep), _p(F), _p(sc), _p(sg), len(sc), int(bCoarse), int(checkOri), _p(m), C.byref(nm)))
+    k = np.nonzero(m >= 0)[0]
+    return nm.value, np.stack([k, m[k]], axis=1).astype(np.int32)
+
+
+def KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, level, q_desc, inv_sigma2=None, taken=None, accept_thr=0.0, ctx=None):
+    """Search core of Fuse / SearchBySim3 / SearchByProjection(KeyFrame*, Scw, ...) (src/ORBmatcher.cc:1512-1578, :1829-1860,
+    :548-588). Returns (best_idx, best_dist) or (best_idx, best_dist, taken) when `taken` is given."""
+    c = ctx or default_context()
+    kps = np.ascontiguousarray(kps, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
+    radius = np.ascontiguousarray(radius, np.float32); level = np.ascontiguousarray(level, np.int32)
+    q_desc = np.ascontiguousarray(q_desc, np.uint8)
+    M = len(valid)
+    bi = np.zeros(M, np.int32); bd = np.zeros(M, np.int32)
+    isg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    tk = None if taken is None else np.array(taken, np.uint8)
+    c.check(c.L.eorb_kf_radius_match(c.h, _p(kps), len(kps), _p(desc), desc.shape[1], C.byref(gb), M, _p(valid), _p(uv), _p(radius),
+                                     _p(level), _p(q_desc), None if isg is None else _p(isg), 0 if isg is None else len(isg),
+                                     None if tk is None else _p(tk), float(accept_thr), _p(bi), _p(bd)))
+    return (bi, bd) if tk is None else (bi, bd, tk)
+
+
+def Fuse(kps, desc, gb, valid, uv, level, scale_factors, inv_sigma2, q_desc, th=3.0, ctx=None):
+    """Search part of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:1407-1617): returns best_idx per map point
+    with bestDist <= TH_LOW (-1 otherwise); the caller performs Replace / AddObservation (:1581-1600) in order."""
+    sf = np.asarray(scale_factors, np.float32)
+    lv = np.ascontiguousarray(level, np.int32)
+    radius = (np.float32(th) * sf[np.clip(lv, 0, len(sf) - 1)]).astype(np.float32)
+    bi, bd = KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, lv, q_desc, inv_sigma2=inv_sigma2, ctx=ctx)
+    return np.where(bd <= 50, bi, -1).astype(np.int32)
+
+
+def SearchBySim3(kf1, kf2, q1, q2, th=7.5, ctx=None):
+    """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1743-1967) after projection. kf = (kps, desc, gb, scale_factors);
+    q1 = (valid, uv in KF2, level, mp_desc) for the map points of KF1 (valid already excludes vbAlreadyMatched1, bad points and
+    the depth / image / distance gates), q2 likewise into KF1.  Returns (nFound, match12) with match12[i1] = i2 or -1."""
+    def side(kf, q):
+        kps, desc, gb, sf = kf
+        valid, uv, level, qd = q
+        sf = np.asarray(sf, np.float32); lv = np.ascontiguousarray(level, np.int32)
+        radius = (np.float32(th) * sf[np.clip(lv, 0, len(sf) - 1)]).astype(np.float32)
+        bi, bd = KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, lv, qd, ctx=ctx)
+        return np.where(bd <= 100, bi, -1)                                   # TH_HIGH (:1862, :1942)
+    vn1 = side(kf2, q1); vn2 = side(kf1, q2)
+    i1 = np.arange(len(vn1))
+    ok = (vn1 >= 0) & (vn2[np.clip(vn1, 0, max(len(vn2) - 1, 0))] == i1) if len(vn2) else np.zeros(len(vn1), bool)
+    return int(ok.sum()), np.where(ok, vn1, -1).astype(np.int32)
+
+
 def ComputeDistinctiveDescriptors(desc, offsets, ctx=None):
     """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for a batch of map points (CSR offsets)."""
     c = ctx or default_context()

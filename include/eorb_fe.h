@@ -174,6 +174,17 @@ int eorb_search_by_projection_last(eorb_ctx* ctx,
         const float* level_scale /* n_last: getORBScaleFactor(octave) or the AKAZE factor */,
         const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri, int* nmatches);
 
+/* replaces ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist)
+ * (src/ORBmatcher.cc:2189-2312; MixedMatcher.cpp:928-1063; relocalisation, f3).  One query per pKF feature i:
+ * valid[i] = map point present, !isBad(), not in sAlreadyFound, projection inside the image and distance gates passed
+ * (:2207-2234, on the host); uv, pred_level = PredictScale, level_scale = getORBScaleFactor / getAKAZEScaleFactor of that level,
+ * mp_desc = pMP->GetDescriptor().  cur_mp in/out: -1 free, anything else occupied; a match writes i (the pKF feature index). */
+int eorb_search_by_projection_kf(eorb_ctx* ctx,
+        const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
+        const eorb_keypoint* kf_kps, int n_kf, const uint8_t* kf_is_orb,
+        const uint8_t* valid, const float* uv, const int32_t* pred_level, const float* level_scale, const uint8_t* mp_desc,
+        const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int ORBdist, int checkOri, int* nmatches);
+
 /* replaces the mono branch of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
  * (src/ORBmatcher.cc:44-219; MixedMatcher.cpp:500-691). */
 int eorb_search_by_projection_map(eorb_ctx* ctx,
@@ -200,6 +211,34 @@ int eorb_search_by_bow_kf(eorb_ctx* ctx,
         const eorb_keypoint* kps2, int n2, const uint8_t* desc2, const uint8_t* has_mp2,
         const uint32_t* nodes2, const int32_t* node_off2, const int32_t* idx2, int nn2,
         int32_t* match12, float nnratio, int checkOri, int* nmatches);
+
+/* replaces the mono branch of ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo=false, bCoarse)
+ * (src/ORBmatcher.cc:975-1214; MixedMatcher.cpp:1326-1573; local mapping, f3).  elig1[i] = !pKF1->GetMapPoint(i) &&
+ * isORBDescValid(i), elig2 likewise (vbMatched2 is never written by the reference).  ep[2] = the epipole
+ * pKF2->mpCamera->project(R2w*Cw+t2w) (:982-987); F12[9] row-major = K1.t().inv()*t12x*R12*K2.inv(), the matrix
+ * Pinhole::epipolarConstrain rebuilds for every candidate (Pinhole.cpp:137-140).  scale2[l] = pKF2->getORBScaleFactor(l),
+ * sigma2_2[l] = pKF2->getORBLevelSigma2(l).  match12[n1] out = vMatches12 (the caller forms vMatchedPairs, :1203-1211). */
+int eorb_search_for_triangulation(eorb_ctx* ctx,
+        const eorb_keypoint* kps1, int n1, const uint8_t* desc1, int stride1, const uint8_t* elig1,
+        const uint32_t* nodes1, const int32_t* node_off1, const int32_t* idx1, int nn1,
+        const eorb_keypoint* kps2, int n2, const uint8_t* desc2, int stride2, const uint8_t* elig2,
+        const uint32_t* nodes2, const int32_t* node_off2, const int32_t* idx2, int nn2,
+        const float* ep, const float* F12, const float* scale2, const float* sigma2_2, int nlevels,
+        int bCoarse, int checkOri, int32_t* match12, int* nmatches);
+
+/* replaces the search core shared by ORBmatcher::Fuse (src/ORBmatcher.cc:1512-1578 and :1700-1720), SearchBySim3
+ * (:1829-1860, :1909-1940) and SearchByProjection(KeyFrame*, Scw, ...) (:548-588, :667-706): for every projected map point
+ * m (valid[m], uv, radius = th*getORBScaleFactor(level), predicted level, descriptor) the best keypoint among
+ * KeyFrame::GetFeaturesInArea(u, v, radius) (src/KeyFrame.cc:873-917) with octave in [level-1, level].  Projection and the
+ * map update stay with the caller.
+ *   inv_sigma2 != NULL : Fuse's mono reprojection gate e2*inv_sigma2[octave] > 5.99 (:1557-1564)
+ *   taken != NULL      : n flags in/out, SearchByProjection(KF,Scw) semantics: queries in order, flagged keypoints skipped,
+ *                        taken[best] = 1 when (float)best_dist <= accept_thr (= TH_LOW*ratioHamming, :582-586)
+ * best_idx[m] = -1 and best_dist[m] = 256 when no keypoint qualifies. */
+int eorb_kf_radius_match(eorb_ctx* ctx,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const eorb_grid_bounds* gb,
+        int M, const uint8_t* valid, const float* uv, const float* radius, const int32_t* level, const uint8_t* q_desc,
+        const float* inv_sigma2, int nlevels, uint8_t* taken, float accept_thr, int32_t* best_idx, int32_t* best_dist);
 
 /* replaces MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423; f3), batched over M map points: the
  * descriptors observed for map point m are rows offsets[m] .. offsets[m+1]-1 of desc (n x 32); best[m] = the row (relative

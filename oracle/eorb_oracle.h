@@ -233,6 +233,30 @@ int orc_search_by_bow_kf(const orc_keypoint* kps1, int n1, const uint8_t* desc1,
                          const uint32_t* nodes2, const int32_t* off2, const int32_t* idx2, int nn2,
                          int32_t* match12, float nnratio, int checkOri);
 
+/* mono branch of ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo=false, bCoarse) (:975-1214)
+ * with the MixedMatcher gate (MixedMatcher.cpp:1326-1573) folded into elig: elig1[i] = !GetMapPoint(i) && isORBDescValid(i).
+ * ep = pKF2->mpCamera->project(R2w*Cw+t2w) and F12 = K1.t().inv()*t12x*R12*K2.inv() (Pinhole.cpp:137-140, constant over the
+ * call) are computed by the caller.  scale2[l] = pKF2->getORBScaleFactor(l), sigma2_2[l] = pKF2->getORBLevelSigma2(l).
+ * match12[n1] out (vMatches12). */
+int orc_search_for_triangulation(const orc_keypoint* kps1, int n1, const uint8_t* desc1, int stride1, const uint8_t* elig1,
+                                 const uint32_t* nodes1, const int32_t* off1, const int32_t* idx1, int nn1,
+                                 const orc_keypoint* kps2, int n2, const uint8_t* desc2, int stride2, const uint8_t* elig2,
+                                 const uint32_t* nodes2, const int32_t* off2, const int32_t* idx2, int nn2,
+                                 const float ep[2], const float F12[9], const float* scale2, const float* sigma2_2,
+                                 int bCoarse, int checkOri, int32_t* match12);
+
+/* the search core shared by ORBmatcher::Fuse (:1512-1578, :1619-1741), SearchBySim3 (:1829-1860, :1909-1940) and
+ * SearchByProjection(KeyFrame*, Scw, ...) (:548-588): for query m (a projected map point: uv, radius = th*scaleFactor(level),
+ * predicted level, descriptor) the best keypoint of the KeyFrame among KeyFrame::GetFeaturesInArea(u,v,radius)
+ * (KeyFrame.cc:873-917) with octave in [level-1, level].
+ *  inv_sigma2 != NULL : Fuse's mono reprojection gate (:1557-1564) e2*inv_sigma2[octave] > 5.99 -> skip
+ *  taken != NULL      : SearchByProjection(KF,Scw) semantics: queries in order, candidates with taken[idx] skipped, and
+ *                       taken[bestIdx] = 1 when (float)bestDist <= accept_thr (:582-586)
+ * best_idx[m] = -1 / best_dist[m] = 256 when nothing qualifies (the callers' INT_MAX start behaves the same). */
+void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
+                         const int32_t* level, const uint8_t* q_desc, const float* inv_sigma2, uint8_t* taken,
+                         float accept_thr, int32_t* best_idx, int32_t* best_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for M map points: descriptors of map point m are rows
  * offsets[m]..offsets[m+1]-1 of desc (n x 32); best[m] = row (relative to offsets[m]) with the least median distance to
  * the others (first minimum), or -1 when the map point has no descriptor. */

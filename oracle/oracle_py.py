@@ -117,6 +117,11 @@ def lib(fast=False):
     L.orc_search_by_bow.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, cf, ci]
     L.orc_search_by_bow_kf.restype = ci
     L.orc_search_by_bow_kf.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, cf, ci]
+    L.orc_search_for_triangulation.restype = ci
+    L.orc_search_for_triangulation.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci,
+                                               vp, vp, vp, vp, ci, ci, vp]
+    L.orc_kf_radius_match.restype = None
+    L.orc_kf_radius_match.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     L.orc_distinctive_descriptors.restype = None; L.orc_distinctive_descriptors.argtypes = [vp, vp, ci, vp]
     L.orc_sort_by_response.restype = None; L.orc_sort_by_response.argtypes = [vp, ci, vp]
     L.orc_resolve_num_mixed.restype = None
@@ -440,3 +445,32 @@ def distinctive_descriptors(desc, offsets):
     best = np.zeros(len(offsets) - 1, np.int32)
     lib().orc_distinctive_descriptors(_p(desc), _p(offsets), len(offsets) - 1, _p(best))
     return best
+
+
+def search_for_triangulation(kps1, desc1, elig1, fv1, kps2, desc2, elig2, fv2, ep, F12, scale2, sigma2_2, coarse=False, checkOri=True):
+    kps1 = np.ascontiguousarray(kps1, KP_DTYPE); kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    e1 = np.ascontiguousarray(elig1, np.uint8); e2 = np.ascontiguousarray(elig2, np.uint8)
+    n1, o1, i1 = [np.ascontiguousarray(a, t) for a, t in zip(fv1, (np.uint32, np.int32, np.int32))]
+    n2, o2, i2 = [np.ascontiguousarray(a, t) for a, t in zip(fv2, (np.uint32, np.int32, np.int32))]
+    ep = np.ascontiguousarray(ep, np.float32); F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
+    m = np.full(len(kps1), -1, np.int32)
+    n = lib().orc_search_for_triangulation(_p(kps1), len(kps1), _p(desc1), desc1.shape[1], _p(e1), _p(n1), _p(o1), _p(i1), len(n1),
+                                           _p(kps2), len(kps2), _p(desc2), desc2.shape[1], _p(e2), _p(n2), _p(o2), _p(i2), len(n2),
+                                           _p(ep), _p(F), _p(sc), _p(sg), int(coarse), int(checkOri), _p(m))
+    return n, m
+
+
+def kf_radius_match(frame, valid, uv, radius, level, q_desc, inv_sigma2=None, taken=None, accept_thr=0.0):
+    """frame: oracle Frame (KeyFrame grid).  Returns (best_idx, best_dist[, taken])."""
+    valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
+    radius = np.ascontiguousarray(radius, np.float32); level = np.ascontiguousarray(level, np.int32)
+    q_desc = np.ascontiguousarray(q_desc, np.uint8)
+    M = len(valid)
+    bi = np.zeros(M, np.int32); bd = np.zeros(M, np.int32)
+    isg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+    tk = None if taken is None else np.array(taken, np.uint8)
+    lib().orc_kf_radius_match(frame.h, M, _p(valid), _p(uv), _p(radius), _p(level), _p(q_desc),
+                              None if isg is None else _p(isg), None if tk is None else _p(tk), float(accept_thr), _p(bi), _p(bd))
+    return (bi, bd) if tk is None else (bi, bd, tk)

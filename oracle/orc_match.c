@@ -506,3 +506,108 @@ void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, in
         best[m] = BestIdx;
     }
 }
+
+/* Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:134-157) with F12 given */
+static int epipolar_ok(const orc_keypoint* kp1, const orc_keypoint* kp2, const float* F, float unc)
+{
+    const float a = kp1->x * F[0] + kp1->y * F[3] + F[6];
+    const float b = kp1->x * F[1] + kp1->y * F[4] + F[7];
+    const float c = kp1->x * F[2] + kp1->y * F[5] + F[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84f * unc;                       /* DEF_EC_DIST_COEF, include/CameraModels/Pinhole.h:36 */
+}
+
+/* ORBmatcher::SearchForTriangulation :975-1214 (mono: no mpCamera2, mvuRight < 0, bOnlyStereo = false) */
+int orc_search_for_triangulation(const orc_keypoint* kps1, int n1, const uint8_t* desc1, int stride1, const uint8_t* elig1,
+                                 const uint32_t* nodes1, const int32_t* off1, const int32_t* idx1, int nn1,
+                                 const orc_keypoint* kps2, int n2, const uint8_t* desc2, int stride2, const uint8_t* elig2,
+                                 const uint32_t* nodes2, const int32_t* off2, const int32_t* idx2, int nn2,
+                                 const float ep[2], const float F12[9], const float* scale2, const float* sigma2_2,
+                                 int bCoarse, int checkOri, int32_t* match12)
+{
+    (void)n2;
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n1 ? n1 : 1)); rotN[i] = 0; }
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
+                const int id1 = idx1[i1];
+                if (!elig1[id1]) continue;                                   /* pMP1 (:1046) / !isORBDescValid */
+                const orc_keypoint* kp1 = &kps1[id1];
+                const uint8_t* d1 = desc1 + (size_t)stride1 * id1;
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                    const int id2 = idx2[i2];
+                    if (!elig2[id2]) continue;                               /* vbMatched2 is never set in this function */
+                    const int dist = orc_descriptor_distance(d1, desc2 + (size_t)stride2 * id2);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const orc_keypoint* kp2 = &kps2[id2];
+                    const float distex = ep[0] - kp2->x, distey = ep[1] - kp2->y;
+                    if (distex * distex + distey * distey < 100 * scale2[kp2->octave]) continue;
+                    if (epipolar_ok(kp1, kp2, F12, sigma2_2[kp2->octave]) || bCoarse) { bestIdx2 = id2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[id1] = bestIdx2;
+                    nmatches++;
+                    if (checkOri) {
+                        int bin = rot_bin(kp1->angle, kps2[bestIdx2].angle);
+                        rotHist[bin][rotN[bin]++] = id1;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) a++;
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) b++;
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    return nmatches;
+}
+
+/* Fuse :1512-1578 / Fuse(Scw) :1619-1741 / SearchBySim3 :1829-1860 / SearchByProjection(KF,Scw) :548-588 search core */
+void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
+                         const int32_t* level, const uint8_t* q_desc, const float* inv_sigma2, uint8_t* taken,
+                         float accept_thr, int32_t* best_idx, int32_t* best_dist)
+{
+    int* cand = (int*)malloc(sizeof(int) * (kf->N ? kf->N : 1));
+    for (int m = 0; m < M; m++) {
+        best_idx[m] = -1; best_dist[m] = 256;
+        if (!valid[m]) continue;
+        const float u = uv[2 * m], v = uv[2 * m + 1];
+        const int nc = orc_get_features_in_area(kf, u, v, radius[m], -1, -1, cand, kf->N);
+        const int L = level[m];
+        int bestDist = 256, bestIdx = -1;
+        for (int j = 0; j < nc; j++) {
+            const int idx = cand[j];
+            if (taken && taken[idx]) continue;
+            const int kpLevel = kf->kps[idx].octave;
+            if (kpLevel < L - 1 || kpLevel > L) continue;
+            if (inv_sigma2) {
+                const float ex = u - kf->kps[idx].x, ey = v - kf->kps[idx].y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = orc_descriptor_distance(q_desc + 32 * (size_t)m, kf->desc + (size_t)kf->desc_stride * idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[m] = bestIdx; best_dist[m] = bestDist;
+        if (taken && bestIdx >= 0 && (float)bestDist <= accept_thr) taken[bestIdx] = 1;
+    }
+    free(cand);
+}

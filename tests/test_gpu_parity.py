@@ -374,6 +374,111 @@ def test_search_by_bow_keyframes(oracle, fe, ctx, ori):
     assert gn == 0 and np.all(gm == -1)
 
 
+def _correlated_fvs(k1, k2, shift, nn, rng):
+    """Feature vectors in which spatially matching features mostly share a vocabulary node."""
+    fv1 = _feature_vector(len(k1), nn, rng)
+    node1 = np.zeros(len(k1), np.int64)
+    for a in range(len(fv1[0])):
+        node1[fv1[2][fv1[1][a]:fv1[1][a + 1]]] = fv1[0][a]
+    dx = k2["x"][:, None] - (k1["x"][None, :] - shift); dy = k2["y"][:, None] - (k1["y"][None, :] + shift)
+    near = np.argmin(dx * dx + dy * dy, axis=1)
+    node2 = np.where(rng.uniform(size=len(k2)) < 0.85, node1[near], rng.integers(0, nn, len(k2)) * 7 + 3)
+    ids = np.unique(node2); off = [0]; idx = []
+    for nid in ids:
+        m = np.nonzero(node2 == nid)[0]; rng.shuffle(m); idx.extend(m.tolist()); off.append(len(idx))
+    return fv1, (ids.astype(np.uint32), np.array(off, np.int32), np.array(idx, np.int32))
+
+
+@pytest.mark.parametrize("ori,coarse", [(True, False), (False, False), (True, True)])
+def test_search_for_triangulation(oracle, fe, ctx, ori, coarse):
+    """f3: mono ORBmatcher::SearchForTriangulation (:975-1214) with the MixedMatcher eligibility gate."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=47, shift=3)
+    rng = np.random.default_rng(21)
+    fv1, fv2 = _correlated_fvs(k1, k2, 3, 40, rng)
+    e1 = (rng.uniform(size=len(k1)) < 0.75).astype(np.uint8)
+    e2 = (rng.uniform(size=len(k2)) < 0.75).astype(np.uint8)
+    scale = (1.2 ** np.arange(4)).astype(np.float32); sigma2 = (scale * scale).astype(np.float32)
+    a = 0.7
+    Fd = np.array([[0, 0, a], [0, 0, a], [-a, -a, 0]], np.float64)           # translation along (-1, +1): x+y is preserved
+    total = 0
+    for trial, ep in enumerate([(120.0, 90.0), (-500.0, 40.0), (60.5, 130.25)]):
+        F = (Fd + rng.normal(0, 1e-5 if trial < 2 else 2e-3, (3, 3))).astype(np.float32)
+        on, om = oracle.search_for_triangulation(k1, d1, e1, fv1, k2, d2, e2, fv2, ep, F, scale, sigma2, coarse, ori)
+        gn, pairs = fe.SearchForTriangulation(k1, d1, e1, fv1, k2, d2, e2, fv2, ep, F, scale, sigma2, coarse, ori, ctx=ctx)
+        ok = np.nonzero(om >= 0)[0]
+        assert on == gn and np.array_equal(pairs, np.stack([ok, om[ok]], axis=1))
+        assert np.all(e1[pairs[:, 0]] == 1) and np.all(e2[pairs[:, 1]] == 1)
+        total += on
+    assert total > 40
+    # octave outside the level tables is an argument error, not a fault
+    bad = k2.copy(); bad["octave"][np.nonzero(e2)[0][0]] = 9
+    with pytest.raises(fe.EorbError):
+        fe.SearchForTriangulation(k1, d1, e1, fv1, bad, d2, e2, fv2, (0, 0), F, scale, sigma2, ctx=ctx)
+
+
+def _radius_queries(k1, k2, d2, rng, M=1500):
+    pick = rng.integers(0, len(k2), M)
+    uv = np.stack([k2["x"][pick] + 3 + rng.normal(0, 1.5, M), k2["y"][pick] - 3 + rng.normal(0, 1.5, M)], axis=1).astype(np.float32)
+    uv[:20] = rng.uniform(-40, 300, (20, 2))                                  # outside / on the border of the grid
+    level = (k2["octave"][pick] + rng.integers(0, 2, M)).astype(np.int32)
+    qd = d2[pick].copy()
+    flip = rng.uniform(size=(M, 256)) < 0.04
+    qd ^= np.packbits(flip, axis=1)
+    valid = (rng.uniform(size=M) < 0.9).astype(np.uint8)
+    return valid, uv, level, qd
+
+
+def test_kf_radius_match_fuse_sim3(oracle, fe, ctx):
+    """f3: the search core of Fuse / SearchBySim3 / SearchByProjection(KF, Scw): independent and in-order variants."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=53, shift=3)
+    rng = np.random.default_rng(9)
+    F1 = oracle.Frame(k1, d1, 240, 180); gb = fe.grid_bounds(240, 180)
+    scale = (1.2 ** np.arange(6)).astype(np.float32)
+    valid, uv, level, qd = _radius_queries(k1, k2, d2, rng)
+    for th in (3.0, 7.5):
+        radius = (np.float32(th) * scale[level]).astype(np.float32)
+        obi, obd = oracle.kf_radius_match(F1, valid, uv, radius, level, qd)
+        gbi, gbd = fe.KeyFrameRadiusMatch(k1, d1, gb, valid, uv, radius, level, qd, ctx=ctx)
+        assert np.array_equal(obi, gbi) and np.array_equal(obd, gbd)
+        assert (obi >= 0).sum() > 300 and np.all(obi[valid == 0] == -1)
+    # Fuse: reprojection gate + TH_LOW
+    inv_sigma2 = (1.0 / (scale * scale)).astype(np.float32)
+    radius = (np.float32(3.0) * scale[level]).astype(np.float32)
+    obi, obd = oracle.kf_radius_match(F1, valid, uv, radius, level, qd, inv_sigma2=inv_sigma2)
+    gbi, gbd = fe.KeyFrameRadiusMatch(k1, d1, gb, valid, uv, radius, level, qd, inv_sigma2=inv_sigma2, ctx=ctx)
+    assert np.array_equal(obi, gbi) and np.array_equal(obd, gbd)
+    fused = fe.Fuse(k1, d1, gb, valid, uv, level, scale, inv_sigma2, qd, th=3.0, ctx=ctx)
+    assert np.array_equal(fused, np.where(obd <= 50, obi, -1)) and (fused >= 0).sum() > 100
+    # SearchByProjection(KeyFrame, Scw, vpPoints, vpMatched, th, ratioHamming): in-order with vpMatched
+    taken0 = (rng.uniform(size=len(k1)) < 0.2).astype(np.uint8)
+    for ratio in (1.0, 0.8):
+        o = oracle.kf_radius_match(F1, valid, uv, radius, level, qd, taken=taken0, accept_thr=50 * ratio)
+        g = fe.KeyFrameRadiusMatch(k1, d1, gb, valid, uv, radius, level, qd, taken=taken0, accept_thr=50 * ratio, ctx=ctx)
+        assert all(np.array_equal(a, b) for a, b in zip(o, g))
+        assert o[2].sum() > taken0.sum() + 100 and not np.array_equal(o[0], obi)
+    # SearchBySim3: both directions + agreement
+    v2, uv2, lv2, qd2 = _radius_queries(k2, k1, d1, rng, M=len(k2))
+    uv2[:, 0] -= 6; uv2[:, 1] += 6
+    F2 = oracle.Frame(k2, d2, 240, 180)
+    v1, uv1, lv1, qd1 = valid[:len(k1)], uv[:len(k1)], level[:len(k1)], qd[:len(k1)]
+    # make the two directions consistent for part of the points: KF1 point i projects onto its true match in KF2 and back
+    dx = k2["x"][None, :] - (k1["x"][:, None] - 3); dy = k2["y"][None, :] - (k1["y"][:, None] + 3)
+    nn12 = np.argmin(dx * dx + dy * dy, axis=1)
+    uv1 = np.stack([k2["x"][nn12], k2["y"][nn12]], axis=1).astype(np.float32); lv1 = k2["octave"][nn12].astype(np.int32); qd1 = d1.copy()
+    uv2 = np.stack([k2["x"] + 3, k2["y"] - 3], axis=1).astype(np.float32); lv2 = k2["octave"].astype(np.int32); qd2 = d2.copy()
+    v1 = np.ones(len(k1), np.uint8); v2 = np.ones(len(k2), np.uint8)
+    r1 = (np.float32(7.5) * scale[lv1]).astype(np.float32); r2 = (np.float32(7.5) * scale[lv2]).astype(np.float32)
+    a1, ad1 = oracle.kf_radius_match(F2, v1, uv1, r1, lv1, qd1)
+    a2, ad2 = oracle.kf_radius_match(F1, v2, uv2, r2, lv2, qd2)
+    vn1 = np.where(ad1 <= 100, a1, -1); vn2 = np.where(ad2 <= 100, a2, -1)
+    exp = np.full(len(k1), -1, np.int32)
+    for i1 in range(len(k1)):                                                 # :1951-1964
+        if vn1[i1] >= 0 and vn2[vn1[i1]] == i1:
+            exp[i1] = vn1[i1]
+    nf, m12 = fe.SearchBySim3((k1, d1, gb, scale), (k2, d2, gb, scale), (v1, uv1, lv1, qd1), (v2, uv2, lv2, qd2), th=7.5, ctx=ctx)
+    assert nf == (exp >= 0).sum() and np.array_equal(m12, exp) and nf > 100
+
+
 def test_distinctive_descriptors(oracle, fe, ctx):
     """f3: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:349-423), batched; sizes 0, 1, 2, even/odd, > 64 rows."""
     rng = np.random.default_rng(5)
