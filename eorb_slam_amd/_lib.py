@@ -100,6 +100,8 @@ def lib():
     L.eorb_search_by_projection_last.restype = ci
     L.eorb_search_by_projection_last.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp,
                                                  C.POINTER(GridBounds), vp, cf, ci, ci, pi]
+    L.eorb_search_by_projection_kf.restype = ci
+    L.eorb_search_by_projection_kf.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, pi]
     L.eorb_search_by_projection_map.restype = ci
     L.eorb_search_by_projection_map.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp,
                                                 C.POINTER(GridBounds), vp, cf, cf, pi]

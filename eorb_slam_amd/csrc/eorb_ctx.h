@@ -85,7 +85,7 @@ struct eorb_ctx {
     std::vector<eorb::ProfEntry> profs;
 
     // accumulation workspaces
-    eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax;
+    eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order;
     // extractor workspaces
     eorb::OrbState orb;
     eorb::DevBuf pyr, score, blur, cell_cnt, cell_cand, lvl_cnt, lvl_kp, kp_angle, out_kp, out_desc, out_oob,

@@ -137,6 +137,45 @@ __global__ __launch_bounds__(64) void ev_bin_kernel(const eorb_event16* __restri
     }
 }
 
+// Heaviest-first launch order for K2 (longest-processing-time-first): event data is spatially concentrated (on the reference's
+// `shapes` sequences one tile holds ~6 % of a slice's entries), and a workgroup that starts its long tile late is the tail of the
+// launch.  K1b sums every (slice, tile)'s entries; K1c bucket-sorts the work items by a 2-bits-per-octave log weight.
+__global__ void ev_tile_weight_kernel(const int* __restrict__ slice_chunk0, const uint16_t* __restrict__ segoff, int NT, int total,
+                                      uint32_t* __restrict__ weight)
+{
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= total) return;
+    const int slice = item / NT, tile = item - slice * NT;
+    const int c0 = slice_chunk0[slice], c1 = slice_chunk0[slice + 1];
+    uint32_t w = 0;
+    for (int c = c0; c < c1; c++) {
+        const uint16_t* so = segoff + (size_t)c * (NT + 1) + tile;
+        w += (uint32_t)so[1] - (uint32_t)so[0];
+    }
+    weight[item] = w;
+}
+
+__global__ __launch_bounds__(1024) void ev_tile_order_kernel(const uint32_t* __restrict__ weight, int total, int32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __syncthreads();
+    auto bucket = [](uint32_t w) -> int {
+        if (w == 0) return 63;
+        const int lg = 31 - __clz(w);                                  // floor(log2 w)
+        const int half = (lg > 0) ? (int)((w >> (lg - 1)) & 1u) : 0;
+        return 62 - min(62, 2 * lg + half);                            // 0 = heaviest
+    };
+    for (int i = threadIdx.x; i < total; i += blockDim.x) atomicAdd(&hist[bucket(weight[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 64; b++) { const uint32_t n = hist[b]; hist[b] = run; run += n; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += blockDim.x) order[atomicAdd(&hist[bucket(weight[i])], 1u)] = i;
+}
+
 struct GatherParams {
     int W, H, h, TX, TY, NT, cap;
     int mode_count;
@@ -174,6 +213,7 @@ __device__ unsigned long long g_diag[16];
 // 2: count image (ev2im)
 template <bool POL, int MODE>
 __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__ slice_chunk0,   // B+1
+                                                                  const int32_t* __restrict__ order,      // work items, heaviest first
                                                                   GatherParams P, const uint16_t* __restrict__ segoff,
                                                                   const float* __restrict__ entries,
                                                                   float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
@@ -191,10 +231,7 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
     if (tid < 32) tab[tid] = kExp2Tab[tid];
     if (tid == 0) s_nb = 0;
     for (int i = tid; i < 2 * 16 * 64; i += blockDim.x) (&vals[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nbk = gridDim.x;
-    const int per = (nbk + 7) / 8;
-    const int logical = (blockIdx.x % 8) * per + blockIdx.x / 8;     // XCD-aware: neighbouring tiles share an L2
-    if (logical >= P.total) return;
+    const int logical = order[blockIdx.x];
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
     const int c0 = slice_chunk0[slice], c1 = slice_chunk0[slice + 1];
@@ -806,9 +843,16 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
             G.fast_norm = (ddmax < 60.0) && (G.norm < 1e3f) && (G.norm > 1e-3f);
         }
         const int nb = B * NT;
-        const int grid = ((nb + 7) / 8) * 8;
-        // the kernel derives `per` from gridDim; pass the padded grid and let surplus blocks exit
+        const int grid = nb;
         GatherParams G2 = G;
+        if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
+        uint32_t* d_weight = (uint32_t*)c->tile_order.p; int32_t* d_order = (int32_t*)c->tile_order.p + nb;
+        {
+            ProfScope ps(c, "ev_tile_order");
+            ev_tile_weight_kernel<<<(nb + 255) / 256, 256, 0, c->stream>>>(d_slice_c0, (const uint16_t*)c->segoff.p, NT, nb, d_weight);
+            ev_tile_order_kernel<<<1, 1024, 0, c->stream>>>(d_weight, nb, d_order);
+            EORB_LAUNCH_CHECK(c, "ev_tile_order kernels");
+        }
         ProfScope ps(c, "ev_gather");
         int maxch = 1;
         for (int b = 0; b < B; b++) maxch = std::max(maxch, slice_c0[b + 1] - slice_c0[b]);
@@ -819,7 +863,7 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
                                          return (v >= 192 && v <= 1024 && v % 64 == 0) ? v : kGatherThreads; }();
         const int mode = mode_count ? 2 : ((G2.div_is_pow2 && G2.fast_norm) ? 1 : 0);
         const uint16_t* so = (const uint16_t*)c->segoff.p; const float* en = (const float*)c->entries.p;
-#define LAUNCH_G(PP, MM) ev_gather_kernel<PP, MM><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, G2, so, en, d_f32, d_minmax_enc)
+#define LAUNCH_G(PP, MM) ev_gather_kernel<PP, MM><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, d_order, G2, so, en, d_f32, d_minmax_enc)
         if (pol) { if (mode == 2) LAUNCH_G(true, 2); else if (mode == 1) LAUNCH_G(true, 1); else LAUNCH_G(true, 0); }
         else { if (mode == 2) LAUNCH_G(false, 2); else if (mode == 1) LAUNCH_G(false, 1); else LAUNCH_G(false, 0); }
 #undef LAUNCH_G

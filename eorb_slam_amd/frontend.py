@@ -287,6 +287,22 @@ class ORBmatcher:
                                                    int(self.mbCheckOrientation), C.byref(nm)))
         return nm.value, cm
 
+    def SearchByProjectionKF(self, Cur, kf_kps, kf_is_orb, valid, uv, pred_level, level_scale, mp_desc, cur_mp, th, ORBdist):
+        """SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist) after projection,
+        src/ORBmatcher.cc:2189-2312 (relocalisation)."""
+        kf_kps = np.ascontiguousarray(kf_kps, KP_DTYPE)
+        kio = None if kf_is_orb is None else np.ascontiguousarray(kf_is_orb, np.uint8)
+        valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
+        pl = np.ascontiguousarray(pred_level, np.int32); ls = np.ascontiguousarray(level_scale, np.float32)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+        cm = np.ascontiguousarray(cur_mp, np.int32).copy(); nm = C.c_int(0)
+        c = self.ctx
+        c.check(c.L.eorb_search_by_projection_kf(c.h, _p(Cur.kps), Cur.N, _p(Cur.desc), Cur.desc.shape[1], _p(Cur.is_orb),
+                                                 _p(kf_kps), len(kf_kps), _p(kio), _p(valid), _p(uv), _p(pl), _p(ls), _p(mp_desc),
+                                                 C.byref(Cur.gb), _p(cm), float(th), int(ORBdist), int(self.mbCheckOrientation),
+                                                 C.byref(nm)))
+        return nm.value, cm
+
     def SearchByProjectionMap(self, F, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, frame_mp, th, level_scale,
                               mp_is_orb=None):
         """SearchByProjection(Frame &F, const vector<MapPoint*>&, th) with Frame::isInFrustum's outputs as inputs,

@@ -233,6 +233,13 @@ int orc_search_by_bow_kf(const orc_keypoint* kps1, int n1, const uint8_t* desc1,
                          const uint32_t* nodes2, const int32_t* off2, const int32_t* idx2, int nn2,
                          int32_t* match12, float nnratio, int checkOri);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (:2189-2312;
+ * MixedMatcher.cpp:928-1063) after projection: query i = pKF feature i (valid, uv, nPredictedLevel, th-free level scale,
+ * map-point descriptor, KeyFrame keypoint angle / type).  cur_mp: -1 free, anything else occupied; matches store i. */
+int orc_search_by_projection_kf(const orc_frame* cur, const orc_keypoint* kf_kps, int n_kf, const uint8_t* kf_is_orb,
+                                const uint8_t* valid, const float* uv, const int32_t* pred_level, const float* level_scale,
+                                const uint8_t* mp_desc, int* cur_mp, float th, int ORBdist, int checkOri);
+
 /* mono branch of ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo=false, bCoarse) (:975-1214)
  * with the MixedMatcher gate (MixedMatcher.cpp:1326-1573) folded into elig: elig1[i] = !GetMapPoint(i) && isORBDescValid(i).
  * ep = pKF2->mpCamera->project(R2w*Cw+t2w) and F12 = K1.t().inv()*t12x*R12*K2.inv() (Pinhole.cpp:137-140, constant over the

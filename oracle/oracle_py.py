@@ -120,6 +120,8 @@ def lib(fast=False):
     L.orc_search_for_triangulation.restype = ci
     L.orc_search_for_triangulation.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci,
                                                vp, vp, vp, vp, ci, ci, vp]
+    L.orc_search_by_projection_kf.restype = ci
+    L.orc_search_by_projection_kf.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]
     L.orc_kf_radius_match.restype = None
     L.orc_kf_radius_match.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
     L.orc_distinctive_descriptors.restype = None; L.orc_distinctive_descriptors.argtypes = [vp, vp, ci, vp]
@@ -474,3 +476,15 @@ def kf_radius_match(frame, valid, uv, radius, level, q_desc, inv_sigma2=None, ta
     lib().orc_kf_radius_match(frame.h, M, _p(valid), _p(uv), _p(radius), _p(level), _p(q_desc),
                               None if isg is None else _p(isg), None if tk is None else _p(tk), float(accept_thr), _p(bi), _p(bd))
     return (bi, bd) if tk is None else (bi, bd, tk)
+
+
+def search_by_projection_kf(cur, kf_kps, kf_is_orb, valid, uv, pred_level, level_scale, mp_desc, cur_mp, th, ORBdist, checkOri=True):
+    kf_kps = np.ascontiguousarray(kf_kps, KP_DTYPE)
+    kio = None if kf_is_orb is None else np.ascontiguousarray(kf_is_orb, np.uint8)
+    valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
+    pl = np.ascontiguousarray(pred_level, np.int32); ls = np.ascontiguousarray(level_scale, np.float32)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    cm = np.ascontiguousarray(cur_mp, np.int32).copy()
+    n = lib().orc_search_by_projection_kf(cur.h, _p(kf_kps), len(kf_kps), _p(kio), _p(valid), _p(uv), _p(pl), _p(ls), _p(mp_desc),
+                                          _p(cm), float(th), int(ORBdist), int(checkOri))
+    return n, cm

@@ -611,3 +611,53 @@ void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const
     }
     free(cand);
 }
+
+/* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) :2189-2312 / MixedMatcher.cpp:928-1063 */
+int orc_search_by_projection_kf(const orc_frame* cur, const orc_keypoint* kf_kps, int n_kf, const uint8_t* kf_is_orb,
+                                const uint8_t* valid, const float* uv, const int32_t* pred_level, const float* level_scale,
+                                const uint8_t* mp_desc, int* cur_mp, float th, int ORBdist, int checkOri)
+{
+    int nmatches = 0;
+    const int Nc = cur->N;
+    int* rotHist[HISTO_LENGTH]; int rotN[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) { rotHist[i] = (int*)malloc(sizeof(int) * (n_kf ? n_kf : 1)); rotN[i] = 0; }
+    int* idxs = (int*)malloc(sizeof(int) * (Nc ? Nc : 1));
+    for (int i = 0; i < n_kf; i++) {
+        if (!valid[i]) continue;
+        const int nPredictedLevel = pred_level[i];
+        const float radius = th * level_scale[i];
+        const int nc = orc_get_features_in_area(cur, uv[2 * i], uv[2 * i + 1], radius, nPredictedLevel - 1, nPredictedLevel + 1, idxs, Nc);
+        if (nc == 0) continue;
+        const int isORBMP = !kf_is_orb || kf_is_orb[i];
+        const uint8_t* dMP = mp_desc + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = idxs[c];
+            if (cur_mp[i2] != -1) continue;                           /* CurrentFrame.getMapPoint(i2) */
+            const int isORBPt = !cur->is_orb || cur->is_orb[i2];
+            if (isORBMP != isORBPt) continue;
+            const int dist = orc_descriptor_distance(dMP, cur->desc + (size_t)i2 * cur->desc_stride);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {
+            cur_mp[bestIdx2] = i;
+            nmatches++;
+            if (checkOri) {
+                int bin = rot_bin(kf_kps[i].angle, cur->kps[bestIdx2].angle);
+                rotHist[bin][rotN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(rotN, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (int j = 0; j < rotN[i]; j++) { cur_mp[rotHist[i][j]] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i = 0; i < HISTO_LENGTH; i++) free(rotHist[i]);
+    free(idxs);
+    return nmatches;
+}

@@ -479,6 +479,30 @@ def test_kf_radius_match_fuse_sim3(oracle, fe, ctx):
     assert nf == (exp >= 0).sum() and np.array_equal(m12, exp) and nf > 100
 
 
+@pytest.mark.parametrize("ori,orbdist", [(True, 100), (True, 64), (False, 100)])
+def test_search_by_projection_keyframe(oracle, fe, ctx, ori, orbdist):
+    """f3: relocalisation SearchByProjection(Frame, KeyFrame, sAlreadyFound, th, ORBdist) (:2189-2312) with the Mixed gate."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=59, shift=3)
+    rng = np.random.default_rng(31)
+    is1 = (rng.uniform(size=len(k1)) < 0.85).astype(np.uint8); is2 = (rng.uniform(size=len(k2)) < 0.85).astype(np.uint8)
+    k1 = k1.copy(); k2 = k2.copy()
+    k1["class_id"] = k1["octave"]; k2["class_id"] = k2["octave"]
+    uv = np.stack([k1["x"] - 3 + rng.normal(0, 1, len(k1)), k1["y"] + 3 + rng.normal(0, 1, len(k1))], axis=1).astype(np.float32)
+    pred = (k1["octave"] + rng.integers(-1, 2, len(k1))).astype(np.int32)
+    scale = (1.2 ** np.arange(8)).astype(np.float32)
+    ls = scale[np.clip(pred, 0, 7)]
+    valid = (rng.uniform(size=len(k1)) < 0.85).astype(np.uint8)
+    cur_mp = np.where(rng.uniform(size=len(k2)) < 0.15, -2, -1).astype(np.int32)      # already-held slots are skipped
+    mp_desc = d1.copy()
+    Cur_o = oracle.Frame(k2, d2, 240, 180, is_orb=is2); Cur_g = fe.FrameView(k2, d2, 240, 180, is_orb=is2)
+    for th in (10.0, 3.0):
+        on, om = oracle.search_by_projection_kf(Cur_o, k1, is1, valid, uv, pred, ls, mp_desc, cur_mp, th, orbdist, ori)
+        gn, gm = fe.ORBmatcher(0.9, ori, ctx).SearchByProjectionKF(Cur_g, k1, is1, valid, uv, pred, ls, mp_desc, cur_mp, th, orbdist)
+        assert on == gn and np.array_equal(om, gm)
+        assert np.all(gm[cur_mp == -2] == -2)
+    assert on > 100
+
+
 def test_distinctive_descriptors(oracle, fe, ctx):
     """f3: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:349-423), batched; sizes 0, 1, 2, even/odd, > 64 rows."""
     rng = np.random.default_rng(5)
