@@ -39,73 +39,116 @@ struct BinParams {
     int W, H, h;          // image size, stamp half window (0 in count mode)
     int TX, TY, NT;       // tiles
     int nbits;            // bits needed for a tile id
-    int cap;              // entries per chunk
+    int dup;              // entry capacity per event (R*R)
     int mode_count;       // 1: ev2im (coords rounded, no stamp)
     int pol;
 };
 
-template <int R, bool POL>
-__global__ __launch_bounds__(64) void ev_bin_kernel(const eorb_event16* __restrict__ ev,
-                                                    const ChunkDesc* __restrict__ chunks, BinParams P,
-                                                    uint16_t* __restrict__ segoff, float* __restrict__ entries)
+__device__ __forceinline__ bool ev_tile_range(const eorb_event16& e, const BinParams& P, int& tx0, int& tx1, int& ty0, int& ty1)
 {
-    extern __shared__ uint32_t cnt[];               // NT + 1
+    const float x = e.x, y = e.y;
+    if (!(x == x && y == y)) return false;          // NaN coordinates (e.g. a one-event MCI window: 0 * inf) convert to
+                                                    // INT_MIN on the reference's x86: never in the image
+    const int xi = P.mode_count ? (int)roundf(x) : (int)floorf(x);
+    const int yi = P.mode_count ? (int)roundf(y) : (int)floorf(y);
+    tx0 = max((xi - P.h) >> 3, 0); tx1 = min((xi + P.h) >> 3, P.TX - 1);
+    ty0 = max((yi - P.h) >> 3, 0); ty1 = min((yi + P.h) >> 3, P.TY - 1);
+    return true;
+}
+
+// K1a: entries of every (chunk, tile)
+__global__ __launch_bounds__(256) void ev_count_kernel(const eorb_event16* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                       BinParams P, uint16_t* __restrict__ segcnt)
+{
+    extern __shared__ uint32_t cnt[];               // NT
+    const ChunkDesc cd = chunks[blockIdx.x];
+    const int NT = P.NT;
+    for (int i = threadIdx.x; i < NT; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const eorb_event16* e = ev + cd.start;
+    for (int k = threadIdx.x; k < cd.n; k += blockDim.x) {
+        int tx0, tx1, ty0, ty1;
+        if (ev_tile_range(e[k], P, tx0, tx1, ty0, ty1))
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&cnt[ty * P.TX + tx], 1u);
+    }
+    __syncthreads();
+    uint16_t* sc = segcnt + (size_t)blockIdx.x * NT;
+    for (int i = threadIdx.x; i < NT; i += blockDim.x) sc[i] = (uint16_t)cnt[i];
+}
+
+// K1b: one workgroup per slice.  Per tile: exclusive scan of its counts over the slice's chunks (segbase) and the total
+// (tile_cnt); then an exclusive scan of the totals over the tiles (tile_base): every tile's entries become ONE contiguous,
+// event-ordered list, so K2 runs full 64-entry batches whatever the chunking.
+__global__ __launch_bounds__(1024) void ev_scan_kernel(const int* __restrict__ slice_chunk0, const uint16_t* __restrict__ segcnt, int NT,
+                                                       uint32_t* __restrict__ segbase, uint32_t* __restrict__ tile_cnt,
+                                                       uint32_t* __restrict__ tile_base)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int slice = blockIdx.x;
+    const int c0 = slice_chunk0[slice], c1 = slice_chunk0[slice + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < NT; t0 += blockDim.x) {
+        const int tile = t0 + threadIdx.x;
+        uint32_t run = 0;
+        if (tile < NT) {
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = segcnt[(size_t)(c + u) * NT + tile];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { segbase[(size_t)(c + u) * NT + tile] = run; run += v[u]; }
+            }
+            for (; c < c1; c++) { const uint32_t v = segcnt[(size_t)c * NT + tile]; segbase[(size_t)c * NT + tile] = run; run += v; }
+            tile_cnt[(size_t)slice * NT + tile] = run;
+        }
+        uint32_t incl = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (tile < NT) tile_base[(size_t)slice * NT + tile] = before + incl - run;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry = before + incl;
+        __syncthreads();
+    }
+}
+
+// K1c: order-preserving scatter.  One wavefront per chunk: lanes = consecutive events, rank among the lanes that target the
+// same tile by ballot matching; tiles are visited in parity classes so a tile is only ever targeted in one pass.
+template <int R, bool POL>
+__global__ __launch_bounds__(64) void ev_scatter_kernel(const eorb_event16* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                        BinParams P, const int64_t* __restrict__ slice_ebase,
+                                                        const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
+                                                        float* __restrict__ entries)
+{
+    extern __shared__ uint32_t cnt[];               // NT: write cursor of every tile list
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x;
     const ChunkDesc cd = chunks[chunk];
     const int NT = P.NT;
-    for (int i = lane; i <= NT; i += 64) cnt[i] = 0;
+    for (int i = lane; i < NT; i += 64) cnt[i] = tile_base[(size_t)cd.slice * NT + i] + segbase[(size_t)chunk * NT + i];
     __syncthreads();
     const eorb_event16* e = ev + cd.start;
     constexpr int ESZ = POL ? 4 : 2;
-
-    // ---- pass A: count ----
-    for (int s = 0; s < cd.n; s += 64) {
-        const int k = s + lane;
-        if (k < cd.n && e[k].x == e[k].x && e[k].y == e[k].y) {      // NaN coordinates (e.g. a one-event MCI window: 0 * inf)
-            const float x = e[k].x, y = e[k].y;                       // convert to INT_MIN on the reference's x86: never in the image
-            const int xi = P.mode_count ? (int)roundf(x) : (int)floorf(x);
-            const int yi = P.mode_count ? (int)roundf(y) : (int)floorf(y);
-            int tx0 = (xi - P.h) >> 3, tx1 = (xi + P.h) >> 3, ty0 = (yi - P.h) >> 3, ty1 = (yi + P.h) >> 3;
-            tx0 = max(tx0, 0); ty0 = max(ty0, 0); tx1 = min(tx1, P.TX - 1); ty1 = min(ty1, P.TY - 1);
-            for (int ty = ty0; ty <= ty1; ty++)
-                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&cnt[ty * P.TX + tx], 1u);
-        }
-    }
-    __syncthreads();
-    // ---- exclusive scan -> segment offsets ----
-    uint32_t running = 0;
-    uint16_t* so = segoff + (size_t)chunk * (NT + 1);
-    for (int i0 = 0; i0 < NT; i0 += 64) {
-        const int i = i0 + lane;
-        uint32_t v = (i < NT) ? cnt[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        const uint32_t excl = running + incl - v;
-        if (i < NT) { cnt[i] = excl; so[i] = (uint16_t)excl; }
-        running += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) so[NT] = (uint16_t)running;
-    __syncthreads();
-    // ---- pass B: order-preserving scatter ----
-    float* out = entries + (size_t)chunk * P.cap * ESZ;
+    float* out = entries + (size_t)slice_ebase[cd.slice] * ESZ;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int s = 0; s < cd.n; s += 64) {
         const int k = s + lane;
-        const bool valid = k < cd.n;
+        bool valid = k < cd.n;
         float x = 0.f, y = 0.f, sg = 1.f;
         int tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0;
-        if (valid && e[k].x == e[k].x && e[k].y == e[k].y) {
-            x = e[k].x; y = e[k].y;
-            if (POL) sg = (__double_as_longlong(e[k].t) < 0) ? -1.0f : 1.0f;
-            const int xi = P.mode_count ? (int)roundf(x) : (int)floorf(x);
-            const int yi = P.mode_count ? (int)roundf(y) : (int)floorf(y);
-            tx0 = max((xi - P.h) >> 3, 0); tx1 = min((xi + P.h) >> 3, P.TX - 1);
-            ty0 = max((yi - P.h) >> 3, 0); ty1 = min((yi + P.h) >> 3, P.TY - 1);
+        if (valid) {
+            const eorb_event16 q = e[k];
+            valid = ev_tile_range(q, P, tx0, tx1, ty0, ty1);
+            x = q.x; y = q.y;
+            if (POL) sg = (__double_as_longlong(q.t) < 0) ? -1.0f : 1.0f;
         }
 #pragma unroll
         for (int cy = 0; cy < R; cy++) {
@@ -126,9 +169,9 @@ __global__ __launch_bounds__(64) void ev_bin_kernel(const eorb_event16* __restri
                 if (has) {
                     const int rank = __popcll(m & lt_mask);
                     const uint32_t base = cnt[key];
-                    const uint32_t pos = base + rank;
-                    if (POL) { float4 v = make_float4(x, y, sg, 0.f); *(float4*)(out + (size_t)pos * 4) = v; }
-                    else { float2 v = make_float2(x, y); *(float2*)(out + (size_t)pos * 2) = v; }
+                    const size_t pos = (size_t)base + rank;
+                    if (POL) { float4 v = make_float4(x, y, sg, 0.f); *(float4*)(out + pos * 4) = v; }
+                    else { float2 v = make_float2(x, y); *(float2*)(out + pos * 2) = v; }
                     if (rank == 0) cnt[key] = base + (uint32_t)__popcll(m);
                 }
                 __syncthreads();
@@ -139,22 +182,7 @@ __global__ __launch_bounds__(64) void ev_bin_kernel(const eorb_event16* __restri
 
 // Heaviest-first launch order for K2 (longest-processing-time-first): event data is spatially concentrated (on the reference's
 // `shapes` sequences one tile holds ~6 % of a slice's entries), and a workgroup that starts its long tile late is the tail of the
-// launch.  K1b sums every (slice, tile)'s entries; K1c bucket-sorts the work items by a 2-bits-per-octave log weight.
-__global__ void ev_tile_weight_kernel(const int* __restrict__ slice_chunk0, const uint16_t* __restrict__ segoff, int NT, int total,
-                                      uint32_t* __restrict__ weight)
-{
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= total) return;
-    const int slice = item / NT, tile = item - slice * NT;
-    const int c0 = slice_chunk0[slice], c1 = slice_chunk0[slice + 1];
-    uint32_t w = 0;
-    for (int c = c0; c < c1; c++) {
-        const uint16_t* so = segoff + (size_t)c * (NT + 1) + tile;
-        w += (uint32_t)so[1] - (uint32_t)so[0];
-    }
-    weight[item] = w;
-}
-
+// launch.  Bucket sort of the (slice, tile) work items by a 2-bits-per-octave log weight.
 __global__ __launch_bounds__(1024) void ev_tile_order_kernel(const uint32_t* __restrict__ weight, int total, int32_t* __restrict__ order)
 {
     __shared__ uint32_t hist[64];
@@ -177,7 +205,7 @@ __global__ __launch_bounds__(1024) void ev_tile_order_kernel(const uint32_t* __r
 }
 
 struct GatherParams {
-    int W, H, h, TX, TY, NT, cap;
+    int W, H, h, TX, TY, NT;
     int mode_count;
     int total;           // number of (slice, tile) work items
     float two_sig2;      // 2.0f * sig2
@@ -212,9 +240,10 @@ __device__ unsigned long long g_diag[16];
 // MODE 0: general sigma (IEEE divisions); 1: 2*sig2 a power of two and reciprocal+fma normalisation (sigma = 1, 0.5, 2 ...);
 // 2: count image (ev2im)
 template <bool POL, int MODE>
-__global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__ slice_chunk0,   // B+1
+__global__ __launch_bounds__(1024) void ev_gather_kernel(const int64_t* __restrict__ slice_ebase, // B: first entry of the slice
                                                                   const int32_t* __restrict__ order,      // work items, heaviest first
-                                                                  GatherParams P, const uint16_t* __restrict__ segoff,
+                                                                  GatherParams P, const uint32_t* __restrict__ tile_cnt,
+                                                                  const uint32_t* __restrict__ tile_base,
                                                                   const float* __restrict__ entries,
                                                                   float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
 {
@@ -224,17 +253,13 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
     __shared__ uint16_t offs[2][66];                // exclusive prefix of the rectangle sizes; [64] = number of pairs
     __shared__ uint64_t pm[3][64];                  // per pixel: bit e set = entry e of the batch touches it
     __shared__ float4 vals[2][16 * 64];             // [rank / 4][pixel] . (rank % 4)
-    __shared__ int s_nb;
-    extern __shared__ uint32_t segs[];              // per chunk of the slice: o0 | o1 << 16 for this tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = (int)(blockDim.x >> 6), nprod = nwaves - 2;      // wave 0 adds, wave 1 set-up, the rest values
     if (tid < 32) tab[tid] = kExp2Tab[tid];
-    if (tid == 0) s_nb = 0;
     for (int i = tid; i < 2 * 16 * 64; i += blockDim.x) (&vals[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int logical = order[blockIdx.x];
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
-    const int c0 = slice_chunk0[slice], c1 = slice_chunk0[slice + 1];
     const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = tx0 + lx, py = ty0 + ly;
@@ -243,44 +268,23 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int* __restrict__
     constexpr int ESZ = POL ? 4 : 2;
     const int h = P.h;
     __syncthreads();
-    {   // this tile's segment of every chunk -> LDS; number of 64-entry batches
-        int nb = 0;
-        for (int c = c0 + tid; c < c1; c += blockDim.x) {
-            const uint16_t* so = segoff + (size_t)c * (P.NT + 1) + tile;
-            const uint32_t o0 = so[0], o1 = so[1];
-            segs[c - c0] = o0 | (o1 << 16);
-            nb += ((int)o1 - (int)o0 + 63) >> 6;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) nb += __shfl_xor(nb, d, 64);
-        if (lane == 0 && nb) atomicAdd(&s_nb, nb);
-    }
-    __syncthreads();
-    const int nbatch = s_nb;
-    const int nch = c1 - c0;
+    // the tile's entries: one contiguous event-ordered list (K1b/K1c)
+    const int nent = (int)tile_cnt[logical];
+    const int nbatch = (nent + 63) >> 6;
+    const float* list = entries + ((size_t)slice_ebase[slice] + tile_base[logical]) * ESZ;
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
     bool touched = false;
-    // wave-1 cursor over the tile's segments + one-batch-ahead entry registers
-    int ci = 0, jcur = 0, jend = 0;
+    // wave 1 keeps the next batch in registers (loaded one iteration ahead)
+    int jnext = 0;
     float ex = 0.f, ey = 0.f, esg = 1.f; bool valid = false;
-    auto load_batch = [&]() {              // loads the batch at the cursor (if any) and advances the cursor
-        valid = false;
-        while (ci < nch) {
-            const uint32_t sg = segs[ci];
-            if (jend == 0) { jcur = (int)(sg & 0xffff); jend = (int)(sg >> 16); }
-            if (jcur < jend) break;
-            ci++; jend = 0;
-        }
-        if (ci >= nch) return;
-        const float* base = entries + (size_t)(c0 + ci) * P.cap * ESZ;
-        const int j = jcur + lane;
-        valid = j < jend;
+    auto load_batch = [&]() {
+        const int j = jnext + lane;
+        valid = j < nent;
         if (valid) {
-            if (POL) { float4 v = *(const float4*)(base + (size_t)j * 4); ex = v.x; ey = v.y; esg = v.z; }
-            else { float2 v = *(const float2*)(base + (size_t)j * 2); ex = v.x; ey = v.y; }
+            if (POL) { float4 v = *(const float4*)(list + (size_t)j * 4); ex = v.x; ey = v.y; esg = v.z; }
+            else { float2 v = *(const float2*)(list + (size_t)j * 2); ex = v.x; ey = v.y; }
         }
-        jcur += 64;
-        if (jcur >= jend) { ci++; jend = 0; }
+        jnext += 64;
     };
     if (wave == 1 && nbatch > 0) load_batch();
 #ifdef EORB_DIAG
@@ -781,15 +785,16 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
     const int TX = (W + kTile - 1) / kTile, TY = (H + kTile - 1) / kTile, NT = TX * TY;
     int nbits = 1; while ((1 << nbits) < NT) nbits++;
     const int dup = R * R;
-    const int cap = kChunk * dup;
-    if (cap > 65535) return set_err(c, EORB_E_CONFIG, "ev_accumulate: chunk capacity overflow");
     // chunk list (host) -> device
     std::vector<ChunkDesc> cds;
     std::vector<int> slice_c0(B + 1);
+    std::vector<int64_t> slice_eb(B);
     for (int b = 0; b < B; b++) {
         slice_c0[b] = (int)cds.size();
         const int64_t s = h_offsets[b], e = h_offsets[b + 1];
         if (e < s) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
+        if ((e - s) * dup >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)(e - s));
+        slice_eb[b] = (s - h_offsets[0]) * dup;                 // every event yields at most dup entries
         for (int64_t k = s; k < e; k += kChunk) {
             ChunkDesc cd; cd.start = k; cd.n = (int32_t)std::min<int64_t>(kChunk, e - k); cd.slice = b;
             cds.push_back(cd);
@@ -797,40 +802,60 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
     }
     slice_c0[B] = (int)cds.size();
     const int nchunks = (int)cds.size();
+    const int64_t nev = h_offsets[B] - h_offsets[0];
     const size_t cd_bytes = sizeof(ChunkDesc) * (size_t)std::max(nchunks, 1);
-    const size_t sc_bytes = sizeof(int) * (size_t)(B + 1);
+    const size_t sc_bytes = (sizeof(int) * (size_t)(B + 1) + 7) & ~(size_t)7;
+    const size_t eb_bytes = sizeof(int64_t) * (size_t)B;
+    const int nb = B * NT;
     int rc;
-    if ((rc = ensure(c, c->chunks, cd_bytes + sc_bytes))) return rc;
-    if ((rc = ensure(c, c->segoff, sizeof(uint16_t) * (size_t)std::max(nchunks, 1) * (NT + 1)))) return rc;
+    if ((rc = ensure(c, c->chunks, cd_bytes + sc_bytes + eb_bytes))) return rc;
+    // segcnt u16 [nchunks][NT] | segbase u32 [nchunks][NT]
+    const size_t cnt_bytes = (sizeof(uint16_t) * (size_t)std::max(nchunks, 1) * NT + 15) & ~(size_t)15;
+    if ((rc = ensure(c, c->segoff, cnt_bytes + sizeof(uint32_t) * (size_t)std::max(nchunks, 1) * NT))) return rc;
     const int esz = pol ? 4 : 2;
-    if ((rc = ensure(c, c->entries, sizeof(float) * esz * (size_t)std::max(nchunks, 1) * cap))) return rc;
-    char* hp = (char*)pinned(c, cd_bytes + sc_bytes);
+    if ((rc = ensure(c, c->entries, sizeof(float) * esz * (size_t)std::max<int64_t>(nev, 1) * dup))) return rc;
+    // tile_cnt | tile_base | order
+    if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * 3 * (size_t)nb))) return rc;
+    char* hp = (char*)pinned(c, cd_bytes + sc_bytes + eb_bytes);
     if (!hp) return set_err(c, EORB_E_HIP, "pinned alloc failed");
     if (nchunks) memcpy(hp, cds.data(), sizeof(ChunkDesc) * nchunks);
-    memcpy(hp + cd_bytes, slice_c0.data(), sc_bytes);
-    EORB_HIP(c, hipMemcpyAsync(c->chunks.p, hp, cd_bytes + sc_bytes, hipMemcpyHostToDevice, c->stream));
+    memcpy(hp + cd_bytes, slice_c0.data(), sizeof(int) * (size_t)(B + 1));
+    memcpy(hp + cd_bytes + sc_bytes, slice_eb.data(), eb_bytes);
+    EORB_HIP(c, hipMemcpyAsync(c->chunks.p, hp, cd_bytes + sc_bytes + eb_bytes, hipMemcpyHostToDevice, c->stream));
     const ChunkDesc* d_chunks = (const ChunkDesc*)c->chunks.p;
     const int* d_slice_c0 = (const int*)((char*)c->chunks.p + cd_bytes);
+    const int64_t* d_slice_eb = (const int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes);
+    uint16_t* d_segcnt = (uint16_t*)c->segoff.p;
+    uint32_t* d_segbase = (uint32_t*)((char*)c->segoff.p + cnt_bytes);
+    uint32_t* d_tile_cnt = (uint32_t*)c->tile_order.p;
+    uint32_t* d_tile_base = d_tile_cnt + nb;
+    int32_t* d_order = (int32_t*)(d_tile_cnt + 2 * (size_t)nb);
 
     {
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
     }
-    if (nchunks) {
-        BinParams P{W, H, h, TX, TY, NT, nbits, cap, mode_count, pol};
-        const size_t lds = sizeof(uint32_t) * (NT + 1);
+    {
+        BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol};
+        const size_t lds = sizeof(uint32_t) * (size_t)NT;
+        if (lds > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
         ProfScope ps(c, "ev_bin");
-        uint16_t* so = (uint16_t*)c->segoff.p; float* en = (float*)c->entries.p;
-#define LAUNCH_BIN(RR, PP) ev_bin_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, so, en)
-        if (R == 1) { if (pol) LAUNCH_BIN(1, true); else LAUNCH_BIN(1, false); }
-        else if (R == 2) { if (pol) LAUNCH_BIN(2, true); else LAUNCH_BIN(2, false); }
-        else { if (pol) LAUNCH_BIN(3, true); else LAUNCH_BIN(3, false); }
+        float* en = (float*)c->entries.p;
+        if (nchunks) ev_count_kernel<<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, P, d_segcnt);
+        ev_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
+        if (nchunks) {
+#define LAUNCH_BIN(RR, PP) ev_scatter_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, d_slice_eb, d_segbase, d_tile_base, en)
+            if (R == 1) { if (pol) LAUNCH_BIN(1, true); else LAUNCH_BIN(1, false); }
+            else if (R == 2) { if (pol) LAUNCH_BIN(2, true); else LAUNCH_BIN(2, false); }
+            else { if (pol) LAUNCH_BIN(3, true); else LAUNCH_BIN(3, false); }
 #undef LAUNCH_BIN
-        EORB_LAUNCH_CHECK(c, "ev_bin_kernel");
+        }
+        ev_tile_order_kernel<<<1, 1024, 0, c->stream>>>(d_tile_cnt, nb, d_order);
+        EORB_LAUNCH_CHECK(c, "ev_bin kernels");
     }
     {
         const float sig2 = sigma * sigma;
-        GatherParams G{W, H, h, TX, TY, NT, cap, mode_count, B * NT, 2.0f * sig2,
+        GatherParams G{W, H, h, TX, TY, NT, mode_count, nb, 2.0f * sig2,
                        2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0};
         {
             int ex2 = 0;
@@ -842,28 +867,12 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
             const double ddmax = (double)(h + 1) * (h + 1) / (double)sig2;
             G.fast_norm = (ddmax < 60.0) && (G.norm < 1e3f) && (G.norm > 1e-3f);
         }
-        const int nb = B * NT;
-        const int grid = nb;
-        GatherParams G2 = G;
-        if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
-        uint32_t* d_weight = (uint32_t*)c->tile_order.p; int32_t* d_order = (int32_t*)c->tile_order.p + nb;
-        {
-            ProfScope ps(c, "ev_tile_order");
-            ev_tile_weight_kernel<<<(nb + 255) / 256, 256, 0, c->stream>>>(d_slice_c0, (const uint16_t*)c->segoff.p, NT, nb, d_weight);
-            ev_tile_order_kernel<<<1, 1024, 0, c->stream>>>(d_weight, nb, d_order);
-            EORB_LAUNCH_CHECK(c, "ev_tile_order kernels");
-        }
         ProfScope ps(c, "ev_gather");
-        int maxch = 1;
-        for (int b = 0; b < B; b++) maxch = std::max(maxch, slice_c0[b + 1] - slice_c0[b]);
-        const size_t lds = sizeof(uint32_t) * (size_t)maxch;
-        if (lds > 16 * 1024)
-            return set_err(c, EORB_E_CAPACITY, "ev_accumulate: more than %d chunks (%d events) per slice", 4096, 4096 * kChunk);
         static const int gthreads = [] { const char* e = getenv("EORB_GATHER_THREADS"); int v = e ? atoi(e) : kGatherThreads;
                                          return (v >= 192 && v <= 1024 && v % 64 == 0) ? v : kGatherThreads; }();
-        const int mode = mode_count ? 2 : ((G2.div_is_pow2 && G2.fast_norm) ? 1 : 0);
-        const uint16_t* so = (const uint16_t*)c->segoff.p; const float* en = (const float*)c->entries.p;
-#define LAUNCH_G(PP, MM) ev_gather_kernel<PP, MM><<<grid, gthreads, lds, c->stream>>>(d_slice_c0, d_order, G2, so, en, d_f32, d_minmax_enc)
+        const int mode = mode_count ? 2 : ((G.div_is_pow2 && G.fast_norm) ? 1 : 0);
+        const float* en = (const float*)c->entries.p;
+#define LAUNCH_G(PP, MM) ev_gather_kernel<PP, MM><<<nb, gthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en, d_f32, d_minmax_enc)
         if (pol) { if (mode == 2) LAUNCH_G(true, 2); else if (mode == 1) LAUNCH_G(true, 1); else LAUNCH_G(true, 0); }
         else { if (mode == 2) LAUNCH_G(false, 2); else if (mode == 1) LAUNCH_G(false, 1); else LAUNCH_G(false, 0); }
 #undef LAUNCH_G
