@@ -239,8 +239,16 @@ __device__ unsigned long long g_diag[16];
 
 // MODE 0: general sigma (IEEE divisions); 1: 2*sig2 a power of two and reciprocal+fma normalisation (sigma = 1, 0.5, 2 ...);
 // 2: count image (ev2im)
+#ifdef EORB_GATHER_WPE
+#define EORB_GATHER_ATTR __attribute__((amdgpu_waves_per_eu(EORB_GATHER_WPE, EORB_GATHER_WPE)))
+#else
+#define EORB_GATHER_ATTR
+#endif
+#ifndef EORB_GATHER_U
+#define EORB_GATHER_U 4
+#endif
 template <bool POL, int MODE>
-__global__ __launch_bounds__(1024) void ev_gather_kernel(const int64_t* __restrict__ slice_ebase, // B: first entry of the slice
+__global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const int64_t* __restrict__ slice_ebase, // B: first entry of the slice
                                                                   const int32_t* __restrict__ order,      // work items, heaviest first
                                                                   GatherParams P, const uint32_t* __restrict__ tile_cnt,
                                                                   const uint32_t* __restrict__ tile_base,
@@ -249,8 +257,9 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int64_t* __restri
 {
     __shared__ uint64_t tab[32];
     __shared__ EvEntryInfo einfo[2][64];
-    __shared__ uint2 rinfo[2][64];                  // x: a0 | b0 << 4 | w << 8 | h << 12 (tile-local tap rectangle); y: 65536/h + 1
-    __shared__ uint16_t offs[2][66];                // exclusive prefix of the rectangle sizes; [64] = number of pairs
+    __shared__ uint32_t rinfo[2][64];               // a0 | b0 << 4 | w << 8 | h << 12 (tile-local tap rectangle) | first column << 16
+    __shared__ uint8_t owner[2][512];               // stamp column (entries' rectangles laid side by side) -> entry
+    __shared__ int ncols[2];
     __shared__ uint64_t pm[3][64];                  // per pixel: bit e set = entry e of the batch touches it
     __shared__ float4 vals[2][16 * 64];             // [rank / 4][pixel] . (rank % 4)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -358,14 +367,14 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int64_t* __restri
                 }
                 EvEntryInfo ei; ei.xy = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16); ei.xr = xr; ei.yr = yr; ei.sg = esg;
                 einfo[bs2][lane] = ei;
-                rinfo[bs2][lane] = make_uint2((uint32_t)ra0 | ((uint32_t)rb0 << 4) | ((uint32_t)rw << 8) | ((uint32_t)rh << 12),
-                                              rh > 0 ? 65536u / (uint32_t)rh + 1u : 0u);
-                const int np = rw * rh;
-                int incl = np;
+                int incl = rw;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-                offs[bs2][lane] = (uint16_t)(incl - np);
-                if (lane == 63) offs[bs2][64] = (uint16_t)incl;
+                const int coff = incl - rw;
+                rinfo[bs2][lane] = (uint32_t)ra0 | ((uint32_t)rb0 << 4) | ((uint32_t)rw << 8) | ((uint32_t)rh << 12) | ((uint32_t)coff << 16);
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < rw) owner[bs2][coff + k] = (uint8_t)lane;
+                if (lane == 63) ncols[bs2] = incl;
                 uint64_t mine = 0;
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
@@ -381,86 +390,37 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int64_t* __restri
                 d_setup += __builtin_readcyclecounter() - d_s;
 #endif
             }
-            // ---- values(t-1): the (entry, tap) pairs of the batch are dealt evenly to the lanes of waves 2.. ----
+            // ---- values(t-1): lane = one stamp column of one entry (the set-up wave laid the entries' tile-local rectangles
+            //      side by side: column g belongs to entry owner[g]); the lane walks the column's rows, two at a time ----
             if (wave >= 2 && t >= 1 && t <= nbatch) {
                 const int bs3 = (t - 1) % 3, bs2 = (t - 1) & 1;
-                const int T = offs[bs2][64];
-                const int G = nprod * 64, g = (wave - 2) * 64 + lane;
-                const int K = (T + G - 1) / G;
-                const int p0 = g * K, p1 = min(p0 + K, T);
+                const int C = ncols[bs2];
                 float* vbase = (float*)vals[bs2];
-                if (p0 < p1) {
-                    // owner of the first pair: last e with offs[e] <= p0 (empty entries share an offset with their successor)
-                    int e = 0;
-                    {
-                        int lo = 0, hi = 63;
+                for (int g0 = (wave - 2) * 64; g0 < C; g0 += nprod * 64) {
+                    const int g = g0 + lane;
+                    const bool act = g < C;
+                    const int e = act ? (int)owner[bs2][g] : 0;
+                    const uint32_t ri = rinfo[bs2][e];
+                    const EvEntryInfo ei = einfo[bs2][e];
+                    const int qx = (int)(ri & 15u) + (g - (int)(ri >> 16));
+                    const int b0 = (int)((ri >> 4) & 15u);
+                    const int rh = act ? (int)((ri >> 12) & 15u) : 0;
+                    const int xi = (int)(int16_t)(ei.xy & 0xffff), yi = (int)(int16_t)(ei.xy >> 16);
+                    const float fx = (float)(tx0 + qx - xi) - ei.xr;            // exp_XY2f(i-xRes, j-yRes) :59-65
+                    const float xx = fx * fx;
+                    const uint64_t below = (1ull << e) - 1ull;
+                    const int dy0 = ty0 + b0 - yi;
+                    constexpr int U = 2;
+                    for (int jj = 0; __any(jj < rh); jj += U) {
+                        int pix[U], rank[U]; bool on[U]; float v[U];
 #pragma unroll
-                        for (int it = 0; it < 6; it++) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if ((int)offs[bs2][mid] <= p0) lo = mid; else hi = mid - 1;
+                        for (int u = 0; u < U; u++) {
+                            on[u] = jj + u < rh;
+                            pix[u] = on[u] ? (b0 + jj + u) * 8 + qx : 0;
+                            rank[u] = __popcll(pm[bs3][pix[u]] & below);
                         }
-                        e = lo;
-                    }
-                    int ebeg = offs[bs2][e], eend = offs[bs2][e + 1];
-                    EvEntryInfo cei = einfo[bs2][e];                     // current entry, re-read only when it changes
-                    uint2 cri = rinfo[bs2][e];
-#ifdef EORB_DIAG
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    d_setup += __builtin_readcyclecounter() - d_s;
-#endif
-                    constexpr int U = 4;                                // taps in flight per lane
-                    for (int k0 = p0; k0 < p1; k0 += U) {
-                        EvEntryInfo ei[U]; int pix[U], rank[U], ppx[U], ppy[U]; bool on[U];
-                        if (k0 + U <= p1 && k0 + U <= eend) {
-                            // common case: the U pairs belong to the current entry -> straight-line code, no LDS walk
-                            const int rhh = (int)((cri.x >> 12) & 15u);
-                            const int r0 = k0 - ebeg;
-                            int ii = (int)(((uint32_t)r0 * cri.y) >> 16);                  // r / h  (r < 64, h <= 8)
-                            int jj = r0 - ii * rhh;
-                            const int ax = (int)(cri.x & 15u), by = (int)((cri.x >> 4) & 15u);
-                            const uint64_t below = (1ull << e) - 1ull;
-#pragma unroll
-                            for (int u = 0; u < U; u++) {
-                                const int qx = ax + ii, qy = by + jj;
-                                pix[u] = qy * 8 + qx; ppx[u] = tx0 + qx; ppy[u] = ty0 + qy;
-                                ei[u] = cei; on[u] = true;
-#ifdef EORB_EXPERIMENT_NOPM
-                                rank[u] = (k0 - p0 + u) & 63;
-#else
-                                rank[u] = __popcll(pm[bs3][pix[u]] & below);
-#endif
-                                jj++;
-                                if (jj == rhh) { jj = 0; ii++; }
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < U; u++) {
-                                const int p = k0 + u;
-                                on[u] = p < p1;
-                                if (on[u]) {
-                                    if (p >= eend) {
-                                        do { e++; ebeg = eend; eend = offs[bs2][e + 1]; } while (p >= eend);
-                                        cei = einfo[bs2][e]; cri = rinfo[bs2][e];
-                                    }
-                                    const uint2 ri = cri;
-                                    const int r = p - ebeg;
-                                    const int rhh = (int)((ri.x >> 12) & 15u);
-                                    const int ii = (int)(((uint32_t)r * ri.y) >> 16);      // r / h  (r < 64, h <= 8)
-                                    const int jj = r - ii * rhh;
-                                    const int qx = (int)(ri.x & 15u) + ii, qy = (int)((ri.x >> 4) & 15u) + jj;
-                                    pix[u] = qy * 8 + qx; ppx[u] = tx0 + qx; ppy[u] = ty0 + qy;
-                                    ei[u] = cei;
-                                    const uint64_t mk = pm[bs3][pix[u]];
-                                    rank[u] = __popcll(mk & ((1ull << e) - 1ull));
-                                } else { pix[u] = 0; rank[u] = 0; ppx[u] = 0; ppy[u] = 0; ei[u] = EvEntryInfo{0u, 0.f, 0.f, 1.f}; }
-                            }
-                        }
-                        float v[U];
-#ifdef EORB_EXPERIMENT_NOEXP
-                        if (true) { for (int u = 0; u < U; u++) v[u] = 0.001f; } else
-#endif
                         if (MODE == 1) {
-                            // exp_XY2f (:59-65) for four taps, written stage by stage so the dependent f64 chains interleave.
+                            // four-stage form of glibc's expf so the dependent f64 chains of the U rows interleave.
                             // dd /= 2*sig2 with a power-of-two divisor == product with its exact reciprocal (same real number,
                             // same rounding); ev / norm = correctly rounded quotient from the correctly rounded reciprocal
                             // (Markstein), valid while the residual is a normal float: the host selects MODE 1 only when
@@ -470,9 +430,8 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int64_t* __restri
                             const double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
 #pragma unroll
                             for (int u = 0; u < U; u++) {
-                                const int dx = ppx[u] - (int)(int16_t)(ei[u].xy & 0xffff), dy = ppy[u] - (int)(int16_t)(ei[u].xy >> 16);
-                                const float fx = (float)dx - ei[u].xr, fy = (float)dy - ei[u].yr;
-                                const float xx = fx * fx, yy = fy * fy;
+                                const float fy = (float)(dy0 + jj + u) - ei.yr;
+                                const float yy = fy * fy;
                                 float dd = xx + yy;
                                 dd = dd * P.inv_two_sig2;
                                 nd[u] = -dd;
@@ -503,24 +462,19 @@ __global__ __launch_bounds__(1024) void ev_gather_kernel(const int64_t* __restri
                         } else {
 #pragma unroll
                             for (int u = 0; u < U; u++) {
-#ifdef EORB_EXPERIMENT_NOEXP
-                                v[u] = 0.001f;
-#else
                                 if (MODE == 2) v[u] = 0.001f;
                                 else {
-                                    const int dx = ppx[u] - (int)(int16_t)(ei[u].xy & 0xffff), dy = ppy[u] - (int)(int16_t)(ei[u].xy >> 16);
-                                    const float fx = (float)dx - ei[u].xr, fy = (float)dy - ei[u].yr;   // exp_XY2f(i-xRes, j-yRes) :59-65
-                                    const float xx = fx * fx, yy = fy * fy;
+                                    const float fy = (float)(dy0 + jj + u) - ei.yr;
+                                    const float yy = fy * fy;
                                     float dd = xx + yy;
                                     dd = dd / P.two_sig2;
                                     v[u] = dev_expf_nonpos<true>(-dd, tab) / P.norm;
                                 }
-#endif
                             }
                         }
 #pragma unroll
                         for (int u = 0; u < U; u++)
-                            if (on[u]) vbase[((rank[u] >> 2) * 64 + pix[u]) * 4 + (rank[u] & 3)] = POL ? ei[u].sg * v[u] : v[u];
+                            if (on[u]) vbase[((rank[u] >> 2) * 64 + pix[u]) * 4 + (rank[u] & 3)] = POL ? ei.sg * v[u] : v[u];
                     }
                 }
             }
