@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--events", type=int, default=1000000, help="events per slice")
     ap.add_argument("--cpu-slices", type=int, default=64, help="slices timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--input", choices=["raw", "float"], default="float",
+                    help="raw: sensor-pixel events (x,y,t,p) + the calibrator's undistortion maps resolved on the GPU; "
+                         "float: events already undistorted by the loader (EventData)")
     return ap.parse_args()
 
 
@@ -63,8 +66,13 @@ def main():
     W, H, B, NEV = 240, 180, a.batch, a.events
     orb = dict(nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0, edgeTh=19)
     # ---- synthetic input: B independent slices per rank (seeded), packed to the 16 B HBM record ----
-    slices = [synth.shapes_events(NEV, W, H, seed=2 + 1000 * rank + b, motion=0.5, undistort=True) for b in range(B)]
-    ev16 = np.concatenate([frontend.pack_events(s) for s in slices])
+    pairs = [synth.shapes_events(NEV, W, H, seed=2 + 1000 * rank + b, motion=0.5, undistort=True, return_raw=True) for b in range(B)]
+    slices = [p[0] for p in pairs]
+    use_raw = a.input == "raw"
+    if use_raw:
+        ev16 = np.concatenate([p[1] for p in pairs])               # eorb_raw_event, 16 B
+    else:
+        ev16 = np.concatenate([frontend.pack_events(s) for s in slices])
     offsets = np.arange(B + 1, dtype=np.int64) * NEV
 
     stream = torch.cuda.current_stream()
@@ -72,6 +80,9 @@ def main():
     fb = frontend.FrontEndBatch(W, H, 1.0, False, max_batch=B, max_events=NEV, match=True, windowSize=100, nnratio=0.9,
                                 checkOri=True, ctx=ctx, **orb)
     cap = fb.cap
+    if use_raw:
+        mx, my = synth.undistort_lut(W, H)
+        frontend.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx)
     d_ev = torch.from_numpy(ev16.view(np.uint8)).to(dev)
     d_img = torch.empty(B * W * H, dtype=torch.uint8, device=dev)
     d_kp = torch.empty(B * cap * 28, dtype=torch.uint8, device=dev)
@@ -85,7 +96,7 @@ def main():
 
     def step():
         fb.run_dev(d_ev.data_ptr(), offsets, d_img.data_ptr(), d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(),
-                   d_m.data_ptr(), d_nm.data_ptr())
+                   d_m.data_ptr(), d_nm.data_ptr(), raw=use_raw)
         if world > 1:       # final keypoint gather (RCCL over xGMI), fixed-capacity records
             dist.gather(d_n, gather_n, dst=0)
             dist.gather(d_kp, gather_kp, dst=0)
@@ -127,7 +138,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: synthetic %d events/slice on %dx%d (shapes generator, DAVIS "
                                    "pixels LUT-undistorted with the EvETHZ intrinsics like the reference loader), ev2im_gauss sigma=1 -> ORB-1000 (1.2, 4 levels, FAST 10/0, "
                                    "edge 19) -> SearchForInitialization vs previous slice" % (NEV, W, H),
-                       "slices_per_step_per_gpu": B, "events_per_slice": NEV, "image": [W, H],
+                       "slices_per_step_per_gpu": B, "events_per_slice": NEV, "image": [W, H], "input": a.input,
                        "parallelism": "1 process/GPU, independent slices, RCCL gather of keypoints" if world > 1 else "1 GPU",
                        "mean_keypoints": float(nk.mean()), "mean_matches": float(nm[1:].mean()) if B > 1 else 0.0},
         }

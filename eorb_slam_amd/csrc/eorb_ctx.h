@@ -86,6 +86,10 @@ struct eorb_ctx {
 
     // accumulation workspaces
     eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order;
+    // raw sensor events: undistortion maps (float2 per sensor pixel) and the tables derived from them
+    eorb::DevBuf lut, src_info, stamps;
+    int lut_w = 0, lut_h = 0, lut_check = 1;
+    int lut_key_W = -1, lut_key_H = -1, lut_key_mode = -1; float lut_key_sigma = -1.f;
     // extractor workspaces
     eorb::OrbState orb;
     eorb::DevBuf pyr, score, blur, cell_cnt, cell_cand, lvl_cnt, lvl_kp, kp_angle, out_kp, out_desc, out_oob,
@@ -120,9 +124,10 @@ struct ProfScope {
 #define EORB_LAUNCH_CHECK(c, what) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return eorb::hip_check((c), e__, what); } while (0)
 
 // ev_accum.hip
-int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_offsets, int B, int W, int H,
+int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
                       uint32_t* d_minmax_enc);
+int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, int H, double tsFactor, eorb_event* d_out, uint32_t* d_blk);
 // orb_extract.hip
 int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
                     int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono);

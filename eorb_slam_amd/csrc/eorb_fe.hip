@@ -143,7 +143,7 @@ void eorb_destroy(eorb_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->pyr, &c->score,
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->lut, &c->src_info, &c->stamps, &c->pyr, &c->score,
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
@@ -218,10 +218,14 @@ int eorb_dev_download(eorb_ctx* c, void* h, const void* d, size_t bytes)
 
 // ---- event accumulation, host buffers -------------------------------------------------------------
 static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, int H, float sigma, int pol, int normalized,
-                          int mode_count, float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8)
+                          int mode_count, float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8,
+                          const eorb_raw_event* rawev = nullptr)
 {
     if (!c) return EORB_E_ARG;
-    if (W <= 0 || H <= 0 || (n && !ev)) return set_err(c, EORB_E_ARG, "ev2im: bad arguments");
+    const int raw = rawev != nullptr;
+    if (raw && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "ev2im_raw: eorb_set_undistort_maps not called");
+    if (raw) ev = nullptr;
+    if (W <= 0 || H <= 0 || (n && !ev && !raw)) return set_err(c, EORB_E_ARG, "ev2im: bad arguments");
     hipSetDevice(c->device);
     int rc;
     const size_t npix = (size_t)W * H;
@@ -229,7 +233,15 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
     if ((rc = ensure(c, c->img_f32, sizeof(float) * npix))) return rc;
     if ((rc = ensure(c, c->img_u8, npix))) return rc;
     if ((rc = ensure(c, c->minmax, 64))) return rc;
-    if (n) {
+    if (n && raw) {
+        for (size_t i = 0; i < n; i++)
+            if ((int)rawev[i].x >= c->lut_w || (int)rawev[i].y >= c->lut_h)       // the reference asserts (MyCalibrator.cpp:176)
+                return set_err(c, EORB_E_ARG, "ev2im_raw: event %zu at (%u,%u) lies outside the %dx%d maps", i, rawev[i].x, rawev[i].y,
+                               c->lut_w, c->lut_h);
+        static_assert(sizeof(eorb_raw_event) == sizeof(eorb_event16), "raw and packed events share the 16-byte slot");
+        EORB_HIP(c, hipMemcpyAsync(c->ev16.p, rawev, sizeof(eorb_raw_event) * n, hipMemcpyHostToDevice, c->stream));
+        EORB_HIP(c, hipStreamSynchronize(c->stream));
+    } else if (n) {
         std::vector<eorb_event16> packed(n);
         eorb_pack_events(ev, n, packed.data());
         EORB_HIP(c, hipMemcpyAsync(c->ev16.p, packed.data(), sizeof(eorb_event16) * n, hipMemcpyHostToDevice, c->stream));
@@ -239,7 +251,7 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
     uint32_t* mm = (uint32_t*)c->minmax.p;
     float* mmf = (float*)((char*)c->minmax.p + 16);
     EORB_HIP(c, hipMemsetAsync(c->img_u8.p, 0, npix, c->stream));
-    rc = ev_accumulate_dev(c, (const eorb_event16*)c->ev16.p, offs, 1, W, H, sigma, pol, mode_count, (float*)c->img_f32.p,
+    rc = ev_accumulate_dev(c, c->ev16.p, raw, offs, 1, W, H, sigma, pol, mode_count, (float*)c->img_f32.p,
                            (uint8_t*)c->img_u8.p, normalized, mm);
     if (rc) return rc;
     if ((rc = ev_decode_minmax(c, mm, mmf, 1))) return rc;
@@ -267,6 +279,68 @@ int eorb_ev2im_gauss(eorb_ctx* c, const eorb_event* ev, size_t n, int W, int H, 
 }
 
 static int up(eorb_ctx* c, DevBuf& b, const void* h, size_t bytes);
+
+// ---- raw sensor events + undistortion maps ----------------------------------------------------------
+int eorb_set_undistort_maps(eorb_ctx* c, const float* mapX, const float* mapY, int LW, int LH, int checkInImage)
+{
+    if (!c) return EORB_E_ARG;
+    if (!mapX || !mapY || LW <= 0 || LH <= 0 || LW > 65535 || LH > 65535 || (int64_t)LW * LH >= (1ll << 31))
+        return set_err(c, EORB_E_ARG, "set_undistort_maps: bad arguments");
+    hipSetDevice(c->device);
+    const size_t n = (size_t)LW * LH;
+    std::vector<float> xy(2 * n);
+    for (size_t i = 0; i < n; i++) { xy[2 * i] = mapX[i]; xy[2 * i + 1] = mapY[i]; }
+    int rc;
+    if ((rc = up(c, c->lut, xy.data(), sizeof(float) * 2 * n))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    c->lut_w = LW; c->lut_h = LH; c->lut_check = checkInImage != 0;
+    c->lut_key_W = c->lut_key_H = c->lut_key_mode = -1; c->lut_key_sigma = -1.f;      // derived tables are stale
+    return EORB_OK;
+}
+
+int eorb_undistort_events(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int W, int H, double tsFactor, eorb_event* out, size_t* n_out)
+{
+    if (!c) return EORB_E_ARG;
+    if (!c->lut_w) return set_err(c, EORB_E_NOTCONF, "undistort_events: eorb_set_undistort_maps not called");
+    if ((n && (!raw || !out)) || !n_out || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "undistort_events: bad arguments");
+    hipSetDevice(c->device);
+    *n_out = 0;
+    if (!n) return EORB_OK;
+    for (size_t i = 0; i < n; i++)
+        if ((int)raw[i].x >= c->lut_w || (int)raw[i].y >= c->lut_h)
+            return set_err(c, EORB_E_ARG, "undistort_events: event %zu at (%u,%u) lies outside the %dx%d maps", i, raw[i].x, raw[i].y,
+                           c->lut_w, c->lut_h);
+    int rc;
+    if ((rc = up(c, c->ev16, raw, sizeof(eorb_raw_event) * n))) return rc;
+    if ((rc = ensure(c, c->entries, sizeof(eorb_event) * n))) return rc;
+    const int nblk = (int)((n + 1023) / 1024);
+    if ((rc = ensure(c, c->segoff, sizeof(uint32_t) * ((size_t)nblk + 2)))) return rc;
+    if ((rc = ev_undistort_dev(c, (const eorb_raw_event*)c->ev16.p, n, W, H, tsFactor, (eorb_event*)c->entries.p, (uint32_t*)c->segoff.p))) return rc;
+    uint32_t kept = 0;
+    EORB_HIP(c, hipMemcpyAsync(&kept, (uint32_t*)c->segoff.p + nblk, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (kept) EORB_HIP(c, hipMemcpyAsync(out, c->entries.p, sizeof(eorb_event) * kept, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    *n_out = kept;
+    return EORB_OK;
+}
+
+int eorb_ev2im_gauss_raw(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int W, int H, float sigma, int pol, int normalized,
+                         float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    if (c && !(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev2im_gauss_raw: sigma must be > 0");
+    if (c && n && !raw) return set_err(c, EORB_E_ARG, "ev2im_gauss_raw: bad arguments");
+    static const eorb_raw_event none{};
+    return ev_host_common(c, nullptr, n, W, H, sigma, pol, normalized, 0, out_f32, out_u8, minmax, nullptr, raw ? raw : &none);
+}
+
+int eorb_ev2im_raw(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int W, int H, int pol, int normalized,
+                   float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8)
+{
+    if (c && n && !raw) return set_err(c, EORB_E_ARG, "ev2im_raw: bad arguments");
+    static const eorb_raw_event none{};
+    return ev_host_common(c, nullptr, n, W, H, 0.f, pol, normalized, 1, out_f32, out_u8, minmax, is_u8, raw ? raw : &none);
+}
 
 // ---- motion-compensated accumulation (f1) ----
 static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, int se3, double angle, const double* axis,
@@ -306,7 +380,7 @@ static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pi
     int64_t offs[2] = {0, (int64_t)n};
     uint32_t* mm = (uint32_t*)c->minmax.p;
     float* mmf = (float*)((char*)c->minmax.p + 16);
-    rc = ev_accumulate_dev(c, (const eorb_event16*)c->ev16.p, offs, 1, W, H, sigma, pol, 0, (float*)c->img_f32.p, (uint8_t*)c->img_u8.p,
+    rc = ev_accumulate_dev(c, c->ev16.p, 0, offs, 1, W, H, sigma, pol, 0, (float*)c->img_f32.p, (uint8_t*)c->img_u8.p,
                            normalized, mm);
     if (rc) return rc;
     if ((rc = ev_decode_minmax(c, mm, mmf, 1))) return rc;
@@ -953,9 +1027,9 @@ int eorb_fe_configure(eorb_ctx* c, const eorb_fe_config* cfg)
     return EORB_OK;
 }
 
-int eorb_fe_run_batch_dev(eorb_ctx* c, const eorb_event16* d_events, const int64_t* h_offsets, int B,
-                          uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
-                          int32_t* d_matches12, int32_t* d_nmatches)
+static int fe_run_batch_common(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B,
+                               uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                               int32_t* d_matches12, int32_t* d_nmatches)
 {
     if (!c) return EORB_E_ARG;
     if (!c->fe_configured) return set_err(c, EORB_E_NOTCONF, "fe_run_batch: eorb_fe_configure not called");
@@ -968,7 +1042,7 @@ int eorb_fe_run_batch_dev(eorb_ctx* c, const eorb_event16* d_events, const int64
     eorb_keypoint* wk = (eorb_keypoint*)c->out_kp.p;
     uint8_t* wd = (uint8_t*)c->m_a.p;
     int32_t* wn = (int32_t*)c->out_n.p;                 // [0] prev, [1..B] this batch, then mono index
-    int rc = ev_accumulate_dev(c, d_events, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 1,
+    int rc = ev_accumulate_dev(c, d_events, raw, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 1,
                                (uint32_t*)c->minmax.p);
     if (rc) return rc;
     rc = orb_extract_dev(c, img, f.W, npix, B, f.lap0, f.lap1, f.want_desc, wk + cap, wd + 32 * cap, nullptr, wn + 1,
@@ -1001,6 +1075,21 @@ int eorb_fe_run_batch_dev(eorb_ctx* c, const eorb_event16* d_events, const int64
     EORB_HIP(c, hipMemcpyAsync(wn, wn + B, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
     c->fe_has_prev = true;
     return EORB_OK;
+}
+
+int eorb_fe_run_batch_dev(eorb_ctx* c, const eorb_event16* d_events, const int64_t* h_offsets, int B,
+                          uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                          int32_t* d_matches12, int32_t* d_nmatches)
+{
+    return fe_run_batch_common(c, d_events, 0, h_offsets, B, d_images, d_kps, d_desc, d_nkps, d_matches12, d_nmatches);
+}
+
+int eorb_fe_run_batch_raw_dev(eorb_ctx* c, const eorb_raw_event* d_events, const int64_t* h_offsets, int B,
+                              uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                              int32_t* d_matches12, int32_t* d_nmatches)
+{
+    if (c && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "fe_run_batch_raw: eorb_set_undistort_maps not called");
+    return fe_run_batch_common(c, d_events, 1, h_offsets, B, d_images, d_kps, d_desc, d_nkps, d_matches12, d_nmatches);
 }
 
 }  // extern "C"

@@ -42,6 +42,9 @@ struct BinParams {
     int dup;              // entry capacity per event (R*R)
     int mode_count;       // 1: ev2im (coords rounded, no stamp)
     int pol;
+    // raw sensor events (eorb_raw_event) resolved through the undistortion maps: per sensor pixel xi | yi << 16 (int16 each)
+    int raw, LW, LH;
+    const uint32_t* src_info;
 };
 
 __device__ __forceinline__ bool ev_tile_range(const eorb_event16& e, const BinParams& P, int& tx0, int& tx1, int& ty0, int& ty1)
@@ -51,6 +54,20 @@ __device__ __forceinline__ bool ev_tile_range(const eorb_event16& e, const BinPa
                                                     // INT_MIN on the reference's x86: never in the image
     const int xi = P.mode_count ? (int)roundf(x) : (int)floorf(x);
     const int yi = P.mode_count ? (int)roundf(y) : (int)floorf(y);
+    tx0 = max((xi - P.h) >> 3, 0); tx1 = min((xi + P.h) >> 3, P.TX - 1);
+    ty0 = max((yi - P.h) >> 3, 0); ty1 = min((yi + P.h) >> 3, P.TY - 1);
+    return true;
+}
+
+// raw event -> sensor pixel index and its integer image position; events off the maps or (checkInImage) mapped outside the
+// image carry xi = yi = -32768 and therefore touch no tile
+__device__ __forceinline__ bool ev_tile_range_raw(const eorb_raw_event& q, const BinParams& P, int& tx0, int& tx1, int& ty0, int& ty1,
+                                                  uint32_t& src, uint32_t& info)
+{
+    if ((int)q.x >= P.LW || (int)q.y >= P.LH) return false;
+    src = (uint32_t)q.y * (uint32_t)P.LW + q.x;
+    info = P.src_info[src];
+    const int xi = (int)(int16_t)(info & 0xffff), yi = (int)(int16_t)(info >> 16);
     tx0 = max((xi - P.h) >> 3, 0); tx1 = min((xi + P.h) >> 3, P.TX - 1);
     ty0 = max((yi - P.h) >> 3, 0); ty1 = min((yi + P.h) >> 3, P.TY - 1);
     return true;
@@ -68,7 +85,9 @@ __global__ __launch_bounds__(256) void ev_count_kernel(const eorb_event16* __res
     const eorb_event16* e = ev + cd.start;
     for (int k = threadIdx.x; k < cd.n; k += blockDim.x) {
         int tx0, tx1, ty0, ty1;
-        if (ev_tile_range(e[k], P, tx0, tx1, ty0, ty1))
+        uint32_t src, info;
+        if (P.raw ? ev_tile_range_raw(((const eorb_raw_event*)e)[k], P, tx0, tx1, ty0, ty1, src, info)
+                  : ev_tile_range(e[k], P, tx0, tx1, ty0, ty1))
             for (int ty = ty0; ty <= ty1; ty++)
                 for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&cnt[ty * P.TX + tx], 1u);
     }
@@ -145,10 +164,18 @@ __global__ __launch_bounds__(64) void ev_scatter_kernel(const eorb_event16* __re
         float x = 0.f, y = 0.f, sg = 1.f;
         int tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0;
         if (valid) {
-            const eorb_event16 q = e[k];
-            valid = ev_tile_range(q, P, tx0, tx1, ty0, ty1);
-            x = q.x; y = q.y;
-            if (POL) sg = (__double_as_longlong(q.t) < 0) ? -1.0f : 1.0f;
+            if (P.raw) {
+                // entry = { sensor pixel | negative polarity << 31, xi | yi << 16 } in the float2 slot
+                const eorb_raw_event q = ((const eorb_raw_event*)e)[k];
+                uint32_t src = 0, info = 0;
+                valid = ev_tile_range_raw(q, P, tx0, tx1, ty0, ty1, src, info);
+                x = __uint_as_float(src | (q.p ? 0u : 0x80000000u)); y = __uint_as_float(info);
+            } else {
+                const eorb_event16 q = e[k];
+                valid = ev_tile_range(q, P, tx0, tx1, ty0, ty1);
+                x = q.x; y = q.y;
+                if (POL) sg = (__double_as_longlong(q.t) < 0) ? -1.0f : 1.0f;
+            }
         }
 #pragma unroll
         for (int cy = 0; cy < R; cy++) {
@@ -213,6 +240,8 @@ struct GatherParams {
     float inv_two_sig2;  // exact reciprocal when two_sig2 is a power of two
     float rcp_norm;      // RN(1/norm)
     int div_is_pow2, fast_norm;
+    const float* stamps;  // RAW: per sensor pixel the (2h+1)^2 stamp values, [column][row]
+    int stamp_stride;
 };
 
 // K2: one 512-thread workgroup per 8x8 tile (EORB_GATHER_THREADS overrides: 256..1024 measured, 512 fastest); the tile's entries are consumed in batches of 64 (event order)
@@ -247,7 +276,7 @@ __device__ unsigned long long g_diag[16];
 #ifndef EORB_GATHER_U
 #define EORB_GATHER_U 4
 #endif
-template <bool POL, int MODE>
+template <bool POL, int MODE, bool RAW>
 __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const int64_t* __restrict__ slice_ebase, // B: first entry of the slice
                                                                   const int32_t* __restrict__ order,      // work items, heaviest first
                                                                   GatherParams P, const uint32_t* __restrict__ tile_cnt,
@@ -274,7 +303,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     const int px = tx0 + lx, py = ty0 + ly;
     const bool inimg = px < P.W && py < P.H;
     const int xhi = min(tx0 + kTile - 1, P.W - 1), yhi = min(ty0 + kTile - 1, P.H - 1);
-    constexpr int ESZ = POL ? 4 : 2;
+    constexpr int ESZ = RAW ? 2 : (POL ? 4 : 2);
     const int h = P.h;
     __syncthreads();
     // the tile's entries: one contiguous event-ordered list (K1b/K1c)
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
         const int j = jnext + lane;
         valid = j < nent;
         if (valid) {
-            if (POL) { float4 v = *(const float4*)(list + (size_t)j * 4); ex = v.x; ey = v.y; esg = v.z; }
+            if (!RAW && POL) { float4 v = *(const float4*)(list + (size_t)j * 4); ex = v.x; ey = v.y; esg = v.z; }
             else { float2 v = *(const float2*)(list + (size_t)j * 2); ex = v.x; ey = v.y; }
         }
         jnext += 64;
@@ -352,7 +381,12 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                 uint32_t xm = 0, ym = 0;
                 int ra0 = 0, rb0 = 0, rw = 0, rh = 0;
                 if (valid) {
-                    if (MODE == 2) { xi = (int)roundf(ex); yi = (int)roundf(ey); }          // roundFloatCoord :46-49
+                    if (RAW) {                                                               // integer position from the maps (K1c)
+                        const uint32_t w0 = __float_as_uint(ex), w1 = __float_as_uint(ey);
+                        xi = (int)(int16_t)(w1 & 0xffff); yi = (int)(int16_t)(w1 >> 16);
+                        xr = __uint_as_float(w0 & 0x7fffffffu);                             // sensor pixel index rides in the xr slot
+                        esg = (w0 >> 31) ? -1.0f : 1.0f;
+                    } else if (MODE == 2) { xi = (int)roundf(ex); yi = (int)roundf(ey); }   // roundFloatCoord :46-49
                     else {                                                                   // breakFloatCoords :51-57
                         xi = (int)floorf(ex); yi = (int)floorf(ey);
                         xr = ex - (float)xi; yr = ey - (float)yi;
@@ -410,6 +444,29 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     const float xx = fx * fx;
                     const uint64_t below = (1ull << e) - 1ull;
                     const int dy0 = ty0 + b0 - yi;
+                    if (RAW && MODE != 2) {
+                        // stamp values of this sensor pixel come from the table built once per (maps, sigma): column i, rows j0..
+                        const float* sp = P.stamps + (size_t)__float_as_uint(ei.xr) * P.stamp_stride + (tx0 + qx - xi + h) * (2 * h + 1)
+                                          + (dy0 + h);
+                        constexpr int UR = 4;
+                        for (int jj = 0; __any(jj < rh); jj += UR) {
+                            float v[UR]; int pix[UR], rank[UR]; bool on[UR];
+#pragma unroll
+                            for (int u = 0; u < UR; u++) {
+                                on[u] = jj + u < rh;
+                                v[u] = on[u] ? sp[jj + u] : 0.f;
+                            }
+#pragma unroll
+                            for (int u = 0; u < UR; u++) {
+                                pix[u] = on[u] ? (b0 + jj + u) * 8 + qx : 0;
+                                rank[u] = __popcll(pm[bs3][pix[u]] & below);
+                            }
+#pragma unroll
+                            for (int u = 0; u < UR; u++)
+                                if (on[u]) vbase[((rank[u] >> 2) * 64 + pix[u]) * 4 + (rank[u] & 3)] = POL ? ei.sg * v[u] : v[u];
+                        }
+                        continue;
+                    }
                     constexpr int U = 2;
                     for (int jj = 0; __any(jj < rh); jj += U) {
                         int pix[U], rank[U]; bool on[U]; float v[U];
@@ -727,12 +784,118 @@ int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm
     return EORB_OK;
 }
 
+// ---- raw sensor events: tables derived from the undistortion maps (MyCalibrator::mUndistMapX/Y, Utils/MyCalibrator.cpp:164-180) ----
+// per sensor pixel: integer image position floor(x) (breakFloatCoords :51-57) or round (roundFloatCoord :46-49); -32768 when the
+// undistorted point fails MyCalibrator::isInImage (:31-34) and the loader would have dropped the event (EventLoader.cpp:295-296)
+__global__ void ev_src_info_kernel(const float2* __restrict__ lut, int n, int W, int H, int check, int mode_count, uint32_t* __restrict__ info)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 q = lut[i];
+    const bool in = (q.x >= 0 && q.x < (float)W) && (q.y >= 0 && q.y < (float)H);
+    int xi = -32768, yi = -32768;
+    if ((in || !check) && q.x == q.x && q.y == q.y) {
+        const float fx = mode_count ? roundf(q.x) : floorf(q.x), fy = mode_count ? roundf(q.y) : floorf(q.y);
+        xi = (int)fminf(fmaxf(fx, -32000.f), 32000.f); yi = (int)fminf(fmaxf(fy, -32000.f), 32000.f);
+    }
+    info[i] = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16);
+}
+
+// stamp table: S[src][i][j] = exp_XY2f(i - h - xRes, j - h - yRes) (:59-65, :236-249), evaluated exactly as K2's value waves do
+__global__ void ev_stamp_kernel(const float2* __restrict__ lut, const uint32_t* __restrict__ info, int n, GatherParams P,
+                                float* __restrict__ stamps)
+{
+    __shared__ uint64_t tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    __syncthreads();
+    const int SW = 2 * P.h + 1;
+    const size_t total = (size_t)n * SW * SW;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+        const int src = (int)(k / (SW * SW)), r = (int)(k - (size_t)src * SW * SW);
+        const int i = r / SW, j = r - i * SW;
+        const uint32_t w = info[src];
+        const int xi = (int)(int16_t)(w & 0xffff), yi = (int)(int16_t)(w >> 16);
+        float v = 0.f;
+        if (xi != -32768) {
+            const float2 q = lut[src];
+            const float xr = q.x - (float)xi, yr = q.y - (float)yi;
+            const float fx = (float)(i - P.h) - xr, fy = (float)(j - P.h) - yr;
+            const float xx = fx * fx, yy = fy * fy;
+            float dd = xx + yy;
+            dd = dd / P.two_sig2;
+            v = dev_expf_nonpos<true>(-dd, tab) / P.norm;
+        }
+        stamps[k] = v;
+    }
+}
+
+// EventDataStore::getEventChunkRectified (EventLoader.cpp:264-305) after parsing: map lookup, ts / tsFactor, checkInImage,
+// order-preserving compaction (blocks of 1024 events: count -> scan over blocks -> write)
+__device__ __forceinline__ bool ev_keep(const float2 q, int W, int H, int check)
+{
+    return !check || ((q.x >= 0 && q.x < (float)W) && (q.y >= 0 && q.y < (float)H));
+}
+__global__ __launch_bounds__(1024) void ev_undistort_count_kernel(const eorb_raw_event* __restrict__ raw, size_t n, const float2* __restrict__ lut,
+                                                                  int LW, int W, int H, int check, uint32_t* __restrict__ blk)
+{
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const size_t k = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    bool keep = false;
+    if (k < n) keep = ev_keep(lut[(size_t)raw[k].y * LW + raw[k].x], W, H, check);
+    const uint64_t m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = cnt;
+}
+__global__ void ev_undistort_scan_kernel(uint32_t* blk, int nblk)
+{   // single thread: nblk <= a few thousand
+    uint32_t run = 0;
+    for (int i = 0; i < nblk; i++) { const uint32_t v = blk[i]; blk[i] = run; run += v; }
+    blk[nblk] = run;
+}
+__global__ __launch_bounds__(1024) void ev_undistort_write_kernel(const eorb_raw_event* __restrict__ raw, size_t n, const float2* __restrict__ lut,
+                                                                  int LW, int W, int H, int check, double tsFactor,
+                                                                  const uint32_t* __restrict__ blk, eorb_event* __restrict__ out)
+{
+    __shared__ uint32_t wbase[17];
+    const size_t k = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool keep = false; float2 q = make_float2(0.f, 0.f); eorb_raw_event r{};
+    if (k < n) { r = raw[k]; q = lut[(size_t)r.y * LW + r.x]; keep = ev_keep(q, W, H, check); }
+    const uint64_t m = __ballot(keep);
+    if (lane == 0) wbase[wave + 1] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { wbase[0] = 0; for (int w = 1; w <= 16; w++) wbase[w] += wbase[w - 1]; }
+    __syncthreads();
+    if (keep) {
+        const uint32_t pos = blk[blockIdx.x] + wbase[wave] + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        eorb_event e{};
+        e.ts = r.t / tsFactor; e.x = q.x; e.y = q.y; e.p = r.p ? 1 : 0;
+        out[pos] = e;
+    }
+}
+
+int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, int H, double tsFactor, eorb_event* d_out, uint32_t* d_blk)
+{
+    const int nblk = (int)((n + 1023) / 1024);
+    ProfScope ps(c, "ev_undistort");
+    ev_undistort_count_kernel<<<nblk, 1024, 0, c->stream>>>(d_raw, n, (const float2*)c->lut.p, c->lut_w, W, H, c->lut_check, d_blk);
+    ev_undistort_scan_kernel<<<1, 1, 0, c->stream>>>(d_blk, nblk);
+    ev_undistort_write_kernel<<<nblk, 1024, 0, c->stream>>>(d_raw, n, (const float2*)c->lut.p, c->lut_w, W, H, c->lut_check, tsFactor, d_blk, d_out);
+    EORB_LAUNCH_CHECK(c, "ev_undistort kernels");
+    return EORB_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
-int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_offsets, int B, int W, int H,
+int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
                       uint32_t* d_minmax_enc)
 {
     if (B <= 0 || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "ev_accumulate: bad size");
+    if (raw && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "ev_accumulate: raw events need eorb_set_undistort_maps first");
+    const eorb_event16* d_ev = (const eorb_event16*)d_events;          // eorb_raw_event has the same 16-byte stride
     const int h = mode_count ? 0 : (int)ceil((double)sigma * 3.0);     // lenHalfWin :222
     if (h > 8) return set_err(c, EORB_E_CONFIG, "ev_accumulate: sigma %.3f gives half window %d > 8", sigma, h);
     const int R = (2 * h <= kTile) ? ((h == 0) ? 1 : 2) : 3;            // max tiles an event spans per axis
@@ -785,12 +948,44 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
     uint32_t* d_tile_base = d_tile_cnt + nb;
     int32_t* d_order = (int32_t*)(d_tile_cnt + 2 * (size_t)nb);
 
+    const float sig2 = sigma * sigma;
+    GatherParams G{W, H, h, TX, TY, NT, mode_count, nb, 2.0f * sig2,
+                   2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0, nullptr, 0};
+    {
+        int ex2 = 0;
+        const float mant = frexpf(G.two_sig2, &ex2);
+        G.div_is_pow2 = (mant == 0.5f) && ex2 > -100 && ex2 < 100;
+        G.inv_two_sig2 = G.div_is_pow2 ? 1.0f / G.two_sig2 : 0.f;
+        G.rcp_norm = (float)(1.0 / (double)G.norm);
+        // the residual ev*2^-24 must stay a normal float: exp(-dd_max) > 1e-27, dd_max = (h+1)^2 / sig2
+        const double ddmax = (double)(h + 1) * (h + 1) / (double)sig2;
+        G.fast_norm = (ddmax < 60.0) && (G.norm < 1e3f) && (G.norm > 1e-3f);
+    }
+    if (raw) {
+        // tables derived from the maps; rebuilt only when (image size, sigma, mode) change
+        const int nsrc = c->lut_w * c->lut_h;
+        const int SW = 2 * h + 1;
+        if (c->lut_key_W != W || c->lut_key_H != H || c->lut_key_sigma != sigma || c->lut_key_mode != mode_count) {
+            ProfScope ps(c, "ev_stamp_tables");
+            if ((rc = ensure(c, c->src_info, sizeof(uint32_t) * (size_t)nsrc))) return rc;
+            ev_src_info_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, nsrc, W, H, c->lut_check, mode_count,
+                                                                            (uint32_t*)c->src_info.p);
+            if (!mode_count) {
+                if ((rc = ensure(c, c->stamps, sizeof(float) * (size_t)nsrc * SW * SW))) return rc;
+                ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
+                                                             (float*)c->stamps.p);
+            }
+            EORB_LAUNCH_CHECK(c, "ev_stamp_tables kernels");
+            c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
+        }
+        G.stamps = (const float*)c->stamps.p; G.stamp_stride = SW * SW;
+    }
     {
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
     }
     {
-        BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol};
+        BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
         if (lds > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
         ProfScope ps(c, "ev_bin");
@@ -799,36 +994,27 @@ int ev_accumulate_dev(eorb_ctx* c, const eorb_event16* d_ev, const int64_t* h_of
         ev_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
         if (nchunks) {
 #define LAUNCH_BIN(RR, PP) ev_scatter_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, d_slice_eb, d_segbase, d_tile_base, en)
-            if (R == 1) { if (pol) LAUNCH_BIN(1, true); else LAUNCH_BIN(1, false); }
-            else if (R == 2) { if (pol) LAUNCH_BIN(2, true); else LAUNCH_BIN(2, false); }
-            else { if (pol) LAUNCH_BIN(3, true); else LAUNCH_BIN(3, false); }
+            const bool wide = pol && !raw;                       // raw entries keep the polarity in the sensor-pixel word
+            if (R == 1) { if (wide) LAUNCH_BIN(1, true); else LAUNCH_BIN(1, false); }
+            else if (R == 2) { if (wide) LAUNCH_BIN(2, true); else LAUNCH_BIN(2, false); }
+            else { if (wide) LAUNCH_BIN(3, true); else LAUNCH_BIN(3, false); }
 #undef LAUNCH_BIN
         }
         ev_tile_order_kernel<<<1, 1024, 0, c->stream>>>(d_tile_cnt, nb, d_order);
         EORB_LAUNCH_CHECK(c, "ev_bin kernels");
     }
     {
-        const float sig2 = sigma * sigma;
-        GatherParams G{W, H, h, TX, TY, NT, mode_count, nb, 2.0f * sig2,
-                       2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0};
-        {
-            int ex2 = 0;
-            const float mant = frexpf(G.two_sig2, &ex2);
-            G.div_is_pow2 = (mant == 0.5f) && ex2 > -100 && ex2 < 100;
-            G.inv_two_sig2 = G.div_is_pow2 ? 1.0f / G.two_sig2 : 0.f;
-            G.rcp_norm = (float)(1.0 / (double)G.norm);
-            // the residual ev*2^-24 must stay a normal float: exp(-dd_max) > 1e-27, dd_max = (h+1)^2 / sig2
-            const double ddmax = (double)(h + 1) * (h + 1) / (double)sig2;
-            G.fast_norm = (ddmax < 60.0) && (G.norm < 1e3f) && (G.norm > 1e-3f);
-        }
         ProfScope ps(c, "ev_gather");
         static const int gthreads = [] { const char* e = getenv("EORB_GATHER_THREADS"); int v = e ? atoi(e) : kGatherThreads;
                                          return (v >= 192 && v <= 1024 && v % 64 == 0) ? v : kGatherThreads; }();
         const int mode = mode_count ? 2 : ((G.div_is_pow2 && G.fast_norm) ? 1 : 0);
         const float* en = (const float*)c->entries.p;
-#define LAUNCH_G(PP, MM) ev_gather_kernel<PP, MM><<<nb, gthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en, d_f32, d_minmax_enc)
-        if (pol) { if (mode == 2) LAUNCH_G(true, 2); else if (mode == 1) LAUNCH_G(true, 1); else LAUNCH_G(true, 0); }
-        else { if (mode == 2) LAUNCH_G(false, 2); else if (mode == 1) LAUNCH_G(false, 1); else LAUNCH_G(false, 0); }
+#define LAUNCH_G(PP, MM, RR) ev_gather_kernel<PP, MM, RR><<<nb, gthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en, d_f32, d_minmax_enc)
+        if (raw) {
+            if (pol) { if (mode == 2) LAUNCH_G(true, 2, true); else LAUNCH_G(true, 0, true); }
+            else { if (mode == 2) LAUNCH_G(false, 2, true); else LAUNCH_G(false, 0, true); }
+        } else if (pol) { if (mode == 2) LAUNCH_G(true, 2, false); else if (mode == 1) LAUNCH_G(true, 1, false); else LAUNCH_G(true, 0, false); }
+        else { if (mode == 2) LAUNCH_G(false, 2, false); else if (mode == 1) LAUNCH_G(false, 1, false); else LAUNCH_G(false, 0, false); }
 #undef LAUNCH_G
         EORB_LAUNCH_CHECK(c, "ev_gather_kernel");
     }

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .synth import EVENT_DTYPE, KP_DTYPE
+from .synth import EVENT_DTYPE, KP_DTYPE, RAW_DTYPE
 
 EV16_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("t", "<f8")])
 
@@ -136,6 +136,46 @@ class EvImConverter:
             return f32, (u8 if normalized else None), mm
         return u8 if normalized else f32
 
+
+    # ---- raw sensor events + MyCalibrator undistortion maps (src/Event/EventLoader.cpp:264-305, Utils/MyCalibrator.cpp:164-180) ----
+    @staticmethod
+    def set_undistort_maps(mapX, mapY, checkInImage=True, ctx=None):
+        ctx = ctx or default_context()
+        mx = np.ascontiguousarray(mapX, np.float32); my = np.ascontiguousarray(mapY, np.float32)
+        ctx.check(ctx.L.eorb_set_undistort_maps(ctx.h, _p(mx), _p(my), mx.shape[1], mx.shape[0], int(checkInImage)))
+
+    @staticmethod
+    def undistort_events(raw, imWidth, imHeight, tsFactor=1.0, ctx=None):
+        """The rectification of EventDataStore::getEventChunkRectified: raw (RAW_DTYPE) -> EVENT_DTYPE events kept by checkInImage."""
+        ctx = ctx or default_context()
+        raw = np.ascontiguousarray(raw, RAW_DTYPE)
+        out = np.zeros(len(raw), EVENT_DTYPE); k = C.c_size_t(0)
+        ctx.check(ctx.L.eorb_undistort_events(ctx.h, _p(raw), len(raw), imWidth, imHeight, float(tsFactor), _p(out), C.byref(k)))
+        return out[:k.value].copy()
+
+    @staticmethod
+    def ev2im_gauss_raw(raw, imWidth, imHeight, sigma=1.0, pol=False, normalized=True, ctx=None, return_all=False):
+        ctx = ctx or default_context()
+        raw = np.ascontiguousarray(raw, RAW_DTYPE)
+        f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8)
+        mm = np.zeros(2, np.float32)
+        ctx.check(ctx.L.eorb_ev2im_gauss_raw(ctx.h, _p(raw), len(raw), imWidth, imHeight, float(sigma), int(pol),
+                                             int(normalized), _p(f32), _p(u8), _p(mm)))
+        if return_all:
+            return f32, (u8 if normalized else None), mm
+        return u8 if normalized else f32
+
+    @staticmethod
+    def ev2im_raw(raw, imWidth, imHeight, pol=False, normalized=True, ctx=None, return_all=False):
+        ctx = ctx or default_context()
+        raw = np.ascontiguousarray(raw, RAW_DTYPE)
+        f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8)
+        mm = np.zeros(2, np.float32); is_u8 = C.c_int(0)
+        ctx.check(ctx.L.eorb_ev2im_raw(ctx.h, _p(raw), len(raw), imWidth, imHeight, int(pol), int(normalized),
+                                       _p(f32), _p(u8), _p(mm), C.byref(is_u8)))
+        if return_all:
+            return f32, (u8 if is_u8.value else None), mm
+        return u8 if is_u8.value else f32
 
     @staticmethod
     def ev2mci_gg_f_se3(vEvData, cam, angle, axis, t, medDepth, imWidth, imHeight, sigma=1.0, pol=False, normalized=False,
@@ -472,10 +512,12 @@ class FrontEndBatch:
         self.cap = self.ctx.L.eorb_orb_max_keypoints(self.ctx.h)
         self.W, self.H = W, H
 
-    def run_dev(self, d_events, offsets, d_images=None, d_kps=None, d_desc=None, d_nkps=None, d_m12=None, d_nm=None):
-        """d_* are raw device pointers (ints), e.g. torch tensors' data_ptr(); offsets: int64[B+1] on the host."""
+    def run_dev(self, d_events, offsets, d_images=None, d_kps=None, d_desc=None, d_nkps=None, d_m12=None, d_nm=None, raw=False):
+        """d_* are raw device pointers (ints), e.g. torch tensors' data_ptr(); offsets: int64[B+1] on the host.
+        raw=True: d_events holds eorb_raw_event records (sensor pixels; set_undistort_maps first)."""
         offsets = np.ascontiguousarray(offsets, np.int64)
         B = len(offsets) - 1
         vp = lambda x: C.c_void_p(x) if x else None
-        self.ctx.check(self.ctx.L.eorb_fe_run_batch_dev(self.ctx.h, vp(d_events), _p(offsets), B, vp(d_images), vp(d_kps),
-                                                        vp(d_desc), vp(d_nkps), vp(d_m12), vp(d_nm)))
+        fn = self.ctx.L.eorb_fe_run_batch_raw_dev if raw else self.ctx.L.eorb_fe_run_batch_dev
+        self.ctx.check(fn(self.ctx.h, vp(d_events), _p(offsets), B, vp(d_images), vp(d_kps),
+                          vp(d_desc), vp(d_nkps), vp(d_m12), vp(d_nm)))

@@ -10,6 +10,8 @@ import numpy as np
 
 # layout of one event at the drop-in boundary: include/Event/EventData.h:36-58 (24 B, AoS)
 EVENT_DTYPE = np.dtype([("ts", "<f8"), ("x", "<f4"), ("y", "<f4"), ("p", "u1"), ("pad", "u1", (7,))])
+# eorb_raw_event (16 B): sensor pixel, polarity, timestamp
+RAW_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("p", "<u4"), ("t", "<f8")])
 # cv::KeyPoint layout (28 B)
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -34,7 +36,7 @@ def undistort_lut(W=240, H=180, K=EVETHZ_K, iters=8):
 
 
 def shapes_events(n, W=240, H=180, seed=1, undistort=False, n_poly=3, noise_frac=0.05, t0=0.0, dt=1e-6,
-                  motion=1.0):
+                  motion=1.0, return_raw=False):
     """`n` events from the edges of `n_poly` moving quadrilaterals (K = 4*n_poly = 12 edges by
     default) plus uniform noise.  Raw coordinates are integer pixels; with undistort=True they are
     mapped through the EvETHZ LUT and events leaving the image are dropped and re-drawn, like the
@@ -42,6 +44,7 @@ def shapes_events(n, W=240, H=180, seed=1, undistort=False, n_poly=3, noise_frac
     rng = np.random.default_rng(seed)
     lut = undistort_lut(W, H) if undistort else None
     out = np.zeros(n, EVENT_DTYPE)
+    rawx = np.zeros(n, np.uint16); rawy = np.zeros(n, np.uint16)
     filled = 0
     # polygon vertices at slice start and their displacement over the slice
     ctr = rng.uniform([0.25 * W, 0.25 * H], [0.75 * W, 0.75 * H], size=(n_poly, 1, 2))
@@ -64,18 +67,32 @@ def shapes_events(n, W=240, H=180, seed=1, undistort=False, n_poly=3, noise_frac
         if lut is not None:
             xf = lut[0][yi, xi]; yf = lut[1][yi, xi]
             ok = (xf >= 0) & (xf < W) & (yf >= 0) & (yf < H)       # MyCalibrator::isInImage on floats
-            xf, yf, tt = xf[ok], yf[ok], tt[ok]
+            xf, yf, tt, xi, yi = xf[ok], yf[ok], tt[ok], xi[ok], yi[ok]
         else:
             xf = xi.astype(np.float32); yf = yi.astype(np.float32)
         k = min(len(xf), n - filled)
         out["x"][filled:filled + k] = xf[:k]; out["y"][filled:filled + k] = yf[:k]
         out["ts"][filled:filled + k] = tt[:k]
+        rawx[filled:filled + k] = xi[:k]; rawy[filled:filled + k] = yi[:k]
         filled += k
     order = np.argsort(out["ts"], kind="stable")
     out = out[order]
     out["ts"] = t0 + np.arange(n) * dt                      # monotone, us resolution
     out["p"] = rng.integers(0, 2, n).astype(np.uint8)
-    return out
+    if not return_raw:
+        return out
+    raw = np.zeros(n, RAW_DTYPE)
+    raw["x"] = rawx[order]; raw["y"] = rawy[order]; raw["p"] = out["p"]; raw["t"] = out["ts"]
+    return out, raw
+
+
+def random_raw_events(n, W=240, H=180, seed=0):
+    """Uniform sensor-pixel events (eorb_raw_event records)."""
+    rng = np.random.default_rng(seed)
+    raw = np.zeros(n, RAW_DTYPE)
+    raw["x"] = rng.integers(0, W, n); raw["y"] = rng.integers(0, H, n)
+    raw["p"] = rng.integers(0, 2, n); raw["t"] = 1e6 + np.arange(n) * 3.0
+    return raw
 
 
 def random_events(n, W=240, H=180, seed=0, frac=True, margin=4.0):

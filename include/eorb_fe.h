@@ -53,6 +53,14 @@ typedef struct {
     double t;
 } eorb_event16;
 
+/* one event as the sensor / dataset delivers it (src/Event/EventLoader.cpp:80-92 "ts x y p"): integer pixel, polarity,
+ * timestamp.  16 B, the same HBM footprint as eorb_event16. */
+typedef struct {
+    uint16_t x, y;
+    uint32_t p;         /* 0 = negative, otherwise positive */
+    double   t;
+} eorb_raw_event;
+
 /* cv::KeyPoint (28 B): what ORBextractor::operator() fills (_keypoints) */
 typedef struct {
     float   x, y;
@@ -106,6 +114,27 @@ int eorb_ev2im_gauss(eorb_ctx* ctx, const eorb_event* ev, size_t n, int W, int H
                      int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
 
 /* ---- motion-compensated accumulation (host buffers) ------------------------------------------------ */
+/* ---- raw sensor events through the undistortion maps ------------------------------
+ * mapX / mapY = MyCalibrator::mUndistMapX / mUndistMapY (Utils/MyCalibrator.cpp:60-101, LH x LW floats each, built by the
+ * caller with cv::undistortPoints as the reference does).  checkInImage = the flag the loader passes to
+ * getEventChunkRectified (EventLoader.cpp:264-305): events whose undistorted point fails MyCalibrator::isInImage(x, y)
+ * for the accumulation image (:31-34) are dropped. */
+int eorb_set_undistort_maps(eorb_ctx* ctx, const float* mapX, const float* mapY, int LW, int LH, int checkInImage);
+
+/* replaces the rectification loop of EventDataStore::getEventChunkRectified (src/Event/EventLoader.cpp:264-305) after
+ * parsing: out[k] = {raw.t / tsFactor, mapX[y][x], mapY[y][x], p} (MyCalibrator::undistPointMaps :164-180) for the events
+ * kept by checkInImage against a W x H image, in order.  out has room for n events; *n_out = number kept. */
+int eorb_undistort_events(eorb_ctx* ctx, const eorb_raw_event* raw, size_t n, int W, int H, double tsFactor,
+                          eorb_event* out, size_t* n_out);
+
+/* = eorb_undistort_events followed by eorb_ev2im_gauss / eorb_ev2im on the kept events, fused: the stamp of a sensor
+ * pixel depends only on its map entry, so the (2h+1)^2 values per pixel are tabulated once per (maps, sigma) and the
+ * accumulation kernel only orders and adds them.  Bit-identical to the two-step path. */
+int eorb_ev2im_gauss_raw(eorb_ctx* ctx, const eorb_raw_event* raw, size_t n, int W, int H, float sigma, int pol,
+                         int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+int eorb_ev2im_raw(eorb_ctx* ctx, const eorb_raw_event* raw, size_t n, int W, int H, int pol, int normalized,
+                   float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8);
+
 typedef struct { float fx, fy, cx, cy; } eorb_pinhole;     /* Pinhole::mvParameters (CameraModels/Pinhole.cpp:30-62) */
 
 /* replaces EvImConverter::ev2mci_gg_f(evs, pCamera, Tcw, medDepth, W, H, sigma, pol, normalized)
@@ -281,6 +310,11 @@ int eorb_fe_configure(eorb_ctx* ctx, const eorb_fe_config* cfg);
  * Outputs (device pointers, any may be NULL): d_images u8 B*W*H; d_kps B*cap; d_desc B*cap*32;
  * d_nkps int32 B; d_matches12 int32 B*cap (for slice b: index into slice b, per keypoint of b-1);
  * d_nmatches int32 B.  cap = eorb_orb_max_keypoints(). */
+/* as eorb_fe_run_batch_dev, for raw sensor events resident in HBM (eorb_set_undistort_maps first) */
+int eorb_fe_run_batch_raw_dev(eorb_ctx* ctx, const eorb_raw_event* d_events, const int64_t* h_offsets, int B,
+                              uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                              int32_t* d_matches12, int32_t* d_nmatches);
+
 int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int64_t* h_offsets, int B,
                           uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                           int32_t* d_matches12, int32_t* d_nmatches);

@@ -90,6 +90,15 @@ int orc_ev2im_gauss(const orc_event* ev, size_t n, int W, int H, float sigma, in
 double orc_dsin(double x);
 double orc_dcos(double x);
 
+/* raw sensor event (dataset line "ts x y p", EventLoader.cpp:80-92) */
+typedef struct { uint16_t x, y; uint32_t p; double t; } orc_raw_event;
+
+/* EventDataStore::getEventChunkRectified (src/Event/EventLoader.cpp:264-305) after parsing, for n raw events:
+ * MyCalibrator::undistPointMaps (Utils/MyCalibrator.cpp:164-180: dst = (mapX[y][x], mapY[y][x]) with x = (int)src.x),
+ * ts / tsFactor (:120-123), checkInImage -> MyCalibrator::isInImage against W x H (:31-34).  Returns the number kept. */
+size_t orc_undistort_events(const orc_raw_event* raw, size_t n, const float* mapX, const float* mapY, int LW, int LH,
+                            int W, int H, int checkInImage, double tsFactor, orc_event* out);
+
 typedef struct { float fx, fy, cx, cy; } orc_pinhole;          /* Pinhole::mvParameters (float), CameraModels/Pinhole.cpp */
 
 /* per-event warp of ev2mci_gg_f(evs, cam, Tcw, medDepth, ...) (:304-335): angle/axis = Eigen::AngleAxisd(R) and tt = t of

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 EVENT_DTYPE = np.dtype([("ts", "<f8"), ("x", "<f4"), ("y", "<f4"), ("p", "u1"), ("pad", "u1", (7,))])
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
-assert EVENT_DTYPE.itemsize == 24 and KP_DTYPE.itemsize == 28
+RAW_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("p", "<u4"), ("t", "<f8")])
+assert EVENT_DTYPE.itemsize == 24 and KP_DTYPE.itemsize == 28 and RAW_DTYPE.itemsize == 16
 
 
 class OrbParams(C.Structure):
@@ -488,3 +489,16 @@ def search_by_projection_kf(cur, kf_kps, kf_is_orb, valid, uv, pred_level, level
     n = lib().orc_search_by_projection_kf(cur.h, _p(kf_kps), len(kf_kps), _p(kio), _p(valid), _p(uv), _p(pl), _p(ls), _p(mp_desc),
                                           _p(cm), float(th), int(ORBdist), int(checkOri))
     return n, cm
+
+
+def undistort_events(raw, mapX, mapY, W, H, checkInImage=True, tsFactor=1.0):
+    raw = np.ascontiguousarray(raw, RAW_DTYPE)
+    mapX = np.ascontiguousarray(mapX, np.float32); mapY = np.ascontiguousarray(mapY, np.float32)
+    out = np.zeros(len(raw), EVENT_DTYPE)
+    L = lib()
+    L.orc_undistort_events.restype = C.c_size_t
+    L.orc_undistort_events.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, C.c_void_p]
+    k = L.orc_undistort_events(_p(raw), len(raw), _p(mapX), _p(mapY), mapX.shape[1], mapX.shape[0], W, H, int(checkInImage),
+                               float(tsFactor), _p(out))
+    return out[:k].copy()

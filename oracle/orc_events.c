@@ -252,3 +252,20 @@ void orc_cv_normalize_minmax_u8(const float* img, size_t npix, uint8_t* dst)
         dst[i] = (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
     }
 }
+
+/* EventDataStore::getEventChunkRectified :264-305 (parse excluded) */
+size_t orc_undistort_events(const orc_raw_event* raw, size_t n, const float* mapX, const float* mapY, int LW, int LH,
+                            int W, int H, int checkInImage, double tsFactor, orc_event* out)
+{
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        const int x = (int)raw[i].x, y = (int)raw[i].y;                 /* static_cast<int>(srcPt.x) :172-173 */
+        if (x < 0 || x >= LW || y < 0 || y >= LH) continue;             /* assert :175 */
+        const float ux = mapX[(size_t)y * LW + x], uy = mapY[(size_t)y * LW + x];
+        if (checkInImage && !((ux >= 0 && ux < (float)W) && (uy >= 0 && uy < (float)H))) continue;   /* :295-296 */
+        memset(&out[k], 0, sizeof(orc_event));
+        out[k].ts = raw[i].t / tsFactor; out[k].x = ux; out[k].y = uy; out[k].p = raw[i].p ? 1 : 0;
+        k++;
+    }
+    return k;
+}

@@ -559,6 +559,110 @@ def test_frontend_batch_ragged_and_empty_slices(oracle, fe):
     c.close()
 
 
+def _maps(W=240, H=180):
+    mx, my = synth.undistort_lut(W, H)
+    return np.ascontiguousarray(mx, np.float32), np.ascontiguousarray(my, np.float32)
+
+
+@pytest.mark.parametrize("check", [True, False])
+def test_raw_undistort_events(oracle, fe, ctx, check):
+    """f4: the rectification loop of EventDataStore::getEventChunkRectified (EventLoader.cpp:264-305) on device."""
+    W, H = 240, 180
+    mx, my = _maps(W, H)
+    raw = synth.random_raw_events(70001, W, H, seed=4)                  # corners of the sensor map outside the image
+    fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=ctx)
+    for tsf in (1.0, 1e6):
+        o = oracle.undistort_events(raw, mx, my, W, H, check, tsf)
+        g = fe.EvImConverter.undistort_events(raw, W, H, tsf, ctx=ctx)
+        assert len(o) == len(g) and np.array_equal(o.view(np.uint8), g.view(np.uint8))
+    assert (len(o) < len(raw)) == check
+    assert len(fe.EvImConverter.undistort_events(raw[:0], W, H, ctx=ctx)) == 0
+    bad = raw[:10].copy(); bad["x"][3] = W
+    with pytest.raises(fe.EorbError):
+        fe.EvImConverter.undistort_events(bad, W, H, ctx=ctx)
+
+
+@pytest.mark.parametrize("sigma,pol", [(1.0, False), (1.0, True), (0.7, False), (1.5, True), (2.0, False)])
+def test_raw_ev2im_gauss_equals_loader_then_ev2im_gauss(oracle, fe, ctx, sigma, pol):
+    """f4 fused: raw sensor events + maps -> image must equal undistort -> ev2im_gauss of the reference, bit for bit."""
+    W, H = 240, 180
+    mx, my = _maps(W, H)
+    _, raw = synth.shapes_events(60000, W, H, seed=71, return_raw=True, undistort=True)
+    raw2 = synth.random_raw_events(30000, W, H, seed=9)                 # includes pixels that leave the image
+    raw = np.concatenate([raw, raw2]); raw["t"] = np.arange(len(raw)) * 1e-6
+    for check in (True, False):
+        fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=ctx)
+        ev = oracle.undistort_events(raw, mx, my, W, H, check, 1.0)
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, pol, True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, pol, True, ctx=ctx, return_all=True)
+        assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)) and np.array_equal(ou, gu)
+        assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32))
+    # the table is rebuilt when sigma changes and reused otherwise: second call, same answer
+    gf2 = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, pol, False, ctx=ctx)
+    assert np.array_equal(gf2.view(np.uint32), gf.view(np.uint32))
+    # empty
+    z = fe.EvImConverter.ev2im_gauss_raw(raw[:0], W, H, sigma, pol, False, ctx=ctx)
+    assert (z == 0).all()
+
+
+def test_raw_ev2im_count(oracle, fe, ctx):
+    W, H = 240, 180
+    mx, my = _maps(W, H)
+    raw = synth.random_raw_events(50000, W, H, seed=19)
+    fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx)
+    ev = oracle.undistort_events(raw, mx, my, W, H, True, 1.0)
+    for pol in (False, True):
+        of, ou, omm = oracle.ev2im(ev, W, H, pol, True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_raw(raw, W, H, pol, True, ctx=ctx, return_all=True)
+        assert np.array_equal(of.view(np.uint32), gf.view(np.uint32))
+        assert (ou is None) == (gu is None) and (ou is None or np.array_equal(ou, gu))
+
+
+def test_raw_needs_maps(fe):
+    c = fe.Context()
+    with pytest.raises(fe.EorbError):
+        fe.EvImConverter.ev2im_gauss_raw(synth.random_raw_events(10), 240, 180, ctx=c)
+    c.close()
+
+
+def test_frontend_batch_raw_equals_float_path(oracle, fe):
+    """The batched pipeline fed with raw sensor events gives the images / keypoints / matches of the float-event path."""
+    W, H, B, n = 240, 180, 4, 50000
+    mx, my = _maps(W, H)
+    pairs = [synth.shapes_events(n, W, H, seed=80 + b, motion=0.3, undistort=True, return_raw=True) for b in range(B)]
+    outs = []
+    for use_raw in (False, True):
+        fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=n)
+        c, cap = fb.ctx, fb.cap
+        if use_raw:
+            fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
+            blob = np.concatenate([p[1] for p in pairs])
+        else:
+            blob = np.concatenate([fe.pack_events(p[0]) for p in pairs])
+        d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
+        d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32)
+        d_n = c.dev_alloc(B * 4); d_m = c.dev_alloc(B * cap * 4); d_nm = c.dev_alloc(B * 4)
+        fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * n, d_img, d_kp, d_desc, d_n, d_m, d_nm, raw=use_raw)
+        c.sync()
+        imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
+        nk = np.zeros(B, np.int32); c.download(nk, d_n)
+        kps = np.zeros((B, cap), synth.KP_DTYPE); c.download(kps, d_kp)
+        desc = np.zeros((B, cap, 32), np.uint8); c.download(desc, d_desc)
+        m12 = np.zeros((B, cap), np.int32); c.download(m12, d_m)
+        nm = np.zeros(B, np.int32); c.download(nm, d_nm)
+        outs.append((imgs, nk, [kps[b, :nk[b]].copy() for b in range(B)], [desc[b, :nk[b]].copy() for b in range(B)],
+                     [m12[b, :nk[b - 1]].copy() for b in range(1, B)], nm[1:].copy()))
+        for p in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
+            c.dev_free(p)
+        c.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[5], b[5])
+    for x, y in zip(a[2] + a[3] + a[4], b[2] + b[3] + b[4]):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+    _, ou, _ = oracle.ev2im_gauss(pairs[2][0], W, H, 1.0, False, True)
+    assert np.array_equal(ou, b[0][2]) and a[1].min() > 20
+
+
 def test_large_slice_many_chunks(oracle, fe, ctx):
     """3 M events in one slice: 733 chunks per tile list; order must survive every chunk boundary."""
     ev = synth.shapes_events(3000000, seed=77, undistort=True)
