@@ -231,6 +231,18 @@ __global__ __launch_bounds__(1024) void ev_tile_order_kernel(const uint32_t* __r
     for (int i = threadIdx.x; i < total; i += blockDim.x) order[atomicAdd(&hist[bucket(weight[i])], 1u)] = i;
 }
 
+// wave-wide inclusive prefix sum without LDS round trips: row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 / 31
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);     // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 struct GatherParams {
     int W, H, h, TX, TY, NT;
     int mode_count;
@@ -257,6 +269,7 @@ struct GatherParams {
 //                       :251-254): the only sequential part; lists are read four ranks at a time (ds_read_b128).
 // With pol == false every increment is >= 0, so the running max is the final value and the running min stays 0.
 struct EvEntryInfo { uint32_t xy; float xr, yr, sg; };      // xi | yi << 16 (int16 each)
+constexpr int kValStride = 68;     // floats per pixel list: 64 ranks, padded so 16 lanes' ds_read_b128 hit 16 distinct bank groups
 #ifndef EORB_GATHER_THREADS
 #define EORB_GATHER_THREADS 512
 #endif
@@ -290,11 +303,11 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     __shared__ uint8_t owner[2][512];               // stamp column (entries' rectangles laid side by side) -> entry
     __shared__ int ncols[2];
     __shared__ uint64_t pm[3][64];                  // per pixel: bit e set = entry e of the batch touches it
-    __shared__ float4 vals[2][16 * 64];             // [rank / 4][pixel] . (rank % 4)
+    __shared__ __attribute__((aligned(16))) float vals[2][kValStride * 64 + 4];   // [pixel][rank] (+4: sink for masked stores)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = (int)(blockDim.x >> 6), nprod = nwaves - 2;      // wave 0 adds, wave 1 set-up, the rest values
     if (tid < 32) tab[tid] = kExp2Tab[tid];
-    for (int i = tid; i < 2 * 16 * 64; i += blockDim.x) (&vals[0][0])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < 2 * (kValStride * 64 + 4); i += blockDim.x) (&vals[0][0])[i] = 0.f;
     const int logical = order[blockIdx.x];
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
@@ -338,10 +351,10 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                 const int bs3 = (t - 2) % 3, bs2 = t & 1;
                 const uint64_t m = pm[bs3][lane];
                 const int cnt = __popcll(m);
-                int mx = cnt;
+                int mx = 0;                                             // wave max of cnt (<= 64) by bisection on ballots
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
-                float4* vb = vals[bs2] + lane;
+                for (int b = 6; b >= 0; b--) { const int tr = mx | (1 << b); if (__any(cnt >= tr)) mx = tr; }
+                float4* vb = (float4*)(vals[bs2] + lane * kValStride);
                 touched = touched || (cnt > 0);
                 const int ng = (mx + 3) >> 2;
                 const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -350,22 +363,22 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     // +0.0f leaves acc unchanged bit for bit (acc is never -0.0): no per-add predicate needed
                     int g = 0;
                     for (; g + 4 <= ng; g += 4) {
-                        const float4 v0 = vb[g * 64], v1 = vb[(g + 1) * 64], v2 = vb[(g + 2) * 64], v3 = vb[(g + 3) * 64];
-                        vb[g * 64] = zero4; vb[(g + 1) * 64] = zero4; vb[(g + 2) * 64] = zero4; vb[(g + 3) * 64] = zero4;
+                        const float4 v0 = vb[g], v1 = vb[g + 1], v2 = vb[g + 2], v3 = vb[g + 3];
+                        vb[g] = zero4; vb[g + 1] = zero4; vb[g + 2] = zero4; vb[g + 3] = zero4;
                         acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
                         acc = acc + v1.x; acc = acc + v1.y; acc = acc + v1.z; acc = acc + v1.w;
                         acc = acc + v2.x; acc = acc + v2.y; acc = acc + v2.z; acc = acc + v2.w;
                         acc = acc + v3.x; acc = acc + v3.y; acc = acc + v3.z; acc = acc + v3.w;
                     }
                     for (; g < ng; g++) {
-                        const float4 v0 = vb[g * 64];
-                        vb[g * 64] = zero4;
+                        const float4 v0 = vb[g];
+                        vb[g] = zero4;
                         acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
                     }
                 } else {
                     for (int g = 0; g < ng; g++) {
-                        const float4 v0 = vb[g * 64];
-                        vb[g * 64] = zero4;
+                        const float4 v0 = vb[g];
+                        vb[g] = zero4;
                         const int k = 4 * g;
 #define EORB_ADD(val, kk) { if ((kk) < cnt) { acc = acc + (val); vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); } }
                         EORB_ADD(v0.x, k + 0) EORB_ADD(v0.y, k + 1) EORB_ADD(v0.z, k + 2) EORB_ADD(v0.w, k + 3)
@@ -401,9 +414,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                 }
                 EvEntryInfo ei; ei.xy = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16); ei.xr = xr; ei.yr = yr; ei.sg = esg;
                 einfo[bs2][lane] = ei;
-                int incl = rw;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+                const int incl = wave_incl_scan(rw);
                 const int coff = incl - rw;
                 rinfo[bs2][lane] = (uint32_t)ra0 | ((uint32_t)rb0 << 4) | ((uint32_t)rw << 8) | ((uint32_t)rh << 12) | ((uint32_t)coff << 16);
 #pragma unroll
@@ -429,7 +440,8 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
             if (wave >= 2 && t >= 1 && t <= nbatch) {
                 const int bs3 = (t - 1) % 3, bs2 = (t - 1) & 1;
                 const int C = ncols[bs2];
-                float* vbase = (float*)vals[bs2];
+                float* vbase = vals[bs2];
+                float* sink = vbase + kValStride * 64;                  // masked-off rows store here (never read)
                 for (int g0 = (wave - 2) * 64; g0 < C; g0 += nprod * 64) {
                     const int g = g0 + lane;
                     const bool act = g < C;
@@ -440,41 +452,43 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     const int b0 = (int)((ri >> 4) & 15u);
                     const int rh = act ? (int)((ri >> 12) & 15u) : 0;
                     const int xi = (int)(int16_t)(ei.xy & 0xffff), yi = (int)(int16_t)(ei.xy >> 16);
-                    const float fx = (float)(tx0 + qx - xi) - ei.xr;            // exp_XY2f(i-xRes, j-yRes) :59-65
-                    const float xx = fx * fx;
                     const uint64_t below = (1ull << e) - 1ull;
                     const int dy0 = ty0 + b0 - yi;
+                    const int pix0 = act ? b0 * 8 + qx : 0;              // pixel of the column's first row; rows step by 8
+                    const uint64_t* pmc = &pm[bs3][pix0];
+                    float* vcol = vbase + pix0 * kValStride;
                     if (RAW && MODE != 2) {
                         // stamp values of this sensor pixel come from the table built once per (maps, sigma): column i, rows j0..
-                        const float* sp = P.stamps + (size_t)__float_as_uint(ei.xr) * P.stamp_stride + (tx0 + qx - xi + h) * (2 * h + 1)
-                                          + (dy0 + h);
+                        const uint32_t soff = act ? __float_as_uint(ei.xr) * (uint32_t)P.stamp_stride + (uint32_t)((tx0 + qx - xi + h) * (2 * h + 1) + (dy0 + h)) : 0u;
+                        const float* sp = P.stamps + soff;
+                        const int rhm1 = max(rh - 1, 0);
                         constexpr int UR = 4;
                         for (int jj = 0; __any(jj < rh); jj += UR) {
-                            float v[UR]; int pix[UR], rank[UR]; bool on[UR];
+                            float v[UR]; int rank[UR]; bool on[UR];
 #pragma unroll
                             for (int u = 0; u < UR; u++) {
                                 on[u] = jj + u < rh;
-                                v[u] = on[u] ? sp[jj + u] : 0.f;
+                                v[u] = sp[min(jj + u, rhm1)];            // clamped, always a valid table slot: no branch around the load
                             }
+#pragma unroll
+                            for (int u = 0; u < UR; u++) rank[u] = __popcll(pmc[on[u] ? (jj + u) * 8 : 0] & below);
 #pragma unroll
                             for (int u = 0; u < UR; u++) {
-                                pix[u] = on[u] ? (b0 + jj + u) * 8 + qx : 0;
-                                rank[u] = __popcll(pm[bs3][pix[u]] & below);
+                                float* dst = on[u] ? vcol + (jj + u) * 8 * kValStride + rank[u] : sink;
+                                *dst = POL ? ei.sg * v[u] : v[u];
                             }
-#pragma unroll
-                            for (int u = 0; u < UR; u++)
-                                if (on[u]) vbase[((rank[u] >> 2) * 64 + pix[u]) * 4 + (rank[u] & 3)] = POL ? ei.sg * v[u] : v[u];
                         }
                         continue;
                     }
+                    const float fx = (float)(tx0 + qx - xi) - ei.xr;            // exp_XY2f(i-xRes, j-yRes) :59-65
+                    const float xx = fx * fx;
                     constexpr int U = 2;
                     for (int jj = 0; __any(jj < rh); jj += U) {
-                        int pix[U], rank[U]; bool on[U]; float v[U];
+                        int rank[U]; bool on[U]; float v[U];
 #pragma unroll
                         for (int u = 0; u < U; u++) {
                             on[u] = jj + u < rh;
-                            pix[u] = on[u] ? (b0 + jj + u) * 8 + qx : 0;
-                            rank[u] = __popcll(pm[bs3][pix[u]] & below);
+                            rank[u] = __popcll(pmc[on[u] ? (jj + u) * 8 : 0] & below);
                         }
                         if (MODE == 1) {
                             // four-stage form of glibc's expf so the dependent f64 chains of the U rows interleave.
@@ -530,8 +544,10 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < U; u++)
-                            if (on[u]) vbase[((rank[u] >> 2) * 64 + pix[u]) * 4 + (rank[u] & 3)] = POL ? ei.sg * v[u] : v[u];
+                        for (int u = 0; u < U; u++) {
+                            float* dst = on[u] ? vcol + (jj + u) * 8 * kValStride + rank[u] : sink;
+                            *dst = POL ? ei.sg * v[u] : v[u];
+                        }
                     }
                 }
             }
