@@ -23,6 +23,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "front-end frames/s (event-accumulate + extract + match) per GPU; HBM GB/s vs roofline"
+# HBM bytes one ev_gather launch moves per million events (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, see
+# profiles/r01_v2_pmc_traffic.txt); bench.py cannot collect PMC counters itself
+GATHER_TRAFFIC_PER_MEV = {"raw": 30.9e6, "float": 30.9e6}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
 
 
@@ -31,11 +34,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="time-slices per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="time-slices per step per GPU")
     ap.add_argument("--events", type=int, default=1000000, help="events per slice")
     ap.add_argument("--cpu-slices", type=int, default=64, help="slices timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
-    ap.add_argument("--input", choices=["raw", "float"], default="float",
+    ap.add_argument("--sequences", type=int, default=1,
+                    help="independent event sequences processed concurrently per GPU, each on its own context / HIP stream; "
+                         "steps alternate between them (a step is still one batch of one sequence)")
+    ap.add_argument("--input", choices=["raw", "float"], default="raw",
                     help="raw: sensor-pixel events (x,y,t,p) + the calibrator's undistortion maps resolved on the GPU; "
                          "float: events already undistorted by the loader (EventData)")
     return ap.parse_args()
@@ -75,32 +81,42 @@ def main():
         ev16 = np.concatenate([frontend.pack_events(s) for s in slices])
     offsets = np.arange(B + 1, dtype=np.int64) * NEV
 
-    stream = torch.cuda.current_stream()
-    ctx = frontend.Context(device=local_rank, stream=stream.cuda_stream)
-    fb = frontend.FrontEndBatch(W, H, 1.0, False, max_batch=B, max_events=NEV, match=True, windowSize=100, nnratio=0.9,
-                                checkOri=True, ctx=ctx, **orb)
-    cap = fb.cap
-    if use_raw:
-        mx, my = synth.undistort_lut(W, H)
-        frontend.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx)
+    S = max(1, a.sequences)
     d_ev = torch.from_numpy(ev16.view(np.uint8)).to(dev)
-    d_img = torch.empty(B * W * H, dtype=torch.uint8, device=dev)
-    d_kp = torch.empty(B * cap * 28, dtype=torch.uint8, device=dev)
-    d_desc = torch.empty(B * cap * 32, dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_m = torch.empty(B * cap, dtype=torch.int32, device=dev)
-    d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    seqs = []
+    for si in range(S):
+        ctx_i = frontend.Context(device=local_rank, stream=streams[si].cuda_stream)
+        fb_i = frontend.FrontEndBatch(W, H, 1.0, False, max_batch=B, max_events=NEV, match=True, windowSize=100, nnratio=0.9,
+                                      checkOri=True, ctx=ctx_i, **orb)
+        if use_raw:
+            mx, my = synth.undistort_lut(W, H)
+            frontend.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx_i)
+        cap = fb_i.cap
+        bufs = dict(img=torch.empty(B * W * H, dtype=torch.uint8, device=dev),
+                    kp=torch.empty(B * cap * 28, dtype=torch.uint8, device=dev),
+                    desc=torch.empty(B * cap * 32, dtype=torch.uint8, device=dev),
+                    n=torch.zeros(B, dtype=torch.int32, device=dev),
+                    m=torch.empty(B * cap, dtype=torch.int32, device=dev),
+                    nm=torch.zeros(B, dtype=torch.int32, device=dev))
+        seqs.append((ctx_i, fb_i, bufs))
+    ctx, fb = seqs[0][0], seqs[0][1]
+    d_kp, d_desc, d_n, d_nm = seqs[0][2]["kp"], seqs[0][2]["desc"], seqs[0][2]["n"], seqs[0][2]["nm"]
     gather_kp = [torch.empty_like(d_kp) for _ in range(world)] if (world > 1 and rank == 0) else None
     gather_desc = [torch.empty_like(d_desc) for _ in range(world)] if (world > 1 and rank == 0) else None
     gather_n = [torch.empty_like(d_n) for _ in range(world)] if (world > 1 and rank == 0) else None
+    step_no = [0]
 
     def step():
-        fb.run_dev(d_ev.data_ptr(), offsets, d_img.data_ptr(), d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(),
-                   d_m.data_ptr(), d_nm.data_ptr(), raw=use_raw)
-        if world > 1:       # final keypoint gather (RCCL over xGMI), fixed-capacity records
-            dist.gather(d_n, gather_n, dst=0)
-            dist.gather(d_kp, gather_kp, dst=0)
-            dist.gather(d_desc, gather_desc, dst=0)
+        si = step_no[0] % S; step_no[0] += 1
+        _, fb_i, bf = seqs[si]
+        with torch.cuda.stream(streams[si]):
+            fb_i.run_dev(d_ev.data_ptr(), offsets, bf["img"].data_ptr(), bf["kp"].data_ptr(), bf["desc"].data_ptr(), bf["n"].data_ptr(),
+                         bf["m"].data_ptr(), bf["nm"].data_ptr(), raw=use_raw)
+            if world > 1:       # final keypoint gather (RCCL over xGMI), fixed-capacity records
+                dist.gather(bf["n"], gather_n, dst=0)
+                dist.gather(bf["kp"], gather_kp, dst=0)
+                dist.gather(bf["desc"], gather_desc, dst=0)
 
     for _ in range(a.warmup):
         step()
@@ -108,7 +124,8 @@ def main():
     if world > 1:
         dist.barrier()
     if not a.no_prof:
-        ctx.prof_reset(); ctx.prof_enable(True)
+        for c_i, _, _ in seqs:
+            c_i.prof_reset(); c_i.prof_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -124,8 +141,11 @@ def main():
         dt = float(t.item())
     prof = {}
     if not a.no_prof:
-        ctx.prof_enable(False)
-        prof = ctx.prof_results()
+        for c_i, _, _ in seqs:
+            c_i.prof_enable(False)
+            for k, (ms, n) in c_i.prof_results().items():
+                a0, n0 = prof.get(k, (0.0, 0))
+                prof[k] = (a0 + ms, n0 + n)
     nk = d_n.cpu().numpy(); nm = d_nm.cpu().numpy()
 
     if rank == 0:
@@ -135,10 +155,13 @@ def main():
             "metric": METRIC, "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: synthetic %d events/slice on %dx%d (shapes generator, DAVIS "
-                                   "pixels LUT-undistorted with the EvETHZ intrinsics like the reference loader), ev2im_gauss sigma=1 -> ORB-1000 (1.2, 4 levels, FAST 10/0, "
-                                   "edge 19) -> SearchForInitialization vs previous slice" % (NEV, W, H),
-                       "slices_per_step_per_gpu": B, "events_per_slice": NEV, "image": [W, H], "input": a.input,
+            "config": {"workload": "BASELINE.json configs[1]: synthetic %d events/slice on %dx%d (shapes generator, DAVIS sensor "
+                                   "pixels; %s), ev2im_gauss sigma=1 -> ORB-1000 (1.2, 4 levels, FAST 10/0, "
+                                   "edge 19) -> SearchForInitialization vs previous slice"
+                                   % (NEV, W, H, "raw (x,y,t,p) records resolved on the GPU through the calibrator's undistortion maps built "
+                                      "from the EvETHZ intrinsics, as the reference loader does on the CPU" if use_raw else
+                                      "already undistorted by the loader through the EvETHZ maps (EventData floats)"),
+                       "slices_per_step_per_gpu": B, "events_per_slice": NEV, "image": [W, H], "input": a.input, "sequences_per_gpu": S,
                        "parallelism": "1 process/GPU, independent slices, RCCL gather of keypoints" if world > 1 else "1 GPU",
                        "mean_keypoints": float(nk.mean()), "mean_matches": float(nm[1:].mean()) if B > 1 else 0.0},
         }
@@ -158,13 +181,13 @@ def main():
             # HBM traffic of the dominant kernel per launch: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload
             # (profiles/r01_pmc_traffic.txt: ev_gather 25.6 MB per 1 Mev slice with the gfx950 x2 FETCH correction), scaled to
             # this launch; bench.py cannot collect PMC counters itself
-            traffic = 25.6e6 * (NEV / 1e6) * B if dom == "ev_gather" else None
+            traffic = GATHER_TRAFFIC_PER_MEV[a.input] * (NEV / 1e6) * B if dom == "ev_gather" else None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": "profiles/r01_pmc_traffic.txt",
+                               "traffic_source": "profiles/r01_v2_pmc_traffic.txt",
                                "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": unit_bytes * B,
-                               "note": "ev_gather is VALU/latency-bound by construction: 49 ordered IEEE expf taps per 16 B event "
-                                       "(DESIGN.md section 4); the HBM fraction is reported as the contract asks"}
+                               "note": "ev_gather is latency/issue-bound by construction: every pixel adds its taps in event order "
+                                       "(49 taps per 16 B event, DESIGN.md section 4); the HBM fraction is reported as the contract asks"}
             out["kernels_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items())}
         # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same workload ----
         if a.cpu_slices > 0:
@@ -174,12 +197,15 @@ def main():
             # warm the page cache / branch predictors on one small slice
             oracle_py.ev2im_gauss(slices[0][:20000], W, H, 1.0, False, True, fast=True)
             prev = None
+            if use_raw:
+                lx, ly = synth.undistort_lut(W, H)
             tc = time.perf_counter()
             done = 0
             reps = 0
             while done < a.cpu_slices:
                 for b in range(ns):
-                    _, u8, _ = oracle_py.ev2im_gauss(slices[b], W, H, 1.0, False, True, fast=True)
+                    evs = oracle_py.undistort_events(pairs[b][1], lx, ly, W, H, True, 1.0) if use_raw else slices[b]
+                    _, u8, _ = oracle_py.ev2im_gauss(evs, W, H, 1.0, False, True, fast=True)
                     _, kps, desc, _ = oe.extract(u8)
                     F = oracle_py.Frame(kps, desc, W, H, fast=True)
                     if prev is not None:
@@ -199,7 +225,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-    ctx.close()
+    for c_i, _, _ in seqs:
+        c_i.close()
 
 
 if __name__ == "__main__":
