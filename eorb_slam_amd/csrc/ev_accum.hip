@@ -4,13 +4,14 @@
 // reference).  The reference adds one (2h+1)^2 Gaussian stamp per event into a float image
 // SEQUENTIALLY; float addition is not associative, so every pixel must receive its contributions in
 // event order.  Design (SURVEY App.B H1):
-//   K1 ev_bin_kernel     one wavefront per chunk of kChunk consecutive events: stable binning of the
-//                        chunk's events into 8x8-pixel tiles (an event is copied to every tile its stamp
-//                        touches).  Counts with LDS atomics, wave scan, then an ORDER-PRESERVING scatter:
-//                        lanes = consecutive events, rank among same-tile lanes by ballot matching.
-//                        Tiles are visited in parity classes so a tile is only ever targeted in one pass.
-//   K2 ev_gather_kernel  one wavefront per tile (lane = pixel): walks the tile's segments chunk by chunk
-//                        (= event order), evaluates the one stamp tap that hits its pixel and adds it.
+//   K1a ev_count_kernel   entries of every (4096-event chunk, 8x8-pixel tile) by LDS atomics (an event is copied to every
+//                        tile its stamp touches).
+//   K1b ev_scan_kernel    scan over chunks and tiles: every tile of every slice gets ONE contiguous event-ordered list.
+//   K1c ev_scatter_kernel one wavefront per chunk, ORDER-PRESERVING scatter into the lists: lanes = consecutive events,
+//                        rank among same-tile lanes by ballot matching; tiles are visited in parity classes so a tile is only
+//                        ever targeted in one pass.
+//   K2 ev_gather_kernel   one workgroup per tile, heaviest tiles first: 64-entry batches through a set-up / value / add
+//                        wave pipeline (see the comment above the kernel); every pixel adds its taps in event order.
 //                        Running min/max (resolveMinMaxVals :32-39) reduced per wave -> atomics.
 //   K3 ev_normalize_kernel  normalizeImage (:67-72): convertTo(CV_8UC1, alpha, beta), round-half-even.
 // All kernels are batched over time-slices (blockIdx ranges over slices x tiles / chunks).
