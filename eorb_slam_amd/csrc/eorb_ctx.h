@@ -96,6 +96,9 @@ struct eorb_ctx {
         out_n, oct_scratch, in_img;
     // matcher workspaces
     eorb::DevBuf m_a, m_b, m_c, m_d, m_e, m_f, m_g, m_h, m_i, m_j;
+    // DBoW2 vocabulary (device copy) for eorb_bow_transform
+    eorb::DevBuf voc;
+    int voc_nnodes = 0, voc_L = 0; size_t voc_off[5] = {0, 0, 0, 0, 0};
     // batched front end
     bool fe_configured = false;
     eorb_fe_config fe{};

@@ -41,6 +41,9 @@ int search_bow_dev(eorb_ctx* c, const eorb_keypoint* kf_kps, const uint8_t* kf_d
                    float nnratio, int checkOri, int kf_kf, const uint8_t* f_has_mp, int32_t* match12, int n_kf);
 int search_tri_dev(eorb_ctx* c, const TriArgs& A);
 int kf_radius_dev(eorb_ctx* c, const RadArgs& A, uint16_t* d_cell);
+int bow_transform_dev(eorb_ctx* c, const uint8_t* d_desc, int n, int stride, const BowVoc& V, int levelsup, int weighting, int norm,
+                      uint32_t* d_word_of, double* d_w_of, uint32_t* d_node_of, uint32_t* d_bow_word, double* d_bow_val,
+                      uint32_t* d_fv_node, int32_t* d_fv_off, int32_t* d_fv_idx, int32_t* d_counts);
 int distinctive_dev(eorb_ctx* c, const uint8_t* d_desc, const int32_t* d_offsets, int M, int32_t* d_best);
 int sort_response_dev(eorb_ctx* c, const eorb_keypoint* d_kps, int n, int32_t* d_perm);
 
@@ -143,7 +146,7 @@ void eorb_destroy(eorb_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->lut, &c->src_info, &c->stamps, &c->pyr, &c->score,
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->lut, &c->src_info, &c->stamps, &c->voc, &c->pyr, &c->score,
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
@@ -933,6 +936,98 @@ int eorb_kf_radius_match(eorb_ctx* c,
     EORB_HIP(c, hipMemcpyAsync(best_idx, c->m_h.p, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipMemcpyAsync(best_dist, (int32_t*)c->m_h.p + M, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
     if (taken) EORB_HIP(c, hipMemcpyAsync(taken, (uint8_t*)c->m_e.p + M, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+int eorb_bow_set_vocabulary(eorb_ctx* c, int nnodes, int L, const int32_t* child_off, const int32_t* child_ids,
+                            const uint8_t* node_desc, const int32_t* word_id, const double* weight)
+{
+    if (!c) return EORB_E_ARG;
+    if (nnodes < 1 || L < 1 || L > 32 || !child_off || !child_ids || !node_desc || !word_id || !weight)
+        return set_err(c, EORB_E_ARG, "bow_set_vocabulary: bad arguments");
+    // a tree rooted at node 0: monotone offsets, every node but the root has exactly one parent, depth <= 32, no cycles
+    const int nch = child_off[nnodes];
+    if (child_off[0] != 0 || nch != nnodes - 1) return set_err(c, EORB_E_ARG, "bow_set_vocabulary: %d child links for %d nodes", nch, nnodes);
+    std::vector<int8_t> depth(nnodes, -1);
+    depth[0] = 0;
+    std::vector<int> stack{0};
+    int visited = 0;
+    while (!stack.empty()) {
+        const int u = stack.back(); stack.pop_back(); visited++;
+        if (child_off[u + 1] < child_off[u]) return set_err(c, EORB_E_ARG, "bow_set_vocabulary: offsets not monotone at node %d", u);
+        for (int k = child_off[u]; k < child_off[u + 1]; k++) {
+            const int v = child_ids[k];
+            if (v <= 0 || v >= nnodes || depth[v] >= 0) return set_err(c, EORB_E_ARG, "bow_set_vocabulary: node %d is not a tree child", v);
+            if (depth[u] >= 32) return set_err(c, EORB_E_ARG, "bow_set_vocabulary: tree deeper than 32");
+            depth[v] = (int8_t)(depth[u] + 1);
+            stack.push_back(v);
+        }
+    }
+    if (visited != nnodes) return set_err(c, EORB_E_ARG, "bow_set_vocabulary: %d of %d nodes reachable from the root", visited, nnodes);
+    hipSetDevice(c->device);
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t off[6]; off[0] = 0;
+    off[1] = off[0] + al(sizeof(int32_t) * ((size_t)nnodes + 1));
+    off[2] = off[1] + al(sizeof(int32_t) * (size_t)std::max(nch, 1));
+    off[3] = off[2] + al(32 * (size_t)nnodes);
+    off[4] = off[3] + al(sizeof(int32_t) * (size_t)nnodes);
+    off[5] = off[4] + al(sizeof(double) * (size_t)nnodes);
+    std::vector<uint8_t> blob(off[5], 0);
+    memcpy(blob.data() + off[0], child_off, sizeof(int32_t) * ((size_t)nnodes + 1));
+    memcpy(blob.data() + off[1], child_ids, sizeof(int32_t) * (size_t)nch);
+    memcpy(blob.data() + off[2], node_desc, 32 * (size_t)nnodes);
+    memcpy(blob.data() + off[3], word_id, sizeof(int32_t) * (size_t)nnodes);
+    memcpy(blob.data() + off[4], weight, sizeof(double) * (size_t)nnodes);
+    int rc;
+    if ((rc = up(c, c->voc, blob.data(), blob.size()))) return rc;
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    c->voc_nnodes = nnodes; c->voc_L = L;
+    for (int i = 0; i < 5; i++) c->voc_off[i] = off[i];
+    return EORB_OK;
+}
+
+int eorb_bow_transform(eorb_ctx* c, const uint8_t* desc, int n, int stride, int levelsup, int weighting, int norm,
+                       uint32_t* bow_word, double* bow_val, int* n_words, uint32_t* fv_node, int32_t* fv_off, int32_t* fv_idx,
+                       int* n_fvnodes, int32_t* word_of, int32_t* node_of)
+{
+    if (!c) return EORB_E_ARG;
+    if (!c->voc_nnodes) return set_err(c, EORB_E_NOTCONF, "bow_transform: eorb_bow_set_vocabulary not called");
+    if (n < 0 || stride < 32 || weighting < 0 || weighting > 3 || norm < 0 || norm > 2 || !n_words || !n_fvnodes || !fv_off ||
+        (n > 0 && (!desc || !bow_word || !bow_val || !fv_node || !fv_idx)))
+        return set_err(c, EORB_E_ARG, "bow_transform: bad arguments");
+    hipSetDevice(c->device);
+    *n_words = 0; *n_fvnodes = 0; fv_off[0] = 0;
+    if (n == 0 || c->voc_nnodes <= 1) return EORB_OK;                       // empty() (:1132)
+    int rc;
+    if ((rc = up(c, c->m_a, desc, (size_t)stride * n))) return rc;
+    // workspace: word_of u32 | node_of u32 | bow_word u32 | fv_node u32 | fv_off i32 (+1) | fv_idx i32 | counts | w_of f64 | bow_val f64
+    const size_t N = (size_t)n;
+    if ((rc = ensure(c, c->m_b, 4 * (6 * N + 8) + 8 * (2 * N + 2)))) return rc;
+    uint32_t* w32 = (uint32_t*)c->m_b.p;
+    uint32_t* d_word_of = w32, *d_node_of = w32 + N, *d_bow_word = w32 + 2 * N, *d_fv_node = w32 + 3 * N;
+    int32_t* d_fv_off = (int32_t*)(w32 + 4 * N), *d_fv_idx = (int32_t*)(w32 + 5 * N + 2), *d_counts = (int32_t*)(w32 + 6 * N + 4);
+    double* d_w_of = (double*)(w32 + 6 * N + 8), *d_bow_val = d_w_of + N + 1;
+    const char* vb = (const char*)c->voc.p;
+    BowVoc V{c->voc_nnodes, c->voc_L, (const int32_t*)(vb + c->voc_off[0]), (const int32_t*)(vb + c->voc_off[1]),
+             (const uint8_t*)(vb + c->voc_off[2]), (const int32_t*)(vb + c->voc_off[3]), (const double*)(vb + c->voc_off[4])};
+    if ((rc = bow_transform_dev(c, (const uint8_t*)c->m_a.p, n, stride, V, levelsup, weighting, norm, d_word_of, d_w_of, d_node_of,
+                                d_bow_word, d_bow_val, d_fv_node, d_fv_off, d_fv_idx, d_counts))) return rc;
+    int32_t cnt[2] = {0, 0};
+    EORB_HIP(c, hipMemcpyAsync(cnt, d_counts, 8, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    *n_words = cnt[0]; *n_fvnodes = cnt[1];
+    if (cnt[0]) {
+        EORB_HIP(c, hipMemcpyAsync(bow_word, d_bow_word, 4 * (size_t)cnt[0], hipMemcpyDeviceToHost, c->stream));
+        EORB_HIP(c, hipMemcpyAsync(bow_val, d_bow_val, 8 * (size_t)cnt[0], hipMemcpyDeviceToHost, c->stream));
+    }
+    EORB_HIP(c, hipMemcpyAsync(fv_off, d_fv_off, 4 * ((size_t)cnt[1] + 1), hipMemcpyDeviceToHost, c->stream));
+    if (cnt[1]) EORB_HIP(c, hipMemcpyAsync(fv_node, d_fv_node, 4 * (size_t)cnt[1], hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    const int nfeat = fv_off[cnt[1]];
+    if (nfeat) EORB_HIP(c, hipMemcpyAsync(fv_idx, d_fv_idx, 4 * (size_t)nfeat, hipMemcpyDeviceToHost, c->stream));
+    if (word_of) EORB_HIP(c, hipMemcpyAsync(word_of, d_word_of, 4 * N, hipMemcpyDeviceToHost, c->stream));
+    if (node_of) EORB_HIP(c, hipMemcpyAsync(node_of, d_node_of, 4 * N, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     return EORB_OK;
 }

@@ -871,6 +871,163 @@ int kf_radius_dev(eorb_ctx* c, const RadArgs& A, uint16_t* d_cell)
     return EORB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// DBoW2 TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1250): the producer of the feature vectors the SearchByBoW kernels consume.
+// K-a: one wave per feature walks the tree; lanes = children of the current node (FORB::distance = popcount), first minimum wins.
+__global__ __launch_bounds__(256) void bow_descend_kernel(const uint8_t* __restrict__ desc, int n, int stride, BowVoc V, int nid_level,
+                                                          uint32_t* __restrict__ word_of, double* __restrict__ w_of, uint32_t* __restrict__ node_of)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (f >= n) return;
+    uint64_t q0, q1, q2, q3;
+    load_desc32(desc + (size_t)f * stride, q0, q1, q2, q3);
+    int node = 0, level = 0, nid = 0;
+    do {
+        ++level;
+        const int c0 = V.child_off[node], nc = V.child_off[node + 1] - c0;
+        uint64_t key = ~0ull;
+        for (int c = lane; c < nc; c += 64) {
+            const int id = V.child_ids[c0 + c];
+            uint64_t t0, t1, t2, t3;
+            load_desc32(V.node_desc + (size_t)id * 32, t0, t1, t2, t3);
+            const int d = __popcll(q0 ^ t0) + __popcll(q1 ^ t1) + __popcll(q2 ^ t2) + __popcll(q3 ^ t3);
+            const uint64_t k = ((uint64_t)d << 32) | (uint32_t)c;
+            key = k < key ? k : key;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(key, d, 64); key = o < key ? o : key; }
+        node = V.child_ids[c0 + (int)(key & 0xffffffffu)];
+        if (level == nid_level) nid = node;
+    } while (V.child_off[node + 1] > V.child_off[node] && level < 64);
+    if (lane == 0) {
+        const double w = V.weight[node];
+        const bool keep = w > 0;                               // stopped words carry weight 0
+        word_of[f] = keep ? (uint32_t)V.word_id[node] : 0xffffffffu;
+        w_of[f] = w;
+        node_of[f] = keep ? (uint32_t)nid : 0xffffffffu;
+    }
+}
+
+// bitonic sort of P (power of two) 64-bit keys in LDS by the whole workgroup
+__device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int P)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// run heads of the sorted keys (upper 32 bits = run id) -> exclusive run index per element, number of runs; wave 0 scans
+__device__ __forceinline__ int block_run_index(const uint64_t* keys, int m, uint32_t* ridx)
+{
+    __shared__ int s_runs;
+    if (threadIdx.x < 64) {
+        int run = 0;
+        for (int i0 = 0; i0 < m; i0 += 64) {
+            const int i = i0 + (int)threadIdx.x;
+            const int head = (i < m) && (i == 0 || (uint32_t)(keys[i] >> 32) != (uint32_t)(keys[i - 1] >> 32));
+            int incl = head;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if ((int)threadIdx.x >= d) incl += t; }
+            if (i < m) ridx[i] = (uint32_t)(run + incl - 1);
+            run += __shfl(incl, 63, 64);
+        }
+        if (threadIdx.x == 0) s_runs = run;
+    }
+    __syncthreads();
+    return s_runs;
+}
+
+// K-b: one workgroup turns the per-feature (word, weight, node) triples into the BowVector (std::map order = ascending word id,
+// weights accumulated in feature order, then BowVector::normalize) and the FeatureVector (ascending node id, features in
+// push_back order).
+__global__ __launch_bounds__(1024) void bow_assemble_kernel(const uint32_t* __restrict__ word_of, const double* __restrict__ w_of,
+                                                            const uint32_t* __restrict__ node_of, int n, int P, int weighting, int norm,
+                                                            uint32_t* __restrict__ bow_word, double* __restrict__ bow_val,
+                                                            uint32_t* __restrict__ fv_node, int32_t* __restrict__ fv_off, int32_t* __restrict__ fv_idx,
+                                                            int32_t* __restrict__ counts /* n_words, n_fvnodes */)
+{
+    extern __shared__ unsigned char smem[];
+    uint64_t* keys = (uint64_t*)smem;                       // P
+    uint32_t* ridx = (uint32_t*)(keys + P);                 // P
+    __shared__ int s_m;
+    __shared__ double s_norm;
+    // ---- BowVector ----
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
+        keys[i] = (i < n && word_of[i] != 0xffffffffu) ? (((uint64_t)word_of[i] << 32) | (uint32_t)i) : ~0ull;
+    block_bitonic_sort(keys, P);
+    if (threadIdx.x == 0) {                                  // valid features sort first: m = first sentinel
+        int lo = 0, hi = P;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] != ~0ull) lo = mid + 1; else hi = mid; }
+        s_m = lo;
+    }
+    __syncthreads();
+    const int m = s_m;
+    const int nw = block_run_index(keys, m, ridx);
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        if (i == 0 || ridx[i] != ridx[i - 1]) {              // run head: addWeight in feature order (same word -> same weight)
+            const double w = w_of[(int)(keys[i] & 0xffffffffu)];
+            double v = w;
+            if (weighting == 0 || weighting == 1)
+                for (int j = i + 1; j < m && ridx[j] == ridx[i]; j++) v += w;
+            bow_word[ridx[i]] = (uint32_t)(keys[i] >> 32);
+            bow_val[ridx[i]] = v;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double nrm = 0.0;
+        if (norm == 1) { for (int i = 0; i < nw; i++) nrm += fabs(bow_val[i]); }
+        else if (norm == 2) { for (int i = 0; i < nw; i++) nrm += bow_val[i] * bow_val[i]; nrm = sqrt(nrm); }
+        else if (weighting == 0 || weighting == 1) nrm = (double)nw;     // "unnecessary when normalizing" branch :1166-1172
+        s_norm = nrm;
+        counts[0] = nw;
+    }
+    __syncthreads();
+    if (s_norm > 0.0 && (norm != 0 || weighting == 0 || weighting == 1))
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) bow_val[i] /= s_norm;
+    __syncthreads();
+    // ---- FeatureVector ----
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
+        keys[i] = (i < n && node_of[i] != 0xffffffffu) ? (((uint64_t)node_of[i] << 32) | (uint32_t)i) : ~0ull;
+    block_bitonic_sort(keys, P);
+    const int nn = block_run_index(keys, m, ridx);
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        fv_idx[i] = (int32_t)(keys[i] & 0xffffffffu);
+        if (i == 0 || ridx[i] != ridx[i - 1]) { fv_node[ridx[i]] = (uint32_t)(keys[i] >> 32); fv_off[ridx[i]] = i; }
+    }
+    if (threadIdx.x == 0) { fv_off[nn] = m; counts[1] = nn; }
+}
+
+int bow_transform_dev(eorb_ctx* c, const uint8_t* d_desc, int n, int stride, const BowVoc& V, int levelsup, int weighting, int norm,
+                      uint32_t* d_word_of, double* d_w_of, uint32_t* d_node_of, uint32_t* d_bow_word, double* d_bow_val,
+                      uint32_t* d_fv_node, int32_t* d_fv_off, int32_t* d_fv_idx, int32_t* d_counts)
+{
+    int P = 64; while (P < n) P <<= 1;
+    const size_t lds = (size_t)P * 12;
+    if (lds > 150 * 1024) return set_err(c, EORB_E_CAPACITY, "bow_transform: %d features exceed the LDS sort", n);
+    ProfScope ps(c, "bow_transform");
+    bow_descend_kernel<<<(n + 3) / 4, 256, 0, c->stream>>>(d_desc, n, stride, V, V.L - levelsup, d_word_of, d_w_of, d_node_of);
+    hipFuncSetAttribute((const void*)bow_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    bow_assemble_kernel<<<1, 1024, lds, c->stream>>>(d_word_of, d_w_of, d_node_of, n, P, weighting, norm, d_bow_word, d_bow_val,
+                                                     d_fv_node, d_fv_off, d_fv_idx, d_counts);
+    EORB_LAUNCH_CHECK(c, "bow_transform kernels");
+    return EORB_OK;
+}
+
 // MixedFrame::sortFeaturesResponse (MixedFrame.cpp:211-225): stable descending order by response.
 // rank(i) = #{j : r_j > r_i} + #{j < i : r_j == r_i}; perm[rank(i)] = i.  n is a few thousand at most.
 __global__ void sort_response_kernel(const eorb_keypoint* __restrict__ kps, int n, int32_t* __restrict__ perm)

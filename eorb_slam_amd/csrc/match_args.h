@@ -26,4 +26,10 @@ struct RadArgs {
     int32_t* best_idx; int32_t* best_dist;
 };
 
+// DBoW2 vocabulary tree, device resident (TemplatedVocabulary::m_nodes flattened; node 0 = root)
+struct BowVoc {
+    int nnodes, L;
+    const int32_t* child_off; const int32_t* child_ids; const uint8_t* node_desc; const int32_t* word_id; const double* weight;
+};
+
 }  // namespace eorb

@@ -456,6 +456,35 @@ def SearchBySim3(kf1, kf2, q1, q2, th=7.5, ctx=None):
     return int(ok.sum()), np.where(ok, vn1, -1).astype(np.int32)
 
 
+class ORBVocabulary:
+    """DBoW2 vocabulary resident on the device (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h); voc = dict(L, child_off, child_ids,
+    node_desc, word_id, weight) as TemplatedVocabulary::loadFromTextFile leaves m_nodes (node 0 = root)."""
+
+    def __init__(self, voc, weighting=0, norm=1, ctx=None):
+        self.ctx = ctx or default_context()
+        self.weighting, self.norm = weighting, norm
+        co = np.ascontiguousarray(voc["child_off"], np.int32); ci = np.ascontiguousarray(voc["child_ids"], np.int32)
+        nd = np.ascontiguousarray(voc["node_desc"], np.uint8); wi = np.ascontiguousarray(voc["word_id"], np.int32)
+        ww = np.ascontiguousarray(voc["weight"], np.float64)
+        c = self.ctx
+        c.check(c.L.eorb_bow_set_vocabulary(c.h, len(co) - 1, int(voc["L"]), _p(co), _p(ci), _p(nd), _p(wi), _p(ww)))
+
+    def transform(self, desc, levelsup=4, return_assignments=False):
+        """ORBVocabulary::transform(vCurrentDesc, mBowVec, mFeatVec, levelsup) (Frame::ComputeBoW).
+        Returns (bow_word, bow_val, (fv_node, fv_off, fv_idx)) [+ word_of, node_of]."""
+        c = self.ctx
+        desc = np.ascontiguousarray(desc, np.uint8); n = len(desc)
+        bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); nw = C.c_int(0)
+        fn = np.zeros(max(n, 1), np.uint32); fo = np.zeros(n + 1, np.int32); fi = np.zeros(max(n, 1), np.int32); nn = C.c_int(0)
+        wo = np.zeros(max(n, 1), np.int32); no = np.zeros(max(n, 1), np.int32)
+        c.check(c.L.eorb_bow_transform(c.h, _p(desc), n, desc.shape[1] if n else 32, int(levelsup), self.weighting, self.norm,
+                                       _p(bw), _p(bv), C.byref(nw), _p(fn), _p(fo), _p(fi), C.byref(nn), _p(wo), _p(no)))
+        fv = (fn[:nn.value].copy(), fo[:nn.value + 1].copy(), fi[:fo[nn.value]].copy())
+        if return_assignments:
+            return bw[:nw.value].copy(), bv[:nw.value].copy(), fv, wo[:n], no[:n]
+        return bw[:nw.value].copy(), bv[:nw.value].copy(), fv
+
+
 def ComputeDistinctiveDescriptors(desc, offsets, ctx=None):
     """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for a batch of map points (CSR offsets)."""
     c = ctx or default_context()

@@ -160,3 +160,42 @@ def random_keypoints(n, W=240, H=180, nlevels=4, scale=1.2, seed=6):
     kp["response"] = rng.integers(1, 120, n).astype(np.float32)
     kp["class_id"] = -1
     return kp
+
+
+def random_vocabulary(k=10, L=3, seed=0, ragged=False, stop_frac=0.02):
+    """A DBoW2-shaped vocabulary tree with random 256-bit node descriptors: k children per node and L levels (ragged=True:
+    2..k children and some branches ending early).  Children of a node are near copies of their parent, so descents are
+    meaningful.  Returns dict(L, child_off, child_ids, node_desc, word_id, weight) with node 0 = root."""
+    rng = np.random.default_rng(seed)
+    desc = [rng.integers(0, 256, 32, dtype=np.uint8)]
+    children = [[]]
+    level = [0]
+    frontier = [0]
+    for lv in range(1, L + 1):
+        nxt = []
+        for u in frontier:
+            if ragged and lv > 1 and rng.uniform() < 0.15:
+                continue                                                # this branch ends early: u stays a word
+            nc = int(rng.integers(2, k + 1)) if ragged else k
+            for _ in range(nc):
+                flip = rng.uniform(size=256) < (0.25 / lv)
+                d = desc[u] ^ np.packbits(flip)
+                desc.append(d); children.append([]); level.append(lv)
+                children[u].append(len(desc) - 1); nxt.append(len(desc) - 1)
+        frontier = nxt
+    n = len(desc)
+    # DBoW2 stores children in creation order but node ids need not be contiguous per parent: shuffle ids (root stays 0)
+    perm = np.concatenate([[0], 1 + rng.permutation(n - 1)])
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    child_off = [0]; child_ids = []
+    for new in range(n):
+        old = perm[new]
+        child_ids.extend(int(inv[c]) for c in children[old]); child_off.append(len(child_ids))
+    node_desc = np.stack([desc[perm[i]] for i in range(n)])
+    is_leaf = np.array([len(children[perm[i]]) == 0 for i in range(n)])
+    word_id = np.full(n, -1, np.int32); word_id[is_leaf] = rng.permutation(int(is_leaf.sum())).astype(np.int32)
+    weight = np.zeros(n, np.float64); weight[is_leaf] = rng.uniform(0.5, 9.0, int(is_leaf.sum()))
+    stop = is_leaf & (rng.uniform(size=n) < stop_frac)
+    weight[stop] = 0.0                                                  # stopWords()
+    return dict(L=L, child_off=np.array(child_off, np.int32), child_ids=np.array(child_ids, np.int32), node_desc=node_desc,
+                word_id=word_id, weight=weight)

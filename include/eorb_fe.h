@@ -274,6 +274,24 @@ int eorb_kf_radius_match(eorb_ctx* ctx,
  * to offsets[m]) with the least median Hamming distance to the others, -1 when there is none. */
 int eorb_distinctive_descriptors(eorb_ctx* ctx, const uint8_t* desc, const int32_t* offsets, int M, int32_t* best);
 
+/* ---- DBoW2 vocabulary transform: the producer of the feature vectors SearchByBoW consumes ----------
+ * The vocabulary tree (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h: m_nodes after loadFromTextFile :1338-1430) flattened:
+ * node 0 = root; children of node i = child_ids[child_off[i] .. child_off[i+1]) in `children` order; a node without children
+ * is a word (Node::isLeaf) with word_id / weight; node_desc = nnodes x 32 bytes (FORB).  Copied to the device once. */
+int eorb_bow_set_vocabulary(eorb_ctx* ctx, int nnodes, int L, const int32_t* child_off, const int32_t* child_ids,
+                            const uint8_t* node_desc, const int32_t* word_id, const double* weight);
+
+/* replaces ORBVocabulary::transform(vCurrentDesc, mBowVec, mFeatVec, levelsup) as called by Frame::ComputeBoW
+ * (src/Frame.cc: levelsup = 4) = TemplatedVocabulary::transform :1125-1190 + the per-feature descent :1208-1250 with
+ * FORB::distance (FORB.cpp:81-101).  weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (WeightingType); norm: 0 none, 1 L1, 2 L2 =
+ * ScoringObject::mustNormalize of the vocabulary's scoring type (ORBvoc.txt: TF_IDF + L1_NORM -> 0, 1).
+ * BowVector out: ascending (bow_word, bow_val)[*n_words]; FeatureVector out: CSR (fv_node ascending, fv_off[*n_fvnodes + 1],
+ * fv_idx in push_back order) -- the layout eorb_search_by_bow takes.  Output arrays sized n (fv_off n + 1).
+ * word_of / node_of (n, may be NULL): word and nid-level node of every feature, -1 for stopped words. */
+int eorb_bow_transform(eorb_ctx* ctx, const uint8_t* desc, int n, int stride, int levelsup, int weighting, int norm,
+                       uint32_t* bow_word, double* bow_val, int* n_words, uint32_t* fv_node, int32_t* fv_off, int32_t* fv_idx,
+                       int* n_fvnodes, int32_t* word_of, int32_t* node_of);
+
 /* replaces MixedFrame::sortFeaturesResponse (src/MixedFrame.cpp:211-225): perm[k] = index of the k-th keypoint in
  * descending-response order, equal responses in insertion order (std::multimap semantics). */
 int eorb_sort_by_response(eorb_ctx* ctx, const eorb_keypoint* kps, int n, int32_t* perm);

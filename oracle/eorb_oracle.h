@@ -278,6 +278,26 @@ void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const
  * the others (first minimum), or -1 when the map point has no descriptor. */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int M, int32_t* best);
 
+/* DBoW2 vocabulary tree (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h: m_nodes) flattened: node 0 = root; children of node i =
+ * child_ids[child_off[i] .. child_off[i+1]) in `children` order; a node without children is a word (isLeaf) with word_id / weight. */
+typedef struct {
+    int nnodes, L;
+    const int32_t* child_off;      /* nnodes + 1 */
+    const int32_t* child_ids;
+    const uint8_t* node_desc;      /* nnodes x 32 (FORB) */
+    const int32_t* word_id;        /* nnodes */
+    const double*  weight;         /* nnodes */
+} orc_vocabulary;
+
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (:1125-1190) with the per-feature descent
+ * (:1208-1250; FORB::distance FORB.cpp:81-101).  weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; norm: 0 none, 1 L1, 2 L2
+ * (ScoringObject::mustNormalize).  BowVector out as ascending (bow_word, bow_val)[*n_words]; FeatureVector out as CSR
+ * (fv_node ascending, fv_off, fv_idx in push_back order)[*n_fvnodes].  Arrays sized n (fv_off n + 1).
+ * word_of / node_of (n, optional): the word and the nid-level node every feature fell into (-1 for stopped words). */
+void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, int stride, int levelsup, int weighting, int norm,
+                       uint32_t* bow_word, double* bow_val, int* n_words, uint32_t* fv_node, int32_t* fv_off, int32_t* fv_idx,
+                       int* n_fvnodes, int32_t* word_of, int32_t* node_of);
+
 /* MixedFrame::sortFeaturesResponse (MixedFrame.cpp:211-225): order = descending response, equal responses keep their
  * insertion order (multimap).  perm[k] = source index of the k-th output element. */
 void orc_sort_by_response(const orc_keypoint* kps, int n, int32_t* perm);

@@ -502,3 +502,24 @@ def undistort_events(raw, mapX, mapY, W, H, checkInImage=True, tsFactor=1.0):
     k = L.orc_undistort_events(_p(raw), len(raw), _p(mapX), _p(mapY), mapX.shape[1], mapX.shape[0], W, H, int(checkInImage),
                                float(tsFactor), _p(out))
     return out[:k].copy()
+
+
+class Vocabulary(C.Structure):
+    _fields_ = [("nnodes", C.c_int), ("L", C.c_int), ("child_off", C.c_void_p), ("child_ids", C.c_void_p),
+                ("node_desc", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p)]
+
+
+def bow_transform(voc, desc, levelsup=4, weighting=0, norm=1):
+    """voc: dict(L, child_off, child_ids, node_desc, word_id, weight). Returns (bow_word, bow_val, (fv_node, fv_off, fv_idx), word_of, node_of)."""
+    co = np.ascontiguousarray(voc["child_off"], np.int32); ci = np.ascontiguousarray(voc["child_ids"], np.int32)
+    nd = np.ascontiguousarray(voc["node_desc"], np.uint8); wi = np.ascontiguousarray(voc["word_id"], np.int32)
+    ww = np.ascontiguousarray(voc["weight"], np.float64)
+    v = Vocabulary(len(co) - 1, int(voc["L"]), co.ctypes.data, ci.ctypes.data, nd.ctypes.data, wi.ctypes.data, ww.ctypes.data)
+    desc = np.ascontiguousarray(desc, np.uint8); n = len(desc)
+    bw = np.zeros(max(n, 1), np.uint32); bv = np.zeros(max(n, 1), np.float64); nw = C.c_int(0)
+    fn = np.zeros(max(n, 1), np.uint32); fo = np.zeros(n + 1, np.int32); fi = np.zeros(max(n, 1), np.int32); nn = C.c_int(0)
+    wo = np.zeros(max(n, 1), np.int32); no = np.zeros(max(n, 1), np.int32)
+    L = lib(); L.orc_bow_transform.restype = None
+    L.orc_bow_transform(C.byref(v), _p(desc), C.c_int(n), C.c_int(desc.shape[1] if n else 32), C.c_int(levelsup), C.c_int(weighting),
+                        C.c_int(norm), _p(bw), _p(bv), C.byref(nw), _p(fn), _p(fo), _p(fi), C.byref(nn), _p(wo), _p(no))
+    return bw[:nw.value].copy(), bv[:nw.value].copy(), (fn[:nn.value].copy(), fo[:nn.value + 1].copy(), fi[:fo[nn.value]].copy()), wo[:n], no[:n]

@@ -661,3 +661,95 @@ int orc_search_by_projection_kf(const orc_frame* cur, const orc_keypoint* kf_kps
     free(idxs);
     return nmatches;
 }
+
+/* FORB::distance, Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101 (bit-parallel popcount over 8 words) */
+static int forb_distance(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb; memcpy(&pa, a + 4 * i, 4); memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+typedef struct { uint32_t key; int idx; double w; } bow_item;
+static int cmp_bow_item(const void* a, const void* b)
+{
+    const bow_item* x = (const bow_item*)a; const bow_item* y = (const bow_item*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->idx - y->idx;
+}
+
+/* TemplatedVocabulary::transform :1125-1190 and :1208-1250 */
+void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, int stride, int levelsup, int weighting, int norm,
+                       uint32_t* bow_word, double* bow_val, int* n_words, uint32_t* fv_node, int32_t* fv_off, int32_t* fv_idx,
+                       int* n_fvnodes, int32_t* word_of, int32_t* node_of)
+{
+    *n_words = 0; *n_fvnodes = 0; fv_off[0] = 0;
+    if (voc->nnodes <= 1 || n <= 0) return;                              /* empty() :1132 */
+    bow_item* words = (bow_item*)malloc(sizeof(bow_item) * n);
+    bow_item* nodes = (bow_item*)malloc(sizeof(bow_item) * n);
+    int m = 0;
+    const int nid_level = voc->L - levelsup;
+    for (int f = 0; f < n; f++) {
+        const uint8_t* feature = desc + (size_t)stride * f;
+        int nid = 0;                                                      /* if(nid_level <= 0) *nid = 0 */
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const int c0 = voc->child_off[final_id], c1 = voc->child_off[final_id + 1];
+            final_id = voc->child_ids[c0];
+            int best_d = forb_distance(feature, voc->node_desc + 32 * (size_t)final_id);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = voc->child_ids[c];
+                const int d = forb_distance(feature, voc->node_desc + 32 * (size_t)id);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (voc->child_off[final_id + 1] > voc->child_off[final_id]);
+        const double w = voc->weight[final_id];
+        if (word_of) word_of[f] = w > 0 ? voc->word_id[final_id] : -1;
+        if (node_of) node_of[f] = w > 0 ? nid : -1;
+        if (w > 0) {                                                      /* not stopped */
+            words[m].key = (uint32_t)voc->word_id[final_id]; words[m].idx = f; words[m].w = w;
+            nodes[m].key = (uint32_t)nid; nodes[m].idx = f; nodes[m].w = 0;
+            m++;
+        }
+    }
+    qsort(words, m, sizeof(bow_item), cmp_bow_item);
+    qsort(nodes, m, sizeof(bow_item), cmp_bow_item);
+    /* BowVector: addWeight accumulates in feature order (TF / TF_IDF), addIfNotExist keeps the first (IDF / BINARY) */
+    int nw = 0;
+    for (int i = 0; i < m; ) {
+        int j = i; double v = words[i].w;
+        for (j = i + 1; j < m && words[j].key == words[i].key; j++)
+            if (weighting == 0 || weighting == 1) v += words[j].w;
+        bow_word[nw] = words[i].key; bow_val[nw] = v; nw++;
+        i = j;
+    }
+    if ((weighting == 0 || weighting == 1) && nw > 0 && norm == 0) {
+        const double nd = (double)nw;
+        for (int i = 0; i < nw; i++) bow_val[i] /= nd;
+    }
+    if (norm != 0) {                                                      /* BowVector::normalize, BowVector.cpp:57-79 */
+        double nrm = 0.0;
+        if (norm == 1) { for (int i = 0; i < nw; i++) nrm += fabs(bow_val[i]); }
+        else { for (int i = 0; i < nw; i++) nrm += bow_val[i] * bow_val[i]; nrm = sqrt(nrm); }
+        if (nrm > 0.0) for (int i = 0; i < nw; i++) bow_val[i] /= nrm;
+    }
+    *n_words = nw;
+    int nn = 0;
+    for (int i = 0; i < m; ) {
+        int j = i;
+        fv_node[nn] = nodes[i].key;
+        for (; j < m && nodes[j].key == nodes[i].key; j++) fv_idx[j] = nodes[j].idx;
+        nn++; fv_off[nn] = j;
+        i = j;
+    }
+    *n_fvnodes = nn;
+    free(words); free(nodes);
+}

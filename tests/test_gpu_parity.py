@@ -503,6 +503,38 @@ def test_search_by_projection_keyframe(oracle, fe, ctx, ori, orbdist):
     assert on > 100
 
 
+@pytest.mark.parametrize("k,L,ragged", [(10, 3, False), (10, 4, False), (7, 5, True), (3, 1, False)])
+def test_bow_transform(oracle, fe, ctx, k, L, ragged):
+    """f4: DBoW2 TemplatedVocabulary::transform (BowVector + FeatureVector) on a synthetic vocabulary tree."""
+    voc = synth.random_vocabulary(k, L, seed=5 + L, ragged=ragged)
+    rng = np.random.default_rng(17)
+    leaves = np.nonzero(voc["word_id"] >= 0)[0]
+    n = 1500
+    desc = voc["node_desc"][rng.choice(leaves, n)].copy()
+    desc ^= np.packbits(rng.uniform(size=(n, 256)) < 0.08, axis=1)
+    desc[:40] = rng.integers(0, 256, (40, 32), dtype=np.uint8)              # far from every node: ties and odd descents
+    desc[40:80] = desc[40]                                                  # the same word many times: repeated addWeight
+    for weighting, norm in ((0, 1), (1, 0), (2, 2), (3, 1), (0, 0)):
+        V = fe.ORBVocabulary(voc, weighting, norm, ctx=ctx)
+        for levelsup in (4, 1, 0, L + 2):
+            ow, ov, ofv, owo, ono = oracle.bow_transform(voc, desc, levelsup, weighting, norm)
+            gw, gv, gfv, gwo, gno = V.transform(desc, levelsup, return_assignments=True)
+            assert np.array_equal(owo, gwo) and np.array_equal(ono, gno)
+            assert np.array_equal(ow, gw) and np.array_equal(ov.view(np.uint64), gv.view(np.uint64))
+            assert all(np.array_equal(a, b) for a, b in zip(ofv, gfv))
+    assert len(ow) >= min(50, len(leaves) - 1) and (L < 3 or (owo < 0).sum() > 0)
+    # the FeatureVector feeds SearchByBoW directly
+    ow, ov, ofv, _, _ = oracle.bow_transform(voc, desc, 1, 0, 1)
+    assert len(ofv[2]) == (owo >= 0).sum() and np.all(np.diff(ofv[0].astype(np.int64)) > 0)
+    # empty input / malformed tree
+    V = fe.ORBVocabulary(voc, 0, 1, ctx=ctx)
+    gw, gv, gfv = V.transform(desc[:0])
+    assert len(gw) == 0 and len(gfv[0]) == 0
+    bad = dict(voc); bad["child_ids"] = voc["child_ids"].copy(); bad["child_ids"][0] = 0
+    with pytest.raises(fe.EorbError):
+        fe.ORBVocabulary(bad, ctx=ctx)
+
+
 def test_distinctive_descriptors(oracle, fe, ctx):
     """f3: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:349-423), batched; sizes 0, 1, 2, even/odd, > 64 rows."""
     rng = np.random.default_rng(5)
