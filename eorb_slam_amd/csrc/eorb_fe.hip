@@ -328,6 +328,40 @@ int eorb_undistort_events(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int 
     return EORB_OK;
 }
 
+int eorb_parse_events_text(eorb_ctx* c, const char* text, size_t nbytes, eorb_raw_event* out, size_t cap, size_t* n_out,
+                           int64_t* bad_line)
+{
+    if (!c) return EORB_E_ARG;
+    if ((nbytes && !text) || !n_out || (cap && !out)) return set_err(c, EORB_E_ARG, "parse_events_text: bad arguments");
+    hipSetDevice(c->device);
+    *n_out = 0; if (bad_line) *bad_line = -1;
+    if (!nbytes) return EORB_OK;
+    // every line of the accepted grammar is at least 8 bytes ("0 0 0 0\n"); shorter ones are comments / blanks or errors, so
+    // the line capacity is bounded by the caller's event capacity plus what the text could hold otherwise
+    const size_t max_lines = nbytes / 2 + 2;
+    int rc;
+    if ((rc = up(c, c->in_img, text, nbytes))) return rc;
+    const size_t nblk = (nbytes + 1023) / 1024;
+    // workspaces: lineend u64 | parsed events | status | block sums
+    if ((rc = ensure(c, c->entries, sizeof(uint64_t) * max_lines))) return rc;
+    if ((rc = ensure(c, c->ev16, sizeof(eorb_raw_event) * max_lines))) return rc;
+    if ((rc = ensure(c, c->segoff, max_lines + 64))) return rc;
+    if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * (std::max(nblk, (max_lines + 1023) / 1024) + 8)))) return rc;
+    if ((rc = ensure(c, c->chunks, sizeof(eorb_raw_event) * max_lines))) return rc;
+    uint32_t res[3];
+    if ((rc = ev_parse_text_dev(c, (const char*)c->in_img.p, nbytes, (uint64_t*)c->entries.p, (eorb_raw_event*)c->ev16.p,
+                                (uint8_t*)c->segoff.p, (eorb_raw_event*)c->chunks.p, (uint32_t*)c->tile_order.p, max_lines, res))) return rc;
+    if (res[2] != 0xffffffffu) {
+        if (bad_line) *bad_line = (int64_t)res[2];
+        return set_err(c, EORB_E_ARG, "parse_events_text: line %u is outside the accepted \"ts x y p\" grammar", res[2]);
+    }
+    if (res[1] > cap) return set_err(c, EORB_E_CAPACITY, "parse_events_text: %u events, room for %zu", res[1], cap);
+    if (res[1]) EORB_HIP(c, hipMemcpyAsync(out, c->chunks.p, sizeof(eorb_raw_event) * (size_t)res[1], hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    *n_out = res[1];
+    return EORB_OK;
+}
+
 int eorb_ev2im_gauss_raw(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int W, int H, float sigma, int pol, int normalized,
                          float* out_f32, uint8_t* out_u8, float* minmax)
 {

@@ -915,6 +915,161 @@ int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, 
     return EORB_OK;
 }
 
+// ---- text half of the event loader (EventLoader.cpp:80-92, :264-305; BaseLoader::isComment DataStore.cpp:111-114) -----------
+// "ts x y p" lines -> eorb_raw_event.  K-a counts line ends per 1024-byte block, K-b scans, K-c writes the line-end positions in
+// order, K-d parses one line per thread (status 0 = event, 1 = comment / blank, 2 = outside the grammar), then the kept events are
+// compacted in order with the same count -> scan -> write scheme.
+__device__ __forceinline__ bool txt_is_end(const char* t, size_t nbytes, size_t i)
+{   // a line ends at '\n' or at the last byte of a buffer that does not end in '\n'
+    return t[i] == '\n' || (i + 1 == nbytes);
+}
+__global__ __launch_bounds__(1024) void txt_count_kernel(const char* __restrict__ t, size_t nbytes, uint32_t* __restrict__ blk)
+{
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const bool e = i < nbytes && txt_is_end(t, nbytes, i);
+    const uint64_t m = __ballot(e);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = cnt;
+}
+__global__ __launch_bounds__(1024) void txt_lineend_kernel(const char* __restrict__ t, size_t nbytes, const uint32_t* __restrict__ blk,
+                                                           uint64_t* __restrict__ lineend)
+{
+    __shared__ uint32_t wbase[17];
+    const size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool e = i < nbytes && txt_is_end(t, nbytes, i);
+    const uint64_t m = __ballot(e);
+    if (lane == 0) wbase[wave + 1] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { wbase[0] = 0; for (int w = 1; w <= 16; w++) wbase[w] += wbase[w - 1]; }
+    __syncthreads();
+    if (e) lineend[blk[blockIdx.x] + wbase[wave] + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = i;
+}
+
+// one decimal token: digits [ '.' digits ].  Returns false when malformed.  mant = the digits without leading zeros (up to 19
+// significant), frac = number of digits after the point, big = more than 19 significant digits.
+__device__ __forceinline__ bool txt_number(const char* t, size_t& p, size_t end, uint64_t& mant, int& frac, bool& big)
+{
+    mant = 0; frac = 0; big = false;
+    int nd = 0, sig = 0; bool point = false;
+    while (p < end) {
+        const char ch = t[p];
+        if (ch >= '0' && ch <= '9') {
+            if (mant != 0 || ch != '0') { if (sig < 19) { mant = mant * 10 + (uint64_t)(ch - '0'); sig++; } else big = true; }
+            nd++; if (point) frac++;
+        } else if (ch == '.' && !point) point = true;
+        else break;
+        p++;
+    }
+    return nd > 0;
+}
+__device__ __forceinline__ void txt_blanks(const char* t, size_t& p, size_t end) { while (p < end && (t[p] == ' ' || t[p] == '\t')) p++; }
+
+__global__ void txt_parse_kernel(const char* __restrict__ t, size_t nbytes, const uint64_t* __restrict__ lineend, uint32_t nlines,
+                                 eorb_raw_event* __restrict__ ev, uint8_t* __restrict__ status)
+{
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= nlines) return;
+    size_t p = li ? (size_t)lineend[li - 1] + 1 : 0;
+    size_t end = (size_t)lineend[li];
+    if (t[end] != '\n') end++;                                    // last line without a newline: its last byte belongs to it
+    if (end > p && t[end - 1] == '\r') end--;
+    txt_blanks(t, p, end);
+    uint8_t st = 1;                                               // comment or blank
+    eorb_raw_event e{};
+    if (p < end && t[p] != '#') {
+        st = 2;
+        uint64_t m[4]; int fr[4]; bool big[4]; bool ok = true;
+        for (int k = 0; k < 4 && ok; k++) { ok = txt_number(t, p, end, m[k], fr[k], big[k]); txt_blanks(t, p, end); }
+        ok = ok && p == end;
+        // ts: Clinger's exact case -- integer mantissa < 2^53 and 10^frac exact in double: one correctly rounded division
+        if (ok && (big[0] || m[0] >= (1ull << 53) || fr[0] > 22)) ok = false;
+        // x, y: integer-valued, 0..65535;  p: 0 or 1
+        for (int k = 1; k <= 2 && ok; k++) {
+            uint64_t v = m[k];
+            for (int d = 0; d < fr[k] && ok; d++) { if (v % 10) ok = false; v /= 10; }
+            if (ok && (big[k] || v > 65535)) ok = false;
+            m[k] = v;
+        }
+        if (ok && (big[3] || fr[3] != 0 || m[3] > 1)) ok = false;
+        if (ok) {
+            double p10 = 1.0;
+            for (int d = 0; d < fr[0]; d++) p10 *= 10.0;          // exact up to 1e22
+            e.t = (double)m[0] / p10;
+            e.x = (uint16_t)m[1]; e.y = (uint16_t)m[2]; e.p = (uint32_t)m[3];
+            st = 0;
+        }
+    }
+    ev[li] = e; status[li] = st;
+}
+
+__global__ __launch_bounds__(1024) void txt_keep_count_kernel(const uint8_t* __restrict__ status, uint32_t nlines, uint32_t* __restrict__ blk,
+                                                              uint32_t* __restrict__ first_bad)
+{
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint8_t st = i < nlines ? status[i] : 1;
+    if (st == 2) atomicMin(first_bad, i);
+    const uint64_t m = __ballot(st == 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&cnt, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = cnt;
+}
+__global__ __launch_bounds__(1024) void txt_keep_write_kernel(const uint8_t* __restrict__ status, const eorb_raw_event* __restrict__ ev,
+                                                              uint32_t nlines, const uint32_t* __restrict__ blk, eorb_raw_event* __restrict__ out)
+{
+    __shared__ uint32_t wbase[17];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool keep = i < nlines && status[i] == 0;
+    const uint64_t m = __ballot(keep);
+    if (lane == 0) wbase[wave + 1] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { wbase[0] = 0; for (int w = 1; w <= 16; w++) wbase[w] += wbase[w - 1]; }
+    __syncthreads();
+    if (keep) out[blk[blockIdx.x] + wbase[wave] + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = ev[i];
+}
+__global__ void txt_set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+
+// d_text: nbytes of text; d_lineend / d_ev / d_status / d_out sized for max_lines; d_blk: (nbytes + 1023) / 1024 + 4 words.
+// h_res[0] = lines, h_res[1] = events kept, h_res[2] = first malformed line (0xffffffff = none)
+int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* d_lineend, eorb_raw_event* d_ev, uint8_t* d_status,
+                      eorb_raw_event* d_out, uint32_t* d_blk, size_t max_lines, uint32_t h_res[3])
+{
+    const int nblk = (int)((nbytes + 1023) / 1024);
+    ProfScope ps(c, "ev_parse_text");
+    txt_count_kernel<<<nblk, 1024, 0, c->stream>>>(d_text, nbytes, d_blk);
+    ev_undistort_scan_kernel<<<1, 1, 0, c->stream>>>(d_blk, nblk);
+    uint32_t nlines = 0;
+    EORB_HIP(c, hipMemcpyAsync(&nlines, d_blk + nblk, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    h_res[0] = nlines; h_res[1] = 0; h_res[2] = 0xffffffffu;
+    if (nlines == 0) return EORB_OK;
+    if (nlines > max_lines) return set_err(c, EORB_E_CAPACITY, "parse_events_text: %u lines, room for %zu", nlines, max_lines);
+    txt_lineend_kernel<<<nblk, 1024, 0, c->stream>>>(d_text, nbytes, d_blk, d_lineend);
+    txt_parse_kernel<<<(nlines + 255) / 256, 256, 0, c->stream>>>(d_text, nbytes, d_lineend, nlines, d_ev, d_status);
+    const int nb2 = (int)((nlines + 1023) / 1024);
+    uint32_t* d_blk2 = d_blk;                                      // the line-end block sums are no longer needed
+    uint32_t* d_bad = d_blk + nb2 + 2;
+    txt_set_u32_kernel<<<1, 1, 0, c->stream>>>(d_bad, 0xffffffffu);
+    txt_keep_count_kernel<<<nb2, 1024, 0, c->stream>>>(d_status, nlines, d_blk2, d_bad);
+    ev_undistort_scan_kernel<<<1, 1, 0, c->stream>>>(d_blk2, nb2);
+    txt_keep_write_kernel<<<nb2, 1024, 0, c->stream>>>(d_status, d_ev, nlines, d_blk2, d_out);
+    EORB_LAUNCH_CHECK(c, "ev_parse_text kernels");
+    uint32_t two[2] = {0, 0};
+    EORB_HIP(c, hipMemcpyAsync(&two[0], d_blk2 + nb2, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(&two[1], d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    h_res[1] = two[0]; h_res[2] = two[1];
+    return EORB_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,

@@ -154,6 +154,15 @@ class EvImConverter:
         return out[:k.value].copy()
 
     @staticmethod
+    def parse_events_text(text, ctx=None):
+        """The text half of the loader (EventLoader.cpp:80-92): bytes of "ts x y p" lines -> RAW_DTYPE events."""
+        ctx = ctx or default_context()
+        cap = text.count(b"\n") + 1
+        out = np.zeros(cap, RAW_DTYPE); k = C.c_size_t(0); bad = C.c_int64(-1)
+        ctx.check(ctx.L.eorb_parse_events_text(ctx.h, text, len(text), _p(out), cap, C.byref(k), C.byref(bad)))
+        return out[:k.value].copy()
+
+    @staticmethod
     def ev2im_gauss_raw(raw, imWidth, imHeight, sigma=1.0, pol=False, normalized=True, ctx=None, return_all=False):
         ctx = ctx or default_context()
         raw = np.ascontiguousarray(raw, RAW_DTYPE)

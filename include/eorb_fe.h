@@ -127,6 +127,16 @@ int eorb_set_undistort_maps(eorb_ctx* ctx, const float* mapX, const float* mapY,
 int eorb_undistort_events(eorb_ctx* ctx, const eorb_raw_event* raw, size_t n, int W, int H, double tsFactor,
                           eorb_event* out, size_t* n_out);
 
+/* replaces the text half of the loader: getline + EventDataStore::parseLine ("stream >> ts >> x >> y >> p",
+ * src/Event/EventLoader.cpp:80-92) + BaseLoader::isComment (Utils/DataStore.cpp:111-114) over a whole buffer of the dataset's
+ * events.txt.  Accepted grammar per line: `ts x y p` as plain decimals (no exponent) separated by blanks / tabs, optional '\r';
+ * ts with at most 19 significant digits, value < 2^53 / 10^frac and at most 22 fractional digits (then one IEEE division gives
+ * strtod's result); x, y integer-valued in 0..65535 (the reference truncates them, MyCalibrator.cpp:172-173); p in {0, 1}.
+ * '#' lines and blank lines are skipped.  Any other line: EORB_E_ARG with *bad_line = its 0-based index (the caller falls back
+ * to its own parser for that file).  out has room for cap events. */
+int eorb_parse_events_text(eorb_ctx* ctx, const char* text, size_t nbytes, eorb_raw_event* out, size_t cap, size_t* n_out,
+                           int64_t* bad_line);
+
 /* = eorb_undistort_events followed by eorb_ev2im_gauss / eorb_ev2im on the kept events, fused: the stamp of a sensor
  * pixel depends only on its map entry, so the (2h+1)^2 values per pixel are tabulated once per (maps, sigma) and the
  * accumulation kernel only orders and adds them.  Bit-identical to the two-step path. */

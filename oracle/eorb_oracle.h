@@ -99,6 +99,13 @@ typedef struct { uint16_t x, y; uint32_t p; double t; } orc_raw_event;
 size_t orc_undistort_events(const orc_raw_event* raw, size_t n, const float* mapX, const float* mapY, int LW, int LH,
                             int W, int H, int checkInImage, double tsFactor, orc_event* out);
 
+/* Text half of EventDataStore::getEventChunkRectified / getTxtData (src/Event/EventLoader.cpp:80-92, :264-305): one event per
+ * line "ts x y p"; lines whose first non-blank character is '#' are comments (BaseLoader::isComment, Utils/DataStore.cpp:111-114).
+ * ts: strtod (istringstream >> double); x, y: strtof then static_cast<int> (MyCalibrator.cpp:172-173); p: 0 / 1.
+ * Accepted grammar (anything else -> returns -(line number) - 1, 0-based): decimal numbers without exponent, separated by
+ * blanks / tabs, optional trailing '\r'; x and y integer-valued, 0..65535.  Blank lines are skipped.  Returns the number of events. */
+long orc_parse_events_text(const char* text, size_t nbytes, orc_raw_event* out, size_t cap);
+
 typedef struct { float fx, fy, cx, cy; } orc_pinhole;          /* Pinhole::mvParameters (float), CameraModels/Pinhole.cpp */
 
 /* per-event warp of ev2mci_gg_f(evs, cam, Tcw, medDepth, ...) (:304-335): angle/axis = Eigen::AngleAxisd(R) and tt = t of

@@ -523,3 +523,15 @@ def bow_transform(voc, desc, levelsup=4, weighting=0, norm=1):
     L.orc_bow_transform(C.byref(v), _p(desc), C.c_int(n), C.c_int(desc.shape[1] if n else 32), C.c_int(levelsup), C.c_int(weighting),
                         C.c_int(norm), _p(bw), _p(bv), C.byref(nw), _p(fn), _p(fo), _p(fi), C.byref(nn), _p(wo), _p(no))
     return bw[:nw.value].copy(), bv[:nw.value].copy(), (fn[:nn.value].copy(), fo[:nn.value + 1].copy(), fi[:fo[nn.value]].copy()), wo[:n], no[:n]
+
+
+def parse_events_text(text):
+    """text: bytes. Returns RAW_DTYPE events, or raises ValueError(line) for a line outside the accepted grammar."""
+    L = lib(); L.orc_parse_events_text.restype = C.c_long
+    L.orc_parse_events_text.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    cap = text.count(b"\n") + 1
+    out = np.zeros(cap, RAW_DTYPE)
+    r = L.orc_parse_events_text(text, len(text), _p(out), cap)
+    if r < 0:
+        raise ValueError(-r - 1)
+    return out[:r].copy()

@@ -269,3 +269,49 @@ size_t orc_undistort_events(const orc_raw_event* raw, size_t n, const float* map
     }
     return k;
 }
+
+/* EventLoader.cpp:80-92 "stream >> ts >> x >> y >> p" over the lines of a text buffer */
+long orc_parse_events_text(const char* text, size_t nbytes, orc_raw_event* out, size_t cap)
+{
+    size_t pos = 0; long line = 0; size_t n = 0;
+    char buf[256];
+    while (pos < nbytes) {
+        size_t end = pos;
+        while (end < nbytes && text[end] != '\n') end++;
+        size_t len = end - pos;
+        if (len > 0 && text[pos + len - 1] == '\r') len--;
+        size_t i = 0;
+        while (i < len && (text[pos + i] == ' ' || text[pos + i] == '\t')) i++;
+        if (i < len && text[pos + i] != '#') {                           /* isComment / blank */
+            if (len >= sizeof(buf)) return -line - 1;
+            memcpy(buf, text + pos, len); buf[len] = 0;
+            for (size_t k = 0; k < len; k++) {                            /* grammar: digits, '.', blanks only */
+                const char ch = buf[k];
+                if (!((ch >= '0' && ch <= '9') || ch == '.' || ch == ' ' || ch == '\t')) return -line - 1;
+            }
+            char* q = buf; char* e;
+            {   /* ts restricted to the exactly convertible case: <= 19 significant digits, mantissa < 2^53, <= 22 fraction digits */
+                const char* d = buf + i; unsigned long long mant = 0; int sig = 0, frac = 0, point = 0, big = 0;
+                for (; (*d >= '0' && *d <= '9') || (*d == '.' && !point); d++) {
+                    if (*d == '.') { point = 1; continue; }
+                    if (mant != 0 || *d != '0') { if (sig < 19) { mant = mant * 10 + (unsigned)(*d - '0'); sig++; } else big = 1; }
+                    if (point) frac++;
+                }
+                if (big || mant >= (1ull << 53) || frac > 22) return -line - 1;
+            }
+            const double ts = strtod(q, &e); if (e == q) return -line - 1; q = e;
+            const float x = strtof(q, &e); if (e == q) return -line - 1; q = e;
+            const float y = strtof(q, &e); if (e == q) return -line - 1; q = e;
+            const long pp = strtol(q, &e, 10); if (e == q) return -line - 1; q = e;
+            while (*q == ' ' || *q == '\t') q++;
+            if (*q != 0 || (pp != 0 && pp != 1)) return -line - 1;
+            if (x != (float)(int)x || y != (float)(int)y || x < 0 || x > 65535 || y < 0 || y > 65535) return -line - 1;
+            if (n >= cap) return -line - 1;
+            memset(&out[n], 0, sizeof(orc_raw_event));
+            out[n].x = (uint16_t)(int)x; out[n].y = (uint16_t)(int)y; out[n].p = (uint32_t)pp; out[n].t = ts;
+            n++;
+        }
+        pos = end + 1; line++;
+    }
+    return (long)n;
+}

@@ -614,6 +614,38 @@ def test_raw_undistort_events(oracle, fe, ctx, check):
         fe.EvImConverter.undistort_events(bad, W, H, ctx=ctx)
 
 
+def test_parse_events_text(oracle, fe, ctx):
+    """f4: the loader's text half on device: comments, blank lines, CRLF, no final newline, many timestamp widths."""
+    rng = np.random.default_rng(23)
+    n = 200000
+    ts = np.cumsum(rng.integers(1, 2000, n)) * 1e-6
+    lines = [b"# events: ts x y p", b"#second header", b""]
+    for i in range(n):
+        style = i % 5
+        if style == 0: tss = "%.9f" % ts[i]
+        elif style == 1: tss = "%.6f" % (1468941032.0 + ts[i])
+        elif style == 2: tss = "%d" % int(ts[i] * 1e6)
+        elif style == 3: tss = "%.3f" % ts[i]
+        else: tss = "%.12f" % ts[i]
+        sep = "\t" if i % 7 == 0 else " "
+        lines.append(("%s%s%d%s%d %d%s" % (tss, sep, rng.integers(0, 240), sep, rng.integers(0, 180), rng.integers(0, 2),
+                                             "\r" if i % 11 == 0 else "")).encode())
+        if i % 50000 == 17: lines.append(b"   # a comment in the middle")
+    lines.append(b"0000123.4500 007 8.000 1")
+    for text in (b"\n".join(lines), b"\n".join(lines) + b"\n"):
+        o = oracle.parse_events_text(text)
+        g = fe.EvImConverter.parse_events_text(text, ctx=ctx)
+        assert len(o) == n + 1 and len(g) == len(o) and np.array_equal(o.view(np.uint8), g.view(np.uint8))
+    assert len(fe.EvImConverter.parse_events_text(b"", ctx=ctx)) == 0
+    assert len(fe.EvImConverter.parse_events_text(b"# only a header\n\n", ctx=ctx)) == 0
+    for bad in (b"1.0 2 3 1\n1e5 2 3 1\n", b"1.0 2 3\n", b"1.0 2.5 3 1\n", b"1.0 2 3 2\n", b"1.0 70000 3 1\n",
+                b"12345678901234567890123 1 2 0\n", b"1.0 2 3 1 9\n", b"abc\n"):
+        with pytest.raises(fe.EorbError):
+            fe.EvImConverter.parse_events_text(b"0.5 1 1 1\n" + bad, ctx=ctx)
+        with pytest.raises(ValueError):
+            oracle.parse_events_text(b"0.5 1 1 1\n" + bad)
+
+
 @pytest.mark.parametrize("sigma,pol", [(1.0, False), (1.0, True), (0.7, False), (1.5, True), (2.0, False)])
 def test_raw_ev2im_gauss_equals_loader_then_ev2im_gauss(oracle, fe, ctx, sigma, pol):
     """f4 fused: raw sensor events + maps -> image must equal undistort -> ev2im_gauss of the reference, bit for bit."""
