@@ -80,6 +80,40 @@ struct EvImConverter {
                                  normalized, out32.ptr(), out8.ptr(), nullptr));
         return normalized;
     }
+    // raw sensor events + MyCalibrator maps (EventLoader.cpp:264-305 fused with ev2im_gauss)
+    static void ev2im_gauss_raw(const std::vector<eorb_raw_event>& vRaw, unsigned imWidth, unsigned imHeight, float sigma, bool pol,
+                                bool normalized, eorb_host::Mat8& out8, eorb_host::Mat32f& out32) {
+        auto& c = eorb_host::thread_context();
+        out8 = eorb_host::Mat8((int)imHeight, (int)imWidth); out32 = eorb_host::Mat32f((int)imHeight, (int)imWidth);
+        c.check(eorb_ev2im_gauss_raw(c.get(), vRaw.data(), vRaw.size(), (int)imWidth, (int)imHeight, sigma, pol, normalized,
+                                     out32.ptr(), out8.ptr(), nullptr));
+    }
+};
+
+// src/Event/EventLoader.cpp: the parts of EventDataStore the GPU takes over
+struct EventDataStore {
+    // MyCalibrator::mUndistMapX / mUndistMapY (LH x LW floats each) for this thread's context
+    static void setUndistortMaps(const std::vector<float>& mapX, const std::vector<float>& mapY, int LW, int LH, bool checkInImage) {
+        auto& c = eorb_host::thread_context();
+        c.check(eorb_set_undistort_maps(c.get(), mapX.data(), mapY.data(), LW, LH, checkInImage));
+    }
+    // getline + parseLine + isComment over a text buffer (:80-92); throws eorb_host::Error for a line outside the grammar
+    static std::vector<eorb_raw_event> parseText(const std::string& text) {
+        auto& c = eorb_host::thread_context();
+        size_t lines = 1; for (char ch : text) lines += ch == '\n';
+        std::vector<eorb_raw_event> out(lines); size_t n = 0; int64_t bad = -1;
+        c.check(eorb_parse_events_text(c.get(), text.data(), text.size(), out.data(), out.size(), &n, &bad));
+        out.resize(n);
+        return out;
+    }
+    // the rectification loop of getEventChunkRectified (:264-305)
+    static std::vector<eorb_host::EventData> rectify(const std::vector<eorb_raw_event>& raw, int imWidth, int imHeight, double tsFactor) {
+        auto& c = eorb_host::thread_context();
+        std::vector<eorb_host::EventData> out(raw.size()); size_t n = 0;
+        c.check(eorb_undistort_events(c.get(), raw.data(), raw.size(), imWidth, imHeight, tsFactor, out.data(), &n));
+        out.resize(n);
+        return out;
+    }
 };
 
 }  // namespace EORB_SLAM
@@ -164,8 +198,97 @@ public:
                                                mbCheckOrientation, &nm));
         return nm;
     }
+    // DBoW2::FeatureVector as CSR (nodes ascending, node_off, idx) -- what ORBVocabulary::transform returns below
+    struct FeatureVector { std::vector<uint32_t> nodes; std::vector<int32_t> off{0}, idx; };
+    // SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:276-478): match_f[j] = KeyFrame feature whose map point goes to F's j
+    int SearchByBoW(const FrameView& KF, const std::vector<uint8_t>& kfHasMP, const FeatureVector& kfFV, const FrameView& F,
+                    const FeatureVector& fFV, std::vector<int>& match_f) {
+        auto& c = eorb_host::thread_context();
+        match_f.assign(F.numAllKPts(), -1); int nm = 0;
+        c.check(eorb_search_by_bow(c.get(), KF.kps->data(), KF.numAllKPts(), KF.desc->ptr(), kfHasMP.data(), kfFV.nodes.data(),
+                                   kfFV.off.data(), kfFV.idx.data(), (int)kfFV.nodes.size(), F.kps->data(), F.numAllKPts(), F.desc->ptr(),
+                                   fFV.nodes.data(), fFV.off.data(), fFV.idx.data(), (int)fFV.nodes.size(), match_f.data(),
+                                   mfNNratio, mbCheckOrientation, &nm));
+        return nm;
+    }
+    // SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (:833-973)
+    int SearchByBoW(const FrameView& KF1, const std::vector<uint8_t>& hasMP1, const FeatureVector& FV1, const FrameView& KF2,
+                    const std::vector<uint8_t>& hasMP2, const FeatureVector& FV2, std::vector<int>& match12, bool) {
+        auto& c = eorb_host::thread_context();
+        match12.assign(KF1.numAllKPts(), -1); int nm = 0;
+        c.check(eorb_search_by_bow_kf(c.get(), KF1.kps->data(), KF1.numAllKPts(), KF1.desc->ptr(), hasMP1.data(), FV1.nodes.data(),
+                                      FV1.off.data(), FV1.idx.data(), (int)FV1.nodes.size(), KF2.kps->data(), KF2.numAllKPts(),
+                                      KF2.desc->ptr(), hasMP2.data(), FV2.nodes.data(), FV2.off.data(), FV2.idx.data(),
+                                      (int)FV2.nodes.size(), match12.data(), mfNNratio, mbCheckOrientation, &nm));
+        return nm;
+    }
+    // SearchForTriangulation (:975-1214, mono): ep / F12 / level tables from the caller (see include/eorb_fe.h)
+    int SearchForTriangulation(const FrameView& KF1, const std::vector<uint8_t>& elig1, const FeatureVector& FV1, const FrameView& KF2,
+                               const std::vector<uint8_t>& elig2, const FeatureVector& FV2, const float ep[2], const float F12[9],
+                               const std::vector<float>& scale2, const std::vector<float>& sigma2_2,
+                               std::vector<std::pair<size_t, size_t>>& vMatchedPairs, bool bCoarse = false) {
+        auto& c = eorb_host::thread_context();
+        std::vector<int> m12(KF1.numAllKPts(), -1); int nm = 0;
+        c.check(eorb_search_for_triangulation(c.get(), KF1.kps->data(), KF1.numAllKPts(), KF1.desc->ptr(), KF1.desc->cols, elig1.data(),
+                                              FV1.nodes.data(), FV1.off.data(), FV1.idx.data(), (int)FV1.nodes.size(), KF2.kps->data(),
+                                              KF2.numAllKPts(), KF2.desc->ptr(), KF2.desc->cols, elig2.data(), FV2.nodes.data(),
+                                              FV2.off.data(), FV2.idx.data(), (int)FV2.nodes.size(), ep, F12, scale2.data(),
+                                              sigma2_2.data(), (int)scale2.size(), bCoarse, mbCheckOrientation, m12.data(), &nm));
+        vMatchedPairs.clear();
+        for (size_t i = 0; i < m12.size(); i++) if (m12[i] >= 0) vMatchedPairs.emplace_back(i, (size_t)m12[i]);     // :1203-1211
+        return nm;
+    }
+    // search core of Fuse / SearchBySim3 / SearchByProjection(KF, Scw): see eorb_kf_radius_match
+    void KeyFrameRadiusMatch(const FrameView& KF, const std::vector<uint8_t>& valid, const std::vector<float>& uv,
+                             const std::vector<float>& radius, const std::vector<int>& level, const eorb_host::Mat8& mpDesc,
+                             const std::vector<float>* invSigma2, std::vector<uint8_t>* taken, float acceptThr,
+                             std::vector<int>& bestIdx, std::vector<int>& bestDist) {
+        auto& c = eorb_host::thread_context();
+        const int M = (int)valid.size();
+        bestIdx.assign(M, -1); bestDist.assign(M, 256);
+        c.check(eorb_kf_radius_match(c.get(), KF.kps->data(), KF.numAllKPts(), KF.desc->ptr(), KF.desc->cols, &KF.gb, M, valid.data(),
+                                     uv.data(), radius.data(), level.data(), mpDesc.ptr(), invSigma2 ? invSigma2->data() : nullptr,
+                                     invSigma2 ? (int)invSigma2->size() : 0, taken ? taken->data() : nullptr, acceptThr,
+                                     bestIdx.data(), bestDist.data()));
+    }
 protected:
     float mfNNratio; bool mbCheckOrientation;
 };
+
+// ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) resident on the device
+class ORBVocabulary {
+public:
+    // m_nodes flattened after loadFromTextFile: node 0 = root (see eorb_bow_set_vocabulary)
+    ORBVocabulary(int L, const std::vector<int32_t>& childOff, const std::vector<int32_t>& childIds, const eorb_host::Mat8& nodeDesc,
+                  const std::vector<int32_t>& wordId, const std::vector<double>& weight, int weighting = 0, int norm = 1)
+        : weighting_(weighting), norm_(norm) {
+        auto& c = eorb_host::thread_context();
+        c.check(eorb_bow_set_vocabulary(c.get(), (int)childOff.size() - 1, L, childOff.data(), childIds.data(), nodeDesc.ptr(),
+                                        wordId.data(), weight.data()));
+    }
+    // transform(vCurrentDesc, mBowVec, mFeatVec, levelsup) (Frame::ComputeBoW)
+    void transform(const eorb_host::Mat8& desc, std::vector<std::pair<uint32_t, double>>& bowVec, ORBmatcher::FeatureVector& featVec,
+                   int levelsup = 4) const {
+        auto& c = eorb_host::thread_context();
+        const int n = desc.rows;
+        std::vector<uint32_t> bw(n ? n : 1); std::vector<double> bv(n ? n : 1); int nw = 0, nn = 0;
+        featVec.nodes.assign(n ? n : 1, 0); featVec.off.assign(n + 1, 0); featVec.idx.assign(n ? n : 1, 0);
+        c.check(eorb_bow_transform(c.get(), desc.ptr(), n, desc.cols ? desc.cols : 32, levelsup, weighting_, norm_, bw.data(), bv.data(),
+                                   &nw, featVec.nodes.data(), featVec.off.data(), featVec.idx.data(), &nn, nullptr, nullptr));
+        bowVec.clear();
+        for (int i = 0; i < nw; i++) bowVec.emplace_back(bw[i], bv[i]);
+        featVec.nodes.resize(nn); featVec.off.resize(nn + 1); featVec.idx.resize(featVec.off[nn]);
+    }
+private:
+    int weighting_, norm_;
+};
+
+// MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for a batch of map points (CSR offsets into desc rows)
+inline std::vector<int> ComputeDistinctiveDescriptors(const eorb_host::Mat8& desc, const std::vector<int32_t>& offsets) {
+    auto& c = eorb_host::thread_context();
+    std::vector<int> best(offsets.size() - 1, -1);
+    c.check(eorb_distinctive_descriptors(c.get(), desc.ptr(), offsets.data(), (int)offsets.size() - 1, best.data()));
+    return best;
+}
 
 }  // namespace ORB_SLAM3

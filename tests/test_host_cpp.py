@@ -24,7 +24,24 @@ int main(int argc, char** argv) {
         eorb_host::Mat8 empty;
         int m1 = ex(empty, kps, lap);
         std::printf("mono=%d empty=%d\n", mono, m1);
-        return (mono == 0 && m1 == -1) ? 0 : 1;
+        // loader on the device: text -> raw events -> rectified EventData == the fused raw image path
+        std::vector<float> mx(240 * 180), my(240 * 180);
+        for (int y = 0; y < 180; y++) for (int x = 0; x < 240; x++) { mx[y * 240 + x] = x + 0.25f * (y % 3) - 0.4f; my[y * 240 + x] = y + 0.125f * (x % 5); }
+        EORB_SLAM::EventDataStore::setUndistortMaps(mx, my, 240, 180, true);
+        std::string text = "# ts x y p\n";
+        for (int i = 0; i < 3000; i++) { char b[64]; std::snprintf(b, sizeof b, "%d.%06d %d %d %d\n", i / 1000, (i * 37) % 1000000, (i * 53) % 240, (i * 29) % 180, i & 1); text += b; }
+        auto raw = EORB_SLAM::EventDataStore::parseText(text);
+        auto evs = EORB_SLAM::EventDataStore::rectify(raw, 240, 180, 1.0);
+        eorb_host::Mat8 a8, b8; eorb_host::Mat32f a32, b32;
+        EORB_SLAM::EvImConverter::ev2im_gauss(evs, 240, 180, 1.0f, true, false, a8, a32);
+        EORB_SLAM::EvImConverter::ev2im_gauss_raw(raw, 240, 180, 1.0f, true, false, b8, b32);
+        bool same = raw.size() == 3000 && evs.size() < raw.size() && evs.size() > 2000;
+        for (int i = 0; i < 240 * 180 && same; i++) same = a32.ptr()[i] == b32.ptr()[i];
+        // one map point observed 5 times: the distinctive descriptor is one of the rows
+        eorb_host::Mat8 d(5, 32); for (int i = 0; i < 5 * 32; i++) d.ptr()[i] = (unsigned char)(i * 7 + (i / 32 == 3 ? 1 : 0));
+        auto best = ORB_SLAM3::ComputeDistinctiveDescriptors(d, std::vector<int32_t>{0, 5});
+        std::printf("raw=%zu kept=%zu same=%d best=%d\n", raw.size(), evs.size(), (int)same, best[0]);
+        return (mono == 0 && m1 == -1 && same && best[0] >= 0 && best[0] < 5) ? 0 : 1;
     } catch (const eorb_host::Error& e) { std::printf("error %d: %s\n", e.code, e.what()); return 2; }
 }
 '''
