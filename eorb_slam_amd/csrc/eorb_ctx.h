@@ -96,6 +96,8 @@ struct eorb_ctx {
         out_n, oct_scratch, in_img;
     // matcher workspaces
     eorb::DevBuf m_a, m_b, m_c, m_d, m_e, m_f, m_g, m_h, m_i, m_j;
+    // pyramidal LK workspaces
+    eorb::DevBuf klt_pyr, klt_der, klt_scratch;
     // DBoW2 vocabulary (device copy) for eorb_bow_transform
     eorb::DevBuf voc;
     int voc_nnodes = 0, voc_L = 0; size_t voc_off[5] = {0, 0, 0, 0, 0};
@@ -133,6 +135,10 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
 int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, int H, double tsFactor, eorb_event* d_out, uint32_t* d_blk);
 int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* d_lineend, eorb_raw_event* d_ev, uint8_t* d_status,
                       eorb_raw_event* d_out, uint32_t* d_blk, size_t max_lines, uint32_t h_res[3]);
+// klt.hip
+int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int W, int H, int stride, const float* d_prev_pts,
+                  float* d_next_pts, int n, int win, int maxLevel, int maxCount, double epsilon, int flags, float minEig,
+                  uint8_t* d_status, float* d_err);
 // orb_extract.hip
 int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
                     int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono);

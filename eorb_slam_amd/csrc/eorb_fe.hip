@@ -146,7 +146,7 @@ void eorb_destroy(eorb_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->lut, &c->src_info, &c->stamps, &c->voc, &c->pyr, &c->score,
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->lut, &c->src_info, &c->stamps, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
@@ -1062,6 +1062,35 @@ int eorb_bow_transform(eorb_ctx* c, const uint8_t* desc, int n, int stride, int 
     if (nfeat) EORB_HIP(c, hipMemcpyAsync(fv_idx, d_fv_idx, 4 * (size_t)nfeat, hipMemcpyDeviceToHost, c->stream));
     if (word_of) EORB_HIP(c, hipMemcpyAsync(word_of, d_word_of, 4 * N, hipMemcpyDeviceToHost, c->stream));
     if (node_of) EORB_HIP(c, hipMemcpyAsync(node_of, d_node_of, 4 * N, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+int eorb_calc_optical_flow_pyr_lk(eorb_ctx* c, const uint8_t* prev, const uint8_t* next, int W, int H, int stride,
+                                  const float* prev_pts, float* next_pts, int n, int win, int maxLevel, int maxCount, double epsilon,
+                                  int flags, float minEigThreshold, uint8_t* status, float* err)
+{
+    if (!c) return EORB_E_ARG;
+    if (!prev || !next || W <= 0 || H <= 0 || stride < W || n < 0 || win < 3 || win > 63 || maxLevel < 0 ||
+        (n > 0 && (!prev_pts || !next_pts || !status || !err)))
+        return set_err(c, EORB_E_ARG, "calc_optical_flow_pyr_lk: bad arguments");
+    hipSetDevice(c->device);
+    if (n == 0) return EORB_OK;
+    int rc;
+    const size_t ib = (size_t)stride * H;
+    if ((rc = ensure(c, c->in_img, 2 * ib))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(c->in_img.p, prev, ib, hipMemcpyHostToDevice, c->stream));
+    EORB_HIP(c, hipMemcpyAsync((uint8_t*)c->in_img.p + ib, next, ib, hipMemcpyHostToDevice, c->stream));
+    if ((rc = up(c, c->m_a, prev_pts, sizeof(float) * 2 * (size_t)n))) return rc;
+    if ((rc = up(c, c->m_b, next_pts, sizeof(float) * 2 * (size_t)n))) return rc;
+    if ((rc = ensure(c, c->m_c, (size_t)n + 16))) return rc;
+    if ((rc = ensure(c, c->m_d, sizeof(float) * (size_t)n))) return rc;
+    if ((rc = klt_track_dev(c, (const uint8_t*)c->in_img.p, (const uint8_t*)c->in_img.p + ib, W, H, stride, (const float*)c->m_a.p,
+                            (float*)c->m_b.p, n, win, maxLevel, maxCount, epsilon, flags, minEigThreshold, (uint8_t*)c->m_c.p,
+                            (float*)c->m_d.p))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(next_pts, c->m_b.p, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(status, c->m_c.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(err, c->m_d.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     return EORB_OK;
 }

@@ -1,0 +1,268 @@
+// klt.hip -- pyramidal Lucas-Kanade tracking on gfx950 for ELK_Tracker (src/Event/KLT_Tracker.cpp:49-98 of the reference):
+// cv::calcOpticalFlowPyrLK(refFrame, currImage, refPoints, kpts, status, err, Size(win, win), maxLevel, criteria, flags).
+// The algorithm is OpenCV 3.4.1's (modules/video/src/lkpyramid.cpp, scalar code path; modules/imgproc/src/pyramids.cpp), restated:
+//   klt_level0 / klt_pyrdown / klt_pad   buildOpticalFlowPyramid: 5x5 [1 4 6 4 1] pyrDown, every level padded by the window size
+//                                        with BORDER_REFLECT_101
+//   klt_scharr                           calcSharrDeriv of the reference-frame levels (int16 dx, dy; zero padding)
+//   klt_track                            LKTrackerInvoker: one thread per point walks the levels coarse to fine; 14-bit
+//                                        fixed-point bilinear patches, float normal equations accumulated in raster order (the
+//                                        order is part of the result, so the window loop of a point is not split over lanes)
+#include "eorb_ctx.h"
+#include "dev_math.h"
+#include <algorithm>
+#include <float.h>
+#include <math.h>
+
+namespace eorb {
+
+constexpr int kKltMaxLevels = 8;
+struct KltLevel { int w, h, stride; size_t img_off, der_off; };     // stride = w + 2 win; offsets of the padded buffers
+struct KltPyr { int levels, win; KltLevel lv[kKltMaxLevels]; };
+
+__device__ __forceinline__ int klt_reflect(int p, int len)
+{   // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do { if (p < 0) p = -p; else p = 2 * len - p - 2; } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// level 0: the image copied into the centre of its padded buffer, padding filled by reflection in the same pass
+__global__ void klt_level0_kernel(const uint8_t* __restrict__ src, int sstride, KltLevel L, int win, uint8_t* __restrict__ pyr)
+{
+    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+    if (X >= L.stride) return;
+    pyr[L.img_off + (size_t)Y * L.stride + X] = src[(size_t)klt_reflect(Y - win, L.h) * sstride + klt_reflect(X - win, L.w)];
+}
+
+// cv::pyrDown 8u: horizontal 1 4 6 4 1 in ints, vertical 1 4 6 4 1, (sum + 128) >> 8; source indices by reflect-101
+__global__ void klt_pyrdown_kernel(KltLevel S, KltLevel D, int win, uint8_t* __restrict__ pyr)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= D.w) return;
+    const uint8_t* s = pyr + S.img_off + (size_t)win * S.stride + win;
+    int xs[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) xs[k] = klt_reflect(2 * x - 2 + k, S.w);
+    int rows[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint8_t* r = s + (size_t)klt_reflect(2 * y - 2 + k, S.h) * S.stride;
+        rows[k] = r[xs[2]] * 6 + (r[xs[1]] + r[xs[3]]) * 4 + r[xs[0]] + r[xs[4]];
+    }
+    const int v = rows[0] + rows[4] + (rows[1] + rows[3]) * 4 + rows[2] * 6;
+    pyr[D.img_off + (size_t)(y + win) * D.stride + x + win] = (uint8_t)((v + 128) >> 8);
+}
+
+// copyMakeBorder(level, padded, win, win, win, win, BORDER_REFLECT_101 | BORDER_ISOLATED) for levels >= 1
+__global__ void klt_pad_kernel(KltLevel L, int win, uint8_t* __restrict__ pyr)
+{
+    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+    if (X >= L.stride) return;
+    const int x = X - win, y = Y - win;
+    if (x >= 0 && x < L.w && y >= 0 && y < L.h) return;
+    uint8_t* b = pyr + L.img_off;
+    b[(size_t)Y * L.stride + X] = b[(size_t)(klt_reflect(y, L.h) + win) * L.stride + klt_reflect(x, L.w) + win];
+}
+
+// calcSharrDeriv: vertical [3 10 3] / [-1 0 1], then horizontal; image borders replicate the inner neighbour
+__global__ void klt_scharr_kernel(KltLevel L, int win, const uint8_t* __restrict__ pyr, int16_t* __restrict__ der)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= L.w) return;
+    const uint8_t* s = pyr + L.img_off + (size_t)win * L.stride + win;
+    const int w = L.w, h = L.h;
+    const int y0 = y > 0 ? y - 1 : (h > 1 ? 1 : 0), y2 = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+    auto T0 = [&](int xx) { return (int)(int16_t)((s[(size_t)y0 * L.stride + xx] + s[(size_t)y2 * L.stride + xx]) * 3 + s[(size_t)y * L.stride + xx] * 10); };
+    auto T1 = [&](int xx) { return (int)(int16_t)(s[(size_t)y2 * L.stride + xx] - s[(size_t)y0 * L.stride + xx]); };
+    const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+    int16_t* d = der + (L.der_off + (size_t)(y + win) * L.stride + x + win) * 2;
+    d[0] = (int16_t)(T0(xp) - T0(xm));
+    d[1] = (int16_t)((T1(xp) + T1(xm)) * 3 + T1(x) * 10);
+}
+
+#define KLT_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+
+struct KltArgs {
+    KltPyr P;                          // reference-frame pyramid (img + derivatives) and, at +next_off, the current frame's
+    size_t next_off;
+    const uint8_t* pyr; const int16_t* der;
+    const float* prev_pts; float* next_pts; int n;
+    int maxCount; double epsilon; int flags; float minEig;
+    uint8_t* status; float* err;
+    short* scratch;                    // [3 * win * win][n]: I patch, dIx, dIy of every point
+};
+
+__global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
+{
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= A.n) return;
+    const int win = A.P.win, n = A.n, WW = win * win;
+    const float halfWin = (win - 1) * 0.5f;
+    short* Iw = A.scratch + pt;                          // element k at Iw[k * n]
+    short* dX = A.scratch + (size_t)WW * n + pt;
+    short* dY = A.scratch + (size_t)2 * WW * n + pt;
+    const int maxLevel = A.P.levels - 1;
+    bool st = true; float errv = 0.f;
+    float outx = A.next_pts[2 * pt], outy = A.next_pts[2 * pt + 1];
+    const float ppx = A.prev_pts[2 * pt], ppy = A.prev_pts[2 * pt + 1];
+    for (int level = maxLevel; level >= 0; level--) {
+        const KltLevel L = A.P.lv[level];
+        const int stp = L.stride;
+        const uint8_t* I = A.pyr + L.img_off + (size_t)win * stp + win;
+        const uint8_t* J = A.pyr + A.next_off + L.img_off + (size_t)win * stp + win;
+        const int16_t* dI = A.der + (L.der_off + (size_t)win * stp + win) * 2;
+        const float sc = (float)(1. / (1 << level));
+        float prevx = ppx * sc, prevy = ppy * sc;
+        float nextx, nexty;
+        if (level == maxLevel) {
+            if (A.flags & 4) { nextx = outx * sc; nexty = outy * sc; }
+            else { nextx = prevx; nexty = prevy; }
+        } else { nextx = outx * 2.f; nexty = outy * 2.f; }
+        outx = nextx; outy = nexty;
+        prevx -= halfWin; prevy -= halfWin;
+        const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+        if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
+            if (level == 0) { st = false; errv = 0.f; }
+            continue;
+        }
+        float a = prevx - (float)ipx, b = prevy - (float)ipy;
+        const int W_BITS = 14, W_BITS1 = 14;
+        const float FLT_SCALE = 1.f / (1 << 20);
+        int iw00 = dev_cvround((1.f - a) * (1.f - b) * (1 << W_BITS));
+        int iw01 = dev_cvround(a * (1.f - b) * (1 << W_BITS));
+        int iw10 = dev_cvround((1.f - a) * b * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        float iA11 = 0.f, iA12 = 0.f, iA22 = 0.f;
+        for (int y = 0; y < win; y++) {
+            const uint8_t* src = I + (ptrdiff_t)(y + ipy) * stp + ipx;
+            const int16_t* ds = dI + ((ptrdiff_t)(y + ipy) * stp + ipx) * 2;
+            for (int x = 0; x < win; x++, ds += 2) {
+                const int ival = KLT_DESCALE(src[x] * iw00 + src[x + 1] * iw01 + src[x + stp] * iw10 + src[x + stp + 1] * iw11, W_BITS1 - 5);
+                const int ixval = KLT_DESCALE(ds[0] * iw00 + ds[2] * iw01 + ds[2 * stp] * iw10 + ds[2 * stp + 2] * iw11, W_BITS1);
+                const int iyval = KLT_DESCALE(ds[1] * iw00 + ds[3] * iw01 + ds[2 * stp + 1] * iw10 + ds[2 * stp + 3] * iw11, W_BITS1);
+                const size_t k = (size_t)(y * win + x) * n;
+                Iw[k] = (short)ival; dX[k] = (short)ixval; dY[k] = (short)iyval;
+                iA11 = iA11 + (float)(ixval * ixval); iA12 = iA12 + (float)(ixval * iyval); iA22 = iA22 + (float)(iyval * iyval);
+            }
+        }
+        const float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float dif = A11 - A22;
+        const float minEig = (A22 + A11 - sqrtf(dif * dif + 4.f * A12 * A12)) / (float)(2 * win * win);
+        if (A.flags & 8) errv = minEig;
+        if (minEig < A.minEig || D < FLT_EPSILON) {
+            if (level == 0) st = false;
+            continue;
+        }
+        D = 1.f / D;
+        nextx -= halfWin; nexty -= halfWin;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < A.maxCount; j++) {
+            const int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
+            if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+                if (level == 0) st = false;
+                break;
+            }
+            a = nextx - (float)inx; b = nexty - (float)iny;
+            iw00 = dev_cvround((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = dev_cvround(a * (1.f - b) * (1 << W_BITS));
+            iw10 = dev_cvround((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            float ib1 = 0.f, ib2 = 0.f;
+            for (int y = 0; y < win; y++) {
+                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx;
+                for (int x = 0; x < win; x++) {
+                    const size_t k = (size_t)(y * win + x) * n;
+                    const int diff = KLT_DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stp] * iw10 + Jp[x + stp + 1] * iw11, W_BITS1 - 5) - Iw[k];
+                    ib1 = ib1 + (float)(diff * dX[k]); ib2 = ib2 + (float)(diff * dY[k]);
+                }
+            }
+            const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            nextx += dx; nexty += dy;
+            outx = nextx + halfWin; outy = nexty + halfWin;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= A.epsilon) break;
+            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (st && level == 0 && !(A.flags & 8)) {
+            const float npx = outx - halfWin, npy = outy - halfWin;
+            const int inx = (int)floorf(npx), iny = (int)floorf(npy);
+            if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) { st = false; continue; }
+            const float aa = npx - (float)inx, bb = npy - (float)iny;
+            iw00 = dev_cvround((1.f - aa) * (1.f - bb) * (1 << W_BITS));
+            iw01 = dev_cvround(aa * (1.f - bb) * (1 << W_BITS));
+            iw10 = dev_cvround((1.f - aa) * bb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            float e = 0.f;
+            for (int y = 0; y < win; y++) {
+                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx;
+                for (int x = 0; x < win; x++) {
+                    const int diff = KLT_DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stp] * iw10 + Jp[x + stp + 1] * iw11, W_BITS1 - 5)
+                                     - Iw[(size_t)(y * win + x) * n];
+                    e = e + fabsf((float)diff);
+                }
+            }
+            errv = e * 1.f / (float)(32 * win * win);
+        }
+    }
+    A.next_pts[2 * pt] = outx; A.next_pts[2 * pt + 1] = outy;
+    A.status[pt] = st ? 1 : 0; A.err[pt] = errv;
+}
+
+// d_prev / d_next: W x H u8 images (row stride `stride`); d_prev_pts, d_next_pts: n x 2 floats; everything device resident
+int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int W, int H, int stride, const float* d_prev_pts,
+                  float* d_next_pts, int n, int win, int maxLevel, int maxCount, double epsilon, int flags, float minEig,
+                  uint8_t* d_status, float* d_err)
+{
+    KltPyr P{}; P.win = win;
+    size_t off = 0;
+    {
+        int w = W, h = H;
+        for (int lv = 0; lv <= maxLevel && lv < kKltMaxLevels; lv++) {
+            KltLevel& L = P.lv[lv];
+            L.w = w; L.h = h; L.stride = w + 2 * win; L.img_off = off; L.der_off = off;
+            off += (((size_t)L.stride * (h + 2 * win)) + 63) & ~(size_t)63;
+            P.levels = lv + 1;
+            w = (w + 1) / 2; h = (h + 1) / 2;
+            if (w <= win || h <= win) break;                      // buildOpticalFlowPyramid stops here
+        }
+    }
+    const size_t one = off;                                       // bytes of one padded pyramid
+    int rc;
+    if ((rc = ensure(c, c->klt_pyr, 2 * one))) return rc;
+    if ((rc = ensure(c, c->klt_der, sizeof(int16_t) * 2 * one))) return rc;
+    if ((rc = ensure(c, c->klt_scratch, sizeof(short) * 3 * (size_t)win * win * std::max(n, 1)))) return rc;
+    uint8_t* pyr = (uint8_t*)c->klt_pyr.p; int16_t* der = (int16_t*)c->klt_der.p;
+    ProfScope ps(c, "klt_track");
+    EORB_HIP(c, hipMemsetAsync(der, 0, sizeof(int16_t) * 2 * one, c->stream));           // derivative padding = BORDER_CONSTANT 0
+    for (int f = 0; f < 2; f++) {
+        uint8_t* base = pyr + (size_t)f * one;
+        const uint8_t* img = f ? d_next : d_prev;
+        for (int lv = 0; lv < P.levels; lv++) {
+            const KltLevel L = P.lv[lv];
+            const dim3 gp((L.stride + 63) / 64, L.h + 2 * win), gi((L.w + 63) / 64, L.h);
+            if (lv == 0) klt_level0_kernel<<<gp, 64, 0, c->stream>>>(img, stride, L, win, base);
+            else {
+                klt_pyrdown_kernel<<<gi, 64, 0, c->stream>>>(P.lv[lv - 1], L, win, base);
+                klt_pad_kernel<<<gp, 64, 0, c->stream>>>(L, win, base);
+            }
+            if (f == 0) klt_scharr_kernel<<<gi, 64, 0, c->stream>>>(L, win, base, der);
+        }
+    }
+    if (n > 0) {
+        KltArgs A{P, one, pyr, der, d_prev_pts, d_next_pts, n, std::min(std::max(maxCount, 0), 100), 0.0, flags, minEig, d_status, d_err,
+                  (short*)c->klt_scratch.p};
+        double eps = std::min(std::max(epsilon, 0.0), 10.0);
+        A.epsilon = eps * eps;
+        klt_track_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(A);
+    }
+    EORB_LAUNCH_CHECK(c, "klt kernels");
+    return EORB_OK;
+}
+
+}  // namespace eorb

@@ -465,6 +465,64 @@ def SearchBySim3(kf1, kf2, q1, q2, th=7.5, ctx=None):
     return int(ok.sum()), np.where(ok, vn1, -1).astype(np.int32)
 
 
+class ELK_Tracker:
+    """EORB_SLAM::ELK_Tracker (src/Event/KLT_Tracker.cpp): pyramidal LK on the device + the reference's match bookkeeping."""
+
+    def __init__(self, kltWinSize=23, maxLevel=1, kltMaxItr=10, kltEps=0.03, ctx=None):
+        self.ctx = ctx or default_context()
+        self.mPatchSz, self.mMaxLevel, self.maxItr, self.eps = kltWinSize, maxLevel, kltMaxItr, kltEps
+        self.mRefFrame = None
+
+    def setRefImage(self, image, refPts):                       # :22-46
+        self.mRefFrame = np.ascontiguousarray(image, np.uint8).copy()
+        self.mRefKPoints = np.ascontiguousarray(refPts, KP_DTYPE).copy()
+        self.mLastTrackedKPts = self.mRefKPoints.copy()
+        self.mRefPoints = np.stack([self.mRefKPoints["x"], self.mRefKPoints["y"]], axis=1).astype(np.float32)
+        self.mLastTrackedPts = self.mRefPoints.copy()
+
+    def calcOpticalFlowPyrLK(self, prev, nxt, prev_pts, next_pts=None, flags=0, minEig=1e-4):
+        c = self.ctx
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        npts = np.zeros_like(pp) if next_pts is None else np.ascontiguousarray(next_pts, np.float32).reshape(-1, 2).copy()
+        n = len(pp)
+        st = np.zeros(max(n, 1), np.uint8); er = np.zeros(max(n, 1), np.float32)
+        c.check(c.L.eorb_calc_optical_flow_pyr_lk(c.h, _p(prev), _p(nxt), prev.shape[1], prev.shape[0], prev.shape[1], _p(pp), _p(npts), n,
+                                                  self.mPatchSz, self.mMaxLevel, self.maxItr, float(self.eps), int(flags), float(minEig),
+                                                  _p(st), _p(er)))
+        return npts, st[:n], er[:n]
+
+    def trackCurrImage(self, currImage, kpts=None):             # :49-98: the initial-flow form when a guess of matching size is given
+        if kpts is not None and len(kpts) == len(self.mRefPoints):
+            return self.calcOpticalFlowPyrLK(self.mRefFrame, currImage, self.mRefPoints, kpts, flags=4)
+        return self.calcOpticalFlowPyrLK(self.mRefFrame, currImage, self.mRefPoints)
+
+    def refineTrackedPts(self, currPts, status, vCntMatches=None):           # :104-151
+        n = len(self.mRefPoints)
+        cnt = np.ones(n, np.int32) if vCntMatches is None or len(vCntMatches) == 0 else np.asarray(vCntMatches, np.int32).copy()
+        p1 = self.mRefKPoints.copy(); p1["x"] = currPts[:, 0]; p1["y"] = currPts[:, 1]
+        H, W = self.mRefFrame.shape
+        ok = (status == 1) & (currPts[:, 0] >= 0) & (currPts[:, 0] < np.float32(W)) & (currPts[:, 1] >= 0) & (currPts[:, 1] < np.float32(H))
+        cnt[ok] += 1
+        m12 = np.where(ok, np.arange(n), -1).astype(np.int32)
+        d = currPts[ok] - self.mRefPoints[ok]
+        disp = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32))
+        return int(ok.sum()), p1, m12, cnt, disp
+
+    def trackAndMatchCurrImage(self, image, vCntMatches=None):               # :215-234
+        pts, st, err = self.trackCurrImage(image, self.mLastTrackedPts)
+        self.mLastTrackedPts = pts
+        nm, p1, m12, cnt, disp = self.refineTrackedPts(pts, st, vCntMatches)
+        self.mLastTrackedKPts = p1
+        return nm, p1, m12, cnt, disp
+
+    def refineFirstOctaveLevel(self, vMatches12, vCntMatches, nMatches):     # :153-181
+        m = np.asarray(vMatches12, np.int32).copy(); cnt = np.asarray(vCntMatches, np.int32).copy()
+        bad = (m >= 0) & (self.mRefKPoints["octave"] > 0)
+        m[bad] = -1; cnt[bad] -= 1
+        return nMatches - int(bad.sum()), m, cnt
+
+
 class ORBVocabulary:
     """DBoW2 vocabulary resident on the device (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h); voc = dict(L, child_off, child_ids,
     node_desc, word_id, weight) as TemplatedVocabulary::loadFromTextFile leaves m_nodes (node 0 = root)."""

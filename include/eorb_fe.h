@@ -284,6 +284,18 @@ int eorb_kf_radius_match(eorb_ctx* ctx,
  * to offsets[m]) with the least median Hamming distance to the others, -1 when there is none. */
 int eorb_distinctive_descriptors(eorb_ctx* ctx, const uint8_t* desc, const int32_t* offsets, int M, int32_t* best);
 
+/* ---- KLT tracker ----------------------------------------------------------------------------------
+ * replaces cv::calcOpticalFlowPyrLK(mRefFrame, currImage, mRefPoints, kpts, status, err, Size(mPatchSz, mPatchSz), mMaxLevel,
+ * mLKCriteria, flags) inside ELK_Tracker::trackCurrImage (src/Event/KLT_Tracker.cpp:49-98; Event.klt.* of
+ * Examples/Event/EvETHZ.yaml:205-208: winSize 23, maxLevel 1, maxIter 10, eps 0.03).  8-bit single-channel images.
+ * TermCriteria(COUNT + EPS, maxCount, epsilon); flags: 4 = OPTFLOW_USE_INITIAL_FLOW (next_pts holds the initial guess),
+ * 8 = OPTFLOW_LK_GET_MIN_EIGENVALS; minEigThreshold = 1e-4 is OpenCV's default.  next_pts (n x 2) in/out, status / err (n) out.
+ * The match bookkeeping around it (refineTrackedPts :104-151, refineFirstOctaveLevel :153-205) is host logic and stays in the
+ * adapter. */
+int eorb_calc_optical_flow_pyr_lk(eorb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int W, int H, int stride,
+                                  const float* prev_pts, float* next_pts, int n, int win, int maxLevel, int maxCount, double epsilon,
+                                  int flags, float minEigThreshold, uint8_t* status, float* err);
+
 /* ---- DBoW2 vocabulary transform: the producer of the feature vectors SearchByBoW consumes ----------
  * The vocabulary tree (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h: m_nodes after loadFromTextFile :1338-1430) flattened:
  * node 0 = root; children of node i = child_ids[child_off[i] .. child_off[i+1]) in `children` order; a node without children

@@ -285,6 +285,12 @@ void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const
  * the others (first minimum), or -1 when the map point has no descriptor. */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* offsets, int M, int32_t* best);
 
+/* cv::calcOpticalFlowPyrLK as ELK_Tracker::trackCurrImage calls it (src/Event/KLT_Tracker.cpp:49-98): see orc_klt.c.
+ * flags: 4 = OPTFLOW_USE_INITIAL_FLOW, 8 = OPTFLOW_LK_GET_MIN_EIGENVALS.  next_pts (n x 2) in/out, status / err (n) out. */
+void orc_calc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int W, int H, int stride, const float* prev_pts,
+                                  float* next_pts, int n, int win, int maxLevel, int maxCount, double epsilon, int flags,
+                                  float minEigThreshold, uint8_t* status, float* err);
+
 /* DBoW2 vocabulary tree (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h: m_nodes) flattened: node 0 = root; children of node i =
  * child_ids[child_off[i] .. child_off[i+1]) in `children` order; a node without children is a word (isLeaf) with word_id / weight. */
 typedef struct {

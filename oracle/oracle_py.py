@@ -535,3 +535,16 @@ def parse_events_text(text):
     if r < 0:
         raise ValueError(-r - 1)
     return out[:r].copy()
+
+
+def calc_optical_flow_pyr_lk(prev, nxt, prev_pts, next_pts=None, win=23, maxLevel=1, maxCount=10, epsilon=0.03, flags=0, minEig=1e-4):
+    prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+    pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+    npts = np.zeros_like(pp) if next_pts is None else np.ascontiguousarray(next_pts, np.float32).reshape(-1, 2).copy()
+    n = len(pp)
+    st = np.zeros(max(n, 1), np.uint8); er = np.zeros(max(n, 1), np.float32)
+    L = lib(); L.orc_calc_optical_flow_pyr_lk.restype = None
+    L.orc_calc_optical_flow_pyr_lk(_p(prev), _p(nxt), C.c_int(prev.shape[1]), C.c_int(prev.shape[0]), C.c_int(prev.shape[1]), _p(pp), _p(npts),
+                                   C.c_int(n), C.c_int(win), C.c_int(maxLevel), C.c_int(maxCount), C.c_double(epsilon), C.c_int(flags),
+                                   C.c_float(minEig), _p(st), _p(er))
+    return npts, st[:n], er[:n]

@@ -535,6 +535,39 @@ def test_bow_transform(oracle, fe, ctx, k, L, ragged):
         fe.ORBVocabulary(bad, ctx=ctx)
 
 
+@pytest.mark.parametrize("win,maxLevel", [(23, 1), (23, 3), (15, 0), (9, 2)])
+def test_klt_pyr_lk(oracle, fe, ctx, win, maxLevel):
+    """f2: cv::calcOpticalFlowPyrLK as ELK_Tracker calls it: points, status and err bit-identical to the oracle restatement,
+    with and without OPTFLOW_USE_INITIAL_FLOW, incl. points at the image border, flat patches and points that leave the image."""
+    W, H = 240, 180
+    img1 = synth.texture_image(W, H, seed=21)
+    rng = np.random.default_rng(4)
+    img2 = np.roll(img1, (2, -3), axis=(0, 1)).astype(np.int32) + rng.integers(-3, 4, (H, W))
+    img2 = np.clip(img2, 0, 255).astype(np.uint8)
+    img2[100:140, 150:200] = 90                                           # a flat block: minEig test and lost tracks
+    e = oracle.OrbExtractor(600, 1.2, 4, 10, 0, edgeTh=19)
+    _, k, _, _ = e.extract(img1)
+    pts = np.stack([k["x"], k["y"]], axis=1).astype(np.float32)
+    extra = np.array([[0.0, 0.0], [239.9, 179.9], [1.5, 100.25], [238.0, 3.0], [-20.0, 50.0], [300.0, 90.0], [120.0, -30.0],
+                      [175.5, 120.5], [5.0, 5.0]], np.float32)
+    pts = np.concatenate([pts + rng.uniform(-0.5, 0.5, pts.shape).astype(np.float32), extra])
+    trk = fe.ELK_Tracker(win, maxLevel, 10, 0.03, ctx=ctx)
+    for flags, guess in ((0, None), (4, pts + np.float32([-2.5, 1.5])), (8, None), (4, pts + np.float32([40.0, -40.0]))):
+        on, os_, oe = oracle.calc_optical_flow_pyr_lk(img1, img2, pts, guess, win, maxLevel, 10, 0.03, flags)
+        gn, gs, ge = trk.calcOpticalFlowPyrLK(img1, img2, pts, guess, flags)
+        assert np.array_equal(os_, gs)
+        assert np.array_equal(on.view(np.uint32), gn.view(np.uint32)) and np.array_equal(oe.view(np.uint32), ge.view(np.uint32))
+    on, os_, oe = oracle.calc_optical_flow_pyr_lk(img1, img2, pts, None, win, maxLevel, 10, 0.03, 0)
+    good = os_ == 1
+    assert good.sum() > 200 and (~good).sum() >= 3
+    d = on[good] - pts[good]
+    assert np.median(np.abs(d - np.float32([-3, 2]))) < 0.2                # it is an optical-flow tracker
+    # ELK_Tracker bookkeeping on top (refineTrackedPts): host logic
+    trk.setRefImage(img1, np.concatenate([k, k[:len(extra)]]))
+    nm, p1, m12, cnt, disp = trk.trackAndMatchCurrImage(img2)
+    assert nm == (m12 >= 0).sum() and len(disp) == nm and nm > 200
+
+
 def test_distinctive_descriptors(oracle, fe, ctx):
     """f3: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:349-423), batched; sizes 0, 1, 2, even/odd, > 64 rows."""
     rng = np.random.default_rng(5)
