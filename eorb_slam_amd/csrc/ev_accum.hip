@@ -428,15 +428,15 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 8; k++) if (k < rw) owner[bs2][coff + k] = (uint8_t)lane;
                 if (lane == 63) ncols[bs2] = incl;
-                uint64_t mine = 0;
+                // colsel / rowsel: every pixel lane keeps the ballot of its own column / row (the lane -> column / row mapping is
+                // a compile-time pattern, so this is 32 selects and no cross-lane traffic)
+                uint64_t cs = 0, rs = 0;
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
                     const uint64_t cb = __ballot((xm >> b) & 1u), rb = __ballot((ym >> b) & 1u);
-                    mine = (lane == b) ? cb : mine;
-                    mine = (lane == 8 + b) ? rb : mine;
+                    cs = (lx == b) ? cb : cs;
+                    rs = (ly == b) ? rb : rs;
                 }
-                const uint64_t cs = (uint64_t)__shfl((unsigned long long)mine, lx, 64);
-                const uint64_t rs = (uint64_t)__shfl((unsigned long long)mine, 8 + ly, 64);
                 pm[bs3][lane] = cs & rs;
                 if (t + 1 < nbatch) load_batch();       // prefetch batch t+1
 #ifdef EORB_DIAG
