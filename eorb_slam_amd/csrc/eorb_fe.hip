@@ -13,6 +13,7 @@ namespace eorb {
 int ev_decode_minmax(eorb_ctx* c, const uint32_t* d_enc, float* d_out, int B);
 int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long* bad_out);
 int ev_diag_read(unsigned long long* out16);
+int ev_trace_read(unsigned long long* out, int n);
 int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], double angle,
                     const double axis[3], const double tt[3], float medDepth, const float* d_depth);
 int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], const float* params, int nparams);
@@ -497,6 +498,7 @@ int eorb_selfcheck_math(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bi
 
 #ifdef EORB_DIAG
 int eorb_diag_read(unsigned long long* out16) { return ev_diag_read(out16); }
+int eorb_trace_read(unsigned long long* out, int n) { return ev_trace_read(out, n); }
 #endif
 
 // ---- ORB extractor, host buffers -----------------------------------------------------------------------

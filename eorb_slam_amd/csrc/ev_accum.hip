@@ -254,7 +254,7 @@ struct GatherParams {
     float rcp_norm;      // RN(1/norm)
     int div_is_pow2, fast_norm;
     const float* stamps;  // RAW: per sensor pixel the (2h+1)^2 stamp values, [column][row]
-    int stamp_stride;
+    int stamp_stride, stamp_colstride;   // floats per sensor pixel / per (16-byte padded) stamp column
 };
 
 // K2: one 512-thread workgroup per 8x8 tile (EORB_GATHER_THREADS overrides: 256..1024 measured, 512 fastest); the tile's entries are consumed in batches of 64 (event order)
@@ -278,6 +278,14 @@ constexpr int kGatherThreads = EORB_GATHER_THREADS;
 
 #ifdef EORB_DIAG
 __device__ unsigned long long g_diag[16];
+#endif
+#ifdef EORB_TRACE
+// timeline of the heaviest tile's workgroup: [wave][batch - 200][stamp], shader-clock ticks
+__device__ unsigned long long g_trace[16 * 64 * 8];
+#define EORB_TR(k) do { if (blockIdx.x == 0 && t >= 200 && t < 264 && lane == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    g_trace[(wave * 64 + (t - 200)) * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define EORB_TR(k) do { } while (0)
 #endif
 
 // MODE 0: general sigma (IEEE divisions); 1: 2*sig2 a power of two and reciprocal+fma normalisation (sigma = 1, 0.5, 2 ...);
@@ -349,12 +357,14 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 #ifdef EORB_DIAG
         const unsigned long long d_s = __builtin_readcyclecounter();
 #endif
+        EORB_TR(0);
         if (wave == 0) {
             // ---- adds(t-2) ----
             if (t >= 2) {
                 const int bs3 = (t - 2) % 3, bs2 = t & 1;
                 const uint64_t m = pm[bs3][lane];
                 const int cnt = __popcll(m);
+                EORB_TR(1);
                 int mx = 0;                                             // wave max of cnt (<= 64) by bisection on ballots
 #pragma unroll
                 for (int b = 6; b >= 0; b--) { const int tr = mx | (1 << b); if (__any(cnt >= tr)) mx = tr; }
@@ -420,6 +430,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                         ra0 = a0; rb0 = b0; rw = a1 - a0 + 1; rh = b1 - b0 + 1;
                     }
                 }
+                EORB_TR(1);
                 EvEntryInfo ei; ei.xy = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16); ei.xr = xr; ei.yr = yr; ei.sg = esg;
                 einfo[bs2][lane] = ei;
                 const int incl = wave_incl_scan(rw);
@@ -428,6 +439,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 8; k++) if (k < rw) owner[bs2][coff + k] = (uint8_t)lane;
                 if (lane == 63) ncols[bs2] = incl;
+                EORB_TR(2);
                 // colsel / rowsel: every pixel lane keeps the ballot of its own column / row (the lane -> column / row mapping is
                 // a compile-time pattern, so this is 32 selects and no cross-lane traffic)
                 uint64_t cs = 0, rs = 0;
@@ -438,6 +450,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     rs = (ly == b) ? rb : rs;
                 }
                 pm[bs3][lane] = cs & rs;
+                EORB_TR(3);
                 if (t + 1 < nbatch) load_batch();       // prefetch batch t+1
 #ifdef EORB_DIAG
                 d_setup += __builtin_readcyclecounter() - d_s;
@@ -448,6 +461,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
             if (wave >= 2 && t >= 1 && t <= nbatch) {
                 const int bs3 = (t - 1) % 3, bs2 = (t - 1) & 1;
                 const int C = ncols[bs2];
+                EORB_TR(1);
                 float* vbase = vals[bs2];
                 float* sink = vbase + kValStride * 64;                  // masked-off rows store here (never read)
 #ifdef EORB_KO_VALS
@@ -463,31 +477,39 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     const int b0 = (int)((ri >> 4) & 15u);
                     const int rh = act ? (int)((ri >> 12) & 15u) : 0;
                     const int xi = (int)(int16_t)(ei.xy & 0xffff), yi = (int)(int16_t)(ei.xy >> 16);
+                    if (g0 == (wave - 2) * 64) EORB_TR(2); else EORB_TR(4);
                     const uint64_t below = (1ull << e) - 1ull;
                     const int dy0 = ty0 + b0 - yi;
                     const int pix0 = act ? b0 * 8 + qx : 0;              // pixel of the column's first row; rows step by 8
                     const uint64_t* pmc = &pm[bs3][pix0];
                     float* vcol = vbase + pix0 * kValStride;
                     if (RAW && MODE != 2) {
-                        // stamp values of this sensor pixel come from the table built once per (maps, sigma): column i, rows j0..
-                        const uint32_t soff = act ? __float_as_uint(ei.xr) * (uint32_t)P.stamp_stride + (uint32_t)((tx0 + qx - xi + h) * (2 * h + 1) + (dy0 + h)) : 0u;
-                        const float* sp = P.stamps + soff;
-                        const int rhm1 = max(rh - 1, 0);
-                        constexpr int UR = 4;
-                        for (int jj = 0; __any(jj < rh); jj += UR) {
-                            float v[UR]; int rank[UR]; bool on[UR];
+                        // stamp values of this sensor pixel come from the table built once per (maps, sigma).  A column of the
+                        // table is padded to a multiple of 4 floats, so the lane fetches it with 16-byte loads and walks its
+                        // slots with static register indices: slot k is tile row b0 + (k - j0) when that row exists.
+                        const int SWP = P.stamp_colstride;
+                        const int j0 = dy0 + h;
+                        const float4* sp4 = (const float4*)(P.stamps + (act ? (size_t)__float_as_uint(ei.xr) * P.stamp_stride + (size_t)(tx0 + qx - xi + h) * SWP : 0));
+                        for (int k0 = 0; k0 < SWP; k0 += 8) {
+                            const float4 c0 = sp4[k0 >> 2];
+                            const float4 c1 = (k0 + 4 < SWP) ? sp4[(k0 >> 2) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (g0 == (wave - 2) * 64 && k0 == 0) EORB_TR(3);
+                            const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                            int pixk[8], rank[8]; bool on[8];
 #pragma unroll
-                            for (int u = 0; u < UR; u++) {
-                                on[u] = jj + u < rh;
-                                v[u] = sp[min(jj + u, rhm1)];            // clamped, always a valid table slot: no branch around the load
+                            for (int u = 0; u < 8; u++) {
+                                const int r = k0 + u - j0;
+                                on[u] = (unsigned)r < (unsigned)rh;
+                                pixk[u] = on[u] ? r * 8 : 0;
+                                rank[u] = __popcll(pmc[pixk[u]] & below);
                             }
+                            if (g0 == (wave - 2) * 64 && k0 == 0) EORB_TR(5);
 #pragma unroll
-                            for (int u = 0; u < UR; u++) rank[u] = __popcll(pmc[on[u] ? (jj + u) * 8 : 0] & below);
-#pragma unroll
-                            for (int u = 0; u < UR; u++) {
-                                float* dst = on[u] ? vcol + (jj + u) * 8 * kValStride + rank[u] : sink;
-                                *dst = POL ? ei.sg * v[u] : v[u];
+                            for (int u = 0; u < 8; u++) {
+                                float* dst = on[u] ? vcol + pixk[u] * kValStride + rank[u] : sink;
+                                *dst = POL ? ei.sg * col[u] : col[u];
                             }
+                            if (g0 == (wave - 2) * 64 && k0 == 0) EORB_TR(7);
                         }
                         continue;
                     }
@@ -566,6 +588,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 #ifdef EORB_DIAG
         d_work += __builtin_readcyclecounter() - d_s;
 #endif
+        EORB_TR(6);
         __syncthreads();
     }
 #ifdef EORB_DIAG
@@ -835,15 +858,15 @@ __global__ void ev_stamp_kernel(const float2* __restrict__ lut, const uint32_t* 
     __shared__ uint64_t tab[32];
     if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
     __syncthreads();
-    const int SW = 2 * P.h + 1;
-    const size_t total = (size_t)n * SW * SW;
+    const int SW = 2 * P.h + 1, SWP = P.stamp_colstride;
+    const size_t total = (size_t)n * SW * SWP;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
-        const int src = (int)(k / (SW * SW)), r = (int)(k - (size_t)src * SW * SW);
-        const int i = r / SW, j = r - i * SW;
+        const int src = (int)(k / (SW * SWP)), r = (int)(k - (size_t)src * SW * SWP);
+        const int i = r / SWP, j = r - i * SWP;
         const uint32_t w = info[src];
         const int xi = (int)(int16_t)(w & 0xffff), yi = (int)(int16_t)(w >> 16);
         float v = 0.f;
-        if (xi != -32768) {
+        if (xi != -32768 && j < SW) {
             const float2 q = lut[src];
             const float xr = q.x - (float)xi, yr = q.y - (float)yi;
             const float fx = (float)(i - P.h) - xr, fy = (float)(j - P.h) - yr;
@@ -1132,7 +1155,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
 
     const float sig2 = sigma * sigma;
     GatherParams G{W, H, h, TX, TY, NT, mode_count, nb, 2.0f * sig2,
-                   2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0, nullptr, 0};
+                   2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0, nullptr, 0, 0};
     {
         int ex2 = 0;
         const float mant = frexpf(G.two_sig2, &ex2);
@@ -1146,21 +1169,22 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     if (raw) {
         // tables derived from the maps; rebuilt only when (image size, sigma, mode) change
         const int nsrc = c->lut_w * c->lut_h;
-        const int SW = 2 * h + 1;
+        const int SW = 2 * h + 1, SWP = (SW + 3) & ~3;
+        G.stamp_stride = SW * SWP; G.stamp_colstride = SWP;
         if (c->lut_key_W != W || c->lut_key_H != H || c->lut_key_sigma != sigma || c->lut_key_mode != mode_count) {
             ProfScope ps(c, "ev_stamp_tables");
             if ((rc = ensure(c, c->src_info, sizeof(uint32_t) * (size_t)nsrc))) return rc;
             ev_src_info_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, nsrc, W, H, c->lut_check, mode_count,
                                                                             (uint32_t*)c->src_info.p);
             if (!mode_count) {
-                if ((rc = ensure(c, c->stamps, sizeof(float) * (size_t)nsrc * SW * SW))) return rc;
+                if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 8)))) return rc;
                 ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
                                                              (float*)c->stamps.p);
             }
             EORB_LAUNCH_CHECK(c, "ev_stamp_tables kernels");
             c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
         }
-        G.stamps = (const float*)c->stamps.p; G.stamp_stride = SW * SW;
+        G.stamps = (const float*)c->stamps.p;
     }
     {
         ProfScope ps(c, "ev_minmax_init");
@@ -1254,6 +1278,17 @@ int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long
     EORB_HIP(c, hipMemcpyAsync(bad_out, c->minmax.p, 8, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     return EORB_OK;
+}
+
+int ev_trace_read(unsigned long long* out, int n)
+{
+#ifdef EORB_TRACE
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * std::min(n, 16 * 64 * 8));
+    return 1;
+#else
+    (void)out; (void)n; return 0;
+#endif
 }
 
 int ev_diag_read(unsigned long long* out16)
