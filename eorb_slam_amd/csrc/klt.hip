@@ -4,9 +4,10 @@
 //   klt_level0 / klt_pyrdown / klt_pad   buildOpticalFlowPyramid: 5x5 [1 4 6 4 1] pyrDown, every level padded by the window size
 //                                        with BORDER_REFLECT_101
 //   klt_scharr                           calcSharrDeriv of the reference-frame levels (int16 dx, dy; zero padding)
-//   klt_track                            LKTrackerInvoker: one thread per point walks the levels coarse to fine; 14-bit
-//                                        fixed-point bilinear patches, float normal equations accumulated in raster order (the
-//                                        order is part of the result, so the window loop of a point is not split over lanes)
+//   klt_track                            LKTrackerInvoker: one wavefront per point walks the levels coarse to fine; 14-bit
+//                                        fixed-point bilinear patches computed lane-parallel into LDS, the float normal
+//                                        equations summed from there in raster order by single lanes (the order is part of
+//                                        the result)
 #include "eorb_ctx.h"
 #include "dev_math.h"
 #include <algorithm>
@@ -90,22 +91,40 @@ struct KltArgs {
     const float* prev_pts; float* next_pts; int n;
     int maxCount; double epsilon; int flags; float minEig;
     uint8_t* status; float* err;
-    short* scratch;                    // [3 * win * win][n]: I patch, dIx, dIy of every point
 };
 
+constexpr int kKltMaxWin = 31;         // window side handled by the LDS patch buffers (the reference uses 23)
+
+// float sum of v[0..n) in index order, by ONE lane (the order is part of the result); four values per LDS read
+__device__ __forceinline__ float klt_ordered_sum(const float* v, int n)
+{
+    float s = 0.f;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+        const float4 q = *(const float4*)(v + k);
+        s = s + q.x; s = s + q.y; s = s + q.z; s = s + q.w;
+    }
+    for (; k < n; k++) s = s + v[k];
+    return s;
+}
+
+// One wavefront per point.  Lanes share the window's pixels for the fixed-point patch arithmetic (independent per pixel); the
+// float accumulations of the normal equations run in raster order on single lanes (lane 0: A11 / b1 / err, lane 1: A12 / b2,
+// lane 2: A22) from products staged in LDS.
 __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
 {
-    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pt >= A.n) return;
-    const int win = A.P.win, n = A.n, WW = win * win;
+    __shared__ short sI[kKltMaxWin * kKltMaxWin], sDx[kKltMaxWin * kKltMaxWin], sDy[kKltMaxWin * kKltMaxWin];
+    __shared__ __attribute__((aligned(16))) float sP0[kKltMaxWin * kKltMaxWin + 3], sP1[kKltMaxWin * kKltMaxWin + 3],
+        sP2[kKltMaxWin * kKltMaxWin + 3];
+    const int pt = blockIdx.x, lane = threadIdx.x;
+    const int win = A.P.win, WW = win * win;
     const float halfWin = (win - 1) * 0.5f;
-    short* Iw = A.scratch + pt;                          // element k at Iw[k * n]
-    short* dX = A.scratch + (size_t)WW * n + pt;
-    short* dY = A.scratch + (size_t)2 * WW * n + pt;
     const int maxLevel = A.P.levels - 1;
     bool st = true; float errv = 0.f;
     float outx = A.next_pts[2 * pt], outy = A.next_pts[2 * pt + 1];
     const float ppx = A.prev_pts[2 * pt], ppy = A.prev_pts[2 * pt + 1];
+    const int W_BITS = 14, W_BITS1 = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
     for (int level = maxLevel; level >= 0; level--) {
         const KltLevel L = A.P.lv[level];
         const int stp = L.stride;
@@ -127,26 +146,27 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
             continue;
         }
         float a = prevx - (float)ipx, b = prevy - (float)ipy;
-        const int W_BITS = 14, W_BITS1 = 14;
-        const float FLT_SCALE = 1.f / (1 << 20);
         int iw00 = dev_cvround((1.f - a) * (1.f - b) * (1 << W_BITS));
         int iw01 = dev_cvround(a * (1.f - b) * (1 << W_BITS));
         int iw10 = dev_cvround((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-        float iA11 = 0.f, iA12 = 0.f, iA22 = 0.f;
-        for (int y = 0; y < win; y++) {
-            const uint8_t* src = I + (ptrdiff_t)(y + ipy) * stp + ipx;
-            const int16_t* ds = dI + ((ptrdiff_t)(y + ipy) * stp + ipx) * 2;
-            for (int x = 0; x < win; x++, ds += 2) {
-                const int ival = KLT_DESCALE(src[x] * iw00 + src[x + 1] * iw01 + src[x + stp] * iw10 + src[x + stp + 1] * iw11, W_BITS1 - 5);
-                const int ixval = KLT_DESCALE(ds[0] * iw00 + ds[2] * iw01 + ds[2 * stp] * iw10 + ds[2 * stp + 2] * iw11, W_BITS1);
-                const int iyval = KLT_DESCALE(ds[1] * iw00 + ds[3] * iw01 + ds[2 * stp + 1] * iw10 + ds[2 * stp + 3] * iw11, W_BITS1);
-                const size_t k = (size_t)(y * win + x) * n;
-                Iw[k] = (short)ival; dX[k] = (short)ixval; dY[k] = (short)iyval;
-                iA11 = iA11 + (float)(ixval * ixval); iA12 = iA12 + (float)(ixval * iyval); iA22 = iA22 + (float)(iyval * iyval);
-            }
+        __syncthreads();                                          // the previous level's readers are done with the buffers
+        for (int k = lane; k < WW; k += 64) {
+            const int y = k / win, x = k - y * win;
+            const uint8_t* src = I + (ptrdiff_t)(y + ipy) * stp + ipx + x;
+            const int16_t* ds = dI + ((ptrdiff_t)(y + ipy) * stp + ipx + x) * 2;
+            const int ival = KLT_DESCALE(src[0] * iw00 + src[1] * iw01 + src[stp] * iw10 + src[stp + 1] * iw11, W_BITS1 - 5);
+            const int ixval = KLT_DESCALE(ds[0] * iw00 + ds[2] * iw01 + ds[2 * stp] * iw10 + ds[2 * stp + 2] * iw11, W_BITS1);
+            const int iyval = KLT_DESCALE(ds[1] * iw00 + ds[3] * iw01 + ds[2 * stp + 1] * iw10 + ds[2 * stp + 3] * iw11, W_BITS1);
+            sI[k] = (short)ival; sDx[k] = (short)ixval; sDy[k] = (short)iyval;
+            sP0[k] = (float)(ixval * ixval); sP1[k] = (float)(ixval * iyval); sP2[k] = (float)(iyval * iyval);
         }
-        const float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
+        __syncthreads();
+        float acc = 0.f;
+        if (lane == 0) acc = klt_ordered_sum(sP0, WW);
+        else if (lane == 1) acc = klt_ordered_sum(sP1, WW);
+        else if (lane == 2) acc = klt_ordered_sum(sP2, WW);
+        const float A11 = __shfl(acc, 0, 64) * FLT_SCALE, A12 = __shfl(acc, 1, 64) * FLT_SCALE, A22 = __shfl(acc, 2, 64) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dif = A11 - A22;
         const float minEig = (A22 + A11 - sqrtf(dif * dif + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -169,16 +189,18 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
             iw01 = dev_cvround(a * (1.f - b) * (1 << W_BITS));
             iw10 = dev_cvround((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            float ib1 = 0.f, ib2 = 0.f;
-            for (int y = 0; y < win; y++) {
-                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx;
-                for (int x = 0; x < win; x++) {
-                    const size_t k = (size_t)(y * win + x) * n;
-                    const int diff = KLT_DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stp] * iw10 + Jp[x + stp + 1] * iw11, W_BITS1 - 5) - Iw[k];
-                    ib1 = ib1 + (float)(diff * dX[k]); ib2 = ib2 + (float)(diff * dY[k]);
-                }
+            __syncthreads();                                      // last iteration's sums have been read
+            for (int k = lane; k < WW; k += 64) {
+                const int y = k / win, x = k - y * win;
+                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx + x;
+                const int diff = KLT_DESCALE(Jp[0] * iw00 + Jp[1] * iw01 + Jp[stp] * iw10 + Jp[stp + 1] * iw11, W_BITS1 - 5) - sI[k];
+                sP0[k] = (float)(diff * sDx[k]); sP1[k] = (float)(diff * sDy[k]);
             }
-            const float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+            __syncthreads();
+            float sb = 0.f;
+            if (lane == 0) sb = klt_ordered_sum(sP0, WW);
+            else if (lane == 1) sb = klt_ordered_sum(sP1, WW);
+            const float b1 = __shfl(sb, 0, 64) * FLT_SCALE, b2 = __shfl(sb, 1, 64) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
             nextx += dx; nexty += dy;
             outx = nextx + halfWin; outy = nexty + halfWin;
@@ -198,20 +220,24 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
             iw01 = dev_cvround(aa * (1.f - bb) * (1 << W_BITS));
             iw10 = dev_cvround((1.f - aa) * bb * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            float e = 0.f;
-            for (int y = 0; y < win; y++) {
-                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx;
-                for (int x = 0; x < win; x++) {
-                    const int diff = KLT_DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stp] * iw10 + Jp[x + stp + 1] * iw11, W_BITS1 - 5)
-                                     - Iw[(size_t)(y * win + x) * n];
-                    e = e + fabsf((float)diff);
-                }
+            __syncthreads();
+            for (int k = lane; k < WW; k += 64) {
+                const int y = k / win, x = k - y * win;
+                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx + x;
+                const int diff = KLT_DESCALE(Jp[0] * iw00 + Jp[1] * iw01 + Jp[stp] * iw10 + Jp[stp + 1] * iw11, W_BITS1 - 5) - sI[k];
+                sP0[k] = fabsf((float)diff);
             }
+            __syncthreads();
+            float e = 0.f;
+            if (lane == 0) e = klt_ordered_sum(sP0, WW);
+            e = __shfl(e, 0, 64);
             errv = e * 1.f / (float)(32 * win * win);
         }
     }
-    A.next_pts[2 * pt] = outx; A.next_pts[2 * pt + 1] = outy;
-    A.status[pt] = st ? 1 : 0; A.err[pt] = errv;
+    if (lane == 0) {
+        A.next_pts[2 * pt] = outx; A.next_pts[2 * pt + 1] = outy;
+        A.status[pt] = st ? 1 : 0; A.err[pt] = errv;
+    }
 }
 
 // d_prev / d_next: W x H u8 images (row stride `stride`); d_prev_pts, d_next_pts: n x 2 floats; everything device resident
@@ -219,6 +245,7 @@ int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int
                   float* d_next_pts, int n, int win, int maxLevel, int maxCount, double epsilon, int flags, float minEig,
                   uint8_t* d_status, float* d_err)
 {
+    if (win > kKltMaxWin) return set_err(c, EORB_E_CAPACITY, "klt: window %d exceeds the %d-pixel LDS patch", win, kKltMaxWin);
     KltPyr P{}; P.win = win;
     size_t off = 0;
     {
@@ -236,7 +263,6 @@ int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int
     int rc;
     if ((rc = ensure(c, c->klt_pyr, 2 * one))) return rc;
     if ((rc = ensure(c, c->klt_der, sizeof(int16_t) * 2 * one))) return rc;
-    if ((rc = ensure(c, c->klt_scratch, sizeof(short) * 3 * (size_t)win * win * std::max(n, 1)))) return rc;
     uint8_t* pyr = (uint8_t*)c->klt_pyr.p; int16_t* der = (int16_t*)c->klt_der.p;
     ProfScope ps(c, "klt_track");
     EORB_HIP(c, hipMemsetAsync(der, 0, sizeof(int16_t) * 2 * one, c->stream));           // derivative padding = BORDER_CONSTANT 0
@@ -255,11 +281,10 @@ int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int
         }
     }
     if (n > 0) {
-        KltArgs A{P, one, pyr, der, d_prev_pts, d_next_pts, n, std::min(std::max(maxCount, 0), 100), 0.0, flags, minEig, d_status, d_err,
-                  (short*)c->klt_scratch.p};
+        KltArgs A{P, one, pyr, der, d_prev_pts, d_next_pts, n, std::min(std::max(maxCount, 0), 100), 0.0, flags, minEig, d_status, d_err};
         double eps = std::min(std::max(epsilon, 0.0), 10.0);
         A.epsilon = eps * eps;
-        klt_track_kernel<<<(n + 63) / 64, 64, 0, c->stream>>>(A);
+        klt_track_kernel<<<n, 64, 0, c->stream>>>(A);
     }
     EORB_LAUNCH_CHECK(c, "klt kernels");
     return EORB_OK;
