@@ -45,6 +45,8 @@ int kf_radius_dev(eorb_ctx* c, const RadArgs& A, uint16_t* d_cell);
 int bow_transform_dev(eorb_ctx* c, const uint8_t* d_desc, int n, int stride, const BowVoc& V, int levelsup, int weighting, int norm,
                       uint32_t* d_word_of, double* d_w_of, uint32_t* d_node_of, uint32_t* d_bow_word, double* d_bow_val,
                       uint32_t* d_fv_node, int32_t* d_fv_off, int32_t* d_fv_idx, int32_t* d_counts);
+int window_match_dev(eorb_ctx* c, const uint8_t* d_q, int nq, int q_stride, const uint8_t* d_t, int t_stride, const int32_t* d_off,
+                     const int32_t* d_cand, int32_t* d_out);
 int distinctive_dev(eorb_ctx* c, const uint8_t* d_desc, const int32_t* d_offsets, int M, int32_t* d_best);
 int sort_response_dev(eorb_ctx* c, const eorb_keypoint* d_kps, int n, int32_t* d_perm);
 
@@ -1093,6 +1095,35 @@ int eorb_calc_optical_flow_pyr_lk(eorb_ctx* c, const uint8_t* prev, const uint8_
     EORB_HIP(c, hipMemcpyAsync(next_pts, c->m_b.p, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipMemcpyAsync(status, c->m_c.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipMemcpyAsync(err, c->m_d.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+int eorb_hamming_window_match(eorb_ctx* c, const uint8_t* q_desc, int nq, int q_stride, const uint8_t* t_desc, int nt, int t_stride,
+                              const int32_t* cand_offsets, const int32_t* cand_idx, int32_t* best_idx, int32_t* best_d,
+                              int32_t* second_idx, int32_t* second_d)
+{
+    if (!c) return EORB_E_ARG;
+    if (nq < 0 || nt < 0 || q_stride < 32 || t_stride < 32 || (nq > 0 && (!q_desc || !cand_offsets || !best_idx || !best_d || !second_idx || !second_d)))
+        return set_err(c, EORB_E_ARG, "hamming_window_match: bad arguments");
+    hipSetDevice(c->device);
+    if (nq == 0) return EORB_OK;
+    const int ncand = cand_offsets[nq];
+    for (int q = 0; q < nq; q++) if (cand_offsets[q + 1] < cand_offsets[q]) return set_err(c, EORB_E_ARG, "hamming_window_match: offsets not monotone");
+    for (int k = 0; k < ncand; k++) if (cand_idx[k] < 0 || cand_idx[k] >= nt) return set_err(c, EORB_E_ARG, "hamming_window_match: candidate %d out of range", cand_idx[k]);
+    int rc;
+    if ((rc = up(c, c->m_a, q_desc, (size_t)q_stride * nq))) return rc;
+    if ((rc = up(c, c->m_b, t_desc, (size_t)t_stride * std::max(nt, 1)))) return rc;
+    if ((rc = up(c, c->m_c, cand_offsets, sizeof(int32_t) * ((size_t)nq + 1)))) return rc;
+    if ((rc = up(c, c->m_d, cand_idx, sizeof(int32_t) * (size_t)std::max(ncand, 1)))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * 4 * (size_t)nq))) return rc;
+    if ((rc = window_match_dev(c, (const uint8_t*)c->m_a.p, nq, q_stride, (const uint8_t*)c->m_b.p, t_stride, (const int32_t*)c->m_c.p,
+                               (const int32_t*)c->m_d.p, (int32_t*)c->m_h.p))) return rc;
+    int32_t* o = (int32_t*)c->m_h.p;
+    EORB_HIP(c, hipMemcpyAsync(best_idx, o, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(best_d, o + nq, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(second_idx, o + 2 * (size_t)nq, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipMemcpyAsync(second_d, o + 3 * (size_t)nq, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     return EORB_OK;
 }

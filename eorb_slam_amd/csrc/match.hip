@@ -1028,6 +1028,55 @@ int bow_transform_dev(eorb_ctx* c, const uint8_t* d_desc, int n, int stride, con
     return EORB_OK;
 }
 
+// generic windowed matcher (SURVEY §8(b) eorb_hamming_window_match): one wave per query, lanes over its candidate list; key =
+// dist << 32 | position keeps the reference's first-wins order for both the best and the second best
+__global__ __launch_bounds__(256) void window_match_kernel(const uint8_t* __restrict__ q_desc, int nq, int q_stride,
+                                                           const uint8_t* __restrict__ t_desc, int t_stride,
+                                                           const int32_t* __restrict__ off, const int32_t* __restrict__ cand,
+                                                           int32_t* __restrict__ out /* 4 x nq */)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (q >= nq) return;
+    uint64_t q0, q1, q2, q3;
+    load_desc32(q_desc + (size_t)q * q_stride, q0, q1, q2, q3);
+    uint64_t k0 = ~0ull, k1 = ~0ull;
+    const int c0 = off[q], c1 = off[q + 1];
+    for (int k = c0 + lane; k < c1; k += 64) {
+        const int c = cand[k];
+        uint64_t t0, t1, t2, t3;
+        load_desc32(t_desc + (size_t)c * t_stride, t0, t1, t2, t3);
+        const int d = __popcll(q0 ^ t0) + __popcll(q1 ^ t1) + __popcll(q2 ^ t2) + __popcll(q3 ^ t3);
+        const uint64_t key = ((uint64_t)d << 32) | (uint32_t)(k - c0);
+        if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
+        const uint64_t lo = k0 < o0 ? k0 : o0, hi = k0 < o0 ? o0 : k0, s1 = k1 < o1 ? k1 : o1;
+        k0 = lo; k1 = hi < s1 ? hi : s1;
+    }
+    if (lane == 0) {
+        // the sequential rule only records a second best that was seen while it was >= the then-best: with first-wins ties the
+        // top two keys of (dist, position) are exactly best and second
+        const bool hb = k0 != ~0ull, hs = k1 != ~0ull;
+        out[q] = hb ? cand[c0 + (int)(k0 & 0xffffffffu)] : -1;
+        out[nq + q] = hb ? (int)(k0 >> 32) : 256;
+        out[2 * nq + q] = hs ? cand[c0 + (int)(k1 & 0xffffffffu)] : -1;
+        out[3 * nq + q] = hs ? (int)(k1 >> 32) : 256;
+    }
+}
+
+int window_match_dev(eorb_ctx* c, const uint8_t* d_q, int nq, int q_stride, const uint8_t* d_t, int t_stride, const int32_t* d_off,
+                     const int32_t* d_cand, int32_t* d_out)
+{
+    if (nq <= 0) return EORB_OK;
+    ProfScope ps(c, "hamming_window_match");
+    window_match_kernel<<<(nq + 3) / 4, 256, 0, c->stream>>>(d_q, nq, q_stride, d_t, t_stride, d_off, d_cand, d_out);
+    EORB_LAUNCH_CHECK(c, "window_match_kernel");
+    return EORB_OK;
+}
+
 // MixedFrame::sortFeaturesResponse (MixedFrame.cpp:211-225): stable descending order by response.
 // rank(i) = #{j : r_j > r_i} + #{j < i : r_j == r_i}; perm[rank(i)] = i.  n is a few thousand at most.
 __global__ void sort_response_kernel(const eorb_keypoint* __restrict__ kps, int n, int32_t* __restrict__ perm)

@@ -552,6 +552,19 @@ class ORBVocabulary:
         return bw[:nw.value].copy(), bv[:nw.value].copy(), fv
 
 
+def HammingWindowMatch(q_desc, t_desc, cand_offsets, cand_idx, ctx=None):
+    """Best / second-best candidate per query in candidate order (the loop body of the windowed matchers, ORBmatcher.cc:754-774).
+    Returns (best_idx, best_dist, second_idx, second_dist)."""
+    c = ctx or default_context()
+    q = np.ascontiguousarray(q_desc, np.uint8); t = np.ascontiguousarray(t_desc, np.uint8)
+    co = np.ascontiguousarray(cand_offsets, np.int32); ci = np.ascontiguousarray(cand_idx, np.int32)
+    nq = len(q)
+    out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+    c.check(c.L.eorb_hamming_window_match(c.h, _p(q), nq, q.shape[1] if nq else 32, _p(t), len(t), t.shape[1] if len(t) else 32, _p(co), _p(ci),
+                                          _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3])))
+    return tuple(o[:nq] for o in out)
+
+
 def ComputeDistinctiveDescriptors(desc, offsets, ctx=None):
     """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for a batch of map points (CSR offsets)."""
     c = ctx or default_context()

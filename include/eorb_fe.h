@@ -314,6 +314,14 @@ int eorb_bow_transform(eorb_ctx* ctx, const uint8_t* desc, int n, int stride, in
                        uint32_t* bow_word, double* bow_val, int* n_words, uint32_t* fv_node, int32_t* fv_off, int32_t* fv_idx,
                        int* n_fvnodes, int32_t* word_of, int32_t* node_of);
 
+/* The loop body every windowed matcher of src/ORBmatcher.cc shares (e.g. :754-774, :95-130, :2050-2070): for query q the
+ * candidates cand_idx[cand_offsets[q] .. cand_offsets[q+1]) (what GetFeaturesInArea returned, after the caller's gates) are
+ * visited in order with `if (d < best) {second = best; best = d} else if (d < second) second = d` on the first 32 descriptor
+ * bytes.  For adapters that keep the greedy bookkeeping on the host.  Absent: index -1, distance 256. */
+int eorb_hamming_window_match(eorb_ctx* ctx, const uint8_t* q_desc, int nq, int q_stride, const uint8_t* t_desc, int nt, int t_stride,
+                              const int32_t* cand_offsets, const int32_t* cand_idx, int32_t* best_idx, int32_t* best_d,
+                              int32_t* second_idx, int32_t* second_d);
+
 /* replaces MixedFrame::sortFeaturesResponse (src/MixedFrame.cpp:211-225): perm[k] = index of the k-th keypoint in
  * descending-response order, equal responses in insertion order (std::multimap semantics). */
 int eorb_sort_by_response(eorb_ctx* ctx, const eorb_keypoint* kps, int n, int32_t* perm);

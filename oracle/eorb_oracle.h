@@ -311,6 +311,13 @@ void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, in
                        uint32_t* bow_word, double* bow_val, int* n_words, uint32_t* fv_node, int32_t* fv_off, int32_t* fv_idx,
                        int* n_fvnodes, int32_t* word_of, int32_t* node_of);
 
+/* the inner loop every windowed matcher of ORBmatcher.cc shares (e.g. :754-774): per query the candidates
+ * cand_idx[cand_offsets[q] .. cand_offsets[q+1]) are visited in order with `if (d < best) {second = best; best = d; idx = c}
+ * else if (d < second) second = d`.  best_idx / second_idx = -1 and distances = 256 when absent.  First 32 bytes of each row. */
+void orc_hamming_window_match(const uint8_t* q_desc, int nq, int q_stride, const uint8_t* t_desc, int t_stride,
+                              const int32_t* cand_offsets, const int32_t* cand_idx, int32_t* best_idx, int32_t* best_d,
+                              int32_t* second_idx, int32_t* second_d);
+
 /* MixedFrame::sortFeaturesResponse (MixedFrame.cpp:211-225): order = descending response, equal responses keep their
  * insertion order (multimap).  perm[k] = source index of the k-th output element. */
 void orc_sort_by_response(const orc_keypoint* kps, int n, int32_t* perm);

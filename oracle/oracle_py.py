@@ -548,3 +548,14 @@ def calc_optical_flow_pyr_lk(prev, nxt, prev_pts, next_pts=None, win=23, maxLeve
                                    C.c_int(n), C.c_int(win), C.c_int(maxLevel), C.c_int(maxCount), C.c_double(epsilon), C.c_int(flags),
                                    C.c_float(minEig), _p(st), _p(er))
     return npts, st[:n], er[:n]
+
+
+def hamming_window_match(q_desc, t_desc, cand_offsets, cand_idx):
+    q = np.ascontiguousarray(q_desc, np.uint8); t = np.ascontiguousarray(t_desc, np.uint8)
+    co = np.ascontiguousarray(cand_offsets, np.int32); ci = np.ascontiguousarray(cand_idx, np.int32)
+    nq = len(q)
+    out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+    L = lib(); L.orc_hamming_window_match.restype = None
+    L.orc_hamming_window_match(_p(q), C.c_int(nq), C.c_int(q.shape[1] if nq else 32), _p(t), C.c_int(t.shape[1] if len(t) else 32), _p(co), _p(ci),
+                               _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]))
+    return tuple(o[:nq] for o in out)

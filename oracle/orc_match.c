@@ -753,3 +753,20 @@ void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, in
     *n_fvnodes = nn;
     free(words); free(nodes);
 }
+
+/* shared inner loop of the windowed matchers (ORBmatcher.cc:754-774 and its siblings) */
+void orc_hamming_window_match(const uint8_t* q_desc, int nq, int q_stride, const uint8_t* t_desc, int t_stride,
+                              const int32_t* cand_offsets, const int32_t* cand_idx, int32_t* best_idx, int32_t* best_d,
+                              int32_t* second_idx, int32_t* second_d)
+{
+    for (int q = 0; q < nq; q++) {
+        int bd = 256, bi = -1, sd = 256, si = -1;
+        for (int k = cand_offsets[q]; k < cand_offsets[q + 1]; k++) {
+            const int c = cand_idx[k];
+            const int d = orc_descriptor_distance(q_desc + (size_t)q_stride * q, t_desc + (size_t)t_stride * c);
+            if (d < bd) { sd = bd; si = bi; bd = d; bi = c; }
+            else if (d < sd) { sd = d; si = c; }
+        }
+        best_idx[q] = bi; best_d[q] = bd; second_idx[q] = si; second_d[q] = sd;
+    }
+}

@@ -568,6 +568,24 @@ def test_klt_pyr_lk(oracle, fe, ctx, win, maxLevel):
     assert nm == (m12 >= 0).sum() and len(disp) == nm and nm > 200
 
 
+def test_hamming_window_match(oracle, fe, ctx):
+    """The shared inner loop of the windowed matchers: candidate lists from GetFeaturesInArea, best / second in visiting order."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=61, shift=3)
+    F2 = oracle.Frame(k2, d2, 240, 180)
+    offs = [0]; cand = []
+    rng = np.random.default_rng(3)
+    for i in range(len(k1)):
+        c = F2.features_in_area(float(k1["x"][i]) - 3, float(k1["y"][i]) + 3, float(rng.choice([0.5, 8.0, 30.0, 100.0])))
+        cand.extend(c.tolist()); offs.append(len(cand))
+    dd2 = d2.copy(); dd2[::7] = dd2[3]                                    # many equal distances: the visiting order decides
+    o = oracle.hamming_window_match(d1, dd2, offs, cand)
+    g = fe.HammingWindowMatch(d1, dd2, offs, cand, ctx=ctx)
+    assert all(np.array_equal(a, b) for a, b in zip(o, g))
+    assert (o[0] < 0).sum() > 0 and (o[2] >= 0).sum() > 100 and len(cand) > 5000
+    with pytest.raises(fe.EorbError):
+        fe.HammingWindowMatch(d1[:2], dd2, [0, 1, 2], [0, len(dd2)], ctx=ctx)
+
+
 def test_distinctive_descriptors(oracle, fe, ctx):
     """f3: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:349-423), batched; sizes 0, 1, 2, even/odd, > 64 rows."""
     rng = np.random.default_rng(5)
