@@ -208,3 +208,106 @@ def test_extract_empty_image_returns_minus_one(oracle):
     L = oracle.lib()
     n = C.c_int()
     assert L.orc_orb_extract(e.h, None, 0, 0, 0, 0, 1000, 1, None, None, None, 0, C.byref(n)) == -1
+
+
+# ---- known answers for the "next" rows (loader, vocabulary, KeyFrame matchers, LK) derived by hand from the reference -------------
+
+def test_loader_text_and_rectification_known_answers(oracle):
+    """EventLoader.cpp:80-92 "stream >> ts >> x >> y >> p", isComment DataStore.cpp:111-114, ts/tsFactor :120-123,
+    undistPointMaps MyCalibrator.cpp:164-180, isInImage :31-34."""
+    raw = oracle.parse_events_text(b"# header\n0.003811000 96 133 0\n  1468941032.229165\t13 7 1\r\n\n12.5 3 4 1")
+    assert raw["x"].tolist() == [96, 13, 3] and raw["y"].tolist() == [133, 7, 4] and raw["p"].tolist() == [0, 1, 1]
+    assert raw["t"].tolist() == [0.003811, 1468941032.229165, 12.5]          # strtod of the same literals
+    mx = np.arange(20, dtype=np.float32).reshape(1, 20).repeat(10, 0) + 0.25   # map: x + 0.25, y - 0.5
+    my = np.arange(10, dtype=np.float32).reshape(10, 1).repeat(20, 1) - 0.5
+    r = np.zeros(3, oracle.RAW_DTYPE); r["x"] = [3, 19, 5]; r["y"] = [4, 9, 0]; r["p"] = [1, 0, 1]; r["t"] = [2e6, 4e6, 6e6]
+    ev = oracle.undistort_events(r, mx, my, 20, 10, True, 1e6)
+    # (5, 0) maps to y = -0.5: outside the image, dropped; the others keep their order
+    assert ev["x"].tolist() == [3.25, 19.25] and ev["y"].tolist() == [3.5, 8.5] and ev["ts"].tolist() == [2.0, 4.0] and ev["p"].tolist() == [1, 0]
+    assert len(oracle.undistort_events(r, mx, my, 20, 10, False, 1e6)) == 3
+    with pytest.raises(ValueError):
+        oracle.parse_events_text(b"1.0 2 3 1\n1.0 2 3 7\n")
+
+
+def test_bow_transform_known_answers(oracle):
+    """TemplatedVocabulary::transform :1125-1250 on a 2-level binary tree: descent by Hamming distance, addWeight in feature
+    order, L1 normalisation, FeatureVector at the level above the words."""
+    z = np.zeros(32, np.uint8); f = np.full(32, 255, np.uint8)
+    half = z.copy(); half[:16] = 255
+    q1 = z.copy(); q1[:4] = 255; q3 = f.copy(); q3[:4] = 0
+    # nodes: 0 root; 1 = 000.., 2 = 111..; words: 3 (child of 1) = 000.., 4 (child of 1) = 32 leading ones; 5 (of 2) = 111.., 6 (of 2) = half
+    voc = dict(L=2, child_off=[0, 2, 4, 6, 6, 6, 6, 6], child_ids=[1, 2, 3, 4, 5, 6],
+               node_desc=np.stack([z, z, f, z, q1, f, half]), word_id=[-1, -1, -1, 0, 1, 2, 3],
+               weight=[0, 0, 0, 2.0, 1.0, 4.0, 0.0])
+    h2 = half.copy(); h2[16] = 255                # 136 ones: nearer to node 2, then 8 bits from the stopped word's descriptor
+    desc = np.stack([z, z, q1, f, h2])           # words 0, 0, 1, 2 and the stopped word 3
+    bw, bv, fv, wo, no = oracle.bow_transform(voc, desc, levelsup=1, weighting=0, norm=1)
+    assert wo.tolist() == [0, 0, 1, 2, -1] and no.tolist() == [1, 1, 1, 2, -1]
+    assert bw.tolist() == [0, 1, 2] and bv.tolist() == [4.0 / 9.0, 1.0 / 9.0, 4.0 / 9.0]     # (2+2, 1, 4) / 9
+    assert fv[0].tolist() == [1, 2] and fv[1].tolist() == [0, 3, 4] and fv[2].tolist() == [0, 1, 2, 3]
+    # a tie between siblings goes to the first child (strict '<' :1229): `half` is 128 bits from both level-1 nodes -> node 1,
+    # then 128 from word 0 and 96 from word 1
+    assert oracle.bow_transform(voc, half[None], 1, 0, 1)[3].tolist() == [1]
+    tie = z.copy(); tie[:2] = 255                 # 16 bits from word 0 and 16 from word 1 -> the first
+    assert oracle.bow_transform(voc, tie[None], 1, 0, 1)[3].tolist() == [0]
+    # BINARY weighting keeps the first weight, no normalisation -> the idf weights themselves
+    bw, bv, _, _, _ = oracle.bow_transform(voc, desc, 1, 3, 0)
+    assert bv.tolist() == [2.0, 1.0, 4.0]
+
+
+def test_distinctive_descriptor_and_window_match_known_answers(oracle):
+    """MapPoint.cc:349-423: the descriptor with the least median distance to the others; ORBmatcher.cc:754-774 best / second."""
+    a = np.zeros(32, np.uint8)
+    b = a.copy(); b[0] = 0xFF            # 8 bits from a
+    c = a.copy(); c[:2] = 0xFF           # 16 from a, 8 from b
+    # medians (index floor(0.5*(N-1)) = 1 of the sorted rows incl. the zero self-distance): a -> 8, b -> 8, c -> 8 ... first wins
+    assert oracle.distinctive_descriptors(np.stack([a, b, c]), [0, 3]).tolist() == [0]
+    d = a.copy(); d[:4] = 0xFF           # 32 from a, 24 from b, 16 from c
+    # rows sorted: a [0,8,16,32], b [0,8,8,24], c [0,8,16,16], d [0,16,24,32]; median index 1 -> all 8 except d (16): first wins
+    assert oracle.distinctive_descriptors(np.stack([a, b, c, d]), [0, 4]).tolist() == [0]
+    # five descriptors: median index 2: a [0,8,16,32,40]->16, b [0,8,8,24,32]->8
+    e = a.copy(); e[:5] = 0xFF
+    assert oracle.distinctive_descriptors(np.stack([a, b, c, d, e]), [0, 5]).tolist() == [1]
+    bi, bd, si, sd = oracle.hamming_window_match(np.stack([a]), np.stack([c, b, b, a]), [0, 3], [0, 1, 2])
+    assert (bi[0], bd[0], si[0], sd[0]) == (1, 8, 2, 8)                      # first of the two equal candidates is "best"
+    bi, bd, si, sd = oracle.hamming_window_match(np.stack([a]), np.stack([c, b]), [0, 0], [])
+    assert (bi[0], bd[0], si[0], sd[0]) == (-1, 256, -1, 256)
+
+
+def test_epipolar_and_triangulation_known_answers(oracle):
+    """Pinhole::epipolarConstrain Pinhole.cpp:142-156 with F for a pure x-translation (lines y2 = y1): dsqr = (y2-y1)^2 < 3.84*unc;
+    SearchForTriangulation :1066-1145 keeps the LAST of equally distant passing candidates."""
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    kp = np.zeros(1, oracle.KP_DTYPE); kp["x"] = 50; kp["y"] = 40; kp["angle"] = 10
+    k2 = np.zeros(4, oracle.KP_DTYPE); k2["x"] = [80, 90, 100, 110]; k2["y"] = [40, 41.9, 42.1, 40]; k2["angle"] = 10
+    d1 = np.zeros((1, 32), np.uint8); d2 = np.zeros((4, 32), np.uint8)
+    fv1 = ([7], [0, 1], [0]); fv2 = ([7], [0, 4], [0, 1, 2, 3])
+    one = np.ones(1, np.float32)
+    n, m = oracle.search_for_triangulation(kp, d1, [1], fv1, k2, d2, [1, 1, 1, 1], fv2, (-1000.0, 0.0), F, one, one, False, True)
+    assert n == 1 and m.tolist() == [3]                      # candidates 0, 1, 3 pass (1.9^2 = 3.61 < 3.84), all distance 0 -> the last
+    n, m = oracle.search_for_triangulation(kp, d1, [1], fv1, k2[:3], d2[:3], [1, 1, 1], fv2[:1] + ([0, 3], [0, 1, 2]), (-1000.0, 0.0), F, one, one, False, True)
+    assert m.tolist() == [1]                                 # 2.1^2 = 4.41 fails
+    n, m = oracle.search_for_triangulation(kp, d1, [1], fv1, k2, d2, [1, 1, 1, 1], fv2, (109.0, 40.0), F, one, one, False, True)
+    assert m.tolist() == [1]                                 # candidate 3 lies within sqrt(100*scale) = 10 px of the epipole
+    n, m = oracle.search_for_triangulation(kp, d1, [0], fv1, k2, d2, [1, 1, 1, 1], fv2, (-1000.0, 0.0), F, one, one, False, True)
+    assert n == 0 and m.tolist() == [-1]                     # pKF1 feature already has a map point
+
+
+def test_pyr_lk_known_answers(oracle):
+    """calcOpticalFlowPyrLK: a smooth pattern shifted by whole pixels is tracked to the shift; a flat patch fails the minimum
+    eigenvalue test; a point whose window leaves the padded image loses its status."""
+    yy, xx = np.mgrid[0:120, 0:160]
+    img1 = (127 + 60 * np.sin(xx / 7.0) * np.cos(yy / 9.0) + 40 * np.sin((xx + 2 * yy) / 11.0)).astype(np.uint8)
+    img2 = np.roll(img1, (1, 2), axis=(0, 1))                # content moves +2 in x, +1 in y
+    pts = np.array([[60.0, 50.0], [80.5, 70.25], [100.0, 40.0]], np.float32)
+    n, st, er = oracle.calc_optical_flow_pyr_lk(img1, img2, pts, None, 23, 1, 10, 0.03, 0)
+    assert st.tolist() == [1, 1, 1] and np.abs(n - pts - np.float32([2, 1])).max() < 0.05 and er.max() < 1.0
+    flat = np.full((120, 160), 77, np.uint8)
+    n, st, er = oracle.calc_optical_flow_pyr_lk(flat, flat, pts[:1], None, 23, 1, 10, 0.03, 0)
+    assert st.tolist() == [0]                                # A = 0: minEig < 1e-4
+    n, st, er = oracle.calc_optical_flow_pyr_lk(img1, img2, np.float32([[-40.0, 50.0]]), None, 23, 1, 10, 0.03, 0)
+    assert st.tolist() == [0] and er.tolist() == [0.0]
+    # maxLevel is cut where the next level would not exceed the window (buildOpticalFlowPyramid): 160x120 -> 80x60 -> 40x30 -> 20x15 (<= 23)
+    a = oracle.calc_optical_flow_pyr_lk(img1, img2, pts, None, 23, 2, 10, 0.03, 0)
+    b = oracle.calc_optical_flow_pyr_lk(img1, img2, pts, None, 23, 6, 10, 0.03, 0)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
