@@ -312,11 +312,11 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     __shared__ uint8_t owner[2][512];               // stamp column (entries' rectangles laid side by side) -> entry
     __shared__ int ncols[2];
     __shared__ uint64_t pm[3][64];                  // per pixel: bit e set = entry e of the batch touches it
-    __shared__ __attribute__((aligned(16))) float vals[2][kValStride * 64 + 4];   // [pixel][rank] (+4: sink for masked stores)
+    __shared__ __attribute__((aligned(16))) float vals[2][kValStride * 64 + 64];  // [pixel][rank] (+64: sink rows for masked stores)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = (int)(blockDim.x >> 6), nprod = nwaves - 2;      // wave 0 adds, wave 1 set-up, the rest values
     if (tid < 32) tab[tid] = kExp2Tab[tid];
-    for (int i = tid; i < 2 * (kValStride * 64 + 4); i += blockDim.x) (&vals[0][0])[i] = 0.f;
+    for (int i = tid; i < 2 * (kValStride * 64 + 64); i += blockDim.x) (&vals[0][0])[i] = 0.f;
     const int logical = order[blockIdx.x];
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
@@ -490,27 +490,29 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                         const int SWP = P.stamp_colstride;
                         const int j0 = dy0 + h;
                         const float4* sp4 = (const float4*)(P.stamps + (act ? (size_t)__float_as_uint(ei.xr) * P.stamp_stride + (size_t)(tx0 + qx - xi + h) * SWP : 0));
-                        for (int k0 = 0; k0 < SWP; k0 += 8) {
+                        // slot k of the column is tile row k - j0: the list row is addressed relative to "row 0 of the column" with
+                        // compile-time offsets; slots outside [j0, j0 + rh) store into the sink rows
+                        float* v_r0 = vcol - j0 * 8 * kValStride;
+                        auto slots8 = [&](int k0) {
                             const float4 c0 = sp4[k0 >> 2];
                             const float4 c1 = (k0 + 4 < SWP) ? sp4[(k0 >> 2) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (g0 == (wave - 2) * 64 && k0 == 0) EORB_TR(3);
                             const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                            int pixk[8], rank[8]; bool on[8];
+                            int rank[8]; bool on[8];
 #pragma unroll
                             for (int u = 0; u < 8; u++) {
                                 const int r = k0 + u - j0;
                                 on[u] = (unsigned)r < (unsigned)rh;
-                                pixk[u] = on[u] ? r * 8 : 0;
-                                rank[u] = __popcll(pmc[pixk[u]] & below);
+                                rank[u] = __popcll(pmc[on[u] ? r * 8 : 0] & below);
                             }
-                            if (g0 == (wave - 2) * 64 && k0 == 0) EORB_TR(5);
 #pragma unroll
                             for (int u = 0; u < 8; u++) {
-                                float* dst = on[u] ? vcol + pixk[u] * kValStride + rank[u] : sink;
-                                *dst = POL ? ei.sg * col[u] : col[u];
+                                const int k = k0 + u;
+                                float* base = on[u] ? v_r0 : sink - k * 8 * kValStride;
+                                base[k * 8 * kValStride + rank[u]] = POL ? ei.sg * col[u] : col[u];
                             }
-                            if (g0 == (wave - 2) * 64 && k0 == 0) EORB_TR(7);
-                        }
+                        };
+                        slots8(0);
+                        for (int k0 = 8; k0 < SWP; k0 += 8) slots8(k0);
                         continue;
                     }
                     const float fx = (float)(tx0 + qx - xi) - ei.xr;            // exp_XY2f(i-xRes, j-yRes) :59-65
