@@ -440,15 +440,20 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                 for (int k = 0; k < 8; k++) if (k < rw) owner[bs2][coff + k] = (uint8_t)lane;
                 if (lane == 63) ncols[bs2] = incl;
                 EORB_TR(2);
-                // colsel / rowsel: every pixel lane keeps the ballot of its own column / row (the lane -> column / row mapping is
-                // a compile-time pattern, so this is 32 selects and no cross-lane traffic)
-                uint64_t cs = 0, rs = 0;
+                // colsel / rowsel: the 16 ballots (wave-uniform) are dropped into lanes 0..15 of one register pair with
+                // v_writelane, then every pixel lane fetches the pair of its column (lane lx) and of its row (lane 8 + ly)
+                uint32_t blo = 0, bhi = 0;
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
                     const uint64_t cb = __ballot((xm >> b) & 1u), rb = __ballot((ym >> b) & 1u);
-                    cs = (lx == b) ? cb : cs;
-                    rs = (ly == b) ? rb : rs;
+                    // gfx940+: a VALU-written SGPR needs 2 wait states before a VALU reads it; the compiler does not see inside the asm
+                    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(blo) : "s"((uint32_t)cb), "n"(b));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(bhi) : "s"((uint32_t)(cb >> 32)), "n"(b));
+                    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(blo) : "s"((uint32_t)rb), "n"(8 + b));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(bhi) : "s"((uint32_t)(rb >> 32)), "n"(8 + b));
                 }
+                const uint64_t cs = ((uint64_t)(uint32_t)__shfl((int)bhi, lx, 64) << 32) | (uint32_t)__shfl((int)blo, lx, 64);
+                const uint64_t rs = ((uint64_t)(uint32_t)__shfl((int)bhi, 8 + ly, 64) << 32) | (uint32_t)__shfl((int)blo, 8 + ly, 64);
                 pm[bs3][lane] = cs & rs;
                 EORB_TR(3);
                 if (t + 1 < nbatch) load_batch();       // prefetch batch t+1
