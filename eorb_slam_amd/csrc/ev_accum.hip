@@ -327,6 +327,10 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     const int xhi = min(tx0 + kTile - 1, P.W - 1), yhi = min(ty0 + kTile - 1, P.H - 1);
     constexpr int ESZ = RAW ? 2 : (POL ? 4 : 2);
     const int h = P.h;
+    // the tile constants the set-up wave uses per entry live in VGPRs: as scalars they are spilled (the kernel needs > 102 SGPRs)
+    // and reloaded with v_readlane in every batch
+    int v_tx0 = tx0, v_ty0 = ty0, v_xhi = xhi, v_yhi = yhi, v_h = h;
+    asm volatile("" : "+v"(v_tx0), "+v"(v_ty0), "+v"(v_xhi), "+v"(v_yhi), "+v"(v_h));
     __syncthreads();
     // the tile's entries: one contiguous event-ordered list (K1b/K1c)
     const int nent = (int)tile_cnt[logical];
@@ -422,8 +426,8 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                         xi = (int)floorf(ex); yi = (int)floorf(ey);
                         xr = ex - (float)xi; yr = ey - (float)yi;
                     }
-                    const int a0 = max(xi - h, tx0) - tx0, a1 = min(xi + h, xhi) - tx0;
-                    const int b0 = max(yi - h, ty0) - ty0, b1 = min(yi + h, yhi) - ty0;
+                    const int a0 = max(xi - v_h, v_tx0) - v_tx0, a1 = min(xi + v_h, v_xhi) - v_tx0;
+                    const int b0 = max(yi - v_h, v_ty0) - v_ty0, b1 = min(yi + v_h, v_yhi) - v_ty0;
                     if (a1 >= a0 && b1 >= b0) {
                         xm = ((2u << a1) - 1u) & ~((1u << a0) - 1u);
                         ym = ((2u << b1) - 1u) & ~((1u << b0) - 1u);
