@@ -498,7 +498,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                         // slots with static register indices: slot k is tile row b0 + (k - j0) when that row exists.
                         const int SWP = P.stamp_colstride;
                         const int j0 = dy0 + h;
-                        const float4* sp4 = (const float4*)(P.stamps + (act ? (size_t)__float_as_uint(ei.xr) * P.stamp_stride + (size_t)(tx0 + qx - xi + h) * SWP : 0));
+                        const float4* sp4 = (const float4*)(P.stamps + (act ? __float_as_uint(ei.xr) * (uint32_t)P.stamp_stride + (uint32_t)((tx0 + qx - xi + h) * SWP) : 0u));   // < 2^32 floats (checked on the host)
                         // slot k of the column is tile row k - j0: the list row is addressed relative to "row 0 of the column" with
                         // compile-time offsets; slots outside [j0, j0 + rh) store into the sink rows
                         float* v_r0 = vcol - j0 * 8 * kValStride;
@@ -506,13 +506,15 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                             const float4 c0 = sp4[k0 >> 2];
                             const float4 c1 = (k0 + 4 < SWP) ? sp4[(k0 >> 2) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
                             const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                            int rank[8]; bool on[8];
+                            int rank[8]; bool on[8]; uint64_t mk[8];
 #pragma unroll
-                            for (int u = 0; u < 8; u++) {
+                            for (int u = 0; u < 8; u++) {                 // all mask reads in flight before the first use
                                 const int r = k0 + u - j0;
                                 on[u] = (unsigned)r < (unsigned)rh;
-                                rank[u] = __popcll(pmc[on[u] ? r * 8 : 0] & below);
+                                mk[u] = pmc[on[u] ? r * 8 : 0];
                             }
+#pragma unroll
+                            for (int u = 0; u < 8; u++) rank[u] = __popcll(mk[u] & below);
 #pragma unroll
                             for (int u = 0; u < 8; u++) {
                                 const int k = k0 + u;
@@ -1188,6 +1190,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             ev_src_info_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, nsrc, W, H, c->lut_check, mode_count,
                                                                             (uint32_t*)c->src_info.p);
             if (!mode_count) {
+                if ((size_t)nsrc * SW * SWP >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
                 if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 8)))) return rc;
                 ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
                                                              (float*)c->stamps.p);
