@@ -502,6 +502,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                         // slot k of the column is tile row k - j0: the list row is addressed relative to "row 0 of the column" with
                         // compile-time offsets; slots outside [j0, j0 + rh) store into the sink rows
                         float* v_r0 = vcol - j0 * 8 * kValStride;
+                        const int rhm1 = max(rh - 1, 0);
                         auto slots8 = [&](int k0) {
                             const float4 c0 = sp4[k0 >> 2];
                             const float4 c1 = (k0 + 4 < SWP) ? sp4[(k0 >> 2) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                             for (int u = 0; u < 8; u++) {                 // all mask reads in flight before the first use
                                 const int r = k0 + u - j0;
                                 on[u] = (unsigned)r < (unsigned)rh;
-                                mk[u] = pmc[on[u] ? r * 8 : 0];
+                                mk[u] = pmc[min(max(r, 0), rhm1) * 8];     // slots outside the rectangle read one of its rows; unused
                             }
 #pragma unroll
                             for (int u = 0; u < 8; u++) rank[u] = __popcll(mk[u] & below);
