@@ -412,28 +412,25 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
             if (wave == 1 && t < nbatch) {
                 // ---- set-up(t) from the registers loaded one iteration ago ----
                 const int bs3 = t % 3, bs2 = t & 1;
-                int xi = 0, yi = 0; float xr = 0.f, yr = 0.f;
-                uint32_t xm = 0, ym = 0;
-                int ra0 = 0, rb0 = 0, rw = 0, rh = 0;
-                if (valid) {
-                    if (RAW) {                                                               // integer position from the maps (K1c)
-                        const uint32_t w0 = __float_as_uint(ex), w1 = __float_as_uint(ey);
-                        xi = (int)(int16_t)(w1 & 0xffff); yi = (int)(int16_t)(w1 >> 16);
-                        xr = __uint_as_float(w0 & 0x7fffffffu);                             // sensor pixel index rides in the xr slot
-                        esg = (w0 >> 31) ? -1.0f : 1.0f;
-                    } else if (MODE == 2) { xi = (int)roundf(ex); yi = (int)roundf(ey); }   // roundFloatCoord :46-49
-                    else {                                                                   // breakFloatCoords :51-57
-                        xi = (int)floorf(ex); yi = (int)floorf(ey);
-                        xr = ex - (float)xi; yr = ey - (float)yi;
-                    }
-                    const int a0 = max(xi - v_h, v_tx0) - v_tx0, a1 = min(xi + v_h, v_xhi) - v_tx0;
-                    const int b0 = max(yi - v_h, v_ty0) - v_ty0, b1 = min(yi + v_h, v_yhi) - v_ty0;
-                    if (a1 >= a0 && b1 >= b0) {
-                        xm = ((2u << a1) - 1u) & ~((1u << a0) - 1u);
-                        ym = ((2u << b1) - 1u) & ~((1u << b0) - 1u);
-                        ra0 = a0; rb0 = b0; rw = a1 - a0 + 1; rh = b1 - b0 + 1;
-                    }
+                // straight-line decode: lanes without an entry get a position far outside the image, which makes the rectangle empty
+                int xi, yi; float xr = 0.f, yr = 0.f;
+                if (RAW) {                                                               // integer position from the maps (K1c)
+                    const uint32_t w0 = __float_as_uint(ex), w1 = __float_as_uint(ey);
+                    xi = (int)(int16_t)(w1 & 0xffff); yi = (int)(int16_t)(w1 >> 16);
+                    xr = __uint_as_float(w0 & 0x7fffffffu);                             // sensor pixel index rides in the xr slot
+                    esg = (w0 >> 31) ? -1.0f : 1.0f;
+                } else if (MODE == 2) { xi = (int)roundf(ex); yi = (int)roundf(ey); }   // roundFloatCoord :46-49
+                else {                                                                   // breakFloatCoords :51-57
+                    xi = (int)floorf(ex); yi = (int)floorf(ey);
+                    xr = ex - (float)xi; yr = ey - (float)yi;
                 }
+                xi = valid ? xi : -32768;
+                const int a0 = max(xi - v_h, v_tx0) - v_tx0, a1 = min(xi + v_h, v_xhi) - v_tx0;
+                const int b0 = max(yi - v_h, v_ty0) - v_ty0, b1 = min(yi + v_h, v_yhi) - v_ty0;
+                const bool ok = a1 >= a0 && b1 >= b0;
+                const uint32_t xm = ok ? ((2u << (a1 & 31)) - 1u) & ~((1u << (a0 & 31)) - 1u) : 0u;
+                const uint32_t ym = ok ? ((2u << (b1 & 31)) - 1u) & ~((1u << (b0 & 31)) - 1u) : 0u;
+                const int ra0 = a0 & 15, rb0 = b0 & 15, rw = ok ? a1 - a0 + 1 : 0, rh = ok ? b1 - b0 + 1 : 0;
                 EORB_TR(1);
                 EvEntryInfo ei; ei.xy = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16); ei.xr = xr; ei.yr = yr; ei.sg = esg;
                 einfo[bs2][lane] = ei;
