@@ -257,17 +257,19 @@ struct GatherParams {
     int stamp_stride, stamp_colstride;   // floats per sensor pixel / per (16-byte padded) stamp column
 };
 
-// K2: one 512-thread workgroup per 8x8 tile (EORB_GATHER_THREADS overrides: 256..1024 measured, 512 fastest); the tile's entries are consumed in batches of 64 (event order)
-// through a 3-stage software pipeline with ONE barrier per batch:
-//   wave 1, set-up(t)   lane = entry (loaded one batch ahead): floor/frac (breakFloatCoords :51-57) and the 8-bit
-//                       column / row masks of the stamp taps that land on this tile; 16 ballots turn them into
-//                       colsel[x] / rowsel[y] (bit e set = entry e touches that column / row), so pixel (x,y) is
-//                       touched by exactly the entries colsel[x] & rowsel[y] -- in event order by bit index.
-//   waves 2-7, values(t-1)  lane = pixel: for every set bit e of its mask (each wave takes 1/6 of the bits) the stamp
-//                       value exp_XY2f (:59-65) goes to the pixel's list slot rank = popcount(mask below e): a
-//                       per-pixel list already in event order.  No divergence on the tap window, no search.
-//   wave 0, adds(t-2)   lane = pixel: acc += list[k], k = 0..popcount(mask)-1 (newVal = image + polSign*val,
-//                       :251-254): the only sequential part; lists are read four ranks at a time (ds_read_b128).
+// K2: one 512-thread workgroup per 8x8 tile, heaviest tiles first (EORB_GATHER_THREADS overrides: 384..704 measured, 512 fastest;
+// 4 workgroups per CU: 8 waves/SIMD at <= 64 VGPRs, 40.7 KB of LDS).  The tile's entries are consumed in batches of 64 (event
+// order) through a 3-stage software pipeline with ONE barrier per batch:
+//   wave 1, set-up(t)   lane = entry (loaded one batch ahead): integer position / residuals (breakFloatCoords :51-57) and the
+//                       tile-local rectangle of stamp taps.  16 ballots over its 8-bit column / row masks give colsel[x] /
+//                       rowsel[y] (bit e set = entry e touches that column / row): pixel (x,y) is touched by exactly the entries
+//                       pm = colsel[x] & rowsel[y], in event order by bit index.  A DPP prefix sum of the rectangle widths lays
+//                       the entries' stamp columns side by side; owner[column] = entry.
+//   waves 2-7, values(t-1)  lane = one stamp column (a round = 64 columns): its rows' values -- exp_XY2f (:59-65) evaluated in
+//                       f64 like glibc's expf, or, for raw sensor events, a 16-byte read of the per-pixel stamp table -- go to
+//                       the pixels' list slots rank = popcount(pm below the entry): per-pixel lists already in event order.
+//   wave 0, adds(t-2)   lane = pixel: acc += list[k], k = 0..count-1 (newVal = image + polSign*val, :251-254): the only
+//                       sequential part; lists are read four ranks at a time (ds_read_b128) and cleared behind the read.
 // With pol == false every increment is >= 0, so the running max is the final value and the running min stays 0.
 struct EvEntryInfo { uint32_t xy; float xr, yr, sg; };      // xi | yi << 16 (int16 each)
 constexpr int kValStride = 68;     // floats per pixel list: 64 ranks, padded so 16 lanes' ds_read_b128 hit 16 distinct bank groups
