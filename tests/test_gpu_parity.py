@@ -720,6 +720,26 @@ def test_raw_ev2im_gauss_equals_loader_then_ev2im_gauss(oracle, fe, ctx, sigma, 
     assert (z == 0).all()
 
 
+def test_raw_mvsec_size_and_wide_stamps(oracle, fe, ctx):
+    """346x260 sensor (C4 geometry) with maps that move pixels by several px and stamps of 11x11 / 17x17 taps (column stride 12 / 20)."""
+    W, H = 346, 260
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    r2 = ((xx - 170.0) / 220.0) ** 2 + ((yy - 128.0) / 220.0) ** 2
+    mx = (xx + (xx - 170.0) * (0.08 * r2 - 0.03 * r2 * r2) + 0.37).astype(np.float32)
+    my = (yy + (yy - 128.0) * (0.08 * r2 - 0.03 * r2 * r2) - 0.21).astype(np.float32)
+    raw = synth.random_raw_events(120000, W, H, seed=33)
+    raw["x"][:30000] = np.clip(np.random.default_rng(1).normal(200, 6, 30000), 0, W - 1).astype(np.uint16)      # a hot spot
+    raw["y"][:30000] = np.clip(np.random.default_rng(2).normal(90, 6, 30000), 0, H - 1).astype(np.uint16)
+    np.random.default_rng(3).shuffle(raw)
+    fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx)
+    ev = oracle.undistort_events(raw, mx, my, W, H, True, 1.0)
+    assert 0 < len(ev) < len(raw)
+    for sigma, pol in ((1.5, False), (2.5, True), (1.0, False)):
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, pol, True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, pol, True, ctx=ctx, return_all=True)
+        assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)) and np.array_equal(ou, gu)
+
+
 def test_raw_ev2im_count(oracle, fe, ctx):
     W, H = 240, 180
     mx, my = _maps(W, H)
