@@ -798,6 +798,45 @@ def test_frontend_batch_raw_equals_float_path(oracle, fe):
     assert np.array_equal(ou, b[0][2]) and a[1].min() > 20
 
 
+def test_full_size_batch_properties(oracle, fe):
+    """BASELINE.json configs[1] sizes (1 000 000 events per slice): the raw and the float inputs give the same images / keypoints,
+    a slice's result does not depend on its position or company in the batch, and one slice is checked against the oracle."""
+    W, H, N = 240, 180, 1000000
+    mx, my = _maps(W, H)
+    pairs = [synth.shapes_events(N, W, H, seed=2 + b, motion=0.5, undistort=True, return_raw=True) for b in range(3)]
+
+    def run(order, use_raw):
+        B = len(order)
+        fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=N)
+        c, cap = fb.ctx, fb.cap
+        if use_raw:
+            fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
+            blob = np.concatenate([pairs[i][1] for i in order])
+        else:
+            blob = np.concatenate([fe.pack_events(pairs[i][0]) for i in order])
+        d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
+        d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32); d_n = c.dev_alloc(B * 4)
+        fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * N, d_img, d_kp, d_desc, d_n, raw=use_raw)
+        c.sync()
+        imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
+        nk = np.zeros(B, np.int32); c.download(nk, d_n)
+        kps = np.zeros((B, cap), synth.KP_DTYPE); c.download(kps, d_kp)
+        desc = np.zeros((B, cap, 32), np.uint8); c.download(desc, d_desc)
+        for p in (d_ev, d_img, d_kp, d_desc, d_n):
+            c.dev_free(p)
+        c.close()
+        return {i: (imgs[j].copy(), kps[j, :nk[j]].copy(), desc[j, :nk[j]].copy()) for j, i in enumerate(order)}
+
+    a = run([0, 1, 2], True)
+    b = run([2, 0], False)
+    c1 = run([1], True)
+    for i, other in ((0, b), (2, b), (1, c1)):
+        assert np.array_equal(a[i][0], other[i][0])
+        assert np.array_equal(a[i][1].view(np.uint8), other[i][1].view(np.uint8)) and np.array_equal(a[i][2], other[i][2])
+    _, ou, _ = oracle.ev2im_gauss(pairs[1][0], W, H, 1.0, False, True, fast=True)
+    assert np.array_equal(ou, a[1][0]) and len(a[1][1]) > 50
+
+
 def test_large_slice_many_chunks(oracle, fe, ctx):
     """3 M events in one slice: 733 chunks per tile list; order must survive every chunk boundary."""
     ev = synth.shapes_events(3000000, seed=77, undistort=True)
