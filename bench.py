@@ -24,8 +24,8 @@ sys.path.insert(0, ROOT)
 
 METRIC = "front-end frames/s (event-accumulate + extract + match) per GPU; HBM GB/s vs roofline"
 # HBM bytes one ev_gather launch moves per million events (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, see
-# profiles/r01_v5_pmc_traffic.txt); bench.py cannot collect PMC counters itself
-GATHER_TRAFFIC_PER_MEV = {"raw": 31.7e6, "float": 30.9e6}
+# profiles/r01_v6_pmc_traffic.txt); bench.py cannot collect PMC counters itself
+GATHER_TRAFFIC_PER_MEV = {"raw": 33.0e6, "float": 30.9e6}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
 
 
@@ -184,7 +184,7 @@ def main():
             traffic = GATHER_TRAFFIC_PER_MEV[a.input] * (NEV / 1e6) * B if dom == "ev_gather" else None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": "profiles/r01_v5_pmc_traffic.txt",
+                               "traffic_source": "profiles/r01_v6_pmc_traffic.txt",
                                "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": unit_bytes * B,
                                "note": "ev_gather is latency/issue-bound by construction: every pixel adds its taps in event order "
                                        "(49 taps per 16 B event, DESIGN.md section 4); the HBM fraction is reported as the contract asks"}
