@@ -190,7 +190,7 @@ def main():
                                        "(49 taps per 16 B event, DESIGN.md section 4); the HBM fraction is reported as the contract asks"}
             out["kernels_ms_per_step"] = {k: v[0] / a.steps for k, v in sorted(prof.items())}
         # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same workload ----
-        if a.cpu_slices > 0:
+        if a.cpu_slices > 0 and world == 1:       # reported at N=1 only (the contract); N>1 runs stay short
             from oracle import oracle_py
             oe = oracle_py.OrbExtractor(fast=True, imWidth=W, **orb)
             ns = min(a.cpu_slices, B)
