@@ -261,15 +261,15 @@ struct GatherParams {
 // 4 workgroups per CU: 8 waves/SIMD at <= 64 VGPRs, 40.7 KB of LDS).  The tile's entries are consumed in batches of 64 (event
 // order) through a 3-stage software pipeline with ONE barrier per batch:
 //   wave 1, set-up(t)   lane = entry (loaded one batch ahead): integer position / residuals (breakFloatCoords :51-57) and the
-//                       tile-local rectangle of stamp taps.  16 ballots over its 8-bit column / row masks give colsel[x] /
-//                       rowsel[y] (bit e set = entry e touches that column / row): pixel (x,y) is touched by exactly the entries
-//                       pm = colsel[x] & rowsel[y], in event order by bit index.  A DPP prefix sum of the rectangle widths lays
-//                       the entries' stamp columns side by side; owner[column] = entry.
+//                       tile-local rectangle of stamp taps.  A DPP prefix sum of the rectangle widths lays the entries' stamp
+//                       columns side by side; owner[column] = entry.
 //   waves 2-7, values(t-1)  lane = one stamp column (a round = 64 columns): its rows' values -- exp_XY2f (:59-65) evaluated in
 //                       f64 like glibc's expf, or, for raw sensor events, a 16-byte read of the per-pixel stamp table -- go to
-//                       the pixels' list slots rank = popcount(pm below the entry): per-pixel lists already in event order.
-//   wave 0, adds(t-2)   lane = pixel: acc += list[k], k = 0..count-1 (newVal = image + polSign*val, :251-254): the only
-//                       sequential part; lists are read four ranks at a time (ds_read_b128) and cleared behind the read.
+//                       slot e (the entry's position in the batch) of the pixels' lists: vals[pixel][e].
+//   wave 0, adds(t-2)   lane = pixel: acc += list[e], e = 0..63 (newVal = image + polSign*val, :251-254): the only sequential
+//                       part.  Slots of entries that do not touch the pixel hold +0.0f, and x + 0.0f == x bit for bit, so the
+//                       order of the real adds is the event order and no masks, counts or ranks are needed; lists are read four
+//                       slots at a time (ds_read_b128) and cleared behind the read.
 // With pol == false every increment is >= 0, so the running max is the final value and the running min stays 0.
 struct EvEntryInfo { uint32_t xy; float xr, yr, sg; };      // xi | yi << 16 (int16 each)
 constexpr int kValStride = 68;     // floats per pixel list: 64 ranks, padded so 16 lanes' ds_read_b128 hit 16 distinct bank groups
@@ -313,11 +313,12 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     __shared__ uint32_t rinfo[2][64];               // a0 | b0 << 4 | w << 8 | h << 12 (tile-local tap rectangle) | first column << 16
     __shared__ uint8_t owner[2][512];               // stamp column (entries' rectangles laid side by side) -> entry
     __shared__ int ncols[2];
-    __shared__ uint64_t pm[3][64];                  // per pixel: bit e set = entry e of the batch touches it
+    __shared__ int any_ok;                          // some entry of the tile touches an in-image pixel
     __shared__ __attribute__((aligned(16))) float vals[2][kValStride * 64 + 64];  // [pixel][rank] (+64: sink rows for masked stores)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwaves = (int)(blockDim.x >> 6), nprod = nwaves - 2;      // wave 0 adds, wave 1 set-up, the rest values
     if (tid < 32) tab[tid] = kExp2Tab[tid];
+    if (tid == 0) any_ok = 0;
     for (int i = tid; i < 2 * (kValStride * 64 + 64); i += blockDim.x) (&vals[0][0])[i] = 0.f;
     const int logical = order[blockIdx.x];
     const int slice = logical / P.NT;
@@ -339,7 +340,6 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     const int nbatch = (nent + 63) >> 6;
     const float* list = entries + ((size_t)slice_ebase[slice] + tile_base[logical]) * ESZ;
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
-    bool touched = false;
     // wave 1 keeps the next batch in registers (loaded one iteration ahead)
     int jnext = 0;
     float ex = 0.f, ey = 0.f, esg = 1.f; bool valid = false;
@@ -365,55 +365,38 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 #endif
         EORB_TR(0);
         if (wave == 0) {
-            // ---- adds(t-2) ----
+            // ---- adds(t-2): slot e of a pixel's list holds entry e's tap, or +0.0f when that entry does not touch the pixel.
+            //      Adding +0.0f leaves acc unchanged bit for bit (acc is never -0.0), so the wave adds all 64 slots in order
+            //      without masks, counts or ranks, and clears the list behind the read ----
             if (t >= 2) {
-                const int bs3 = (t - 2) % 3, bs2 = t & 1;
-                const uint64_t m = pm[bs3][lane];
-                const int cnt = __popcll(m);
+                const int bs2 = t & 1;
                 EORB_TR(1);
-                int mx = 0;                                             // wave max of cnt (<= 64) by bisection on ballots
-#pragma unroll
-                for (int b = 6; b >= 0; b--) { const int tr = mx | (1 << b); if (__any(cnt >= tr)) mx = tr; }
                 float4* vb = (float4*)(vals[bs2] + lane * kValStride);
-                touched = touched || (cnt > 0);
-#ifdef EORB_KO_ADDS
-                const int ng = 0;
-#else
-                const int ng = (mx + 3) >> 2;
-#endif
                 const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!POL) {
-                    // list slots beyond a pixel's count hold +0.0f (the buffers are cleared after use), and adding
-                    // +0.0f leaves acc unchanged bit for bit (acc is never -0.0): no per-add predicate needed
-                    int g = 0;
-                    for (; g + 4 <= ng; g += 4) {
-                        const float4 v0 = vb[g], v1 = vb[g + 1], v2 = vb[g + 2], v3 = vb[g + 3];
-                        vb[g] = zero4; vb[g + 1] = zero4; vb[g + 2] = zero4; vb[g + 3] = zero4;
+#ifndef EORB_KO_ADDS
+#pragma unroll
+                for (int g = 0; g < 16; g += 4) {
+                    const float4 v0 = vb[g], v1 = vb[g + 1], v2 = vb[g + 2], v3 = vb[g + 3];
+                    vb[g] = zero4; vb[g + 1] = zero4; vb[g + 2] = zero4; vb[g + 3] = zero4;
+                    if (!POL) {
                         acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
                         acc = acc + v1.x; acc = acc + v1.y; acc = acc + v1.z; acc = acc + v1.w;
                         acc = acc + v2.x; acc = acc + v2.y; acc = acc + v2.z; acc = acc + v2.w;
                         acc = acc + v3.x; acc = acc + v3.y; acc = acc + v3.z; acc = acc + v3.w;
-                    }
-                    for (; g < ng; g++) {
-                        const float4 v0 = vb[g];
-                        vb[g] = zero4;
-                        acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
-                    }
-                } else {
-                    for (int g = 0; g < ng; g++) {
-                        const float4 v0 = vb[g];
-                        vb[g] = zero4;
-                        const int k = 4 * g;
-#define EORB_ADD(val, kk) { if ((kk) < cnt) { acc = acc + (val); vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); } }
-                        EORB_ADD(v0.x, k + 0) EORB_ADD(v0.y, k + 1) EORB_ADD(v0.z, k + 2) EORB_ADD(v0.w, k + 3)
+                    } else {
+                        // running extremes (resolveMinMaxVals :32-39) only move on a real add: a tap is never 0
+#define EORB_ADD(val) { if ((val) != 0.0f) { acc = acc + (val); vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); } }
+                        EORB_ADD(v0.x) EORB_ADD(v0.y) EORB_ADD(v0.z) EORB_ADD(v0.w) EORB_ADD(v1.x) EORB_ADD(v1.y) EORB_ADD(v1.z) EORB_ADD(v1.w)
+                        EORB_ADD(v2.x) EORB_ADD(v2.y) EORB_ADD(v2.z) EORB_ADD(v2.w) EORB_ADD(v3.x) EORB_ADD(v3.y) EORB_ADD(v3.z) EORB_ADD(v3.w)
 #undef EORB_ADD
                     }
                 }
+#endif
             }
         } else {
             if (wave == 1 && t < nbatch) {
                 // ---- set-up(t) from the registers loaded one iteration ago ----
-                const int bs3 = t % 3, bs2 = t & 1;
+                const int bs2 = t & 1;
                 // straight-line decode: lanes without an entry get a position far outside the image, which makes the rectangle empty
                 int xi, yi; float xr = 0.f, yr = 0.f;
                 if (RAW) {                                                               // integer position from the maps (K1c)
@@ -430,8 +413,6 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                 const int a0 = max(xi - v_h, v_tx0) - v_tx0, a1 = min(xi + v_h, v_xhi) - v_tx0;
                 const int b0 = max(yi - v_h, v_ty0) - v_ty0, b1 = min(yi + v_h, v_yhi) - v_ty0;
                 const bool ok = a1 >= a0 && b1 >= b0;
-                const uint32_t xm = ok ? ((2u << (a1 & 31)) - 1u) & ~((1u << (a0 & 31)) - 1u) : 0u;
-                const uint32_t ym = ok ? ((2u << (b1 & 31)) - 1u) & ~((1u << (b0 & 31)) - 1u) : 0u;
                 const int ra0 = a0 & 15, rb0 = b0 & 15, rw = ok ? a1 - a0 + 1 : 0, rh = ok ? b1 - b0 + 1 : 0;
                 EORB_TR(1);
                 EvEntryInfo ei; ei.xy = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16); ei.xr = xr; ei.yr = yr; ei.sg = esg;
@@ -442,22 +423,8 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 8; k++) if (k < rw) owner[bs2][coff + k] = (uint8_t)lane;
                 if (lane == 63) ncols[bs2] = incl;
+                if (__any(ok) && lane == 0) any_ok = 1;
                 EORB_TR(2);
-                // colsel / rowsel: the 16 ballots (wave-uniform) are dropped into lanes 0..15 of one register pair with
-                // v_writelane, then every pixel lane fetches the pair of its column (lane lx) and of its row (lane 8 + ly)
-                uint32_t blo = 0, bhi = 0;
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    const uint64_t cb = __ballot((xm >> b) & 1u), rb = __ballot((ym >> b) & 1u);
-                    // gfx940+: a VALU-written SGPR needs 2 wait states before a VALU reads it; the compiler does not see inside the asm
-                    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(blo) : "s"((uint32_t)cb), "n"(b));
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(bhi) : "s"((uint32_t)(cb >> 32)), "n"(b));
-                    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(blo) : "s"((uint32_t)rb), "n"(8 + b));
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(bhi) : "s"((uint32_t)(rb >> 32)), "n"(8 + b));
-                }
-                const uint64_t cs = ((uint64_t)(uint32_t)__shfl((int)bhi, lx, 64) << 32) | (uint32_t)__shfl((int)blo, lx, 64);
-                const uint64_t rs = ((uint64_t)(uint32_t)__shfl((int)bhi, 8 + ly, 64) << 32) | (uint32_t)__shfl((int)blo, 8 + ly, 64);
-                pm[bs3][lane] = cs & rs;
                 EORB_TR(3);
                 if (t + 1 < nbatch) load_batch();       // prefetch batch t+1
 #ifdef EORB_DIAG
@@ -467,7 +434,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
             // ---- values(t-1): lane = one stamp column of one entry (the set-up wave laid the entries' tile-local rectangles
             //      side by side: column g belongs to entry owner[g]); the lane walks the column's rows, two at a time ----
             if (wave >= 2 && t >= 1 && t <= nbatch) {
-                const int bs3 = (t - 1) % 3, bs2 = (t - 1) & 1;
+                const int bs2 = (t - 1) & 1;
                 const int C = ncols[bs2];
                 EORB_TR(1);
                 float* vbase = vals[bs2];
@@ -486,11 +453,9 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     const int rh = act ? (int)((ri >> 12) & 15u) : 0;
                     const int xi = (int)(int16_t)(ei.xy & 0xffff), yi = (int)(int16_t)(ei.xy >> 16);
                     if (g0 == (wave - 2) * 64) EORB_TR(2); else EORB_TR(4);
-                    const uint64_t below = (1ull << e) - 1ull;
                     const int dy0 = ty0 + b0 - yi;
                     const int pix0 = act ? b0 * 8 + qx : 0;              // pixel of the column's first row; rows step by 8
-                    const uint64_t* pmc = &pm[bs3][pix0];
-                    float* vcol = vbase + pix0 * kValStride;
+                    float* vcol = vbase + pix0 * kValStride + e;          // the entry's slot in that pixel's list
                     if (RAW && MODE != 2) {
                         // stamp values of this sensor pixel come from the table built once per (maps, sigma).  A column of the
                         // table is padded to a multiple of 4 floats, so the lane fetches it with 16-byte loads and walks its
@@ -501,25 +466,16 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                         // slot k of the column is tile row k - j0: the list row is addressed relative to "row 0 of the column" with
                         // compile-time offsets; slots outside [j0, j0 + rh) store into the sink rows
                         float* v_r0 = vcol - j0 * 8 * kValStride;
-                        const int rhm1 = max(rh - 1, 0);
                         auto slots8 = [&](int k0) {
                             const float4 c0 = sp4[k0 >> 2];
                             const float4 c1 = (k0 + 4 < SWP) ? sp4[(k0 >> 2) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
                             const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                            int rank[8]; bool on[8]; uint64_t mk[8];
-#pragma unroll
-                            for (int u = 0; u < 8; u++) {                 // all mask reads in flight before the first use
-                                const int r = k0 + u - j0;
-                                on[u] = (unsigned)r < (unsigned)rh;
-                                mk[u] = pmc[min(max(r, 0), rhm1) * 8];     // slots outside the rectangle read one of its rows; unused
-                            }
-#pragma unroll
-                            for (int u = 0; u < 8; u++) rank[u] = __popcll(mk[u] & below);
 #pragma unroll
                             for (int u = 0; u < 8; u++) {
                                 const int k = k0 + u;
-                                float* base = on[u] ? v_r0 : sink - k * 8 * kValStride;
-                                base[k * 8 * kValStride + rank[u]] = POL ? ei.sg * col[u] : col[u];
+                                const bool on = (unsigned)(k - j0) < (unsigned)rh;
+                                float* base = on ? v_r0 : sink - k * 8 * kValStride;
+                                base[k * 8 * kValStride] = POL ? ei.sg * col[u] : col[u];
                             }
                         };
                         slots8(0);
@@ -530,12 +486,9 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     const float xx = fx * fx;
                     constexpr int U = EORB_GATHER_U;
                     for (int jj = 0; __any(jj < rh); jj += U) {
-                        int rank[U]; bool on[U]; float v[U];
+                        bool on[U]; float v[U];
 #pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            on[u] = jj + u < rh;
-                            rank[u] = __popcll(pmc[on[u] ? (jj + u) * 8 : 0] & below);
-                        }
+                        for (int u = 0; u < U; u++) on[u] = jj + u < rh;
                         if (MODE == 1) {
                             // four-stage form of glibc's expf so the dependent f64 chains of the U rows interleave.
                             // dd /= 2*sig2 with a power-of-two divisor == product with its exact reciprocal (same real number,
@@ -591,7 +544,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                         }
 #pragma unroll
                         for (int u = 0; u < U; u++) {
-                            float* dst = on[u] ? vcol + (jj + u) * 8 * kValStride + rank[u] : sink;
+                            float* dst = on[u] ? vcol + (jj + u) * 8 * kValStride : sink;
                             *dst = POL ? ei.sg * v[u] : v[u];
                         }
                     }
@@ -615,7 +568,9 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     }
 #endif
     if (wave != 0) return;
-    if (!POL && touched) vmax = fmaxf(vmax, acc);
+    // an add of a tap that underflowed to 0 still counts as a visit (newVal > maxVal, :255): a tile with any visited pixel offers
+    // 0 as a candidate for the maximum; real adds were tracked above (POL) / are the final values (no polarity: increments >= 0)
+    if (any_ok) vmax = fmaxf(vmax, POL ? 0.0f : acc);
     if (inimg) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = acc;
     else { vmax = -1000000.0f; vmin = 0.0f; }
 #pragma unroll
