@@ -402,7 +402,8 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                 if (RAW) {                                                               // integer position from the maps (K1c)
                     const uint32_t w0 = __float_as_uint(ex), w1 = __float_as_uint(ey);
                     xi = (int)(int16_t)(w1 & 0xffff); yi = (int)(int16_t)(w1 >> 16);
-                    xr = __uint_as_float(w0 & 0x7fffffffu);                             // sensor pixel index rides in the xr slot
+                    // the sensor pixel's row of the stamp table (float index < 2^32, checked on the host) rides in the xr slot
+                    xr = __uint_as_float(__umul24(w0 & 0x7fffffffu, (uint32_t)P.stamp_stride));
                     esg = (w0 >> 31) ? -1.0f : 1.0f;
                 } else if (MODE == 2) { xi = (int)roundf(ex); yi = (int)roundf(ey); }   // roundFloatCoord :46-49
                 else {                                                                   // breakFloatCoords :51-57
@@ -455,31 +456,39 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     if (g0 == (wave - 2) * 64) EORB_TR(2); else EORB_TR(4);
                     const int dy0 = ty0 + b0 - yi;
                     const int pix0 = act ? b0 * 8 + qx : 0;              // pixel of the column's first row; rows step by 8
-                    float* vcol = vbase + pix0 * kValStride + e;          // the entry's slot in that pixel's list
+                    float* vcol = vbase + __umul24(pix0, kValStride) + e; // the entry's slot in that pixel's list
                     if (RAW && MODE != 2) {
                         // stamp values of this sensor pixel come from the table built once per (maps, sigma).  A column of the
                         // table is padded to a multiple of 4 floats, so the lane fetches it with 16-byte loads and walks its
                         // slots with static register indices: slot k is tile row b0 + (k - j0) when that row exists.
                         const int SWP = P.stamp_colstride;
                         const int j0 = dy0 + h;
-                        const float4* sp4 = (const float4*)(P.stamps + (act ? __float_as_uint(ei.xr) * (uint32_t)P.stamp_stride + (uint32_t)((tx0 + qx - xi + h) * SWP) : 0u));   // < 2^32 floats (checked on the host)
+                        const float4* sp4 = (const float4*)(P.stamps + (act ? __float_as_uint(ei.xr) + __umul24(tx0 + qx - xi + h, SWP) : 0u));
                         // slot k of the column is tile row k - j0: the list row is addressed relative to "row 0 of the column" with
                         // compile-time offsets; slots outside [j0, j0 + rh) store into the sink rows
-                        float* v_r0 = vcol - j0 * 8 * kValStride;
+                        // byte offsets inside vals[][]: slot k of the column stores at row0 + k * (one tile row of lists) when bit k of
+                        // the column's row mask is set, else into the sink words; the select is a sign-extended bit (v_bfe_i32)
+                        // driving a bitfield insert (v_bfi_b32): no compare, no VCC round trip
+                        char* const lds0 = (char*)&vals[0][0];
+                        constexpr uint32_t kRowBytes = 8 * kValStride * 4;
+                        const uint32_t row0 = (uint32_t)((char*)vcol - lds0) - __umul24(j0, kRowBytes);
+                        const uint32_t sink0 = (uint32_t)((char*)sink - lds0);
+                        const uint32_t rmask = ((1u << rh) - 1u) << j0;          // rh = 0 for lanes without a column
+                        // t = all ones when slot k is a tile row; off = t ? row0 : sink (asm: the optimiser turns the plain expression
+                        // back into and / compare / select)
+#define EORB_SLOT(kk, val) { uint32_t t_, off_; \
+                            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t_) : "v"(rmask), "s"(kk)); \
+                            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(off_) : "v"(t_), "v"(row0), "s"(sink0 - (uint32_t)(kk) * kRowBytes)); \
+                            *(float*)(lds0 + off_ + (uint32_t)(kk) * kRowBytes) = POL ? ei.sg * (val) : (val); }
                         auto slots8 = [&](int k0) {
                             const float4 c0 = sp4[k0 >> 2];
                             const float4 c1 = (k0 + 4 < SWP) ? sp4[(k0 >> 2) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                            const float col[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                const int k = k0 + u;
-                                const bool on = (unsigned)(k - j0) < (unsigned)rh;
-                                float* base = on ? v_r0 : sink - k * 8 * kValStride;
-                                base[k * 8 * kValStride] = POL ? ei.sg * col[u] : col[u];
-                            }
+                            EORB_SLOT(k0 + 0, c0.x) EORB_SLOT(k0 + 1, c0.y) EORB_SLOT(k0 + 2, c0.z) EORB_SLOT(k0 + 3, c0.w)
+                            EORB_SLOT(k0 + 4, c1.x) EORB_SLOT(k0 + 5, c1.y) EORB_SLOT(k0 + 6, c1.z) EORB_SLOT(k0 + 7, c1.w)
                         };
                         slots8(0);
                         for (int k0 = 8; k0 < SWP; k0 += 8) slots8(k0);
+#undef EORB_SLOT
                         continue;
                     }
                     const float fx = (float)(tx0 + qx - xi) - ei.xr;            // exp_XY2f(i-xRes, j-yRes) :59-65
