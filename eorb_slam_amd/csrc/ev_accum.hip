@@ -593,6 +593,192 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     }
 }
 
+// K2r: the gather for raw sensor events with a Gaussian stamp (the live configuration).  Lists as in K2 (vals[pixel][e], slot e =
+// the entry's position in its 64-entry batch), but a two-stage pipeline without a set-up wave, without masks or sinks, and with no
+// LDS hand-off besides the lists:
+//   waves 1..4, values(t)   lane = entry e of the batch, wave w owns tile columns w-1 and w+3.  Every lane decodes ITS OWN entry
+//                       (8 coalesced bytes; the four waves read the same 512 bytes) and derives the tile-local tap rectangle.  For
+//                       each of its two columns it writes slot e of ALL 8 pixels of the column: the stamp value where the pixel is
+//                       inside the rectangle, +0.0f elsewhere (also when the column misses the rectangle or the lane has no
+//                       entry).  So a batch rewrites every slot of its buffer: nothing is ever cleared, and a store instruction
+//                       writes 64 consecutive words (no bank conflicts).  The 8 values of a column are one 32-byte read of the
+//                       sensor pixel's table row, started at the stamp row that falls on tile row 0 (the table has 8 floats of
+//                       slack on either side; rows outside the rectangle are masked to zero bit-wise).  The lane -> column map is
+//                       static, so the table read for batch t+1 is issued at the end of iteration t and lands during the barrier,
+//                       and the entry of batch t+2 is loaded two iterations ahead: no wave waits for memory.
+//   wave 0, adds(t-1)   lane = pixel: acc += list[e], e = 0..63 in order; x + 0.0f == x bit for bit, so the real adds happen in
+//                       event order (newVal = image + polSign*val, :251-254).  Reads run 16 slots ahead of the adds.
+constexpr int kStampPad = 8;        // floats of slack in front of (and behind) the stamp table
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+template <bool POL>
+__global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __restrict__ slice_ebase,
+                                                                     const int32_t* __restrict__ order, GatherParams P,
+                                                                     const uint32_t* __restrict__ tile_cnt,
+                                                                     const uint32_t* __restrict__ tile_base,
+                                                                     const uint2* __restrict__ entries,
+                                                                     float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
+{
+    __shared__ int any_ok;                          // some entry of the tile touches an in-image pixel
+    __shared__ __attribute__((aligned(16))) float vals[2][kValStride * 64];       // [pixel][entry slot]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) any_ok = 0;
+    for (int i = tid; i < 2 * kValStride * 64; i += blockDim.x) (&vals[0][0])[i] = 0.f;
+    const int logical = order[blockIdx.x];
+    const int slice = logical / P.NT;
+    const int tile = logical - slice * P.NT;
+    const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
+    const int xhi = min(tx0 + kTile - 1, P.W - 1), yhi = min(ty0 + kTile - 1, P.H - 1);
+    const int h = P.h, SWP = P.stamp_colstride;
+    const int nent = (int)tile_cnt[logical];
+    const int nbatch = (nent + 63) >> 6;
+    const uint2* list = entries + (size_t)slice_ebase[slice] + tile_base[logical];
+    constexpr int kRowFloats = 8 * kValStride;
+    float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
+    // ---- value-wave state: two tile columns; the columns of batches t and t+1 in two register sets (landed / being loaded),
+    //      the entry of batch t+2 in registers.  The global loads of this loop are issued from inline asm with hand-placed
+    //      s_waitcnt vmcnt(N): vmcnt retires in order, and every iteration issues the same five loads in the same order
+    //      (entry of batch t+3, then the four column reads of batch t+2; dummy addresses past the end of the list), so "the set
+    //      of batch t has landed" is vmcnt(5) and "the entry of batch t+2 has landed" is vmcnt(4).  (Left to the compiler, the
+    //      waits across the loop's back edge degrade to vmcnt(0), i.e. to a full memory round trip per batch.) ----
+    const int cA = wave - 1, cB = wave + 3;
+    // E: entry registers (two sets as well: the load of batch t+3 must not land in registers prepare() is still reading)
+    struct ColSet { v4f a0, a1, b0, b1; uint32_t mA, mB; float sg; v2u E; bool Ev; };   // tile rows 0..7 of the two columns, row masks
+    ColSet S0, S1;
+    S0.E = S1.E = (v2u){0u, 0u}; S0.Ev = S1.Ev = false;
+    S0.a0 = S0.a1 = S0.b0 = S0.b1 = S1.a0 = S1.a1 = S1.b0 = S1.b1 = (v4f){0.f, 0.f, 0.f, 0.f};
+    S0.mA = S0.mB = S1.mA = S1.mB = 0u; S0.sg = S1.sg = 1.0f;
+    auto load_entry = [&](int t, ColSet& S) {
+        const int j = t * 64 + lane; S.Ev = j < nent;
+        const uint2* p = list + min(j, max(nent - 1, 0));
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(S.E) : "v"(p) : "memory");
+    };
+    // rectangle of an entry, row masks of the two columns, then the table reads
+    auto prepare = [&](ColSet& S, const v2u ent, const bool valid) {
+        const uint32_t w0 = ent.x, w1 = ent.y;
+        const int xi = valid ? (int)(int16_t)(w1 & 0xffff) : -32768, yi = (int)(int16_t)(w1 >> 16);
+        const int a0 = max(xi - h, tx0) - tx0, a1 = min(xi + h, xhi) - tx0;
+        const int b0 = max(yi - h, ty0) - ty0, b1 = min(yi + h, yhi) - ty0;
+        const bool ok = a1 >= a0 && b1 >= b0;
+        if (wave == 1 && __any(ok) && lane == 0) any_ok = 1;
+        const uint32_t rowmask = ok ? ((2u << (b1 & 31)) - 1u) & ~((1u << (b0 & 31)) - 1u) : 0u;     // tile rows b0..b1
+        const bool inA = ok && cA >= a0 && cA <= a1, inB = ok && cB >= a0 && cB <= a1;
+        S.mA = inA ? rowmask : 0u; S.mB = inB ? rowmask : 0u;
+        S.sg = (w0 >> 31) ? -1.0f : 1.0f;
+        // float index of the table value that falls on tile row 0 of column c: row (ty0 - yi + h) of stamp column (tx0 + c - xi + h)
+        const int base = (int)__umul24(w0 & 0x7fffffffu, (uint32_t)P.stamp_stride) + (ty0 - yi + h);
+        const int iA = inA ? base + (int)__umul24((uint32_t)(tx0 + cA - xi + h), (uint32_t)SWP) : 0;
+        const int iB = inB ? base + (int)__umul24((uint32_t)(tx0 + cB - xi + h), (uint32_t)SWP) : 0;
+        const float* pA = P.stamps + iA; const float* pB = P.stamps + iB;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.a0) : "v"(pA) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.a1) : "v"(pA) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.b0) : "v"(pB) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.b1) : "v"(pB) : "memory");
+    };
+    if (wave >= 1) {
+        // in-flight order expected by the loop: columns(0) x4, entry(2) [in S0.E], columns(1) x4
+        load_entry(0, S0);
+        load_entry(1, S1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0.E), "+v"(S1.E) :: "memory");
+        prepare(S0, S0.E, S0.Ev);
+        asm volatile("s_nop 0" : "+v"(S0.E) :: "memory");       // prepare's reads of S0.E are issued before the load below
+        load_entry(2, S0);
+        prepare(S1, S1.E, S1.Ev);
+    }
+    __syncthreads();
+#ifdef EORB_DIAG
+    unsigned long long d_work = 0, d_t0 = __builtin_readcyclecounter(), d_setup = 0;
+#endif
+    // one iteration: adds(t-1) by wave 0, values(t) by the others from register set S, whose registers then take batch t+2
+    auto iteration = [&](int t, ColSet& S, ColSet& T) {      // T: the other set (its entry registers are free)
+#ifdef EORB_DIAG
+        const unsigned long long d_s = __builtin_readcyclecounter();
+#endif
+        if (wave == 0) {
+            // ---- adds(t-1): all 64 slots in order ----
+            if (t >= 1) {
+                const float4* vb = (const float4*)(vals[(t - 1) & 1] + lane * kValStride);
+                float4 q[4] = {vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+                for (int g = 0; g < 16; g += 4) {
+                    float4 n[4];
+                    if (g + 4 < 16) { n[0] = vb[g + 4]; n[1] = vb[g + 5]; n[2] = vb[g + 6]; n[3] = vb[g + 7]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (!POL) { acc = acc + q[u].x; acc = acc + q[u].y; acc = acc + q[u].z; acc = acc + q[u].w; }
+                        else {
+                            // running extremes (resolveMinMaxVals :32-39) only move on a real add: a tap is never 0
+#define EORB_ADD(val) { if ((val) != 0.0f) { acc = acc + (val); vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); } }
+                            EORB_ADD(q[u].x) EORB_ADD(q[u].y) EORB_ADD(q[u].z) EORB_ADD(q[u].w)
+#undef EORB_ADD
+                        }
+                    }
+                    if (g + 4 < 16) { q[0] = n[0]; q[1] = n[1]; q[2] = n[2]; q[3] = n[3]; }
+                }
+            }
+        } else if (t < nbatch) {
+            // ---- values(t): the columns requested two iterations ago; slot `lane` of the 8 pixels of each column ----
+            asm volatile("s_waitcnt vmcnt(5)" : "+v"(S.a0), "+v"(S.a1), "+v"(S.b0), "+v"(S.b1) :: "memory");
+            float* dA = vals[t & 1] + cA * kValStride + lane;
+            float* dB = vals[t & 1] + cB * kValStride + lane;
+            // value where bit r of the column's row mask is set, +0.0f elsewhere (asm: a sign-extended bit as an AND mask)
+#define EORB_ROW(dst, mask, r, val) { uint32_t t_; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t_) : "v"(mask), "s"(r)); \
+                (dst)[(r) * kRowFloats] = __uint_as_float(__float_as_uint(POL ? S.sg * (val) : (val)) & t_); }
+            EORB_ROW(dA, S.mA, 0, S.a0.x) EORB_ROW(dA, S.mA, 1, S.a0.y) EORB_ROW(dA, S.mA, 2, S.a0.z) EORB_ROW(dA, S.mA, 3, S.a0.w)
+            EORB_ROW(dA, S.mA, 4, S.a1.x) EORB_ROW(dA, S.mA, 5, S.a1.y) EORB_ROW(dA, S.mA, 6, S.a1.z) EORB_ROW(dA, S.mA, 7, S.a1.w)
+            EORB_ROW(dB, S.mB, 0, S.b0.x) EORB_ROW(dB, S.mB, 1, S.b0.y) EORB_ROW(dB, S.mB, 2, S.b0.z) EORB_ROW(dB, S.mB, 3, S.b0.w)
+            EORB_ROW(dB, S.mB, 4, S.b1.x) EORB_ROW(dB, S.mB, 5, S.b1.y) EORB_ROW(dB, S.mB, 6, S.b1.z) EORB_ROW(dB, S.mB, 7, S.b1.w)
+#undef EORB_ROW
+#ifdef EORB_DIAG
+            d_setup += __builtin_readcyclecounter() - d_s;
+#endif
+            {
+                // entry of batch t+2 (requested an iteration ago, four loads younger than it in flight); then request the entry of
+                // batch t+3 BEFORE the column reads of batch t+2, so that the next iteration's wait for it leaves those in flight
+                asm volatile("s_waitcnt vmcnt(4)" : "+v"(S.E) :: "memory");
+                load_entry(t + 3, T);
+                prepare(S, S.E, S.Ev);
+            }
+        }
+#ifdef EORB_DIAG
+        d_work += __builtin_readcyclecounter() - d_s;
+#endif
+        __syncthreads();
+    };
+    for (int t = 0; t < nbatch + 1; t += 2) {
+        iteration(t, S0, S1);
+        if (t + 1 < nbatch + 1) iteration(t + 1, S1, S0);
+    }
+#ifdef EORB_DIAG
+    if (nbatch > 1000 && lane == 0) {
+        const unsigned long long tot = __builtin_readcyclecounter() - d_t0;
+        const int role = wave == 0 ? 0 : (wave == 1 ? 1 : 2);
+        atomicAdd(&g_diag[role * 4 + 0], d_work);
+        atomicAdd(&g_diag[role * 4 + 1], tot);
+        atomicAdd(&g_diag[role * 4 + 2], (unsigned long long)nbatch);
+        atomicAdd(&g_diag[role * 4 + 3], d_setup);
+    }
+#endif
+    if (wave != 0) return;
+    const int lx = lane & 7, ly = lane >> 3;
+    const int px = tx0 + lx, py = ty0 + ly;
+    const bool inimg = px < P.W && py < P.H;
+    // an add of a tap that underflowed to 0 still counts as a visit (newVal > maxVal, :255): a tile with any visited pixel offers
+    // 0 as a candidate for the maximum; real adds were tracked above (POL) / are the final values (no polarity: increments >= 0)
+    if (any_ok) vmax = fmaxf(vmax, POL ? 0.0f : acc);
+    if (inimg) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = acc;
+    else { vmax = -1000000.0f; vmin = 0.0f; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+        vmin = fminf(vmin, __shfl_xor(vmin, d, 64));
+    }
+    if (lane == 0) {
+        atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
+        atomicMax(&minmax_enc[slice * 2 + 1], enc_f32(vmax));
+    }
+}
+
 // exhaustive self-check helper: IEEE quotient vs the reciprocal/fma sequence used above
 __global__ void ev_divcheck_kernel(uint32_t lo_bits, uint32_t hi_bits, float norm, float rcp, unsigned long long* bad)
 {
@@ -1112,7 +1298,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     const size_t cnt_bytes = (sizeof(uint16_t) * (size_t)std::max(nchunks, 1) * NT + 15) & ~(size_t)15;
     if ((rc = ensure(c, c->segoff, cnt_bytes + sizeof(uint32_t) * (size_t)std::max(nchunks, 1) * NT))) return rc;
     const int esz = pol ? 4 : 2;
-    if ((rc = ensure(c, c->entries, sizeof(float) * esz * (size_t)std::max<int64_t>(nev, 1) * dup))) return rc;
+    if ((rc = ensure(c, c->entries, sizeof(float) * esz * (size_t)std::max<int64_t>(nev, 1) * dup + 64))) return rc;   // + slack: K2r reads entry 0 of an empty list
     // tile_cnt | tile_base | order
     if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * 3 * (size_t)nb))) return rc;
     char* hp = (char*)pinned(c, cd_bytes + sc_bytes + eb_bytes);
@@ -1155,14 +1341,16 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                                                                             (uint32_t*)c->src_info.p);
             if (!mode_count) {
                 if ((size_t)nsrc * SW * SWP >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
-                if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 8)))) return rc;
+                if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 2 * kStampPad)))) return rc;
+                EORB_HIP(c, hipMemsetAsync(c->stamps.p, 0, sizeof(float) * kStampPad, c->stream));
+                EORB_HIP(c, hipMemsetAsync((float*)c->stamps.p + kStampPad + (size_t)nsrc * SW * SWP, 0, sizeof(float) * kStampPad, c->stream));
                 ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
-                                                             (float*)c->stamps.p);
+                                                             (float*)c->stamps.p + kStampPad);
             }
             EORB_LAUNCH_CHECK(c, "ev_stamp_tables kernels");
             c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
         }
-        G.stamps = (const float*)c->stamps.p;
+        G.stamps = (const float*)c->stamps.p + kStampPad;     // K2r reads up to 7 floats before / behind a column
     }
     {
         ProfScope ps(c, "ev_minmax_init");
@@ -1194,7 +1382,13 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         const int mode = mode_count ? 2 : ((G.div_is_pow2 && G.fast_norm) ? 1 : 0);
         const float* en = (const float*)c->entries.p;
 #define LAUNCH_G(PP, MM, RR) ev_gather_kernel<PP, MM, RR><<<nb, gthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en, d_f32, d_minmax_enc)
-        if (raw) {
+        static const bool old_raw = getenv("EORB_OLD_RAW_GATHER") != nullptr;
+        if (raw && mode != 2 && !old_raw) {
+            const int rthreads = 320;          // the add wave + four value waves (two tile columns each)
+            const uint2* en2 = (const uint2*)c->entries.p;
+            if (pol) ev_gather_raw_kernel<true><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);
+            else ev_gather_raw_kernel<false><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);
+        } else if (raw) {
             if (pol) { if (mode == 2) LAUNCH_G(true, 2, true); else LAUNCH_G(true, 0, true); }
             else { if (mode == 2) LAUNCH_G(false, 2, true); else LAUNCH_G(false, 0, true); }
         } else if (pol) { if (mode == 2) LAUNCH_G(true, 2, false); else if (mode == 1) LAUNCH_G(true, 1, false); else LAUNCH_G(true, 0, false); }
