@@ -596,9 +596,9 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 // K2r: the gather for raw sensor events with a Gaussian stamp (the live configuration).  Lists as in K2 (vals[pixel][e], slot e =
 // the entry's position in its 64-entry batch), but a two-stage pipeline without a set-up wave, without masks or sinks, and with no
 // LDS hand-off besides the lists:
-//   waves 1..4, values(t)   lane = entry e of the batch, wave w owns tile columns w-1 and w+3.  Every lane decodes ITS OWN entry
+//   waves 1..NW, values(t)  lane = entry e of the batch, wave w owns NC = 8/NW tile columns (NC = 2: w-1 and w+3).  Every lane decodes ITS OWN entry
 //                       (8 coalesced bytes; the four waves read the same 512 bytes) and derives the tile-local tap rectangle.  For
-//                       each of its two columns it writes slot e of ALL 8 pixels of the column: the stamp value where the pixel is
+//                       each of its columns it writes slot e of ALL 8 pixels of the column: the stamp value where the pixel is
 //                       inside the rectangle, +0.0f elsewhere (also when the column misses the rectangle or the lane has no
 //                       entry).  So a batch rewrites every slot of its buffer: nothing is ever cleared, and a store instruction
 //                       writes 64 consecutive words (no bank conflicts).  The 8 values of a column are one 32-byte read of the
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 constexpr int kStampPad = 8;        // floats of slack in front of (and behind) the stamp table
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-template <bool POL>
+template <bool POL, int NC>
 __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __restrict__ slice_ebase,
                                                                      const int32_t* __restrict__ order, GatherParams P,
                                                                      const uint32_t* __restrict__ tile_cnt,
@@ -635,25 +635,25 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
     const uint2* list = entries + (size_t)slice_ebase[slice] + tile_base[logical];
     constexpr int kRowFloats = 8 * kValStride;
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
-    // ---- value-wave state: two tile columns; the columns of batches t and t+1 in two register sets (landed / being loaded),
-    //      the entry of batch t+2 in registers.  The global loads of this loop are issued from inline asm with hand-placed
-    //      s_waitcnt vmcnt(N): vmcnt retires in order, and every iteration issues the same five loads in the same order
-    //      (entry of batch t+3, then the four column reads of batch t+2; dummy addresses past the end of the list), so "the set
-    //      of batch t has landed" is vmcnt(5) and "the entry of batch t+2 has landed" is vmcnt(4).  (Left to the compiler, the
-    //      waits across the loop's back edge degrade to vmcnt(0), i.e. to a full memory round trip per batch.) ----
-    const int cA = wave - 1, cB = wave + 3;
+    // ---- value-wave state: NC tile columns (wave w: columns w-1, w-1+NW, ...); the columns of batches t and t+1 in two register
+    //      sets (landed / being loaded), the entry of batch t+2 in registers.  The global loads of this loop are issued from inline
+    //      asm with hand-placed s_waitcnt vmcnt(N): vmcnt retires in order, and every iteration issues the same 1 + 2*NC loads in
+    //      the same order (entry of batch t+3, then the column reads of batch t+2; dummy addresses past the end of the list), so
+    //      "the set of batch t has landed" is vmcnt(2*NC+1) and "the entry of batch t+2 has landed" is vmcnt(2*NC).  (Left to the
+    //      compiler, the waits across the loop's back edge degrade to vmcnt(0): a full memory round trip per batch.) ----
+    constexpr int NW = 8 / NC;                       // value waves
     // E: entry registers (two sets as well: the load of batch t+3 must not land in registers prepare() is still reading)
-    struct ColSet { v4f a0, a1, b0, b1; uint32_t mA, mB; float sg; v2u E; bool Ev; };   // tile rows 0..7 of the two columns, row masks
+    struct ColSet { v4f c[NC][2]; uint32_t m[NC]; float sg; v2u E; bool Ev; };    // tile rows 0..7 of the columns, their row masks
     ColSet S0, S1;
-    S0.E = S1.E = (v2u){0u, 0u}; S0.Ev = S1.Ev = false;
-    S0.a0 = S0.a1 = S0.b0 = S0.b1 = S1.a0 = S1.a1 = S1.b0 = S1.b1 = (v4f){0.f, 0.f, 0.f, 0.f};
-    S0.mA = S0.mB = S1.mA = S1.mB = 0u; S0.sg = S1.sg = 1.0f;
+#pragma unroll
+    for (int k = 0; k < NC; k++) { S0.c[k][0] = S0.c[k][1] = S1.c[k][0] = S1.c[k][1] = (v4f){0.f, 0.f, 0.f, 0.f}; S0.m[k] = S1.m[k] = 0u; }
+    S0.sg = S1.sg = 1.0f; S0.E = S1.E = (v2u){0u, 0u}; S0.Ev = S1.Ev = false;
     auto load_entry = [&](int t, ColSet& S) {
         const int j = t * 64 + lane; S.Ev = j < nent;
         const uint2* p = list + min(j, max(nent - 1, 0));
         asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(S.E) : "v"(p) : "memory");
     };
-    // rectangle of an entry, row masks of the two columns, then the table reads
+    // rectangle of an entry, row masks of the columns, then the table reads
     auto prepare = [&](ColSet& S, const v2u ent, const bool valid) {
         const uint32_t w0 = ent.x, w1 = ent.y;
         const int xi = valid ? (int)(int16_t)(w1 & 0xffff) : -32768, yi = (int)(int16_t)(w1 >> 16);
@@ -662,21 +662,33 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
         const bool ok = a1 >= a0 && b1 >= b0;
         if (wave == 1 && __any(ok) && lane == 0) any_ok = 1;
         const uint32_t rowmask = ok ? ((2u << (b1 & 31)) - 1u) & ~((1u << (b0 & 31)) - 1u) : 0u;     // tile rows b0..b1
-        const bool inA = ok && cA >= a0 && cA <= a1, inB = ok && cB >= a0 && cB <= a1;
-        S.mA = inA ? rowmask : 0u; S.mB = inB ? rowmask : 0u;
         S.sg = (w0 >> 31) ? -1.0f : 1.0f;
         // float index of the table value that falls on tile row 0 of column c: row (ty0 - yi + h) of stamp column (tx0 + c - xi + h)
         const int base = (int)__umul24(w0 & 0x7fffffffu, (uint32_t)P.stamp_stride) + (ty0 - yi + h);
-        const int iA = inA ? base + (int)__umul24((uint32_t)(tx0 + cA - xi + h), (uint32_t)SWP) : 0;
-        const int iB = inB ? base + (int)__umul24((uint32_t)(tx0 + cB - xi + h), (uint32_t)SWP) : 0;
-        const float* pA = P.stamps + iA; const float* pB = P.stamps + iB;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.a0) : "v"(pA) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.a1) : "v"(pA) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.b0) : "v"(pB) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.b1) : "v"(pB) : "memory");
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            const int cc = wave - 1 + k * NW;
+            const bool in = ok && cc >= a0 && cc <= a1;
+            S.m[k] = in ? rowmask : 0u;
+            const float* pc = P.stamps + (in ? base + (int)__umul24((uint32_t)(tx0 + cc - xi + h), (uint32_t)SWP) : 0);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.c[k][0]) : "v"(pc) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.c[k][1]) : "v"(pc) : "memory");
+        }
+    };
+    // wait until all but the n youngest loads have landed; the "+v" operands keep the uses of the set / entry behind the wait
+    auto wait_set = [&](ColSet& S) {
+        if constexpr (NC == 2)
+            asm volatile("s_waitcnt vmcnt(5)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(9)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]),
+                         "+v"(S.c[2][0]), "+v"(S.c[2][1]), "+v"(S.c[3][0]), "+v"(S.c[3][1]) :: "memory");
+    };
+    auto wait_entry = [&](ColSet& S) {
+        if constexpr (NC == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(S.E) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(S.E) :: "memory");
     };
     if (wave >= 1) {
-        // in-flight order expected by the loop: columns(0) x4, entry(2) [in S0.E], columns(1) x4
+        // in-flight order expected by the loop: columns(0), entry(2) [in S0.E], columns(1)
         load_entry(0, S0);
         load_entry(1, S1);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0.E), "+v"(S1.E) :: "memory");
@@ -718,16 +730,16 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
             }
         } else if (t < nbatch) {
             // ---- values(t): the columns requested two iterations ago; slot `lane` of the 8 pixels of each column ----
-            asm volatile("s_waitcnt vmcnt(5)" : "+v"(S.a0), "+v"(S.a1), "+v"(S.b0), "+v"(S.b1) :: "memory");
-            float* dA = vals[t & 1] + cA * kValStride + lane;
-            float* dB = vals[t & 1] + cB * kValStride + lane;
+            wait_set(S);
             // value where bit r of the column's row mask is set, +0.0f elsewhere (asm: a sign-extended bit as an AND mask)
-#define EORB_ROW(dst, mask, r, val) { uint32_t t_; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t_) : "v"(mask), "s"(r)); \
+#define EORB_ROW(dst, mask, r, val) { uint32_t t_; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t_) : "v"(mask), "i"(r)); \
                 (dst)[(r) * kRowFloats] = __uint_as_float(__float_as_uint(POL ? S.sg * (val) : (val)) & t_); }
-            EORB_ROW(dA, S.mA, 0, S.a0.x) EORB_ROW(dA, S.mA, 1, S.a0.y) EORB_ROW(dA, S.mA, 2, S.a0.z) EORB_ROW(dA, S.mA, 3, S.a0.w)
-            EORB_ROW(dA, S.mA, 4, S.a1.x) EORB_ROW(dA, S.mA, 5, S.a1.y) EORB_ROW(dA, S.mA, 6, S.a1.z) EORB_ROW(dA, S.mA, 7, S.a1.w)
-            EORB_ROW(dB, S.mB, 0, S.b0.x) EORB_ROW(dB, S.mB, 1, S.b0.y) EORB_ROW(dB, S.mB, 2, S.b0.z) EORB_ROW(dB, S.mB, 3, S.b0.w)
-            EORB_ROW(dB, S.mB, 4, S.b1.x) EORB_ROW(dB, S.mB, 5, S.b1.y) EORB_ROW(dB, S.mB, 6, S.b1.z) EORB_ROW(dB, S.mB, 7, S.b1.w)
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                float* d = vals[t & 1] + (wave - 1 + k * NW) * kValStride + lane;
+                EORB_ROW(d, S.m[k], 0, S.c[k][0].x) EORB_ROW(d, S.m[k], 1, S.c[k][0].y) EORB_ROW(d, S.m[k], 2, S.c[k][0].z) EORB_ROW(d, S.m[k], 3, S.c[k][0].w)
+                EORB_ROW(d, S.m[k], 4, S.c[k][1].x) EORB_ROW(d, S.m[k], 5, S.c[k][1].y) EORB_ROW(d, S.m[k], 6, S.c[k][1].z) EORB_ROW(d, S.m[k], 7, S.c[k][1].w)
+            }
 #undef EORB_ROW
 #ifdef EORB_DIAG
             d_setup += __builtin_readcyclecounter() - d_s;
@@ -735,7 +747,7 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
             {
                 // entry of batch t+2 (requested an iteration ago, four loads younger than it in flight); then request the entry of
                 // batch t+3 BEFORE the column reads of batch t+2, so that the next iteration's wait for it leaves those in flight
-                asm volatile("s_waitcnt vmcnt(4)" : "+v"(S.E) :: "memory");
+                wait_entry(S);
                 load_entry(t + 3, T);
                 prepare(S, S.E, S.Ev);
             }
@@ -1384,10 +1396,17 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
 #define LAUNCH_G(PP, MM, RR) ev_gather_kernel<PP, MM, RR><<<nb, gthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en, d_f32, d_minmax_enc)
         static const bool old_raw = getenv("EORB_OLD_RAW_GATHER") != nullptr;
         if (raw && mode != 2 && !old_raw) {
-            const int rthreads = 320;          // the add wave + four value waves (two tile columns each)
+            // the add wave + four value waves with two tile columns each (shortest chain per batch), or -- when the launch has
+            // enough tiles to keep every SIMD busy anyway -- two value waves with four columns each (the rectangle arithmetic is
+            // done once per four columns: fewest instructions per batch)
+            static const int nc_env = [] { const char* e = getenv("EORB_GATHER_NC"); return e ? atoi(e) : 0; }();
+            const int NC = nc_env == 2 || nc_env == 4 ? nc_env : (nb >= 16 * 690 ? 4 : 2);
+            const int rthreads = 64 * (1 + 8 / NC);
             const uint2* en2 = (const uint2*)c->entries.p;
-            if (pol) ev_gather_raw_kernel<true><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);
-            else ev_gather_raw_kernel<false><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);
+#define LAUNCH_R(PP, CC) ev_gather_raw_kernel<PP, CC><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc)
+            if (pol) { if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
+            else { if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
+#undef LAUNCH_R
         } else if (raw) {
             if (pol) { if (mode == 2) LAUNCH_G(true, 2, true); else LAUNCH_G(true, 0, true); }
             else { if (mode == 2) LAUNCH_G(false, 2, true); else LAUNCH_G(false, 0, true); }
