@@ -599,8 +599,8 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 //   waves 1..NW, values(t)  lane = entry e of the batch, wave w owns NC = 8/NW tile columns (NC = 2: w-1 and w+3).  Every lane decodes ITS OWN entry
 //                       (8 coalesced bytes; the four waves read the same 512 bytes) and derives the tile-local tap rectangle.  For
 //                       each of its columns it writes slot e of ALL 8 pixels of the column: the stamp value where the pixel is
-//                       inside the rectangle, +0.0f elsewhere (also when the column misses the rectangle or the lane has no
-//                       entry).  So a batch rewrites every slot of its buffer: nothing is ever cleared, and a store instruction
+//                       inside the rectangle, +0.0f elsewhere (a column that misses the rectangle, or a lane without an entry,
+//                       reads the zeros in front of the table).  So a batch rewrites every slot of its buffer: nothing is ever cleared, and a store instruction
 //                       writes 64 consecutive words (no bank conflicts).  The 8 values of a column are one 32-byte read of the
 //                       sensor pixel's table row, started at the stamp row that falls on tile row 0 (the table has 8 floats of
 //                       slack on either side; rows outside the rectangle are masked to zero bit-wise).  The lane -> column map is
@@ -643,11 +643,11 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
     //      compiler, the waits across the loop's back edge degrade to vmcnt(0): a full memory round trip per batch.) ----
     constexpr int NW = 8 / NC;                       // value waves
     // E: entry registers (two sets as well: the load of batch t+3 must not land in registers prepare() is still reading)
-    struct ColSet { v4f c[NC][2]; uint32_t m[NC]; float sg; v2u E; bool Ev; };    // tile rows 0..7 of the columns, their row masks
+    struct ColSet { v4f c[NC][2]; uint32_t m; float sg; v2u E; bool Ev; };        // tile rows 0..7 of the columns, the row mask
     ColSet S0, S1;
 #pragma unroll
-    for (int k = 0; k < NC; k++) { S0.c[k][0] = S0.c[k][1] = S1.c[k][0] = S1.c[k][1] = (v4f){0.f, 0.f, 0.f, 0.f}; S0.m[k] = S1.m[k] = 0u; }
-    S0.sg = S1.sg = 1.0f; S0.E = S1.E = (v2u){0u, 0u}; S0.Ev = S1.Ev = false;
+    for (int k = 0; k < NC; k++) S0.c[k][0] = S0.c[k][1] = S1.c[k][0] = S1.c[k][1] = (v4f){0.f, 0.f, 0.f, 0.f};
+    S0.m = S1.m = 0u; S0.sg = S1.sg = 1.0f; S0.E = S1.E = (v2u){0u, 0u}; S0.Ev = S1.Ev = false;
     auto load_entry = [&](int t, ColSet& S) {
         const int j = t * 64 + lane; S.Ev = j < nent;
         const uint2* p = list + min(j, max(nent - 1, 0));
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
         const int b0 = max(yi - h, ty0) - ty0, b1 = min(yi + h, yhi) - ty0;
         const bool ok = a1 >= a0 && b1 >= b0;
         if (wave == 1 && __any(ok) && lane == 0) any_ok = 1;
-        const uint32_t rowmask = ok ? ((2u << (b1 & 31)) - 1u) & ~((1u << (b0 & 31)) - 1u) : 0u;     // tile rows b0..b1
+        S.m = ok ? ((2u << (b1 & 31)) - 1u) & ~((1u << (b0 & 31)) - 1u) : 0u;     // tile rows b0..b1
         S.sg = (w0 >> 31) ? -1.0f : 1.0f;
         // float index of the table value that falls on tile row 0 of column c: row (ty0 - yi + h) of stamp column (tx0 + c - xi + h)
         const int base = (int)__umul24(w0 & 0x7fffffffu, (uint32_t)P.stamp_stride) + (ty0 - yi + h);
@@ -669,8 +669,8 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
         for (int k = 0; k < NC; k++) {
             const int cc = wave - 1 + k * NW;
             const bool in = ok && cc >= a0 && cc <= a1;
-            S.m[k] = in ? rowmask : 0u;
-            const float* pc = P.stamps + (in ? base + (int)__umul24((uint32_t)(tx0 + cc - xi + h), (uint32_t)SWP) : 0);
+            // a column outside the rectangle reads the 8 zeros in front of the table
+            const float* pc = P.stamps + (in ? base + (int)__umul24((uint32_t)(tx0 + cc - xi + h), (uint32_t)SWP) : -kStampPad);
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.c[k][0]) : "v"(pc) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.c[k][1]) : "v"(pc) : "memory");
         }
@@ -731,14 +731,18 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
         } else if (t < nbatch) {
             // ---- values(t): the columns requested two iterations ago; slot `lane` of the 8 pixels of each column ----
             wait_set(S);
-            // value where bit r of the column's row mask is set, +0.0f elsewhere (asm: a sign-extended bit as an AND mask)
-#define EORB_ROW(dst, mask, r, val) { uint32_t t_; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t_) : "v"(mask), "i"(r)); \
-                (dst)[(r) * kRowFloats] = __uint_as_float(__float_as_uint(POL ? S.sg * (val) : (val)) & t_); }
+            // value where bit r of the entry's row mask is set, +0.0f elsewhere: a sign-extended bit (asm: v_bfe_i32) as an AND mask,
+            // shared by the wave's columns
+            uint32_t rm[8];
+#define EORB_RM(r) asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(rm[r]) : "v"(S.m), "i"(r));
+            EORB_RM(0) EORB_RM(1) EORB_RM(2) EORB_RM(3) EORB_RM(4) EORB_RM(5) EORB_RM(6) EORB_RM(7)
+#undef EORB_RM
+#define EORB_ROW(dst, r, val) (dst)[(r) * kRowFloats] = __uint_as_float(__float_as_uint(POL ? S.sg * (val) : (val)) & rm[r]);
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 float* d = vals[t & 1] + (wave - 1 + k * NW) * kValStride + lane;
-                EORB_ROW(d, S.m[k], 0, S.c[k][0].x) EORB_ROW(d, S.m[k], 1, S.c[k][0].y) EORB_ROW(d, S.m[k], 2, S.c[k][0].z) EORB_ROW(d, S.m[k], 3, S.c[k][0].w)
-                EORB_ROW(d, S.m[k], 4, S.c[k][1].x) EORB_ROW(d, S.m[k], 5, S.c[k][1].y) EORB_ROW(d, S.m[k], 6, S.c[k][1].z) EORB_ROW(d, S.m[k], 7, S.c[k][1].w)
+                EORB_ROW(d, 0, S.c[k][0].x) EORB_ROW(d, 1, S.c[k][0].y) EORB_ROW(d, 2, S.c[k][0].z) EORB_ROW(d, 3, S.c[k][0].w)
+                EORB_ROW(d, 4, S.c[k][1].x) EORB_ROW(d, 5, S.c[k][1].y) EORB_ROW(d, 6, S.c[k][1].z) EORB_ROW(d, 7, S.c[k][1].w)
             }
 #undef EORB_ROW
 #ifdef EORB_DIAG
