@@ -10,8 +10,9 @@
 //   K1c ev_scatter_kernel one wavefront per chunk, ORDER-PRESERVING scatter into the lists: lanes = consecutive events,
 //                        rank among same-tile lanes by ballot matching; tiles are visited in parity classes so a tile is only
 //                        ever targeted in one pass.
-//   K2 ev_gather_kernel   one workgroup per tile, heaviest tiles first: 64-entry batches through a set-up / value / add
-//                        wave pipeline (see the comment above the kernel); every pixel adds its taps in event order.
+//   K2 ev_gather_kernel / K2r ev_gather_raw_kernel   one workgroup per tile, heaviest tiles first: 64-entry batches through a
+//                        pipeline of value waves and one add wave (see the comments above the kernels); every pixel adds its
+//                        taps in event order.
 //                        Running min/max (resolveMinMaxVals :32-39) reduced per wave -> atomics.
 //   K3 ev_normalize_kernel  normalizeImage (:67-72): convertTo(CV_8UC1, alpha, beta), round-half-even.
 // All kernels are batched over time-slices (blockIdx ranges over slices x tiles / chunks).
@@ -257,15 +258,16 @@ struct GatherParams {
     int stamp_stride, stamp_colstride;   // floats per sensor pixel / per (16-byte padded) stamp column
 };
 
-// K2: one 512-thread workgroup per 8x8 tile, heaviest tiles first (EORB_GATHER_THREADS overrides: 384..704 measured, 512 fastest;
-// 4 workgroups per CU: 8 waves/SIMD at <= 64 VGPRs, 40.7 KB of LDS).  The tile's entries are consumed in batches of 64 (event
+// K2: the gather for float events (values from expf) and for count images; raw sensor events with a Gaussian stamp take K2r below.
+// One 512-thread workgroup per 8x8 tile, heaviest tiles first (EORB_GATHER_THREADS overrides: 384..704 measured, 512 fastest;
+// 4 workgroups per CU: 8 waves/SIMD at <= 64 VGPRs, 39 KB of LDS).  The tile's entries are consumed in batches of 64 (event
 // order) through a 3-stage software pipeline with ONE barrier per batch:
 //   wave 1, set-up(t)   lane = entry (loaded one batch ahead): integer position / residuals (breakFloatCoords :51-57) and the
 //                       tile-local rectangle of stamp taps.  A DPP prefix sum of the rectangle widths lays the entries' stamp
 //                       columns side by side; owner[column] = entry.
 //   waves 2-7, values(t-1)  lane = one stamp column (a round = 64 columns): its rows' values -- exp_XY2f (:59-65) evaluated in
-//                       f64 like glibc's expf, or, for raw sensor events, a 16-byte read of the per-pixel stamp table -- go to
-//                       slot e (the entry's position in the batch) of the pixels' lists: vals[pixel][e].
+//                       f64 like glibc's expf -- go to slot e (the entry's position in the batch) of the pixels' lists:
+//                       vals[pixel][e].
 //   wave 0, adds(t-2)   lane = pixel: acc += list[e], e = 0..63 (newVal = image + polSign*val, :251-254): the only sequential
 //                       part.  Slots of entries that do not touch the pixel hold +0.0f, and x + 0.0f == x bit for bit, so the
 //                       order of the real adds is the event order and no masks, counts or ranks are needed; lists are read four
@@ -402,8 +404,6 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                 if (RAW) {                                                               // integer position from the maps (K1c)
                     const uint32_t w0 = __float_as_uint(ex), w1 = __float_as_uint(ey);
                     xi = (int)(int16_t)(w1 & 0xffff); yi = (int)(int16_t)(w1 >> 16);
-                    // the sensor pixel's row of the stamp table (float index < 2^32, checked on the host) rides in the xr slot
-                    xr = __uint_as_float(__umul24(w0 & 0x7fffffffu, (uint32_t)P.stamp_stride));
                     esg = (w0 >> 31) ? -1.0f : 1.0f;
                 } else if (MODE == 2) { xi = (int)roundf(ex); yi = (int)roundf(ey); }   // roundFloatCoord :46-49
                 else {                                                                   // breakFloatCoords :51-57
@@ -457,40 +457,6 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
                     const int dy0 = ty0 + b0 - yi;
                     const int pix0 = act ? b0 * 8 + qx : 0;              // pixel of the column's first row; rows step by 8
                     float* vcol = vbase + __umul24(pix0, kValStride) + e; // the entry's slot in that pixel's list
-                    if (RAW && MODE != 2) {
-                        // stamp values of this sensor pixel come from the table built once per (maps, sigma).  A column of the
-                        // table is padded to a multiple of 4 floats, so the lane fetches it with 16-byte loads and walks its
-                        // slots with static register indices: slot k is tile row b0 + (k - j0) when that row exists.
-                        const int SWP = P.stamp_colstride;
-                        const int j0 = dy0 + h;
-                        const float4* sp4 = (const float4*)(P.stamps + (act ? __float_as_uint(ei.xr) + __umul24(tx0 + qx - xi + h, SWP) : 0u));
-                        // slot k of the column is tile row k - j0: the list row is addressed relative to "row 0 of the column" with
-                        // compile-time offsets; slots outside [j0, j0 + rh) store into the sink rows
-                        // byte offsets inside vals[][]: slot k of the column stores at row0 + k * (one tile row of lists) when bit k of
-                        // the column's row mask is set, else into the sink words; the select is a sign-extended bit (v_bfe_i32)
-                        // driving a bitfield insert (v_bfi_b32): no compare, no VCC round trip
-                        char* const lds0 = (char*)&vals[0][0];
-                        constexpr uint32_t kRowBytes = 8 * kValStride * 4;
-                        const uint32_t row0 = (uint32_t)((char*)vcol - lds0) - __umul24(j0, kRowBytes);
-                        const uint32_t sink0 = (uint32_t)((char*)sink - lds0);
-                        const uint32_t rmask = ((1u << rh) - 1u) << j0;          // rh = 0 for lanes without a column
-                        // t = all ones when slot k is a tile row; off = t ? row0 : sink (asm: the optimiser turns the plain expression
-                        // back into and / compare / select)
-#define EORB_SLOT(kk, val) { uint32_t t_, off_; \
-                            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t_) : "v"(rmask), "s"(kk)); \
-                            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(off_) : "v"(t_), "v"(row0), "s"(sink0 - (uint32_t)(kk) * kRowBytes)); \
-                            *(float*)(lds0 + off_ + (uint32_t)(kk) * kRowBytes) = POL ? ei.sg * (val) : (val); }
-                        auto slots8 = [&](int k0) {
-                            const float4 c0 = sp4[k0 >> 2];
-                            const float4 c1 = (k0 + 4 < SWP) ? sp4[(k0 >> 2) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                            EORB_SLOT(k0 + 0, c0.x) EORB_SLOT(k0 + 1, c0.y) EORB_SLOT(k0 + 2, c0.z) EORB_SLOT(k0 + 3, c0.w)
-                            EORB_SLOT(k0 + 4, c1.x) EORB_SLOT(k0 + 5, c1.y) EORB_SLOT(k0 + 6, c1.z) EORB_SLOT(k0 + 7, c1.w)
-                        };
-                        slots8(0);
-                        for (int k0 = 8; k0 < SWP; k0 += 8) slots8(k0);
-#undef EORB_SLOT
-                        continue;
-                    }
                     const float fx = (float)(tx0 + qx - xi) - ei.xr;            // exp_XY2f(i-xRes, j-yRes) :59-65
                     const float xx = fx * fx;
                     constexpr int U = EORB_GATHER_U;
@@ -1398,22 +1364,20 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         const int mode = mode_count ? 2 : ((G.div_is_pow2 && G.fast_norm) ? 1 : 0);
         const float* en = (const float*)c->entries.p;
 #define LAUNCH_G(PP, MM, RR) ev_gather_kernel<PP, MM, RR><<<nb, gthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en, d_f32, d_minmax_enc)
-        static const bool old_raw = getenv("EORB_OLD_RAW_GATHER") != nullptr;
-        if (raw && mode != 2 && !old_raw) {
+        if (raw && mode != 2) {
             // the add wave + four value waves with two tile columns each (shortest chain per batch), or -- when the launch has
             // enough tiles to keep every SIMD busy anyway -- two value waves with four columns each (the rectangle arithmetic is
             // done once per four columns: fewest instructions per batch)
             static const int nc_env = [] { const char* e = getenv("EORB_GATHER_NC"); return e ? atoi(e) : 0; }();
-            const int NC = nc_env == 2 || nc_env == 4 ? nc_env : (nb >= 16 * 690 ? 4 : 2);
+            const int NC = nc_env == 2 || nc_env == 4 ? nc_env : (nb >= 32768 ? 4 : 2);
             const int rthreads = 64 * (1 + 8 / NC);
             const uint2* en2 = (const uint2*)c->entries.p;
 #define LAUNCH_R(PP, CC) ev_gather_raw_kernel<PP, CC><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc)
             if (pol) { if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
             else { if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
 #undef LAUNCH_R
-        } else if (raw) {
-            if (pol) { if (mode == 2) LAUNCH_G(true, 2, true); else LAUNCH_G(true, 0, true); }
-            else { if (mode == 2) LAUNCH_G(false, 2, true); else LAUNCH_G(false, 0, true); }
+        } else if (raw) {                                  // count image of raw events
+            if (pol) LAUNCH_G(true, 2, true); else LAUNCH_G(false, 2, true);
         } else if (pol) { if (mode == 2) LAUNCH_G(true, 2, false); else if (mode == 1) LAUNCH_G(true, 1, false); else LAUNCH_G(true, 0, false); }
         else { if (mode == 2) LAUNCH_G(false, 2, false); else if (mode == 1) LAUNCH_G(false, 1, false); else LAUNCH_G(false, 0, false); }
 #undef LAUNCH_G
