@@ -585,11 +585,12 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
                                                                      const uint2* __restrict__ entries,
                                                                      float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
 {
-    __shared__ int any_ok;                          // some entry of the tile touches an in-image pixel
-    __shared__ __attribute__((aligned(16))) float vals[2][kValStride * 64];       // [pixel][entry slot]
+    // [pixel][entry slot], 64 floats per pixel and no padding: exactly 32 KB, five workgroups per CU.  The 16-byte groups of a
+    // pixel's list are stored XOR-swizzled (group g of pixel p at g ^ (p & 15)), so that the add wave's ds_read_b128 (lane =
+    // pixel, same logical group) spread over all banks; a value wave's store (lane = slot, one pixel) stays 64 consecutive words.
+    __shared__ __attribute__((aligned(16))) float vals[2][64 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) any_ok = 0;
-    for (int i = tid; i < 2 * kValStride * 64; i += blockDim.x) (&vals[0][0])[i] = 0.f;
+    bool any_ok = false;                             // (wave 1) some entry of the tile touches an in-image pixel
     const int logical = order[blockIdx.x];
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
@@ -599,8 +600,9 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
     const int nent = (int)tile_cnt[logical];
     const int nbatch = (nent + 63) >> 6;
     const uint2* list = entries + (size_t)slice_ebase[slice] + tile_base[logical];
-    constexpr int kRowFloats = 8 * kValStride;
+    constexpr int kRowFloats = 8 * 64;
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
+    uint32_t x16 = (uint32_t)((lane & 15) << 4);
     // ---- value-wave state: NC tile columns (wave w: columns w-1, w-1+NW, ...); the columns of batches t and t+1 in two register
     //      sets (landed / being loaded), the entry of batch t+2 in registers.  The global loads of this loop are issued from inline
     //      asm with hand-placed s_waitcnt vmcnt(N): vmcnt retires in order, and every iteration issues the same 1 + 2*NC loads in
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
         const int a0 = max(xi - h, tx0) - tx0, a1 = min(xi + h, xhi) - tx0;
         const int b0 = max(yi - h, ty0) - ty0, b1 = min(yi + h, yhi) - ty0;
         const bool ok = a1 >= a0 && b1 >= b0;
-        if (wave == 1 && __any(ok) && lane == 0) any_ok = 1;
+        any_ok = any_ok || ok;
         S.m = ok ? ((2u << (b1 & 31)) - 1u) & ~((1u << (b0 & 31)) - 1u) : 0u;     // tile rows b0..b1
         S.sg = (w0 >> 31) ? -1.0f : 1.0f;
         // float index of the table value that falls on tile row 0 of column c: row (ty0 - yi + h) of stamp column (tx0 + c - xi + h)
@@ -645,13 +647,19 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
     auto wait_set = [&](ColSet& S) {
         if constexpr (NC == 2)
             asm volatile("s_waitcnt vmcnt(5)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]) :: "memory");
-        else
+        else if constexpr (NC == 4)
             asm volatile("s_waitcnt vmcnt(9)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]),
                          "+v"(S.c[2][0]), "+v"(S.c[2][1]), "+v"(S.c[3][0]), "+v"(S.c[3][1]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(17)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]),
+                         "+v"(S.c[2][0]), "+v"(S.c[2][1]), "+v"(S.c[3][0]), "+v"(S.c[3][1]),
+                         "+v"(S.c[4][0]), "+v"(S.c[4][1]), "+v"(S.c[5][0]), "+v"(S.c[5][1]),
+                         "+v"(S.c[6][0]), "+v"(S.c[6][1]), "+v"(S.c[7][0]), "+v"(S.c[7][1]) :: "memory");
     };
     auto wait_entry = [&](ColSet& S) {
         if constexpr (NC == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(S.E) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(S.E) :: "memory");
+        else if constexpr (NC == 4) asm volatile("s_waitcnt vmcnt(8)" : "+v"(S.E) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" : "+v"(S.E) :: "memory");
     };
     if (wave >= 1) {
         // in-flight order expected by the loop: columns(0), entry(2) [in S0.E], columns(1)
@@ -675,12 +683,16 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
         if (wave == 0) {
             // ---- adds(t-1): all 64 slots in order ----
             if (t >= 1) {
-                const float4* vb = (const float4*)(vals[(t - 1) & 1] + lane * kValStride);
-                float4 q[4] = {vb[0], vb[1], vb[2], vb[3]};
+                const char* vb = (const char*)(vals[(t - 1) & 1] + lane * 64);
+                // logical group g of this pixel's list: byte offset (g ^ (pixel & 15)) * 16.  x16 is made opaque per iteration:
+                // hoisted out of the loop the 16 offsets would cost 16 VGPRs (and with them the fifth workgroup per CU)
+                asm volatile("" : "+v"(x16));
+#define EORB_RD(g) (*(const float4*)(vb + (((uint32_t)(g) << 4) ^ x16)))
+                float4 q[4] = {EORB_RD(0), EORB_RD(1), EORB_RD(2), EORB_RD(3)};
 #pragma unroll
                 for (int g = 0; g < 16; g += 4) {
                     float4 n[4];
-                    if (g + 4 < 16) { n[0] = vb[g + 4]; n[1] = vb[g + 5]; n[2] = vb[g + 6]; n[3] = vb[g + 7]; }
+                    if (g + 4 < 16) { n[0] = EORB_RD(g + 4); n[1] = EORB_RD(g + 5); n[2] = EORB_RD(g + 6); n[3] = EORB_RD(g + 7); }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         if (!POL) { acc = acc + q[u].x; acc = acc + q[u].y; acc = acc + q[u].z; acc = acc + q[u].w; }
@@ -693,6 +705,7 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
                     }
                     if (g + 4 < 16) { q[0] = n[0]; q[1] = n[1]; q[2] = n[2]; q[3] = n[3]; }
                 }
+#undef EORB_RD
             }
         } else if (t < nbatch) {
             // ---- values(t): the columns requested two iterations ago; slot `lane` of the 8 pixels of each column ----
@@ -703,10 +716,12 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
 #define EORB_RM(r) asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(rm[r]) : "v"(S.m), "i"(r));
             EORB_RM(0) EORB_RM(1) EORB_RM(2) EORB_RM(3) EORB_RM(4) EORB_RM(5) EORB_RM(6) EORB_RM(7)
 #undef EORB_RM
-#define EORB_ROW(dst, r, val) (dst)[(r) * kRowFloats] = __uint_as_float(__float_as_uint(POL ? S.sg * (val) : (val)) & rm[r]);
+            // pixel (c, r) = c + 8r: its swizzle (p & 15) = c | (r & 1) << 3, i.e. odd rows flip bit 3 of the group index (32 floats)
+#define EORB_ROW(dst, r, val) ((r) & 1 ? (dst) + 32 * ((lane & 32) ? -1 : 1) : (dst))[(r) * kRowFloats] = __uint_as_float(__float_as_uint(POL ? S.sg * (val) : (val)) & rm[r]);
 #pragma unroll
             for (int k = 0; k < NC; k++) {
-                float* d = vals[t & 1] + (wave - 1 + k * NW) * kValStride + lane;
+                const int cc = wave - 1 + k * NW;
+                float* d = vals[t & 1] + cc * 64 + ((((lane >> 2) ^ cc) << 2) | (lane & 3));
                 EORB_ROW(d, 0, S.c[k][0].x) EORB_ROW(d, 1, S.c[k][0].y) EORB_ROW(d, 2, S.c[k][0].z) EORB_ROW(d, 3, S.c[k][0].w)
                 EORB_ROW(d, 4, S.c[k][1].x) EORB_ROW(d, 5, S.c[k][1].y) EORB_ROW(d, 6, S.c[k][1].z) EORB_ROW(d, 7, S.c[k][1].w)
             }
@@ -741,13 +756,17 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
         atomicAdd(&g_diag[role * 4 + 3], d_setup);
     }
 #endif
+    // the flag of wave 1 travels through the (now free) list buffer
+    if (wave == 1) { const bool f = __any(any_ok); if (lane == 0) vals[0][0] = f ? 1.0f : 0.0f; }
+    __syncthreads();
     if (wave != 0) return;
+    const bool tile_ok = vals[0][0] != 0.0f;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = tx0 + lx, py = ty0 + ly;
     const bool inimg = px < P.W && py < P.H;
     // an add of a tap that underflowed to 0 still counts as a visit (newVal > maxVal, :255): a tile with any visited pixel offers
     // 0 as a candidate for the maximum; real adds were tracked above (POL) / are the final values (no polarity: increments >= 0)
-    if (any_ok) vmax = fmaxf(vmax, POL ? 0.0f : acc);
+    if (tile_ok) vmax = fmaxf(vmax, POL ? 0.0f : acc);
     if (inimg) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = acc;
     else { vmax = -1000000.0f; vmin = 0.0f; }
 #pragma unroll
@@ -1369,12 +1388,12 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             // enough tiles to keep every SIMD busy anyway -- two value waves with four columns each (the rectangle arithmetic is
             // done once per four columns: fewest instructions per batch)
             static const int nc_env = [] { const char* e = getenv("EORB_GATHER_NC"); return e ? atoi(e) : 0; }();
-            const int NC = nc_env == 2 || nc_env == 4 ? nc_env : (nb >= 32768 ? 4 : 2);
+            const int NC = nc_env == 2 || nc_env == 4 || nc_env == 8 ? nc_env : (nb >= 32768 ? 4 : 2);
             const int rthreads = 64 * (1 + 8 / NC);
             const uint2* en2 = (const uint2*)c->entries.p;
 #define LAUNCH_R(PP, CC) ev_gather_raw_kernel<PP, CC><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc)
-            if (pol) { if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
-            else { if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
+            if (pol) { if (NC == 8) LAUNCH_R(true, 8); else if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
+            else { if (NC == 8) LAUNCH_R(false, 8); else if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
 #undef LAUNCH_R
         } else if (raw) {                                  // count image of raw events
             if (pol) LAUNCH_G(true, 2, true); else LAUNCH_G(false, 2, true);
