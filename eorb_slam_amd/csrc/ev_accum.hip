@@ -578,7 +578,7 @@ constexpr int kStampPad = 8;        // floats of slack in front of (and behind) 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 template <bool POL, int NC>
-__global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __restrict__ slice_ebase,
+__global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const int64_t* __restrict__ slice_ebase,
                                                                      const int32_t* __restrict__ order, GatherParams P,
                                                                      const uint32_t* __restrict__ tile_cnt,
                                                                      const uint32_t* __restrict__ tile_base,
@@ -647,19 +647,13 @@ __global__ __launch_bounds__(320) void ev_gather_raw_kernel(const int64_t* __res
     auto wait_set = [&](ColSet& S) {
         if constexpr (NC == 2)
             asm volatile("s_waitcnt vmcnt(5)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]) :: "memory");
-        else if constexpr (NC == 4)
+        else
             asm volatile("s_waitcnt vmcnt(9)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]),
                          "+v"(S.c[2][0]), "+v"(S.c[2][1]), "+v"(S.c[3][0]), "+v"(S.c[3][1]) :: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(17)" : "+v"(S.c[0][0]), "+v"(S.c[0][1]), "+v"(S.c[1][0]), "+v"(S.c[1][1]),
-                         "+v"(S.c[2][0]), "+v"(S.c[2][1]), "+v"(S.c[3][0]), "+v"(S.c[3][1]),
-                         "+v"(S.c[4][0]), "+v"(S.c[4][1]), "+v"(S.c[5][0]), "+v"(S.c[5][1]),
-                         "+v"(S.c[6][0]), "+v"(S.c[6][1]), "+v"(S.c[7][0]), "+v"(S.c[7][1]) :: "memory");
     };
     auto wait_entry = [&](ColSet& S) {
         if constexpr (NC == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(S.E) :: "memory");
-        else if constexpr (NC == 4) asm volatile("s_waitcnt vmcnt(8)" : "+v"(S.E) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" : "+v"(S.E) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(S.E) :: "memory");
     };
     if (wave >= 1) {
         // in-flight order expected by the loop: columns(0), entry(2) [in S0.E], columns(1)
@@ -1388,12 +1382,12 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             // enough tiles to keep every SIMD busy anyway -- two value waves with four columns each (the rectangle arithmetic is
             // done once per four columns: fewest instructions per batch)
             static const int nc_env = [] { const char* e = getenv("EORB_GATHER_NC"); return e ? atoi(e) : 0; }();
-            const int NC = nc_env == 2 || nc_env == 4 || nc_env == 8 ? nc_env : (nb >= 32768 ? 4 : 2);
+            const int NC = nc_env == 2 || nc_env == 4 ? nc_env : (nb >= 32768 ? 4 : 2);
             const int rthreads = 64 * (1 + 8 / NC);
             const uint2* en2 = (const uint2*)c->entries.p;
 #define LAUNCH_R(PP, CC) ev_gather_raw_kernel<PP, CC><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc)
-            if (pol) { if (NC == 8) LAUNCH_R(true, 8); else if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
-            else { if (NC == 8) LAUNCH_R(false, 8); else if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
+            if (pol) { if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
+            else { if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
 #undef LAUNCH_R
         } else if (raw) {                                  // count image of raw events
             if (pol) LAUNCH_G(true, 2, true); else LAUNCH_G(false, 2, true);
