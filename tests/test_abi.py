@@ -35,9 +35,27 @@ def test_library_contains_gfx950_code_object():
     from eorb_slam_amd import _lib
     data = open(_lib.build(), "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in data, "no gfx950 code object embedded in libeorb_fe.so"
-    for kern in (b"ev_gather_kernel", b"ev_count_kernel", b"ev_scan_kernel", b"ev_scatter_kernel", b"fast_cells_kernel", b"octree_kernel", b"brief_kernel",
+    for kern in (b"ev_gather_kernel", b"ev_gather_raw_kernel", b"ev_count_kernel", b"ev_scan_kernel", b"ev_scatter_kernel", b"fast_cells_kernel", b"octree_kernel", b"brief_kernel",
                  b"search_init_kernel", b"bf_knn2_kernel"):
         assert kern in data, kern
+
+
+def test_raw_gather_kernels_use_no_scratch():
+    """ev_gather_raw_kernel places its own s_waitcnt vmcnt(N) around loads issued from inline asm; a register spill (scratch
+    traffic counts in vmcnt too) would silently break that count, so every instantiation must have a zero private segment."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "eorb_slam_amd", "csrc", "ev_accum.hip")
+    flags = re.search(r"^FLAGS\s*=\s*(.*?)\n\n", open(os.path.join(ROOT, "eorb_slam_amd", "csrc", "Makefile")).read(), re.S | re.M).group(1)
+    flags = [f for f in flags.replace("\\\n", " ").split() if f not in ("-shared", "-fPIC") and not f.startswith("--offload-arch")]
+    p = subprocess.run([hipcc] + flags + ["--offload-arch=gfx950", "--cuda-device-only", "-S", "-o", "-", src], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    blocks = re.findall(r"\.amdhsa_kernel (\S*ev_gather_raw_kernel\S*)(.*?)\.end_amdhsa_kernel", p.stdout, re.S)
+    assert len(blocks) == 4, [b[0] for b in blocks]
+    for name, body in blocks:
+        assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body), name + " spills to scratch"
+        assert int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1)) == 32768, name
 
 
 def test_header_is_plain_c():
