@@ -543,9 +543,11 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
     }
 #endif
     if (wave != 0) return;
-    // an add of a tap that underflowed to 0 still counts as a visit (newVal > maxVal, :255): a tile with any visited pixel offers
-    // 0 as a candidate for the maximum; real adds were tracked above (POL) / are the final values (no polarity: increments >= 0)
-    if (any_ok) vmax = fmaxf(vmax, POL ? 0.0f : acc);
+    // Without polarity every increment is >= 0: the running maximum is the largest final value, and an add of a tap that
+    // underflowed to 0 still counts as a visit (newVal > maxVal, :255), so a tile with any visited pixel offers its pixels' values
+    // (0 where nothing was added).  With polarity the extremes were tracked on the real adds above; taps that underflow to 0
+    // (sigma < 0.2) would add visits the lists cannot tell from "not touched": the host rejects that configuration.
+    if (!POL && any_ok) vmax = fmaxf(vmax, acc);
     if (inimg) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = acc;
     else { vmax = -1000000.0f; vmin = 0.0f; }
 #pragma unroll
@@ -758,9 +760,11 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     const int lx = lane & 7, ly = lane >> 3;
     const int px = tx0 + lx, py = ty0 + ly;
     const bool inimg = px < P.W && py < P.H;
-    // an add of a tap that underflowed to 0 still counts as a visit (newVal > maxVal, :255): a tile with any visited pixel offers
-    // 0 as a candidate for the maximum; real adds were tracked above (POL) / are the final values (no polarity: increments >= 0)
-    if (tile_ok) vmax = fmaxf(vmax, POL ? 0.0f : acc);
+    // Without polarity every increment is >= 0: the running maximum is the largest final value, and an add of a tap that
+    // underflowed to 0 still counts as a visit (newVal > maxVal, :255), so a tile with any visited pixel offers its pixels' values
+    // (0 where nothing was added).  With polarity the extremes were tracked on the real adds above; taps that underflow to 0
+    // (sigma < 0.2) would add visits the lists cannot tell from "not touched": the host rejects that configuration.
+    if (!POL && tile_ok) vmax = fmaxf(vmax, acc);
     if (inimg) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = acc;
     else { vmax = -1000000.0f; vmin = 0.0f; }
 #pragma unroll
@@ -1261,6 +1265,9 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     const eorb_event16* d_ev = (const eorb_event16*)d_events;          // eorb_raw_event has the same 16-byte stride
     const int h = mode_count ? 0 : (int)ceil((double)sigma * 3.0);     // lenHalfWin :222
     if (h > 8) return set_err(c, EORB_E_CONFIG, "ev_accumulate: sigma %.3f gives half window %d > 8", sigma, h);
+    // exp(-d^2 / 2 sigma^2) underflows to 0 inside the window below sigma ~ 0.197 (d^2 up to 8 at h = 1): with polarity the
+    // reference's running maximum then depends on visits that add nothing (see the gather kernels)
+    if (pol && !mode_count && sigma < 0.2f) return set_err(c, EORB_E_CONFIG, "ev_accumulate: polarity images need sigma >= 0.2 (got %.3f)", sigma);
     const int R = (2 * h <= kTile) ? ((h == 0) ? 1 : 2) : 3;            // max tiles an event spans per axis
     const int TX = (W + kTile - 1) / kTile, TY = (H + kTile - 1) / kTile, NT = TX * TY;
     int nbits = 1; while ((1 << nbits) < NT) nbits++;

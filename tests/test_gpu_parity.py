@@ -753,6 +753,68 @@ def test_raw_ev2im_count(oracle, fe, ctx):
         assert (ou is None) == (gu is None) and (ou is None or np.array_equal(ou, gu))
 
 
+def test_polarity_extremes_of_one_sided_images(oracle, fe, ctx):
+    """resolveMinMaxVals (:32-39) is a RUNNING maximum / minimum over every add: with only negative events the maximum is the
+    least negative single tap, not 0 (and the normalised image follows from it); both gathers, raw and float events."""
+    W, H = 240, 180
+    mx, my = _maps(W, H)
+    fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx)
+    for n, polbit in ((1, 0), (1, 1), (700, 0), (700, 1)):
+        raw = synth.random_raw_events(n, W, H, seed=40 + n + polbit)
+        raw["x"] = np.clip(raw["x"], 20, 200); raw["y"] = np.clip(raw["y"], 20, 150); raw["p"] = polbit
+        ev = oracle.undistort_events(raw, mx, my, W, H, True, 1.0)
+        for sigma in (0.5, 1.0, 2.0):
+            of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, True, True)
+            gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, True, True, ctx=ctx, return_all=True)
+            hf, hu, hmm = fe.EvImConverter.ev2im_gauss(ev, W, H, sigma, True, True, ctx=ctx, return_all=True)
+            for f, u, mm in ((gf, gu, gmm), (hf, hu, hmm)):
+                assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), mm.view(np.uint32)), (n, polbit, sigma, omm, mm)
+                assert np.array_equal(of.view(np.uint32), f.view(np.uint32)) and np.array_equal(ou, u)
+    # taps that underflow to 0 make the running maximum depend on visits that add nothing: rejected with polarity, exact without
+    raw = synth.random_raw_events(500, W, H, seed=3)
+    ev = oracle.undistort_events(raw, mx, my, W, H, True, 1.0)
+    with pytest.raises(fe.EorbError):
+        fe.EvImConverter.ev2im_gauss_raw(raw, W, H, 0.1, True, True, ctx=ctx)
+    with pytest.raises(fe.EorbError):
+        fe.EvImConverter.ev2im_gauss(ev, W, H, 0.1, True, True, ctx=ctx)
+    of, ou, omm = oracle.ev2im_gauss(ev, W, H, 0.1, False, True)
+    for f, u, mm in (fe.EvImConverter.ev2im_gauss_raw(raw, W, H, 0.1, False, True, ctx=ctx, return_all=True),
+                     fe.EvImConverter.ev2im_gauss(ev, W, H, 0.1, False, True, ctx=ctx, return_all=True)):
+        assert np.array_equal(of.view(np.uint32), f.view(np.uint32)) and np.array_equal(ou, u)
+        assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), mm.view(np.uint32))
+
+
+def test_raw_accumulation_random_sweep(oracle, fe, ctx):
+    """A seeded sweep over image sizes that are not multiples of the tile, stamps of 3x3 ... 17x17 taps, polarity, maps that throw
+    pixels out of the image with and without checkInImage, event counts on the 64-entry batch boundaries and hot pixels
+    (tools/fuzz_raw.py runs the long version)."""
+    rng = np.random.default_rng(2024)
+    for case in range(80):
+        W, H = [(240, 180), (346, 260), (64, 48), (33, 17), (100, 9), (16, 16), (250, 131)][rng.integers(0, 7)]
+        LW, LH = W + int(rng.integers(0, 5)), H + int(rng.integers(0, 5))
+        sigma = float([0.21, 0.4, 0.5, 0.8, 1.0, 1.0, 1.3, 1.7, 2.0, 2.5][rng.integers(0, 10)])
+        pol, check = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        n = int([0, 1, 63, 64, 65, 127, 128, 129, 1000, 4096, 4097, 20000][rng.integers(0, 12)])
+        yy, xx = np.mgrid[0:LH, 0:LW].astype(np.float64)
+        amp = rng.uniform(0, 6)
+        mx = (xx + amp * np.sin(yy / 17.0) + rng.uniform(-3, 3)).astype(np.float32)
+        my = (yy + amp * np.cos(xx / 23.0) + rng.uniform(-3, 3)).astype(np.float32)
+        raw = np.zeros(n, synth.RAW_DTYPE)
+        if rng.integers(0, 2):
+            raw["x"] = rng.integers(0, LW, n); raw["y"] = rng.integers(0, LH, n)
+        else:
+            raw["x"] = np.clip(rng.normal(LW * rng.uniform(0, 1), 2.5, n), 0, LW - 1)
+            raw["y"] = np.clip(rng.normal(LH * rng.uniform(0, 1), 2.5, n), 0, LH - 1)
+        raw["p"] = rng.integers(0, 2, n); raw["t"] = np.arange(n) * 1e-6
+        fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=ctx)
+        ev = oracle.undistort_events(raw, mx, my, W, H, check, 1.0)
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, pol, True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, pol, True, ctx=ctx, return_all=True)
+        what = dict(case=case, W=W, H=H, sigma=sigma, pol=pol, check=check, n=n)
+        assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)) and np.array_equal(ou, gu), what
+        assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), what
+
+
 def test_raw_needs_maps(fe):
     c = fe.Context()
     with pytest.raises(fe.EorbError):
