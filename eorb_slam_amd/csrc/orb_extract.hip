@@ -860,7 +860,9 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
     }
     for (int l = 0; l < nlevels; l++) {
         LevelGeom& L = o.lv[l];
-        L.cand_cap = L.nCols * L.nRows * cell_cap;
+        // after the 3x3 non-maximum suppression at most every other pixel of a cell (in x and in y) survives: the level's own
+        // cell size bounds its candidates (cell_cap, the largest cell of ANY level, is only the stride of the per-cell arrays)
+        L.cand_cap = L.nCols * L.nRows * (((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
         L.cand_off = cand_total; cand_total += L.cand_cap;
         ncap_max = std::max(ncap_max, L.cand_cap);
     }
