@@ -1,4 +1,4 @@
-"""Re-runs the matcher / tracker / vocabulary parity tests of tests/test_gpu_parity.py on fresh random data: every integer seed the
+"""Re-runs the parity tests (matchers, tracker, vocabulary, accumulation, extractor, batched pipeline) of tests/test_gpu_parity.py on fresh random data: every integer seed the
 tests pass to numpy or to the synthetic generators is offset by the round number.  Parity assertions compare against the CPU
 oracle; the tests' sanity assertions (`assert n > 10`) can fail on an unlucky seed and are reported separately.
 Run on the GPU box: python tools/fuzz_match.py [rounds]"""
@@ -15,7 +15,11 @@ ctx = fe.Context()
 NAMES = ["test_bf_knn2", "test_search_for_initialization", "test_search_for_initialization_mixed_gate", "test_search_by_projection_last",
          "test_search_by_projection_map", "test_tracked_descriptors_and_level_assignment", "test_search_by_bow", "test_search_by_bow_keyframes",
          "test_search_for_triangulation", "test_kf_radius_match_fuse_sim3", "test_search_by_projection_keyframe", "test_bow_transform",
-         "test_klt_pyr_lk", "test_hamming_window_match", "test_distinctive_descriptors", "test_frontend_batch_matches_oracle_pipeline"]
+         "test_klt_pyr_lk", "test_hamming_window_match", "test_distinctive_descriptors", "test_frontend_batch_matches_oracle_pipeline",
+         "test_ev2im_gauss_bit_exact", "test_ev2im_gauss_shapes_lut", "test_ev2im_gauss_hot_pixel_order", "test_frontend_batch_ragged_and_empty_slices",
+         "test_raw_undistort_events", "test_raw_ev2im_gauss_equals_loader_then_ev2im_gauss", "test_raw_mvsec_size_and_wide_stamps",
+         "test_raw_ev2im_count", "test_frontend_batch_raw_equals_float_path", "test_ev2mci_se3", "test_ev2mci_se2_and_focus_contest",
+         "test_orb_extract_texture", "test_orb_extract_event_image", "test_orb_extract_detect_only_fast_mode", "test_orb_extract_mvsec_shape"]
 _rng0 = np.random.default_rng
 _gens = {n: getattr(synth, n) for n in dir(synth) if callable(getattr(synth, n)) and "seed" in inspect.signature(getattr(synth, n)).parameters}
 off = [0]
