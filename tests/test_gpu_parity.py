@@ -815,6 +815,35 @@ def test_raw_accumulation_random_sweep(oracle, fe, ctx):
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), what
 
 
+def test_raw_gather_four_column_variant(oracle):
+    """ev_gather_raw_kernel has two instantiations: two tile columns per value wave (small launches) and four (launches of more
+    than 32768 tiles, e.g. the benchmark's 64 slices).  The second one is forced here (EORB_GATHER_NC=4 is read once per process,
+    hence the child process) and must give the same bit-exact images, also with polarity and wide stamps."""
+    import os, subprocess, sys
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from eorb_slam_amd import frontend as fe, synth
+from oracle import oracle_py as orc
+c = fe.Context()
+for (W, H, n, sigma, pol, seed) in ((240, 180, 300000, 1.0, False, 5), (240, 180, 40000, 1.0, True, 6), (346, 260, 50000, 2.0, False, 7), (64, 48, 129, 0.5, True, 8)):
+    mx, my = synth.undistort_lut(240, 180) if (W, H) == (240, 180) else tuple(np.ascontiguousarray(a, np.float32) for a in np.meshgrid(np.arange(W) + 0.3, np.arange(H) - 0.2))
+    fe.EvImConverter.set_undistort_maps(np.ascontiguousarray(mx), np.ascontiguousarray(my), True, ctx=c)
+    raw = synth.shapes_events(n, W, H, seed=seed, return_raw=True)[1] if W == 240 else synth.random_raw_events(n, W, H, seed=seed)
+    ev = orc.undistort_events(raw, mx, my, W, H, True, 1.0)
+    of, ou, omm = orc.ev2im_gauss(ev, W, H, sigma, pol, True)
+    gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, pol, True, ctx=c, return_all=True)
+    assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)) and np.array_equal(ou, gu), (W, H, n, sigma, pol)
+    assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), (W, H, n, sigma, pol)
+print("nc4 ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EORB_GATHER_NC="4")
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "nc4 ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_raw_needs_maps(fe):
     c = fe.Context()
     with pytest.raises(fe.EorbError):
