@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-row measurements for the SURVEY §8 rows outside the headline pipeline (f1-f4 and the stand-alone matchers): kernel time from
 the library's HIP-event profiler (device work only; the host-buffer entry points also pay PCIe copies) next to the CPU oracle
-on one core, on representative sizes.  Prints one JSON object; run on the GPU box:  python tools/bench_rows.py > rows.json"""
+on one core, on representative sizes.  Prints one JSON object; run on the GPU box:  python tests/fuzz/bench_rows.py > rows.json"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from eorb_slam_amd import frontend as fe, synth  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402

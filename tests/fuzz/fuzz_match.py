@@ -1,7 +1,7 @@
 """Re-runs the parity tests (matchers, tracker, vocabulary, accumulation, extractor, batched pipeline) of tests/test_gpu_parity.py on fresh random data: every integer seed the
 tests pass to numpy or to the synthetic generators is offset by the round number.  Parity assertions compare against the CPU
 oracle; the tests' sanity assertions (`assert n > 10`) can fail on an unlucky seed and are reported separately.
-Run on the GPU box: python tools/fuzz_match.py [rounds]"""
+Run on the GPU box: python tests/fuzz/fuzz_match.py [rounds]"""
 import inspect, os, sys, traceback
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np

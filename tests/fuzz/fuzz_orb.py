@@ -1,6 +1,6 @@
 """Randomised parity sweep of the ORB extractor (pyramid, FAST cells, octree, orientation, blur, rBRIEF, output order) against the
 CPU oracle: random image sizes / contents / extractor parameters.  Configurations the library rejects (EORB_E_CONFIG /
-EORB_E_CAPACITY) are counted, not failed.  Run on the GPU box: python tools/fuzz_orb.py [cases] [seed]"""
+EORB_E_CAPACITY) are counted, not failed.  Run on the GPU box: python tests/fuzz/fuzz_orb.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np

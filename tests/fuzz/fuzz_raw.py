@@ -1,6 +1,6 @@
 """Randomised parity sweep of the raw-event accumulation (ev_gather_raw_kernel + binning) against the CPU oracle: image sizes that are
 not multiples of the tile, sigmas up to the 17x17 stamp, polarity, maps that throw pixels out of the image with and without
-checkInImage, event counts on the 64-entry batch boundaries, hot pixels.  Run on the GPU box: python tools/fuzz_raw.py [cases] [seed]"""
+checkInImage, event counts on the 64-entry batch boundaries, hot pixels.  Run on the GPU box: python tests/fuzz/fuzz_raw.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np

@@ -787,7 +787,7 @@ def test_polarity_extremes_of_one_sided_images(oracle, fe, ctx):
 def test_raw_accumulation_random_sweep(oracle, fe, ctx):
     """A seeded sweep over image sizes that are not multiples of the tile, stamps of 3x3 ... 17x17 taps, polarity, maps that throw
     pixels out of the image with and without checkInImage, event counts on the 64-entry batch boundaries and hot pixels
-    (tools/fuzz_raw.py runs the long version)."""
+    (tests/fuzz/fuzz_raw.py runs the long version)."""
     rng = np.random.default_rng(2024)
     for case in range(80):
         W, H = [(240, 180), (346, 260), (64, 48), (33, 17), (100, 9), (16, 16), (250, 131)][rng.integers(0, 7)]
