@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--sequences", type=int, default=1,
                     help="independent event sequences processed concurrently per GPU, each on its own context / HIP stream; "
                          "steps alternate between them (a step is still one batch of one sequence)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI); gloo only to rehearse the multi-rank logic "
+                         "on a box with fewer GPUs than ranks (records staged through host memory)")
     ap.add_argument("--input", choices=["raw", "float"], default="raw",
                     help="raw: sensor-pixel events (x,y,t,p) + the calibrator's undistortion maps resolved on the GPU; "
                          "float: events already undistorted by the loader (EventData)")
@@ -63,11 +66,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the front end has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    local_rank %= max(torch.cuda.device_count(), 1)     # (a rehearsal with more ranks than GPUs shares devices; no effect on a full node)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, H, B, NEV = 240, 180, a.batch, a.events
     orb = dict(nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0, edgeTh=19)
@@ -93,18 +100,19 @@ def main():
             mx, my = synth.undistort_lut(W, H)
             frontend.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx_i)
         cap = fb_i.cap
+        # keypoint records of a batch = one packed buffer {n[B] | kp[B][cap] | desc[B][cap][32]}: ONE gather per step at N > 1
+        off_kp = (B * 4 + 255) & ~255
+        off_desc = (off_kp + B * cap * 28 + 255) & ~255
+        rec = torch.zeros(off_desc + B * cap * 32, dtype=torch.uint8, device=dev)
         bufs = dict(img=torch.empty(B * W * H, dtype=torch.uint8, device=dev),
-                    kp=torch.empty(B * cap * 28, dtype=torch.uint8, device=dev),
-                    desc=torch.empty(B * cap * 32, dtype=torch.uint8, device=dev),
-                    n=torch.zeros(B, dtype=torch.int32, device=dev),
+                    rec=rec, n=rec[:B * 4].view(torch.int32), kp=rec[off_kp:off_kp + B * cap * 28], desc=rec[off_desc:],
                     m=torch.empty(B * cap, dtype=torch.int32, device=dev),
                     nm=torch.zeros(B, dtype=torch.int32, device=dev))
         seqs.append((ctx_i, fb_i, bufs))
     ctx, fb = seqs[0][0], seqs[0][1]
-    d_kp, d_desc, d_n, d_nm = seqs[0][2]["kp"], seqs[0][2]["desc"], seqs[0][2]["n"], seqs[0][2]["nm"]
-    gather_kp = [torch.empty_like(d_kp) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_desc = [torch.empty_like(d_desc) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_n = [torch.empty_like(d_n) for _ in range(world)] if (world > 1 and rank == 0) else None
+    d_n, d_nm = seqs[0][2]["n"], seqs[0][2]["nm"]
+    gdev = dev if a.backend == "nccl" else torch.device("cpu")
+    gather_rec = [torch.empty_like(seqs[0][2]["rec"], device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     step_no = [0]
 
     def step():
@@ -114,9 +122,7 @@ def main():
             fb_i.run_dev(d_ev.data_ptr(), offsets, bf["img"].data_ptr(), bf["kp"].data_ptr(), bf["desc"].data_ptr(), bf["n"].data_ptr(),
                          bf["m"].data_ptr(), bf["nm"].data_ptr(), raw=use_raw)
             if world > 1:       # final keypoint gather (RCCL over xGMI), fixed-capacity records
-                dist.gather(bf["n"], gather_n, dst=0)
-                dist.gather(bf["kp"], gather_kp, dst=0)
-                dist.gather(bf["desc"], gather_desc, dst=0)
+                dist.gather(bf["rec"] if a.backend == "nccl" else bf["rec"].cpu(), gather_rec, dst=0)
 
     for _ in range(a.warmup):
         step()
@@ -136,7 +142,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = {}
