@@ -5,7 +5,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 from eorb_slam_amd import frontend, synth, _lib
 L=_lib.lib()
-W,H,B,N=240,180,8,1000000
+W,H,B,N=240,180,int(os.environ.get("DIAG_B","8")),1000000
 raw="--raw" in sys.argv
 pairs=[synth.shapes_events(N,W,H,seed=2+b,motion=0.5,undistort=True,return_raw=True) for b in range(B)]
 fb=frontend.FrontEndBatch(W,H,1.0,False,max_batch=B,max_events=N)
