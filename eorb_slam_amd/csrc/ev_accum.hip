@@ -612,6 +612,7 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     //      "the set of batch t has landed" is vmcnt(2*NC+1) and "the entry of batch t+2 has landed" is vmcnt(2*NC).  (Left to the
     //      compiler, the waits across the loop's back edge degrade to vmcnt(0): a full memory round trip per batch.) ----
     constexpr int NW = 8 / NC;                       // value waves
+    const float* const tab0 = P.stamps - kStampPad;  // start of the table's front padding
     // E: entry registers (two sets as well: the load of batch t+3 must not land in registers prepare() is still reading)
     struct ColSet { v4f c[NC][2]; uint32_t m; float sg; v2u E; bool Ev; };        // tile rows 0..7 of the columns, the row mask
     ColSet S0, S1;
@@ -639,10 +640,11 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
         for (int k = 0; k < NC; k++) {
             const int cc = wave - 1 + k * NW;
             const bool in = ok && cc >= a0 && cc <= a1;
-            // a column outside the rectangle reads the 8 zeros in front of the table
-            const float* pc = P.stamps + (in ? base + (int)__umul24((uint32_t)(tx0 + cc - xi + h), (uint32_t)SWP) : -kStampPad);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.c[k][0]) : "v"(pc) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.c[k][1]) : "v"(pc) : "memory");
+            // byte offset from the start of the front padding (scalar base + 32-bit lane offset: no 64-bit address arithmetic);
+            // a column outside the rectangle reads the 8 zeros there
+            const uint32_t off = in ? (uint32_t)(base + kStampPad + (int)__umul24((uint32_t)(tx0 + cc - xi + h), (uint32_t)SWP)) << 2 : 0u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.c[k][0]) : "v"(off), "s"(tab0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(S.c[k][1]) : "v"(off), "s"(tab0) : "memory");
         }
     };
     // wait until all but the n youngest loads have landed; the "+v" operands keep the uses of the set / entry behind the wait
@@ -1342,7 +1344,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             ev_src_info_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, nsrc, W, H, c->lut_check, mode_count,
                                                                             (uint32_t*)c->src_info.p);
             if (!mode_count) {
-                if ((size_t)nsrc * SW * SWP >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
+                if ((size_t)nsrc * SW * SWP * 4 + 256 >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
                 if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 2 * kStampPad)))) return rc;
                 EORB_HIP(c, hipMemsetAsync(c->stamps.p, 0, sizeof(float) * kStampPad, c->stream));
                 EORB_HIP(c, hipMemsetAsync((float*)c->stamps.p + kStampPad + (size_t)nsrc * SW * SWP, 0, sizeof(float) * kStampPad, c->stream));
