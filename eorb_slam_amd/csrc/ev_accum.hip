@@ -564,18 +564,21 @@ __global__ __launch_bounds__(1024) EORB_GATHER_ATTR void ev_gather_kernel(const 
 // K2r: the gather for raw sensor events with a Gaussian stamp (the live configuration).  Lists as in K2 (vals[pixel][e], slot e =
 // the entry's position in its 64-entry batch), but a two-stage pipeline without a set-up wave, without masks or sinks, and with no
 // LDS hand-off besides the lists:
-//   waves 1..NW, values(t)  lane = entry e of the batch, wave w owns NC = 8/NW tile columns (NC = 2: w-1 and w+3).  Every lane decodes ITS OWN entry
-//                       (8 coalesced bytes; the four waves read the same 512 bytes) and derives the tile-local tap rectangle.  For
-//                       each of its columns it writes slot e of ALL 8 pixels of the column: the stamp value where the pixel is
-//                       inside the rectangle, +0.0f elsewhere (a column that misses the rectangle, or a lane without an entry,
-//                       reads the zeros in front of the table).  So a batch rewrites every slot of its buffer: nothing is ever cleared, and a store instruction
-//                       writes 64 consecutive words (no bank conflicts).  The 8 values of a column are one 32-byte read of the
-//                       sensor pixel's table row, started at the stamp row that falls on tile row 0 (the table has 8 floats of
-//                       slack on either side; rows outside the rectangle are masked to zero bit-wise).  The lane -> column map is
-//                       static, so the table read for batch t+1 is issued at the end of iteration t and lands during the barrier,
-//                       and the entry of batch t+2 is loaded two iterations ahead: no wave waits for memory.
+//   waves 1..NW, values(t)  lane = entry e of the batch, wave w owns NC = 8/NW tile columns (w-1, w-1+NW, ...).  Every lane
+//                       decodes ITS OWN entry (8 coalesced bytes; the value waves read the same 512 bytes) and derives the
+//                       tile-local tap rectangle.  For each of its columns it writes slot e of ALL 8 pixels of the column: the
+//                       stamp value where the pixel is inside the rectangle, +0.0f elsewhere (a column that misses the
+//                       rectangle, or a lane without an entry, reads the zeros in front of the table).  So a batch rewrites every
+//                       slot of its buffer: nothing is ever cleared, and a store instruction writes 64 consecutive words (no bank
+//                       conflicts).  The 8 values of a column are one 32-byte read of the sensor pixel's table row, started at the
+//                       stamp row that falls on tile row 0 (the table has 8 floats of slack on either side; rows outside the
+//                       rectangle are masked to zero bit-wise).  The lane -> column map is static, so the table reads of batch
+//                       t+2 are issued at the end of iteration t and have two barriers to land, and the entry of batch t+3 is
+//                       requested just before them: no wave waits for memory.
 //   wave 0, adds(t-1)   lane = pixel: acc += list[e], e = 0..63 in order; x + 0.0f == x bit for bit, so the real adds happen in
 //                       event order (newVal = image + polSign*val, :251-254).  Reads run 16 slots ahead of the adds.
+// NC = 2 (four value waves) has the shortest chain per batch and serves launches that cannot fill the chip; NC = 4 (two value
+// waves: the rectangle arithmetic once per four columns) has the fewest instructions per batch and serves the large ones.
 constexpr int kStampPad = 8;        // floats of slack in front of (and behind) the stamp table
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
