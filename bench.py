@@ -24,8 +24,8 @@ sys.path.insert(0, ROOT)
 
 METRIC = "front-end frames/s (event-accumulate + extract + match) per GPU; HBM GB/s vs roofline"
 # HBM bytes one ev_gather launch moves per million events (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE, see
-# profiles/r01_v7_pmc_traffic.txt; float input: r01_v6); bench.py cannot collect PMC counters itself
-GATHER_TRAFFIC_PER_MEV = {"raw": 32.1e6, "float": 30.9e6}
+# profiles/r01_v8_pmc_traffic.txt; float input: r01_v6); bench.py cannot collect PMC counters itself
+GATHER_TRAFFIC_PER_MEV = {"raw": 31.8e6, "float": 30.9e6}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
 
 
@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="time-slices per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="time-slices per step per GPU")
     ap.add_argument("--events", type=int, default=1000000, help="events per slice")
     ap.add_argument("--cpu-slices", type=int, default=64, help="slices timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="skip per-kernel HIP-event timing")
@@ -185,12 +185,12 @@ def main():
             unit_bytes = acc_bytes if dom.startswith("ev_") else ext_bytes
             achieved = unit_bytes * B / (avg_ms * 1e-3) / 1e9
             # HBM traffic of the dominant kernel per launch: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload
-            # (profiles/r01_v7_pmc_traffic.txt: ev_gather_raw 2 x 1020 MB fetched + 14 MB written per 64 slices of 1 Mev with the
+            # (profiles/r01_v8_pmc_traffic.txt: ev_gather_raw 2 x 2022 MB fetched + 28 MB written per 128 slices of 1 Mev with the
             # gfx950 x2 FETCH correction), scaled to this launch; bench.py cannot collect PMC counters itself
             traffic = GATHER_TRAFFIC_PER_MEV[a.input] * (NEV / 1e6) * B if dom == "ev_gather" else None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": "profiles/r01_v7_pmc_traffic.txt",
+                               "traffic_source": "profiles/r01_v8_pmc_traffic.txt",
                                "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": unit_bytes * B,
                                "note": "ev_gather (ev_gather_raw_kernel for raw events) is issue/latency-bound by construction: every pixel "
                                        "adds its taps in event order (49 taps per 16 B event, DESIGN.md section 4); the HBM fraction is "
