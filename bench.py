@@ -87,6 +87,9 @@ def main():
     else:
         ev16 = np.concatenate([frontend.pack_events(s) for s in slices])
     offsets = np.arange(B + 1, dtype=np.int64) * NEV
+    # host copies are only needed again by the CPU baseline (rank 0 at N = 1): keep those slices, drop the rest (40 MB per slice)
+    keep = min(a.cpu_slices, B) if (a.cpu_slices > 0 and world == 1) else 0
+    pairs = pairs[:keep]; slices = slices[:keep]
 
     S = max(1, a.sequences)
     d_ev = torch.from_numpy(ev16.view(np.uint8)).to(dev)
