@@ -106,16 +106,25 @@ struct eorb_ctx {
     eorb_fe_config fe{};
     eorb::DevBuf fe_prev_kp, fe_prev_desc, fe_prev_n, fe_pm;
     bool fe_has_prev = false;
-    // pinned staging
-    void* pinned = nullptr;
-    size_t pinned_cap = 0;
+    // pinned staging: a ring of slots, each guarded by an event recorded right after the H2D copy that reads it, so that
+    // back-to-back un-synchronised *_dev calls never overwrite a slot whose copy is still queued
+    static constexpr int kPinnedSlots = 4;
+    struct PinnedSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+    PinnedSlot pinned[kPinnedSlots];
+    int pinned_next = 0, pinned_cur = -1;
+    // sticky device status word (bits OR-ed by kernels of the *_dev paths: candidate / node-pool / keypoint overflow);
+    // read back by eorb_sync / eorb_fe_status
+    eorb::DevBuf status;
+    // test hooks (eorb_debug_option): shrink the octree node pool to force an overflow; force the octree's global-memory layout
+    int dbg_pool_shrink = 0, dbg_force_global = 0;
 };
 
 namespace eorb {
 
 int  set_err(eorb_ctx* c, int code, const char* fmt, ...);
 int  ensure(eorb_ctx* c, DevBuf& b, size_t bytes);
-void* pinned(eorb_ctx* c, size_t bytes);
+void* pinned(eorb_ctx* c, size_t bytes);        // next free slot of the pinned ring (waits for the slot's previous copy)
+void pinned_commit(eorb_ctx* c);                // call right after the hipMemcpyAsync that reads the slot
 int  hip_check(eorb_ctx* c, hipError_t e, const char* what);
 
 // scoped per-kernel timing (HIP events on the ctx stream) when profiling is enabled

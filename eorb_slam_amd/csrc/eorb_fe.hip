@@ -77,12 +77,25 @@ int ensure(eorb_ctx* c, DevBuf& b, size_t bytes)
 
 void* pinned(eorb_ctx* c, size_t bytes)
 {
-    if (c->pinned_cap >= bytes) return c->pinned;
-    if (c->pinned) { hipStreamSynchronize(c->stream); hipHostFree(c->pinned); c->pinned = nullptr; c->pinned_cap = 0; }
+    eorb_ctx::PinnedSlot& s = c->pinned[c->pinned_next];
+    c->pinned_cur = c->pinned_next;
+    c->pinned_next = (c->pinned_next + 1) % eorb_ctx::kPinnedSlots;
+    if (s.busy) { hipEventSynchronize(s.ev); s.busy = false; }      // the copy that read this slot has completed
+    if (s.cap >= bytes) return s.p;
+    if (s.p) { hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
     const size_t want = bytes + bytes / 2 + 4096;
-    if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) { c->pinned = nullptr; return nullptr; }
-    c->pinned_cap = want;
-    return c->pinned;
+    if (hipHostMalloc(&s.p, want, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return nullptr; }
+    s.cap = want;
+    return s.p;
+}
+
+void pinned_commit(eorb_ctx* c)
+{
+    if (c->pinned_cur < 0) return;
+    eorb_ctx::PinnedSlot& s = c->pinned[c->pinned_cur];
+    if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; hipStreamSynchronize(c->stream); return; }
+    if (hipEventRecord(s.ev, c->stream) != hipSuccess) { hipStreamSynchronize(c->stream); return; }
+    s.busy = true;
 }
 
 ProfScope::ProfScope(eorb_ctx* cc, const char* name) : c(cc), idx(-1)
@@ -139,6 +152,7 @@ int eorb_create(int device, void* hip_stream, eorb_ctx** out)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return EORB_E_HIP; }
         c->own_stream = true;
     }
+    if (ensure(c, c->status, 64) != EORB_OK || hipMemsetAsync(c->status.p, 0, 64, c->stream) != hipSuccess) { eorb_destroy(c); return EORB_E_HIP; }
     *out = c;
     return EORB_OK;
 }
@@ -153,9 +167,9 @@ void eorb_destroy(eorb_ctx* c)
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
-                      &c->orb.tabs, &c->orb.geom};
+                      &c->orb.tabs, &c->orb.geom, &c->status};
     for (DevBuf* b : bufs) free_buf(*b);
-    if (c->pinned) hipHostFree(c->pinned);
+    for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -163,8 +177,26 @@ void eorb_destroy(eorb_ctx* c)
 int eorb_sync(eorb_ctx* c)
 {
     if (!c) return EORB_E_ARG;
+    hipSetDevice(c->device);
     EORB_HIP(c, hipStreamSynchronize(c->stream));
+    // sticky status of the asynchronous (*_dev) paths: kernels OR their overflow bits into a device word; report it once
+    int32_t bits = 0;
+    EORB_HIP(c, hipMemcpyAsync(&bits, c->status.p, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (bits) {
+        EORB_HIP(c, hipMemsetAsync(c->status.p, 0, sizeof(bits), c->stream));
+        return set_err(c, EORB_E_CAPACITY, "a batched call exceeded an internal capacity (octree flags %d: 1 = candidates, 2 = node pool / "
+                       "size list, 4 = keypoints per level); its keypoints are truncated", bits);
+    }
     return EORB_OK;
+}
+
+int eorb_debug_option(eorb_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return EORB_E_ARG;
+    if (!strcmp(name, "octree_pool_shrink")) { c->dbg_pool_shrink = value; return EORB_OK; }
+    if (!strcmp(name, "octree_force_global")) { c->dbg_force_global = value; return EORB_OK; }
+    return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
 
 const char* eorb_last_error(eorb_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -554,7 +586,10 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     EORB_HIP(c, hipMemcpyAsync(hn, dn, 8, hipMemcpyDeviceToHost, c->stream));
     int flag = 0;
     if ((rc = orb_err_flag(c, 1, &flag))) return rc;
-    if (flag) return set_err(c, EORB_E_CAPACITY, "orb_extract: internal capacity exceeded (flag %d)", flag);
+    if (flag) {
+        hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream);       // reported here, not again by eorb_sync
+        return set_err(c, EORB_E_CAPACITY, "orb_extract: internal capacity exceeded (flag %d)", flag);
+    }
     if (hn[0] > cap) return set_err(c, EORB_E_CAPACITY, "orb_extract: %d keypoints > caller capacity %d", hn[0], cap);
     if (hn[0] > 0) {
         if (kps) EORB_HIP(c, hipMemcpyAsync(kps, c->out_kp.p, sizeof(eorb_keypoint) * hn[0], hipMemcpyDeviceToHost, c->stream));
@@ -1207,12 +1242,14 @@ int eorb_fe_configure(eorb_ctx* c, const eorb_fe_config* cfg)
     if ((rc = ensure(c, c->img_f32, sizeof(float) * npix * B))) return rc;
     if ((rc = ensure(c, c->img_u8, npix * B))) return rc;
     if ((rc = ensure(c, c->minmax, 8 * B + 64))) return rc;
-    if ((rc = ensure(c, c->out_kp, sizeof(eorb_keypoint) * cap * (B + 1)))) return rc;
-    if ((rc = ensure(c, c->m_a, 32 * cap * (B + 1)))) return rc;       // descriptors, slot 0 = previous batch's last slice
-    if ((rc = ensure(c, c->out_n, sizeof(int32_t) * (2 * B + 4)))) return rc;
-    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * cap * B))) return rc;   // matches12
+    // working copies owned by the batched path alone (host entry points on the same context never touch them, so the slice
+    // carried from batch to batch survives an interleaved eorb_orb_extract / matcher call): slot 0 = previous batch's last slice
+    if ((rc = ensure(c, c->fe_prev_kp, sizeof(eorb_keypoint) * cap * (B + 1)))) return rc;
+    if ((rc = ensure(c, c->fe_prev_desc, 32 * cap * (B + 1)))) return rc;
+    if ((rc = ensure(c, c->fe_prev_n, sizeof(int32_t) * (2 * B + 4)))) return rc;
+    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * cap * B))) return rc;   // matches12 (when the caller passes none)
     if ((rc = ensure(c, c->m_j, sizeof(int32_t) * (B + 1)))) return rc;    // nmatches
-    EORB_HIP(c, hipMemsetAsync(c->out_n.p, 0, sizeof(int32_t) * (2 * B + 4), c->stream));
+    EORB_HIP(c, hipMemsetAsync(c->fe_prev_n.p, 0, sizeof(int32_t) * (2 * B + 4), c->stream));
     c->fe_configured = true;
     c->fe_has_prev = false;
     return EORB_OK;
@@ -1230,9 +1267,9 @@ static int fe_run_batch_common(eorb_ctx* c, const void* d_events, int raw, const
     const size_t npix = (size_t)f.W * f.H, cap = c->orb.max_out;
     uint8_t* img = d_images ? d_images : (uint8_t*)c->img_u8.p;
     // working copies: slot 0 of kp/desc/n holds the last slice of the previous batch (frame-to-frame matching)
-    eorb_keypoint* wk = (eorb_keypoint*)c->out_kp.p;
-    uint8_t* wd = (uint8_t*)c->m_a.p;
-    int32_t* wn = (int32_t*)c->out_n.p;                 // [0] prev, [1..B] this batch, then mono index
+    eorb_keypoint* wk = (eorb_keypoint*)c->fe_prev_kp.p;
+    uint8_t* wd = (uint8_t*)c->fe_prev_desc.p;
+    int32_t* wn = (int32_t*)c->fe_prev_n.p;             // [0] prev, [1..B] this batch, then mono index
     int rc = ev_accumulate_dev(c, d_events, raw, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 1,
                                (uint32_t*)c->minmax.p);
     if (rc) return rc;

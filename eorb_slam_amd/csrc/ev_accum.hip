@@ -871,9 +871,11 @@ __global__ void ev_warp_se3_kernel(const eorb_event16* __restrict__ in, eorb_eve
     double np[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        double acc = (d * R[i][0]) * Pv[0];
-        acc = acc + (d * R[i][1]) * Pv[1];
-        acc = acc + (d * R[i][2]) * Pv[2];
+        // Eigen 3.3 fixed-size product: row(i).cwiseProduct(P3D).sum() unrolls as a0 + (a1 + a2)
+        const double a0 = (d * R[i][0]) * Pv[0];
+        const double a1 = (d * R[i][1]) * Pv[1];
+        const double a2 = (d * R[i][2]) * Pv[2];
+        const double acc = a0 + (a1 + a2);
         np[i] = acc + tt[i] * etRate;
     }
     const double u = (double)P.fx * np[0] / np[2] + (double)P.cx;            // Pinhole::project(Eigen::Vector3d)
@@ -1314,6 +1316,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     memcpy(hp + cd_bytes, slice_c0.data(), sizeof(int) * (size_t)(B + 1));
     memcpy(hp + cd_bytes + sc_bytes, slice_eb.data(), eb_bytes);
     EORB_HIP(c, hipMemcpyAsync(c->chunks.p, hp, cd_bytes + sc_bytes + eb_bytes, hipMemcpyHostToDevice, c->stream));
+    pinned_commit(c);
     const ChunkDesc* d_chunks = (const ChunkDesc*)c->chunks.p;
     const int* d_slice_c0 = (const int*)((char*)c->chunks.p + cd_bytes);
     const int64_t* d_slice_eb = (const int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes);

@@ -342,11 +342,8 @@ int search_init_dev(eorb_ctx* c, int npairs,
                      kps2, n2, kp2_stride, desc2, dstride2, desc2_slice, is_orb2, cap1, cap2,
                      GridB{gb.minX, gb.minY, gb.invW, gb.invH}, prev_matched, matches12, nmatches,
                      windowSize, nnratio, checkOri};
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)search_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    // per device, not per process: a second context on another GPU needs the opt-in too (the call is cheap)
+    hipFuncSetAttribute((const void*)search_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     ProfScope ps(c, "search_init");
     search_init_kernel<<<npairs, 256, lds, c->stream>>>(A);
     EORB_LAUNCH_CHECK(c, "search_init_kernel");

@@ -33,8 +33,11 @@ struct DevGeom {
     int iniTh, minTh;
     int umax[16];
     float sf[kMaxLevels];
-    int pts_in_lds;
-    int oct_keys_off, oct_pts_off, oct_nodes_off, oct_vsp_off, oct_lds_bytes;   // per-kernel LDS layout (bytes)
+    // octree working set: items 0 node pool, 1 / 2 the two (size, seq, node) lists, 3 / 4 the key ping-pong buffers, 5 the
+    // candidate points; each lives in LDS (offset into the dynamic LDS block) or, when the 160 KB do not hold it, in the
+    // (slice, level) block of a global scratch buffer (offset into that block)
+    int oct_in_lds[6], oct_off[6];
+    int oct_lds_bytes, oct_gblock_bytes;
     int node_cap_max, vsp_cap_max, ncap_max;
 };
 
@@ -241,9 +244,9 @@ __device__ void wave_sort_u64(uint64_t* a, int n, int lane)
 }
 
 __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ G, const int32_t* __restrict__ cell_cnt,
-                                                    const uint32_t* __restrict__ cell_cand, uint32_t* __restrict__ cand_g,
+                                                    const uint32_t* __restrict__ cell_cand, unsigned char* __restrict__ scratch_g,
                                                     uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_cnt,
-                                                    int32_t* __restrict__ err_flag)
+                                                    int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky)
 {
     extern __shared__ unsigned char smem[];
     const int lane = threadIdx.x;
@@ -252,12 +255,14 @@ __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ 
     const int ncap = G->ncap_max, pool = L.node_cap, vcap = G->vsp_cap_max;
     OctLds S;
     {
-        unsigned char* p = smem;
-        S.keys[0] = (uint16_t*)p; p += sizeof(uint16_t) * ncap;
-        S.keys[1] = (uint16_t*)p; p += sizeof(uint16_t) * ncap;
-        p = (unsigned char*)(((uintptr_t)p + 7) & ~(uintptr_t)7);
-        S.vsp[0] = (uint64_t*)p; p += sizeof(uint64_t) * vcap;
-        S.vsp[1] = (uint64_t*)p; p += sizeof(uint64_t) * vcap;
+        // every item in LDS when the 160 KB hold it, otherwise in this (slice, level)'s block of the global scratch buffer: the
+        // workgroup is one wavefront on one CU, whose own stores are visible to its later loads after __syncthreads()
+        unsigned char* gblk = scratch_g + (size_t)blockIdx.x * G->oct_gblock_bytes;
+        auto item = [&](int k) -> unsigned char* { return (G->oct_in_lds[k] ? smem : gblk) + G->oct_off[k]; };
+        S.keys[0] = (uint16_t*)item(3); S.keys[1] = (uint16_t*)item(4);
+        S.vsp[0] = (uint64_t*)item(1); S.vsp[1] = (uint64_t*)item(2);
+        S.pts = (uint32_t*)item(5);
+        unsigned char* p = item(0);
         const int pc = G->node_cap_max;
         S.x0 = (uint16_t*)p; p += 2 * pc; S.x1 = (uint16_t*)p; p += 2 * pc;
         S.y0 = (uint16_t*)p; p += 2 * pc; S.y1 = (uint16_t*)p; p += 2 * pc;
@@ -266,10 +271,8 @@ __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ 
         S.seq = (uint16_t*)p; p += 2 * pc; S.freel = (uint16_t*)p; p += 2 * pc;
         S.order = (uint16_t*)p; p += 2 * pc;
         S.flags = (uint8_t*)p; p += pc;
-        p = (unsigned char*)(((uintptr_t)p + 3) & ~(uintptr_t)3);
-        if (G->pts_in_lds) S.pts = (uint32_t*)p;
-        else S.pts = cand_g + (size_t)slice * G->cand_total + L.cand_off;
     }
+    auto raise = [&](int bit) { if (lane == 0) { atomicOr(err_flag, bit); atomicOr(sticky, bit); } };
     uint32_t* lkp = lvl_kp + (size_t)slice * G->kp_total + L.kp_off;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     constexpr uint16_t NIL = 0xFFFF;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ 
             }
             n += cc;
         }
-        if (n > ncap) { if (lane == 0) atomicOr(err_flag, 1); n = ncap; }
+        if (n > ncap) { raise(1); n = ncap; }
     }
     __syncthreads();
     if (n == 0) { if (lane == 0) lvl_cnt[slice * G->nlevels + level] = 0; return; }
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ 
             }
         }
     }
-    if (overflow) { if (lane == 0) atomicOr(err_flag, 2); }
+    if (overflow) raise(2);
 
     // ---- retain the best point of each node, in list order (:760-780) ----
     {
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ 
         for (int lit = head; lit != NIL && k < pool; lit = S.next[lit]) { if (lane == 0) S.order[k] = (uint16_t)lit; k++; }
         __syncthreads();
         const int nout = min(k, L.kp_cap);
-        if (k > L.kp_cap && lane == 0) atomicOr(err_flag, 4);
+        if (k > L.kp_cap) raise(4);
         for (int i = lane; i < nout; i += 64) {
             const int id = S.order[i];
             const uint16_t* ks = S.keys[(S.flags[id] >> 1) & 1] + S.start[id];
@@ -869,17 +872,23 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
     if (ncap_max >= 65535) return set_err(c, EORB_E_CAPACITY, "image too large for the 16-bit octree keys");
     o.pyr_bytes = pyr; o.roi_bytes = roi; o.ncells = cells; o.cell_cap = cell_cap;
     o.cand_total = cand_total; o.kp_total = kp_total; o.max_out = kp_total;
-    // octree LDS layout
-    size_t lds = 2 * sizeof(uint16_t) * (size_t)ncap_max;
-    lds = (lds + 7) & ~(size_t)7;
-    lds += 2 * sizeof(uint64_t) * (size_t)vsp_cap_max;
-    lds += (size_t)node_cap_max * (11 * 2 + 1);
-    lds = (lds + 3) & ~(size_t)3;
-    int pts_in_lds = 0;
-    if (lds + sizeof(uint32_t) * (size_t)ncap_max <= 156 * 1024) { pts_in_lds = 1; lds += sizeof(uint32_t) * (size_t)ncap_max; }
-    if (lds > 156 * 1024)
-        return set_err(c, EORB_E_CAPACITY, "octree working set (%zu B) exceeds the 160 KB LDS: image %dx%d too large for this build", lds, W, H);
+    // octree working set: greedy placement into the 160 KB of LDS (most latency-critical first), the rest into a per-(slice,
+    // level) block of global scratch (346x260 with 3 000 features on one level, VGA-class frames)
+    if (c->dbg_pool_shrink > 0)                    // test hook: force node-pool overflows (sticky status of the *_dev paths)
+        for (int l = 0; l < nlevels; l++) o.lv[l].node_cap = std::max(8, o.lv[l].node_cap - c->dbg_pool_shrink);
+    const size_t item_bytes[6] = {((size_t)node_cap_max * (11 * 2 + 1) + 15) & ~(size_t)15,
+                                  sizeof(uint64_t) * (size_t)vsp_cap_max, sizeof(uint64_t) * (size_t)vsp_cap_max,
+                                  (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15, (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15,
+                                  (sizeof(uint32_t) * (size_t)ncap_max + 15) & ~(size_t)15};
+    int oct_in_lds[6], oct_off[6];
+    size_t lds = 0, gblock = 0;
+    const size_t lds_budget = c->dbg_force_global ? 0 : 156 * 1024;
+    for (int k = 0; k < 6; k++) {
+        if (lds + item_bytes[k] <= lds_budget) { oct_in_lds[k] = 1; oct_off[k] = (int)lds; lds += item_bytes[k]; }
+        else { oct_in_lds[k] = 0; oct_off[k] = (int)gblock; gblock += item_bytes[k]; }
+    }
     o.oct_lds = (int)lds;
+    o.oct_scratch = (int)gblock;
 
     DevGeom g{};
     memcpy(g.lv, o.lv, sizeof(o.lv));
@@ -888,7 +897,8 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
     g.kp_total = kp_total; g.max_out = kp_total; g.iniTh = std::min(std::max(p->iniThFAST, 0), 255);
     g.minTh = std::min(std::max(p->minThFAST, 0), 255);
     memcpy(g.umax, o.umax, sizeof(o.umax)); memcpy(g.sf, o.sf, sizeof(o.sf));
-    g.pts_in_lds = pts_in_lds; g.oct_lds_bytes = (int)lds;
+    memcpy(g.oct_in_lds, oct_in_lds, sizeof(oct_in_lds)); memcpy(g.oct_off, oct_off, sizeof(oct_off));
+    g.oct_lds_bytes = (int)lds; g.oct_gblock_bytes = (int)gblock;
     g.node_cap_max = node_cap_max; g.vsp_cap_max = vsp_cap_max; g.ncap_max = ncap_max;
     int rc;
     if ((rc = ensure(c, o.geom, sizeof(DevGeom)))) return rc;
@@ -913,7 +923,7 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     if ((rc = ensure(c, c->blur, nb * o.roi_bytes))) return rc;
     if ((rc = ensure(c, c->cell_cnt, nb * o.ncells * sizeof(int32_t)))) return rc;
     if ((rc = ensure(c, c->cell_cand, nb * o.ncells * (size_t)o.cell_cap * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(c, c->score, nb * o.cand_total * sizeof(uint32_t)))) return rc;          // compact candidates (global pts)
+    if ((rc = ensure(c, c->oct_scratch, nb * o.nlevels * (size_t)o.oct_scratch))) return rc;   // octree items that do not fit the LDS
     if ((rc = ensure(c, c->lvl_kp, nb * o.kp_total * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->lvl_cnt, nb * o.nlevels * sizeof(int32_t) + 64))) return rc;
     if ((rc = ensure(c, c->kp_angle, nb * o.kp_total * sizeof(float)))) return rc;
@@ -941,8 +951,8 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     {
         ProfScope ps(c, "orb_octree");
         octree_kernel<<<B * o.nlevels, 64, o.oct_lds, c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
-                                                                    (uint32_t*)c->score.p, (uint32_t*)c->lvl_kp.p,
-                                                                    (int32_t*)c->lvl_cnt.p, err_flag);
+                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p,
+                                                                    (int32_t*)c->lvl_cnt.p, err_flag, (int32_t*)c->status.p);
         EORB_LAUNCH_CHECK(c, "octree_kernel");
     }
     {

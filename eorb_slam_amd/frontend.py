@@ -55,7 +55,11 @@ class Context:
             raise EorbError(rc, self.L.eorb_last_error(self.h).decode())
 
     def sync(self):
+        """Waits for the stream; raises EorbError(EORB_E_CAPACITY) once if an earlier batched call overflowed internally."""
         self.check(self.L.eorb_sync(self.h))
+
+    def debug_option(self, name, value):
+        self.check(self.L.eorb_debug_option(self.h, name.encode(), int(value)))
 
     # profiling ------------------------------------------------------------------------------------
     def prof_enable(self, on=True):

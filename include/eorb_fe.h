@@ -92,7 +92,13 @@ typedef struct {
 /* hip_stream: a hipStream_t to launch on (e.g. torch's current stream), or NULL for a private one */
 int         eorb_create(int device, void* hip_stream, eorb_ctx** out);
 void        eorb_destroy(eorb_ctx* ctx);
+/* waits for the ctx stream; also reports (once, then clears) the sticky status of the asynchronous *_dev paths:
+ * EORB_E_CAPACITY when a kernel of an earlier batched call overflowed an internal capacity (its keypoints are truncated).
+ * The host-buffer entry points report the same condition from the call itself (eorb_orb_extract). */
 int         eorb_sync(eorb_ctx* ctx);
+/* test hooks, not part of the reference's interface: "octree_pool_shrink" (n > 0: shrink the octree node pool by n at the
+ * next configure, to force the overflow path), "octree_force_global" (1: keep the whole octree working set in global memory) */
+int         eorb_debug_option(eorb_ctx* ctx, const char* name, int value);
 const char* eorb_last_error(eorb_ctx* ctx);
 const char* eorb_version(void);
 /* per-kernel HIP-event timing on the ctx stream (off by default; used by bench.py) */

@@ -130,10 +130,13 @@ void orc_mci_warp_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, dou
         const double d = (double)(depth_per_event ? depth_per_event[k] : medDepth);
         double np[3];
         for (int i = 0; i < 3; i++) {
-            /* (medDepth * newR) * P3D + newT : coefficient-based 3x3 product, left to right */
-            double acc = (d * R[i][0]) * P[0];
-            acc = acc + (d * R[i][1]) * P[1];
-            acc = acc + (d * R[i][2]) * P[2];
+            /* (medDepth * newR) * P3D + newT (:324): Eigen 3.3 (libeigen3-dev, build_eorb_slam.sh:54) evaluates the scaled
+             * matrix into a temporary, then the fixed-size coefficient-based product row(i).cwiseProduct(P3D).sum(), whose
+             * completely unrolled 3-term redux (redux_novec_unroller, halves 1 + 2) associates as a0 + (a1 + a2) */
+            const double a0 = (d * R[i][0]) * P[0];
+            const double a1 = (d * R[i][1]) * P[1];
+            const double a2 = (d * R[i][2]) * P[2];
+            const double acc = a0 + (a1 + a2);
             np[i] = acc + tt[i] * etRate;
         }
         /* Pinhole::project(Eigen::Vector3d) :41-47 */

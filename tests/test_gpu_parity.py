@@ -243,6 +243,77 @@ def test_search_by_projection_map(oracle, fe, ctx):
     assert on > 10
 
 
+def _mix(k, d, rng, frac=(2, 3)):
+    """A MixedFrame stand-in: the first 2/3 of the rows are ORB, the rest "AKAZE" (61-byte rows whose first 32 bytes are
+    compared, octaves of their own scale ladder)."""
+    n = len(k)
+    d61 = np.zeros((n, 61), np.uint8); d61[:, :32] = d; d61[:, 32:] = rng.integers(0, 256, (n, 29))
+    is_orb = (np.arange(n) < n * frac[0] // frac[1]).astype(np.uint8)
+    k = k.copy(); k["class_id"] = np.where(is_orb == 1, -1, 0); k["octave"] = np.where(is_orb == 1, k["octave"], k["octave"] % 3)
+    return k, d61, is_orb
+
+
+AKAZE_SF = np.array([1.0, 1.2599211, 1.5874010, 2.0], np.float32)      # getAKAZEScaleFactor: 2^(level / nOctaveLayers)
+
+
+def test_search_by_projection_last_mixed_gate(oracle, fe, ctx):
+    """MixedMatcher::SearchByProjection(cur, last) (src/MixedMatcher.cpp:693-926): only same-type pairs are compared and the window
+    of an AKAZE map point scales with the AKAZE ladder."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=23, shift=2)
+    rng = np.random.default_rng(4)
+    k1, d1m, o1 = _mix(k1, d1, rng); k2, d2m, o2 = _mix(k2, d2, rng, frac=(3, 5))
+    n1 = len(k1)
+    valid = (rng.uniform(size=n1) < 0.85).astype(np.uint8)
+    uv = np.stack([k1["x"] - 2 + rng.normal(0, 1, n1), k1["y"] + 2 + rng.normal(0, 1, n1)], axis=1).astype(np.float32)
+    mp_obs = (rng.uniform(size=n1) < 0.7).astype(np.uint8)
+    sf = oracle.OrbExtractor(1000, 1.2, 4).scale_factors
+    ls = np.where(o1 == 1, sf[np.clip(k1["octave"], 0, 3)], AKAZE_SF[np.clip(k1["octave"], 0, 3)]).astype(np.float32)
+    cur_mp = np.full(len(k2), -1, np.int32); cur_mp[::17] = -2; cur_mp[5::23] = -3
+    mp_desc = np.ascontiguousarray(d1m[:, :32])
+    totals = []
+    for mode in (0, 1, 2):
+        for ori in (True, False):
+            on, ocm = oracle.search_by_projection_last(oracle.Frame(k2, d2m, 240, 180, o2), oracle.Frame(k1, d1m, 240, 180, o1), valid, uv,
+                                                       mp_desc, mp_obs, cur_mp, 15.0, ls, mode, ori)
+            gn, gcm = fe.ORBmatcher(0.9, ori, ctx).SearchByProjectionLast(fe.FrameView(k2, d2m, 240, 180, o2), fe.FrameView(k1, d1m, 240, 180, o1),
+                                                                          valid, uv, mp_desc, mp_obs, cur_mp, 15.0, ls, mode)
+            assert on == gn and np.array_equal(ocm, gcm)
+            m = ocm >= 0
+            assert np.array_equal(o2[m], o1[ocm[m]]), "a pair of different feature types was matched"
+            totals.append(on)
+    # the gate changes the result: without the type flags more (cross-type) pairs are found
+    on_plain, _ = oracle.search_by_projection_last(oracle.Frame(k2, d2m, 240, 180), oracle.Frame(k1, d1m, 240, 180), valid, uv, mp_desc,
+                                                   mp_obs, cur_mp, 15.0, ls, 0, True)
+    assert totals[0] > 10 and on_plain != totals[0]
+
+
+def test_search_by_projection_map_mixed_gate(oracle, fe, ctx):
+    """MixedMatcher::SearchByProjection(F, vpMapPoints) (src/MixedMatcher.cpp:500-691): isORBMapPoint gate + AKAZE window scale."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=24, shift=1)
+    rng = np.random.default_rng(5)
+    k2, d2m, o2 = _mix(k2, d2, rng)
+    M = len(k1)
+    mp_is_orb = (rng.uniform(size=M) < 0.6).astype(np.uint8)
+    in_view = (rng.uniform(size=M) < 0.9).astype(np.uint8)
+    proj = np.stack([k1["x"] - 1 + rng.normal(0, 0.7, M), k1["y"] + 1 + rng.normal(0, 0.7, M)], axis=1).astype(np.float32)
+    level = np.where(mp_is_orb == 1, k1["octave"], k1["octave"] % 3).astype(np.int32)
+    vc = rng.uniform(0.99, 1.0, M).astype(np.float32)
+    mp_obs = (rng.uniform(size=M) < 0.6).astype(np.uint8)
+    sf = oracle.OrbExtractor(1000, 1.2, 4).scale_factors
+    ls = np.where(mp_is_orb == 1, sf[np.clip(level, 0, 3)], AKAZE_SF[np.clip(level, 0, 3)]).astype(np.float32)
+    fm = np.full(len(k2), -1, np.int32); fm[::19] = -2
+    for th in (1.0, 3.0):
+        on, ofm = oracle.search_by_projection_map(oracle.Frame(k2, d2m, 240, 180, o2), in_view, proj, level, vc, d1, mp_obs, fm, th, 0.8, ls,
+                                                  mp_is_orb=mp_is_orb)
+        gn, gfm = fe.ORBmatcher(0.8, True, ctx).SearchByProjectionMap(fe.FrameView(k2, d2m, 240, 180, o2), in_view, proj, level, vc, d1,
+                                                                      mp_obs, fm, th, ls, mp_is_orb=mp_is_orb)
+        assert on == gn and np.array_equal(ofm, gfm)
+        m = ofm >= 0
+        assert np.array_equal(o2[m], mp_is_orb[ofm[m]]), "a map point was matched to a feature of the other type"
+    on_plain, _ = oracle.search_by_projection_map(oracle.Frame(k2, d2m, 240, 180), in_view, proj, level, vc, d1, mp_obs, fm, 3.0, 0.8, ls)
+    assert on > 10 and on_plain != on
+
+
 # ---- the batched HBM-resident pipeline -------------------------------------------------------------------------------
 def test_frontend_batch_matches_oracle_pipeline(oracle, fe):
     W, H, B, n = 240, 180, 3, 40000
@@ -891,7 +962,8 @@ def test_frontend_batch_raw_equals_float_path(oracle, fe):
 
 def test_full_size_batch_properties(oracle, fe):
     """BASELINE.json configs[1] sizes (1 000 000 events per slice): the raw and the float inputs give the same images / keypoints,
-    a slice's result does not depend on its position or company in the batch, and one slice is checked against the oracle."""
+    a slice's result does not depend on its position or company in the batch, and slices 0 and 1 are checked against the oracle:
+    image, keypoints, descriptors and the match of slice 1 against slice 0."""
     W, H, N = 240, 180, 1000000
     mx, my = _maps(W, H)
     pairs = [synth.shapes_events(N, W, H, seed=2 + b, motion=0.5, undistort=True, return_raw=True) for b in range(3)]
@@ -907,16 +979,19 @@ def test_full_size_batch_properties(oracle, fe):
             blob = np.concatenate([fe.pack_events(pairs[i][0]) for i in order])
         d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
         d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32); d_n = c.dev_alloc(B * 4)
-        fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * N, d_img, d_kp, d_desc, d_n, raw=use_raw)
+        d_m = c.dev_alloc(B * cap * 4); d_nm = c.dev_alloc(B * 4)
+        fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * N, d_img, d_kp, d_desc, d_n, d_m, d_nm, raw=use_raw)
         c.sync()
         imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
         nk = np.zeros(B, np.int32); c.download(nk, d_n)
         kps = np.zeros((B, cap), synth.KP_DTYPE); c.download(kps, d_kp)
         desc = np.zeros((B, cap, 32), np.uint8); c.download(desc, d_desc)
-        for p in (d_ev, d_img, d_kp, d_desc, d_n):
+        m12 = np.zeros((B, cap), np.int32); c.download(m12, d_m)
+        nm = np.zeros(B, np.int32); c.download(nm, d_nm)
+        for p in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
             c.dev_free(p)
         c.close()
-        return {i: (imgs[j].copy(), kps[j, :nk[j]].copy(), desc[j, :nk[j]].copy()) for j, i in enumerate(order)}
+        return {i: (imgs[j].copy(), kps[j, :nk[j]].copy(), desc[j, :nk[j]].copy(), m12[j].copy(), int(nm[j])) for j, i in enumerate(order)}
 
     a = run([0, 1, 2], True)
     b = run([2, 0], False)
@@ -924,8 +999,19 @@ def test_full_size_batch_properties(oracle, fe):
     for i, other in ((0, b), (2, b), (1, c1)):
         assert np.array_equal(a[i][0], other[i][0])
         assert np.array_equal(a[i][1].view(np.uint8), other[i][1].view(np.uint8)) and np.array_equal(a[i][2], other[i][2])
-    _, ou, _ = oracle.ev2im_gauss(pairs[1][0], W, H, 1.0, False, True, fast=True)
-    assert np.array_equal(ou, a[1][0]) and len(a[1][1]) > 50
+    oe = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19, fast=True)
+    ref = []
+    for i in (0, 1):
+        _, ou, _ = oracle.ev2im_gauss(pairs[i][0], W, H, 1.0, False, True, fast=True)
+        assert np.array_equal(ou, a[i][0])
+        _, okp, odesc, _ = oe.extract(ou)
+        assert len(okp) == len(a[i][1]) and np.array_equal(okp.view(np.uint8), a[i][1].view(np.uint8)), "keypoints of slice %d" % i
+        assert np.array_equal(odesc, a[i][2]), "descriptors of slice %d" % i
+        ref.append((okp, odesc))
+    pm = np.stack([ref[0][0]["x"], ref[0][0]["y"]], axis=1)
+    on, om, _ = oracle.search_for_initialization(oracle.Frame(ref[0][0], ref[0][1], W, H), oracle.Frame(ref[1][0], ref[1][1], W, H), pm, 100, 0.9, True)
+    assert on == a[1][4] and np.array_equal(om, a[1][3][:len(ref[0][0])]), "match of slice 1 against slice 0"
+    assert len(a[1][1]) > 50
 
 
 def test_large_slice_many_chunks(oracle, fe, ctx):
@@ -934,6 +1020,114 @@ def test_large_slice_many_chunks(oracle, fe, ctx):
     of, ou, omm = oracle.ev2im_gauss(ev, 240, 180, 1.0, False, True, fast=True)
     gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, 240, 180, 1.0, False, True, ctx=ctx, return_all=True)
     assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm)
+
+
+def test_unsynced_ragged_batches_keep_their_own_tables(oracle, fe):
+    """Back-to-back eorb_fe_run_batch_dev calls without a sync in between, every call with different ragged offsets: each batch must
+    run with ITS chunk table (the host staging buffer is a ring guarded by events), results equal to one-call-one-sync runs."""
+    W, H = 240, 180
+    rng = np.random.default_rng(9)
+    calls = []
+    for k in range(6):
+        B = int(rng.integers(1, 5))
+        ns = [int(v) for v in rng.integers(0, 30000, B)]
+        if k == 2:
+            ns[0] = 0
+        slices = [synth.shapes_events(n, W, H, seed=300 + 10 * k + b, motion=0.4) if n else np.zeros(0, synth.EVENT_DTYPE) for b, n in enumerate(ns)]
+        calls.append((ns, slices))
+    Bmax, nmax = 4, 4 * 30000
+
+    def run(sync_each):
+        fb = fe.FrontEndBatch(W, H, 1.0, False, 500, 1.2, 3, 10, 0, 19, max_batch=Bmax, max_events=nmax)
+        c, cap = fb.ctx, fb.cap
+        bufs = []
+        for ns, slices in calls:
+            B = len(ns)
+            blob = np.concatenate([fe.pack_events(s) for s in slices]) if sum(ns) else np.zeros(1, fe.EV16_DTYPE)
+            d_ev = c.dev_alloc(max(blob.nbytes, 16)); c.upload(d_ev, blob)
+            d = dict(ev=d_ev, img=c.dev_alloc(B * W * H), kp=c.dev_alloc(B * cap * 28), desc=c.dev_alloc(B * cap * 32), n=c.dev_alloc(B * 4),
+                     m=c.dev_alloc(B * cap * 4), nm=c.dev_alloc(B * 4), B=B, offs=np.concatenate([[0], np.cumsum(ns)]).astype(np.int64))
+            bufs.append(d)
+        for d in bufs:
+            fb.run_dev(d["ev"], d["offs"], d["img"], d["kp"], d["desc"], d["n"], d["m"], d["nm"])
+            if sync_each:
+                c.sync()
+        c.sync()
+        out = []
+        for d in bufs:
+            B = d["B"]
+            imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d["img"])
+            nk = np.zeros(B, np.int32); c.download(nk, d["n"])
+            kps = np.zeros((B, cap), synth.KP_DTYPE); c.download(kps, d["kp"])
+            desc = np.zeros((B, cap, 32), np.uint8); c.download(desc, d["desc"])
+            m12 = np.zeros((B, cap), np.int32); c.download(m12, d["m"])
+            nm = np.zeros(B, np.int32); c.download(nm, d["nm"])
+            out.append((imgs, nk, [kps[b, :nk[b]].tobytes() for b in range(B)], [desc[b, :nk[b]].tobytes() for b in range(B)], m12, nm))
+            for k in ("ev", "img", "kp", "desc", "n", "m", "nm"):
+                c.dev_free(d[k])
+        c.close()
+        return out
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] and x[3] == y[3]
+        assert np.array_equal(x[5], y[5])
+    # and the synced run is the oracle's (images of the first and the last call)
+    for k in (0, len(calls) - 1):
+        for bidx, s in enumerate(calls[k][1]):
+            _, ou, _ = oracle.ev2im_gauss(s, W, H, 1.0, False, True)
+            assert np.array_equal(ou, a[k][0][bidx])
+
+
+def test_batched_overflow_is_reported_by_sync(oracle, fe):
+    """The octree kernel ORs its overflow bits into a sticky device word; the batched path returns EORB_OK (it never synchronises)
+    and eorb_sync reports EORB_E_CAPACITY once.  The overflow is forced through the test hook that shrinks the node pool."""
+    W, H, B, n = 240, 180, 2, 60000
+    slices = [synth.shapes_events(n, W, H, seed=50 + b, motion=0.3) for b in range(B)]
+    c = fe.Context()
+    c.debug_option("octree_pool_shrink", 400)
+    fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=n, ctx=c)
+    blob = np.concatenate([fe.pack_events(s) for s in slices])
+    d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
+    fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * n)               # EORB_OK: nothing is read back here
+    with pytest.raises(fe.EorbError) as e:
+        c.sync()
+    assert e.value.code == -3 and "capacity" in str(e.value)
+    c.sync()                                                             # reported once
+    # the host entry point reports it from the call itself
+    img = _event_image(oracle)
+    ge = fe.ORBextractor(1000, 1.2, 4, 10, 0, 19, (W, H), ctx=c)
+    with pytest.raises(fe.EorbError) as e:
+        ge(img)
+    assert e.value.code == -3
+    c.sync()
+    c.dev_free(d_ev); c.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(W=346, H=260, nfeatures=3000, scaleFactor=1.2, nlevels=1, edgeTh=15),          # one level of 3 000 features: > 160 KB
+    dict(W=346, H=260, nfeatures=5000, scaleFactor=1.26, nlevels=6, edgeTh=15),         # the monocular initialiser on EvMVSEC_ETHZ.yaml
+    dict(W=346, H=260, nfeatures=3000, scaleFactor=1.2, nlevels=8, edgeTh=15, th=(20, 7)),
+    dict(W=240, H=180, nfeatures=1000, scaleFactor=1.2, nlevels=4, edgeTh=19, force_global=True),
+])
+def test_octree_working_set_in_global_memory(oracle, fe, cfg):
+    """Octree items that do not fit the 160 KB of LDS live in global scratch (Tracking.cc:119-122 runs 5 x nFeatures for the monocular
+    initialiser); results stay bit-exact.  The last case forces EVERY item into global memory on the default configuration."""
+    W, H = cfg["W"], cfg["H"]
+    ini, mn = cfg.get("th", (10, 0))
+    img = synth.texture_image(W, H, seed=61)
+    c = fe.Context()
+    if cfg.get("force_global"):
+        c.debug_option("octree_force_global", 1)
+    oe = oracle.OrbExtractor(cfg["nfeatures"], cfg["scaleFactor"], cfg["nlevels"], ini, mn, edgeTh=cfg["edgeTh"], imWidth=W)
+    ge = fe.ORBextractor(cfg["nfeatures"], cfg["scaleFactor"], cfg["nlevels"], ini, mn, cfg["edgeTh"], (W, H), ctx=c)
+    for im in (img, np.roll(img, 7, axis=1)):
+        omono, okp, odesc, ooob = oe.extract(im)
+        gmono, gkp, gdesc, goob = ge(im)
+        assert omono == gmono and len(okp) == len(gkp)
+        assert np.array_equal(okp.view(np.uint8), gkp.view(np.uint8)) and np.array_equal(odesc, gdesc) and np.array_equal(ooob, goob)
+    assert len(okp) > 0.6 * cfg["nfeatures"] or cfg["nfeatures"] >= 3000
+    c.close()
 
 
 def test_error_paths_return_codes(fe, ctx):

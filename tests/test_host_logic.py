@@ -70,3 +70,33 @@ def test_two_rank_gather_gloo():
     for p in ps:
         p.join(timeout=60)
     assert all(res)
+
+
+def test_record_layout_round_trip():
+    lay = shard.RecordLayout(5, 1032)
+    assert lay.off_kp % 256 == 0 and lay.off_desc % 256 == 0 and lay.nbytes == lay.off_desc + 5 * 1032 * 32
+    rec = lay.alloc("cpu")
+    n, kp, desc = lay.views(rec)
+    assert n.numel() == 5 and kp.numel() == 5 * 1032 * 28 and desc.numel() == 5 * 1032 * 32
+    n.copy_(torch.arange(5, dtype=torch.int32)); desc.fill_(9)
+    gn, gk, gd = lay.unpack(rec, synth.KP_DTYPE)
+    assert gn.tolist() == [0, 1, 2, 3, 4] and gk.shape == (5, 1032) and int(gd.sum()) == 9 * 5 * 1032 * 32
+
+
+def test_spawned_ranks_gather_packed_records(tmp_path):
+    """The launcher behind `python bench.py --gpus N` (shard.spawn_ranks: N child processes with RANK / WORLD_SIZE / MASTER_* set)
+    and the collective bench.py issues per step (shard.gather_packed on the packed record buffer), world size 2 on gloo."""
+    out = tmp_path / "rank0.txt"
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_worker.py")
+    rc = shard.spawn_ranks(script, [str(out)], 2)
+    assert rc == 0
+    assert out.read_text() == "ok 2"
+
+
+def test_bench_refuses_mismatched_world(monkeypatch):
+    """`--gpus N` must agree with WORLD_SIZE when a launcher set it (the driver's torch.distributed.run form)."""
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
