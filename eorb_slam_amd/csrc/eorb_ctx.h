@@ -96,6 +96,7 @@ struct eorb_ctx {
         out_n, oct_scratch, in_img;
     // matcher workspaces
     eorb::DevBuf m_a, m_b, m_c, m_d, m_e, m_f, m_g, m_h, m_i, m_j;
+    eorb::DevBuf win_ws;                 // candidate lists of the two-phase window matchers
     // pyramidal LK workspaces
     eorb::DevBuf klt_pyr, klt_der, klt_scratch;
     // DBoW2 vocabulary (device copy) for eorb_bow_transform
@@ -117,6 +118,7 @@ struct eorb_ctx {
     eorb::DevBuf status;
     // test hooks (eorb_debug_option): shrink the octree node pool to force an overflow; force the octree's global-memory layout
     int dbg_pool_shrink = 0, dbg_force_global = 0;
+    int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
 };
 
 namespace eorb {

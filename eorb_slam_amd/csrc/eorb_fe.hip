@@ -167,7 +167,7 @@ void eorb_destroy(eorb_ctx* c)
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
-                      &c->orb.tabs, &c->orb.geom, &c->status};
+                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -196,6 +196,8 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!c || !name) return EORB_E_ARG;
     if (!strcmp(name, "octree_pool_shrink")) { c->dbg_pool_shrink = value; return EORB_OK; }
     if (!strcmp(name, "octree_force_global")) { c->dbg_force_global = value; return EORB_OK; }
+    if (!strcmp(name, "win_list_cap")) { c->dbg_win_wcap = value; return EORB_OK; }
+    if (!strcmp(name, "win_pool_cap")) { c->dbg_win_ecap = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
 

@@ -164,166 +164,427 @@ __device__ __forceinline__ void three_maxima(const int* histo, int L, int& ind1,
     else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-// per-keypoint staging of the searched frame in LDS
-struct F2Stage {
-    float*    x;      // N2
-    float*    y;
-    uint16_t* cell;   // ix*48+iy, 0xFFFF = not in grid (PosInGrid false)
-    int8_t*   level;
-    uint8_t*  isorb;
-};
-
 __device__ __forceinline__ int kp_level(const eorb_keypoint& k, bool isorb)
 {   // Frame::getKPtLevelMono / MixedFrame::getKPtLevelMono (MixedFrame.cpp:438-446)
     return isorb ? k.octave : k.class_id;
 }
 
-struct SearchInitArgs {
-    const eorb_keypoint* kps1; const int32_t* n1; size_t kp1_stride;
-    const uint8_t* desc1; int dstride1; size_t desc1_slice; const uint8_t* is_orb1;
-    const eorb_keypoint* kps2; const int32_t* n2; size_t kp2_stride;
-    const uint8_t* desc2; int dstride2; size_t desc2_slice; const uint8_t* is_orb2;
-    int cap1, cap2;
-    GridB g;
-    float* prev_matched;       // per pair: cap1*2 (may be NULL: initialised from kps1 positions)
-    int32_t* matches12;        // per pair: cap1
-    int32_t* nmatches;         // per pair
-    int windowSize; float nnratio; int checkOri;
+// ---------------------------------------------------------------------------------------------------
+// The greedy window matchers: ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:714-831, MixedMatcher.cpp:20-145), the two
+// tracking SearchByProjection variants (ORBmatcher.cc:44-219, :1969-2187; MixedMatcher.cpp:500-926) and the relocalisation variant
+// (:2189-2312), mono branches.  The reference walks the queries in order because a query's outcome depends on what earlier queries
+// matched (vMatchedDistance / vnMatches21; setMapPoint -> "holds an observed map point").  That state only FILTERS candidates; the
+// expensive part -- Frame::GetFeaturesInArea (src/Frame.cc:710-781) + DescriptorDistance (ORBmatcher.cc:2360-2378) over the window
+// -- does not depend on it.  Two phases:
+//   win_cand_kernel     every (query, candidate) pair in parallel: one wavefront per query, lanes over the searched frame (staged in
+//                       LDS), window / level / type tests, distance; the candidates whose distance can still influence the outcome
+//                       (dist < dmax, see the launchers) are appended to the query's list: key = dist | cell | index | level, the
+//                       reference's candidate order (cell ix, cell iy, insertion index) rides in the key for the tie-breaks.
+//   win_resolve_kernel  one wavefront per frame pair walks the queries in order: the (short) list of a query is filtered by the
+//                       current state, the two smallest keys found by a wave reduction, the greedy update applied.  Everything it
+//                       touches sits in LDS; the rotation histogram (ComputeThreeMaxima, :2314-2355) is filled afterwards in
+//                       parallel from the recorded (query, match) pairs (a count is order-independent).
+// A query whose list outgrows its capacity (or the pair's pool) is resolved by a full scan of the searched frame inside phase 2.
+constexpr uint32_t kWinOver = 0xFFFFFFFFu;        // cnt value: list overflowed, resolve by a full scan
+
+struct WinArgs {
+    // searched frame (per pair: pointer + pair * stride)
+    const eorb_keypoint* kps2; size_t kp2_stride; const int32_t* n2p; int n2; const uint8_t* desc2; int dstride2; size_t desc2_slice;
+    const uint8_t* is_orb2; int cap2;
+    // queries
+    const int32_t* nqp; int nq; int capq;
+    // SearchForInitialization: queries = keypoints of frame 1
+    const eorb_keypoint* kps1; size_t kp1_stride; const uint8_t* desc1; int dstride1; size_t desc1_slice; const uint8_t* is_orb1;
+    float* prev_matched; int windowSize;
+    // SearchByProjection: queries = last-frame keypoints / map points
+    const eorb_keypoint* qkps; const uint8_t* q_is_orb; const uint8_t* valid; const float* qf; const int32_t* qlevel;
+    const uint8_t* mp_desc; const uint8_t* mp_obs; const uint8_t* mp_is_orb; float th; int mode; int dist_th;
+    GridB g; float nnratio; int checkOri;
+    int dmax;                  // phase 1 keeps candidates with dist < dmax
+    int wcap;                  // list capacity of one query
+    // phase-1 products (per pair)
+    uint64_t* ent; int ecap; uint32_t* off; uint32_t* cnt; uint32_t* total;
+    // results
+    int32_t* matches12; int32_t* slot_mp; int32_t* nmatches;
 };
 
-__global__ __launch_bounds__(256) void search_init_kernel(SearchInitArgs A)
+struct WinQuery {              // wave-uniform description of one query
+    bool active;
+    float qx, qy, r;
+    int minLevel, maxLevel;
+    bool isorb;
+    uint64_t d0, d1, d2, d3;
+};
+
+// searched-frame record: cell (16 bits, 0xFFFF = PosInGrid false) | level (8 bits, signed) << 16 | isORB << 24
+__device__ __forceinline__ uint32_t f2_info(const eorb_keypoint& k, bool isorb, const GridB& g)
+{
+    // Frame::PosInGrid (Frame.cc:783-793)
+    const int px = (int)roundf((k.x - g.minX) * g.invW);
+    const int py = (int)roundf((k.y - g.minY) * g.invH);
+    const uint32_t cell = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? 0xFFFFu : (uint32_t)(px * kGridRows + py);
+    return cell | ((uint32_t)(kp_level(k, isorb) & 0xff) << 16) | ((uint32_t)isorb << 24);
+}
+
+// KIND 0: SearchForInitialization; 1: SearchByProjection(cur, last) / (cur, KeyFrame); 2: SearchByProjection(F, map points)
+template <int KIND>
+__device__ __forceinline__ WinQuery win_query(const WinArgs& A, int pair, int q)
+{
+    WinQuery Q;
+    Q.active = true; Q.minLevel = Q.maxLevel = 0; Q.qx = Q.qy = Q.r = 0.f; Q.isorb = true; Q.d0 = Q.d1 = Q.d2 = Q.d3 = 0;
+    if (KIND == 0) {
+        const eorb_keypoint k1 = A.kps1[(size_t)pair * A.kp1_stride + q];
+        Q.isorb = A.is_orb1 ? A.is_orb1[(size_t)pair * A.capq + q] != 0 : true;
+        const int level1 = kp_level(k1, Q.isorb);
+        if (level1 > 0) { Q.active = false; return Q; }                                  // :730-732
+        const float* PM = A.prev_matched ? A.prev_matched + ((size_t)pair * A.capq + q) * 2 : nullptr;
+        Q.qx = PM ? PM[0] : k1.x; Q.qy = PM ? PM[1] : k1.y;
+        Q.r = (float)A.windowSize;
+        Q.minLevel = Q.maxLevel = level1;                                                // GetFeaturesInArea(x, y, windowSize, level1, level1)
+        load_desc32(A.desc1 + (size_t)pair * A.desc1_slice + (size_t)q * A.dstride1, Q.d0, Q.d1, Q.d2, Q.d3);
+    } else {
+        if (!A.valid[q]) { Q.active = false; return Q; }
+        int qlev;
+        if (KIND == 2) {
+            const float4 f = ((const float4*)A.qf)[q];
+            Q.qx = f.x; Q.qy = f.y;
+            float r = ((double)f.z > 0.998) ? 2.5f : 4.0f;            // RadiusByViewingCos (:221-227)
+            if (A.th != 1.0f) r *= A.th;                                // bFactor (:49, :73-74)
+            Q.r = r * f.w;
+            qlev = A.qlevel[q];
+            Q.minLevel = qlev - 1; Q.maxLevel = qlev;
+            Q.isorb = A.mp_is_orb ? A.mp_is_orb[q] != 0 : true;
+        } else {
+            Q.qx = A.qf[3 * q]; Q.qy = A.qf[3 * q + 1];
+            Q.isorb = A.q_is_orb ? A.q_is_orb[q] != 0 : true;
+            qlev = kp_level(A.qkps[q], Q.isorb);
+            Q.r = A.th * A.qf[3 * q + 2];
+            if (A.mode == 1) { Q.minLevel = qlev; Q.maxLevel = -1; }
+            else if (A.mode == 2) { Q.minLevel = 0; Q.maxLevel = qlev; }
+            else { Q.minLevel = qlev - 1; Q.maxLevel = qlev + 1; }
+        }
+        const uint64_t* dq = (const uint64_t*)(A.mp_desc + (size_t)q * 32);
+        Q.d0 = dq[0]; Q.d1 = dq[1]; Q.d2 = dq[2]; Q.d3 = dq[3];
+    }
+    return Q;
+}
+
+// candidate test of Frame::GetFeaturesInArea (Frame.cc:747-777) + the MixedMatcher type gate (MixedMatcher.cpp:65-67, :565-568,
+// :787-790).  Returns the key, or ~0 when i2 is no candidate.  key = dist << 44 | cell << 32 | index << 8 | level + 1
+__device__ __forceinline__ uint64_t win_key(const WinQuery& Q, int cx0, int cx1, int cy0, int cy1, uint32_t info, float x, float y,
+                                            const uint64_t* __restrict__ dp, int i2)
+{
+    const int cell = (int)(info & 0xffffu);
+    if (cell == 0xFFFF) return ~0ull;
+    const int cx = cell / kGridRows, cy = cell - cx * kGridRows;
+    if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) return ~0ull;
+    const int lv = (int)(int8_t)((info >> 16) & 0xffu);
+    if ((Q.minLevel > 0) || (Q.maxLevel >= 0)) {                     // bCheckLevels
+        if (lv < Q.minLevel) return ~0ull;
+        if (Q.maxLevel >= 0 && lv > Q.maxLevel) return ~0ull;
+    }
+    const float distx = x - Q.qx, disty = y - Q.qy;
+    if (!(fabsf(distx) < Q.r && fabsf(disty) < Q.r)) return ~0ull;
+    if ((((info >> 24) & 1u) != 0) != Q.isorb) return ~0ull;
+    const int dist = __popcll(Q.d0 ^ dp[0]) + __popcll(Q.d1 ^ dp[1]) + __popcll(Q.d2 ^ dp[2]) + __popcll(Q.d3 ^ dp[3]);
+    return ((uint64_t)dist << 44) | ((uint64_t)cell << 32) | ((uint64_t)(uint32_t)i2 << 8) | (uint64_t)((lv + 1) & 0xff);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
 {
     extern __shared__ unsigned char smem[];
-    const int pair = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int N1 = A.n1[pair], N2 = A.n2[pair];
-    const eorb_keypoint* K1 = A.kps1 + (size_t)pair * A.kp1_stride;
-    const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
-    const uint8_t* D1 = A.desc1 + (size_t)pair * A.desc1_slice;
-    const uint8_t* D2 = A.desc2 + (size_t)pair * A.desc2_slice;
-    const uint8_t* O1 = A.is_orb1 ? A.is_orb1 + (size_t)pair * A.cap1 : nullptr;
-    const uint8_t* O2 = A.is_orb2 ? A.is_orb2 + (size_t)pair * A.cap2 : nullptr;
-    int32_t* M12 = A.matches12 + (size_t)pair * A.cap1;
-    float* PM = A.prev_matched ? A.prev_matched + (size_t)pair * A.cap1 * 2 : nullptr;
-
-    // LDS carve-up (cap2-sized arrays)
+    const int pair = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N2 = A.n2p ? A.n2p[pair] : A.n2;
+    const int NQ = A.nqp ? A.nqp[pair] : A.nq;
+    const int q_lo = blockIdx.x * qpb, q_hi = min(NQ, q_lo + qpb);
+    if (q_lo >= NQ) return;
     const int c2 = A.cap2;
-    uint64_t* red = (uint64_t*)smem;                          // 8 * 8 B
-    int* histo = (int*)(red + 8);                             // 32
-    int* sh_nm = histo + 32;                                  // 4 ints
-    uint64_t* d2 = (uint64_t*)(sh_nm + 4);                    // c2 * 4
-    float* x2 = (float*)(d2 + (size_t)c2 * 4);
+    uint64_t* d2 = (uint64_t*)smem;                                   // c2 * 4
+    uint64_t* wl = d2 + (size_t)c2 * 4 + (size_t)wave * A.wcap;       // 4 * wcap: the waves' candidate lists
+    float* x2 = (float*)(d2 + (size_t)c2 * 4 + (size_t)4 * A.wcap);
     float* y2 = x2 + c2;
-    int* mdist = (int*)(y2 + c2);
-    int* m21 = mdist + c2;
-    uint16_t* cell2 = (uint16_t*)(m21 + c2);
-    int8_t* lev2 = (int8_t*)(cell2 + c2);
-    uint8_t* orb2 = (uint8_t*)(lev2 + c2);
-    int8_t* bin1 = (int8_t*)(orb2 + c2);                      // cap1 entries
-
+    uint32_t* info2 = (uint32_t*)(y2 + c2);
+    const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
+    const uint8_t* D2 = A.desc2 + (size_t)pair * A.desc2_slice;
+    const uint8_t* O2 = A.is_orb2 ? A.is_orb2 + (size_t)pair * A.cap2 : nullptr;
     for (int i = tid; i < N2; i += blockDim.x) {
         const eorb_keypoint k = K2[i];
         const bool isorb = O2 ? O2[i] != 0 : true;
-        x2[i] = k.x; y2[i] = k.y;
-        lev2[i] = (int8_t)kp_level(k, isorb);
-        orb2[i] = isorb;
-        // Frame::PosInGrid (Frame.cc:783-793)
-        const int px = (int)roundf((k.x - A.g.minX) * A.g.invW);
-        const int py = (int)roundf((k.y - A.g.minY) * A.g.invH);
-        cell2[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? (uint16_t)0xFFFF : (uint16_t)(px * kGridRows + py);
+        x2[i] = k.x; y2[i] = k.y; info2[i] = f2_info(k, isorb, A.g);
         load_desc32(D2 + (size_t)i * A.dstride2, d2[(size_t)i * 4 + 0], d2[(size_t)i * 4 + 1], d2[(size_t)i * 4 + 2], d2[(size_t)i * 4 + 3]);
-        mdist[i] = 0x7fffffff; m21[i] = -1;
     }
-    for (int i = tid; i < N1; i += blockDim.x) { M12[i] = -1; bin1[i] = -1; }
+    __syncthreads();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint64_t* ent = A.ent + (size_t)pair * A.ecap;
+    for (int q = q_lo + wave; q < q_hi; q += 4) {
+        const WinQuery Q = win_query<KIND>(A, pair, q);
+        uint32_t n = 0;
+        int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
+        if (Q.active && cell_range(A.g, Q.qx, Q.qy, Q.r, cx0, cx1, cy0, cy1)) {
+            for (int i0 = 0; i0 < N2; i0 += 64) {
+                const int i2 = i0 + lane;
+                uint64_t key = ~0ull;
+                if (i2 < N2) key = win_key(Q, cx0, cx1, cy0, cy1, info2[i2], x2[i2], y2[i2], &d2[(size_t)i2 * 4], i2);
+                const bool ok = key != ~0ull && (int)(key >> 44) < A.dmax;
+                const uint64_t bal = __ballot(ok);
+                if (ok) { const uint32_t pos = n + (uint32_t)__popcll(bal & lt_mask); if (pos < (uint32_t)A.wcap) wl[pos] = key; }
+                n += (uint32_t)__popcll(bal);
+            }
+        }
+        uint32_t off = 0, cnt = n;
+        if (n > (uint32_t)A.wcap) cnt = kWinOver;
+        else if (n > 0) {
+            if (lane == 0) off = atomicAdd(&A.total[pair], n);
+            off = (uint32_t)__shfl((int)off, 0, 64);
+            if (off + n > (uint32_t)A.ecap) cnt = kWinOver;           // the pair's pool is full
+            else for (uint32_t j = lane; j < n; j += 64) ent[off + j] = wl[j];
+        }
+        if (lane == 0) { A.cnt[(size_t)pair * A.capq + q] = cnt; A.off[(size_t)pair * A.capq + q] = off; }
+    }
+}
+
+// wave-wide two smallest keys (smaller = better); result in every lane
+__device__ __forceinline__ void wave_top2(uint64_t& k0, uint64_t& k1)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
+        const uint64_t lo = k0 < o0 ? k0 : o0;
+        const uint64_t hi = k0 < o0 ? o0 : k0;
+        const uint64_t s = k1 < o1 ? k1 : o1;
+        k0 = lo; k1 = hi < s ? hi : s;
+    }
+}
+
+constexpr int kWinLdsEntries = 6144;      // entries of a pair staged in LDS by phase 2 (the rest is read from global memory)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
+{
+    extern __shared__ unsigned char smem[];
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N2 = A.n2p ? A.n2p[pair] : A.n2;
+    const int NQ = A.nqp ? A.nqp[pair] : A.nq;
+    const int c2 = A.cap2, cq = A.capq;
+    // LDS carve-up
+    uint64_t* ents = (uint64_t*)smem;                                 // kWinLdsEntries
+    uint32_t* offs = (uint32_t*)(ents + kWinLdsEntries);              // cq
+    uint32_t* cnts = offs + cq;                                       // cq
+    int* histo = (int*)(cnts + cq);                                   // 32
+    int* sh_nm = histo + 32;                                          // 4
+    int* st_a = sh_nm + 4;                                            // c2: KIND 0 vMatchedDistance, else the slot -> map point table
+    int* match_at = st_a + c2;                                        // cq: candidate matched by query q when it was processed (-1: none)
+    int16_t* m21 = (int16_t*)(match_at + cq);                         // c2: KIND 0 vnMatches21 (-1: none)  [cap1 < 32768]
+    uint8_t* obs = (uint8_t*)(m21 + c2);                              // c2: KIND 1/2 "slot holds an observed map point"
+    uint8_t* qobs = obs + c2;                                         // cq: KIND 1/2 mp_obs of the query's map point
+    int32_t* M12 = A.matches12 ? A.matches12 + (size_t)pair * cq : nullptr;
+    const uint64_t* gent = A.ent + (size_t)pair * A.ecap;
+    const uint32_t total = min(A.total[pair], (uint32_t)A.ecap);
+    for (uint32_t i = tid; i < min(total, (uint32_t)kWinLdsEntries); i += blockDim.x) ents[i] = gent[i];
+    for (int i = tid; i < NQ; i += blockDim.x) {
+        offs[i] = A.off[(size_t)pair * cq + i]; cnts[i] = A.cnt[(size_t)pair * cq + i];
+        match_at[i] = -1;
+        if (KIND != 0) qobs[i] = A.mp_obs[i] != 0;
+    }
+    for (int i = tid; i < N2; i += blockDim.x) {
+        if (KIND == 0) { st_a[i] = 0x7fffffff; m21[i] = -1; }
+        else {
+            // "if(F.getMapPoint(idx)) if(F.getMapPoint(idx)->Observations()>0) continue;" (:91-93, :2045-2047): slot values
+            // -1 / -3 = empty or unobserved, -2 = holds an observed map point, v >= 0 = map point v
+            const int v = A.slot_mp[i];
+            st_a[i] = v;
+            obs[i] = (v == -2) ? 1 : ((v >= 0) ? (A.mp_obs[v] != 0) : 0);
+        }
+    }
+    if (KIND == 0 && M12) for (int i = tid; i < NQ; i += blockDim.x) M12[i] = -1;
     if (tid < 32) histo[tid] = 0;
     if (tid == 0) sh_nm[0] = 0;
     __syncthreads();
 
-    const float r = (float)A.windowSize;
-    for (int i1 = 0; i1 < N1; i1++) {
-        const eorb_keypoint k1 = K1[i1];
-        const bool isorb1 = O1 ? O1[i1] != 0 : true;
-        const int level1 = kp_level(k1, isorb1);
-        if (level1 > 0) continue;
-        const float qx = PM ? PM[2 * i1] : k1.x, qy = PM ? PM[2 * i1 + 1] : k1.y;
-        int cx0, cx1, cy0, cy1;
-        if (!cell_range(A.g, qx, qy, r, cx0, cx1, cy0, cy1)) continue;
-        uint64_t q0, q1, q2, q3;
-        load_desc32(D1 + (size_t)i1 * A.dstride1, q0, q1, q2, q3);
-        // GetFeaturesInArea(x, y, windowSize, level1, level1): bCheckLevels = true (maxLevel >= 0)
-        uint64_t k0 = ~0ull, k1b = ~0ull;
-        for (int i2 = tid; i2 < N2; i2 += blockDim.x) {
-            const int cell = cell2[i2];
-            if (cell == 0xFFFF) continue;
-            const int cx = cell / kGridRows, cy = cell - cx * kGridRows;
-            if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
-            const int lv = lev2[i2];
-            if (lv < level1 || lv > level1) continue;
-            const float distx = x2[i2] - qx, disty = y2[i2] - qy;
-            if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
-            if ((orb2[i2] != 0) != isorb1) continue;                 // MixedMatcher.cpp:65-67
-            const uint64_t* tp = &d2[(size_t)i2 * 4];
-            const int dist = __popcll(q0 ^ tp[0]) + __popcll(q1 ^ tp[1]) + __popcll(q2 ^ tp[2]) + __popcll(q3 ^ tp[3]);
-            if (mdist[i2] <= dist) continue;                          // :755
-            // candidate order of the reference = (ix, iy, insertion index): compose a unique key
-            const uint64_t key = ((uint64_t)dist << 40) | ((uint64_t)cell << 24) | (uint32_t)i2;
-            if (key < k0) { k1b = k0; k0 = key; }
-            else if (key < k1b) k1b = key;
-        }
-        block_top2(k0, k1b, red);
-        if (k0 != ~0ull) {
-            const int bestDist = (int)(k0 >> 40);
-            const int bestDist2 = (k1b == ~0ull) ? 0x7fffffff : (int)(k1b >> 40);
-            const int bestIdx2 = (int)(k0 & 0xffffff);
-            if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) {
-                if (tid == 0) {
-                    int nm = sh_nm[0];
-                    if (m21[bestIdx2] >= 0) { M12[m21[bestIdx2]] = -1; nm--; }
-                    M12[i1] = bestIdx2;
-                    m21[bestIdx2] = i1;
-                    mdist[bestIdx2] = bestDist;
-                    nm++;
-                    sh_nm[0] = nm;
-                    if (A.checkOri) {
-                        const int bin = rot_bin(k1.angle, K2[bestIdx2].angle);
-                        histo[bin]++;
-                        bin1[i1] = (int8_t)bin;
+    if (wave == 0) {
+        int nm = 0;
+        const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
+        const uint8_t* D2 = A.desc2 + (size_t)pair * A.desc2_slice;
+        const uint8_t* O2 = A.is_orb2 ? A.is_orb2 + (size_t)pair * A.cap2 : nullptr;
+        for (int qb = 0; qb < NQ; qb += 64) {
+            const uint32_t myc = (qb + lane < NQ) ? cnts[qb + lane] : 0u;
+            uint64_t act = __ballot(myc != 0u);
+            while (act) {
+                const int bit = __ffsll((unsigned long long)act) - 1;
+                act &= act - 1;
+                const int q = qb + bit;
+                const uint32_t c = (uint32_t)__shfl((int)myc, bit, 64);
+                uint64_t k0 = ~0ull, k1 = ~0ull;
+                auto offer = [&](uint64_t key) {
+                    if (key == ~0ull) return;
+                    const int idx = (int)((key >> 8) & 0xffffffu);
+                    const int dist = (int)(key >> 44);
+                    const bool pass = (KIND == 0) ? (st_a[idx] > dist)                    // "if(vMatchedDistance[i2]<=dist) continue;" :755
+                                                  : (obs[idx] == 0 && dist < 256);        // bestDist starts at 256, strict '<'
+                    if (!pass) return;
+                    if (key < k0) { k1 = k0; k0 = key; }
+                    else if (key < k1) k1 = key;
+                };
+                if (c != kWinOver) {
+                    const uint32_t o = offs[q];
+                    for (uint32_t j = lane; j < c; j += 64) {
+                        const uint32_t e = o + j;
+                        offer(e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e]);
+                    }
+                } else {
+                    // the list overflowed: scan the whole searched frame (global memory) for this query
+                    const WinQuery Q = win_query<KIND>(A, pair, q);
+                    int cx0, cx1, cy0, cy1;
+                    if (Q.active && cell_range(A.g, Q.qx, Q.qy, Q.r, cx0, cx1, cy0, cy1)) {
+                        for (int i2 = lane; i2 < N2; i2 += 64) {
+                            const eorb_keypoint k = K2[i2];
+                            const bool isorb = O2 ? O2[i2] != 0 : true;
+                            uint64_t dd[4];
+                            load_desc32(D2 + (size_t)i2 * A.dstride2, dd[0], dd[1], dd[2], dd[3]);
+                            offer(win_key(Q, cx0, cx1, cy0, cy1, f2_info(k, isorb, A.g), k.x, k.y, dd, i2));
+                        }
+                    }
+                }
+                wave_top2(k0, k1);
+                if (k0 == ~0ull) continue;
+                const int bestDist = (int)(k0 >> 44), bestIdx = (int)((k0 >> 8) & 0xffffffu), bestLevel = (int)(k0 & 0xff) - 1;
+                if (KIND == 0) {
+                    const int bestDist2 = (k1 == ~0ull) ? 0x7fffffff : (int)(k1 >> 44);
+                    if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) {      // :770-772
+                        const int old = m21[bestIdx];
+                        if (old >= 0) nm--;                                                       // :774-778
+                        nm++;
+                        if (lane == 0) {
+                            if (old >= 0) M12[old] = -1;
+                            M12[q] = bestIdx; m21[bestIdx] = (int16_t)q; st_a[bestIdx] = bestDist; match_at[q] = bestIdx;
+                        }
+                    }
+                } else if (KIND == 2) {
+                    int bestDist2 = 256, bestLevel2 = -1;
+                    if (k1 != ~0ull) { bestDist2 = (int)(k1 >> 44); bestLevel2 = (int)(k1 & 0xff) - 1; }
+                    if (bestDist <= TH_HIGH) {                                                    // :131-147
+                        const bool reject = (bestLevel == bestLevel2) && ((float)bestDist > A.nnratio * (float)bestDist2);
+                        if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= A.nnratio * (float)bestDist2)) {
+                            nm++;
+                            if (lane == 0) { st_a[bestIdx] = q; obs[bestIdx] = qobs[q]; }
+                        }
+                    }
+                } else {
+                    if (bestDist <= A.dist_th) {                                                  // :2140 / :2271
+                        nm++;
+                        if (lane == 0) { st_a[bestIdx] = q; obs[bestIdx] = qobs[q]; match_at[q] = bestIdx; }
                     }
                 }
             }
         }
-        __syncthreads();
+        if (lane == 0) sh_nm[0] = nm;
     }
-    __threadfence_block();
     __syncthreads();
-    if (A.checkOri) {
-        int ind1, ind2, ind3;
-        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
-        __syncthreads();
-        // every i1 appears in at most one bin; clearing is independent per i1
-        int dec = 0;
-        for (int i = tid; i < N1; i += blockDim.x) {
-            const int b = bin1[i];
-            if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && M12[i] >= 0) { M12[i] = -1; dec++; }
+    if (KIND == 0) {
+        const eorb_keypoint* K1 = A.kps1 + (size_t)pair * A.kp1_stride;
+        const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
+        int8_t* bin1 = (int8_t*)qobs;                                  // free in this kind: the bin of query q's push
+        if (A.checkOri) {
+            // rotHist[bin].push_back(i1) happened for every match when it was made (:785-797), stolen ones included
+            for (int i = tid; i < NQ; i += blockDim.x) {
+                const int m = match_at[i];
+                int b = -1;
+                if (m >= 0) { b = rot_bin(K1[i].angle, K2[m].angle); atomicAdd(&histo[b], 1); }
+                bin1[i] = (int8_t)b;
+            }
+            __syncthreads();
+            int ind1, ind2, ind3;
+            three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+            int dec = 0;
+            for (int i = tid; i < NQ; i += blockDim.x) {
+                const int b = bin1[i];
+                if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && M12[i] >= 0) { M12[i] = -1; dec++; }
+            }
+            if (dec) atomicSub(&sh_nm[0], dec);
+            __threadfence_block();
+            __syncthreads();
         }
-        if (dec) atomicSub(&sh_nm[0], dec);
-        __syncthreads();
-    }
-    if (PM) {
-        for (int i = tid; i < N1; i += blockDim.x) {
-            const int m = M12[i];
-            if (m >= 0) { PM[2 * i] = x2[m]; PM[2 * i + 1] = y2[m]; }
+        if (A.prev_matched) {
+            float* PM = A.prev_matched + (size_t)pair * cq * 2;
+            for (int i = tid; i < NQ; i += blockDim.x) {
+                const int m = M12[i];
+                if (m >= 0) { const eorb_keypoint k = K2[m]; PM[2 * i] = k.x; PM[2 * i + 1] = k.y; }
+            }
         }
+    } else {
+        if (KIND == 1 && A.checkOri) {
+            // rotHist[bin].push_back(bestIdx2) per match (:2146-2160); losing bins: setMapPoint(idx, NULL), nmatches-- per push
+            unsigned int* hbin = (unsigned int*)ents;                  // the entry buffer is free now: c2 words (c2 <= 2 * kWinLdsEntries)
+            for (int i = tid; i < N2; i += blockDim.x) hbin[i] = 0u;
+            __syncthreads();
+            for (int i = tid; i < NQ; i += blockDim.x) {
+                const int m = match_at[i];
+                if (m >= 0) {
+                    const int b = rot_bin(A.qkps[i].angle, A.kps2[m].angle);
+                    atomicAdd(&histo[b], 1); atomicOr(&hbin[m], 1u << b);
+                }
+            }
+            __syncthreads();
+            int ind1, ind2, ind3;
+            three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
+            unsigned int keep = 0u;
+            if (ind1 >= 0) keep |= 1u << ind1;
+            if (ind2 >= 0) keep |= 1u << ind2;
+            if (ind3 >= 0) keep |= 1u << ind3;
+            for (int i = tid; i < N2; i += blockDim.x)
+                if (hbin[i] & ~keep) st_a[i] = -1;
+            if (tid == 0) {
+                int dec = 0;
+                for (int b = 0; b < HISTO_LENGTH; b++) if (!(keep & (1u << b))) dec += histo[b];
+                sh_nm[0] -= dec;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < N2; i += blockDim.x) A.slot_mp[i] = st_a[i];
     }
     if (tid == 0) A.nmatches[pair] = sh_nm[0];
 }
 
-static size_t search_init_lds(int cap1, int cap2)
+static size_t win_cand_lds(int cap2, int wcap) { return ((size_t)cap2 * (32 + 4 + 4 + 4) + (size_t)4 * wcap * 8 + 15) & ~(size_t)15; }
+static size_t win_resolve_lds(int cap2, int capq)
 {
-    size_t b = 8 * 8 + 32 * 4 + 4 * 4;
-    b += (size_t)cap2 * (32 + 4 + 4 + 4 + 4 + 2 + 1 + 1);
-    b += (size_t)cap1;
-    return (b + 15) & ~(size_t)15;
+    return ((size_t)kWinLdsEntries * 8 + (size_t)capq * (4 + 4 + 4 + 1) + (32 + 4) * 4 + (size_t)cap2 * (4 + 2 + 1) + 15) & ~(size_t)15;
+}
+
+// smallest d in [lo, 256] for which pred(d) holds, else 257 (= keep every candidate)
+template <typename F> static int first_dist(int lo, F pred) { for (int d = lo; d <= 256; d++) if (pred(d)) return d; return 257; }
+
+template <int KIND>
+static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const char* name)
+{
+    if (A.cap2 >= (1 << 24) || A.capq >= 32768) return set_err(c, EORB_E_CAPACITY, "%s: too many keypoints", name);
+    if (A.cap2 > 2 * kWinLdsEntries) return set_err(c, EORB_E_CAPACITY, "%s: %d keypoints in the searched frame (limit %d)", name, A.cap2, 2 * kWinLdsEntries);
+    A.wcap = c->dbg_win_wcap > 0 ? c->dbg_win_wcap : 512;
+    A.ecap = c->dbg_win_ecap > 0 ? c->dbg_win_ecap : std::max(4096, 16 * A.capq);
+    const size_t lds1 = win_cand_lds(A.cap2, A.wcap), lds2 = win_resolve_lds(A.cap2, A.capq);
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024)
+        return set_err(c, EORB_E_CAPACITY, "%s: %zu / %zu B of LDS needed (searched frame %d, queries %d)", name, lds1, lds2, A.cap2, A.capq);
+    int rc;
+    // phase-1 products: entries | off | cnt | total
+    const size_t ent_b = sizeof(uint64_t) * (size_t)npairs * A.ecap, oc_b = sizeof(uint32_t) * (size_t)npairs * A.capq;
+    if ((rc = ensure(c, c->win_ws, ent_b + 2 * oc_b + sizeof(uint32_t) * (size_t)npairs + 64))) return rc;
+    A.ent = (uint64_t*)c->win_ws.p;
+    A.off = (uint32_t*)((char*)c->win_ws.p + ent_b);
+    A.cnt = A.off + (size_t)npairs * A.capq;
+    A.total = A.cnt + (size_t)npairs * A.capq;
+    EORB_HIP(c, hipMemsetAsync(A.total, 0, sizeof(uint32_t) * (size_t)npairs, c->stream));
+    // per device, not per process: a second context on another GPU needs the opt-in too (the call is cheap)
+    hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ProfScope ps(c, name);
+    const int qpb = 32;                    // queries per phase-1 workgroup (8 per wavefront)
+    win_cand_kernel<KIND><<<dim3((nq_max + qpb - 1) / qpb, npairs), 256, lds1, c->stream>>>(A, qpb);
+    win_resolve_kernel<KIND><<<npairs, 256, lds2, c->stream>>>(A);
+    EORB_LAUNCH_CHECK(c, name);
+    return EORB_OK;
 }
 
 int search_init_dev(eorb_ctx* c, int npairs,
@@ -335,196 +596,18 @@ int search_init_dev(eorb_ctx* c, int npairs,
                     int checkOri, int32_t* nmatches)
 {
     if (npairs <= 0) return EORB_OK;
-    const size_t lds = search_init_lds(cap1, cap2);
-    if (lds > 160 * 1024) return set_err(c, EORB_E_CAPACITY, "search_init: %zu B of LDS needed (cap2=%d)", lds, cap2);
-    if (cap2 >= (1 << 24)) return set_err(c, EORB_E_CAPACITY, "search_init: too many keypoints");
-    SearchInitArgs A{kps1, n1, kp1_stride, desc1, dstride1, desc1_slice, is_orb1,
-                     kps2, n2, kp2_stride, desc2, dstride2, desc2_slice, is_orb2, cap1, cap2,
-                     GridB{gb.minX, gb.minY, gb.invW, gb.invH}, prev_matched, matches12, nmatches,
-                     windowSize, nnratio, checkOri};
-    // per device, not per process: a second context on another GPU needs the opt-in too (the call is cheap)
-    hipFuncSetAttribute((const void*)search_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    ProfScope ps(c, "search_init");
-    search_init_kernel<<<npairs, 256, lds, c->stream>>>(A);
-    EORB_LAUNCH_CHECK(c, "search_init_kernel");
-    return EORB_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------------
-// tracking matchers: ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono) (:1969-2187)
-// and ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (:44-219), mono branches, with
-// the MixedMatcher type gate.  One workgroup; queries sequential (setMapPoint feeds later queries).
-struct ProjArgs {
-    const eorb_keypoint* kps; int n; const uint8_t* desc; int stride; const uint8_t* is_orb;     // searched frame
-    int M;                                         // number of queries (last-frame keypoints / map points)
-    const eorb_keypoint* qkps; const uint8_t* q_is_orb;   // LAST variant: last frame keypoints
-    const uint8_t* valid;                          // LAST: valid[i];  MAP: in_view[m]
-    const float* qf;                               // LAST: (u, v, levelScale) x M;  MAP: float4 (x, y, viewCos, levelScale)
-    const int32_t* qlevel;                         // MAP: mnTrackScaleLevel
-    const uint8_t* mp_desc; const uint8_t* mp_obs; const uint8_t* mp_is_orb;
-    GridB g;
-    int32_t* slot_mp;                              // n, in/out
-    float th, nnratio; int mode, checkOri;
-    int dist_th;                                   // LAST: TH_HIGH (:2140) or ORBdist of the KeyFrame variant (:2271)
-    int32_t* nmatches;
-};
-
-__device__ __forceinline__ bool holds_observed(const int* slot, int idx, const uint8_t* mp_obs)
-{   // "if(F.getMapPoint(idx)) if(F.getMapPoint(idx)->Observations()>0) continue;" (:91-93, :2045-2047)
-    const int v = slot[idx];
-    if (v == -1 || v == -3) return false;
-    if (v == -2) return true;
-    return mp_obs[v] != 0;
-}
-
-template <bool MAP>
-__global__ __launch_bounds__(256) void search_proj_kernel(ProjArgs A)
-{
-    extern __shared__ unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int N = A.n;
-    uint64_t* red = (uint64_t*)smem;
-    int* histo = (int*)(red + 8);
-    int* sh_nm = histo + 32;
-    uint64_t* d2 = (uint64_t*)(sh_nm + 4);
-    float* x2 = (float*)(d2 + (size_t)N * 4);
-    float* y2 = x2 + N;
-    int* slot = (int*)(y2 + N);
-    unsigned int* hbin = (unsigned int*)(slot + N);   // LAST: bitmask of the rotation bins keypoint i was pushed to
-    uint16_t* cell2 = (uint16_t*)(hbin + N);
-    int8_t* lev2 = (int8_t*)(cell2 + N);
-    uint8_t* orb2 = (uint8_t*)(lev2 + N);
-    for (int i = tid; i < N; i += blockDim.x) {
-        const eorb_keypoint k = A.kps[i];
-        const bool isorb = A.is_orb ? A.is_orb[i] != 0 : true;
-        x2[i] = k.x; y2[i] = k.y; lev2[i] = (int8_t)kp_level(k, isorb); orb2[i] = isorb;
-        const int px = (int)roundf((k.x - A.g.minX) * A.g.invW);
-        const int py = (int)roundf((k.y - A.g.minY) * A.g.invH);
-        cell2[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? (uint16_t)0xFFFF : (uint16_t)(px * kGridRows + py);
-        load_desc32(A.desc + (size_t)i * A.stride, d2[(size_t)i * 4 + 0], d2[(size_t)i * 4 + 1], d2[(size_t)i * 4 + 2], d2[(size_t)i * 4 + 3]);
-        slot[i] = A.slot_mp[i];
-        hbin[i] = 0u;
-    }
-    if (tid < 32) histo[tid] = 0;
-    if (tid == 0) sh_nm[0] = 0;
-    __syncthreads();
-    for (int q = 0; q < A.M; q++) {
-        if (!A.valid[q]) continue;
-        float qx, qy, radius; int minLevel, maxLevel; bool isorbq; int qlev = 0;
-        if (MAP) {
-            const float4 f = ((const float4*)A.qf)[q];
-            qx = f.x; qy = f.y;
-            float r = ((double)f.z > 0.998) ? 2.5f : 4.0f;        // RadiusByViewingCos (:221-227)
-            if (A.th != 1.0f) r *= A.th;                            // bFactor (:49, :73-74)
-            radius = r * f.w;
-            qlev = A.qlevel[q];
-            minLevel = qlev - 1; maxLevel = qlev;
-            isorbq = A.mp_is_orb ? A.mp_is_orb[q] != 0 : true;
-        } else {
-            qx = A.qf[3 * q]; qy = A.qf[3 * q + 1];
-            isorbq = A.q_is_orb ? A.q_is_orb[q] != 0 : true;
-            qlev = kp_level(A.qkps[q], isorbq);
-            radius = A.th * A.qf[3 * q + 2];
-            if (A.mode == 1) { minLevel = qlev; maxLevel = -1; }
-            else if (A.mode == 2) { minLevel = 0; maxLevel = qlev; }
-            else { minLevel = qlev - 1; maxLevel = qlev + 1; }
-        }
-        int cx0, cx1, cy0, cy1;
-        if (!cell_range(A.g, qx, qy, radius, cx0, cx1, cy0, cy1)) continue;
-        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-        const uint64_t* dq = (const uint64_t*)(A.mp_desc + (size_t)q * 32);
-        const uint64_t q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3];
-        uint64_t k0 = ~0ull, k1 = ~0ull;
-        for (int i2 = tid; i2 < N; i2 += blockDim.x) {
-            const int cell = cell2[i2];
-            if (cell == 0xFFFF) continue;
-            const int cx = cell / kGridRows, cy = cell - cx * kGridRows;
-            if (cx < cx0 || cx > cx1 || cy < cy0 || cy > cy1) continue;
-            const int lv = lev2[i2];
-            if (bCheckLevels) {
-                if (lv < minLevel) continue;
-                if (maxLevel >= 0 && lv > maxLevel) continue;
-            }
-            const float distx = x2[i2] - qx, disty = y2[i2] - qy;
-            if (!(fabsf(distx) < radius && fabsf(disty) < radius)) continue;
-            if (holds_observed(slot, i2, A.mp_obs)) continue;
-            if ((orb2[i2] != 0) != isorbq) continue;
-            const uint64_t* tp = &d2[(size_t)i2 * 4];
-            const int dist = __popcll(q0 ^ tp[0]) + __popcll(q1 ^ tp[1]) + __popcll(q2 ^ tp[2]) + __popcll(q3 ^ tp[3]);
-            // order = (dist, cell ix*48+iy, insertion index); the level rides in the low byte (payload only)
-            const uint64_t key = ((uint64_t)dist << 44) | ((uint64_t)cell << 32) | ((uint64_t)(uint32_t)i2 << 8) | (uint64_t)((lv + 1) & 0xff);
-            if (key < k0) { k1 = k0; k0 = key; }
-            else if (key < k1) k1 = key;
-        }
-        block_top2(k0, k1, red);
-        if (tid == 0 && k0 != ~0ull && (int)(k0 >> 44) < 256) {
-            // the reference starts from bestDist = bestDist2 = 256 / levels -1 with strict '<' updates
-            const int bestDist = (int)(k0 >> 44), bestIdx = (int)((k0 >> 8) & 0xffffff), bestLevel = (int)(k0 & 0xff) - 1;
-            int bestDist2 = 256, bestLevel2 = -1;
-            if (k1 != ~0ull && (int)(k1 >> 44) < 256) { bestDist2 = (int)(k1 >> 44); bestLevel2 = (int)(k1 & 0xff) - 1; }
-            if (MAP) {
-                if (bestDist <= TH_HIGH) {
-                    const bool reject = (bestLevel == bestLevel2) && ((float)bestDist > A.nnratio * (float)bestDist2);
-                    if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= A.nnratio * (float)bestDist2)) {
-                        slot[bestIdx] = q;
-                        sh_nm[0]++;
-                    }
-                }
-            } else {
-                if (bestDist <= A.dist_th) {
-                    slot[bestIdx] = q;
-                    sh_nm[0]++;
-                    if (A.checkOri) {
-                        const int bin = rot_bin(A.qkps[q].angle, A.kps[bestIdx].angle);
-                        histo[bin]++;
-                        hbin[bestIdx] |= (1u << bin);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (!MAP && A.checkOri) {
-        // for every push in a losing bin: setMapPoint(idx, NULL); nmatches-- (:2165-2181)
-        int ind1, ind2, ind3;
-        three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
-        unsigned int keep = 0u;
-        if (ind1 >= 0) keep |= 1u << ind1;
-        if (ind2 >= 0) keep |= 1u << ind2;
-        if (ind3 >= 0) keep |= 1u << ind3;
-        for (int i = tid; i < N; i += blockDim.x)
-            if (hbin[i] & ~keep) slot[i] = -1;
-        __syncthreads();
-        if (tid == 0) {
-            int dec = 0;
-            for (int b = 0; b < HISTO_LENGTH; b++) if (!(keep & (1u << b))) dec += histo[b];
-            sh_nm[0] -= dec;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < N; i += blockDim.x) A.slot_mp[i] = slot[i];
-    if (tid == 0) A.nmatches[0] = sh_nm[0];
-}
-
-static size_t proj_lds(int n)
-{
-    size_t b = 8 * 8 + 32 * 4 + 4 * 4;
-    b += (size_t)n * (32 + 4 + 4 + 4 + 4 + 2 + 1 + 1);
-    return (b + 15) & ~(size_t)15;
-}
-
-template <bool MAP>
-static int launch_proj(eorb_ctx* c, const ProjArgs& A, const char* name)
-{
-    const size_t lds = proj_lds(A.n);
-    if (lds > 160 * 1024) return set_err(c, EORB_E_CAPACITY, "%s: %zu B of LDS needed (n=%d)", name, lds, A.n);
-    hipFuncSetAttribute((const void*)search_proj_kernel<MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    ProfScope ps(c, name);
-    search_proj_kernel<MAP><<<1, 256, lds, c->stream>>>(A);
-    EORB_LAUNCH_CHECK(c, name);
-    return EORB_OK;
+    WinArgs A{};
+    A.kps2 = kps2; A.kp2_stride = kp2_stride; A.n2p = n2; A.desc2 = desc2; A.dstride2 = dstride2; A.desc2_slice = desc2_slice;
+    A.is_orb2 = is_orb2; A.cap2 = cap2;
+    A.nqp = n1; A.capq = cap1;
+    A.kps1 = kps1; A.kp1_stride = kp1_stride; A.desc1 = desc1; A.dstride1 = dstride1; A.desc1_slice = desc1_slice; A.is_orb1 = is_orb1;
+    A.prev_matched = prev_matched; A.windowSize = windowSize;
+    A.g = GridB{gb.minX, gb.minY, gb.invW, gb.invH}; A.nnratio = nnratio; A.checkOri = checkOri;
+    A.matches12 = matches12; A.nmatches = nmatches;
+    // a second-best candidate only matters while "bestDist < bestDist2 * ratio" (:772) can fail for some bestDist <= TH_LOW: every
+    // dist2 with TH_LOW < dist2 * ratio passes like INT_MAX does (float product monotone in dist2); best candidates need dist <= TH_LOW
+    A.dmax = first_dist(TH_LOW + 1, [&](int d) { return (float)TH_LOW < (float)d * nnratio; });
+    return launch_win<0>(c, A, npairs, cap1, "search_init");
 }
 
 int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride,
@@ -533,14 +616,15 @@ int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, c
                          int dist_th, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
                          int32_t* nmatches)
 {
-    ProjArgs A{};
+    WinArgs A{};
     A.dist_th = dist_th;
-    A.kps = cur_kps; A.n = n_cur; A.desc = cur_desc; A.stride = cur_stride; A.is_orb = cur_is_orb;
-    A.M = n_last; A.qkps = last_kps; A.q_is_orb = last_is_orb; A.valid = valid; A.qf = uvs; A.qlevel = nullptr;
-    A.mp_desc = mp_desc; A.mp_obs = mp_obs; A.mp_is_orb = nullptr;
+    A.kps2 = cur_kps; A.n2 = n_cur; A.cap2 = std::max(n_cur, 1); A.desc2 = cur_desc; A.dstride2 = cur_stride; A.is_orb2 = cur_is_orb;
+    A.nq = n_last; A.capq = std::max(n_last, 1); A.qkps = last_kps; A.q_is_orb = last_is_orb; A.valid = valid; A.qf = uvs;
+    A.mp_desc = mp_desc; A.mp_obs = mp_obs;
     A.g = GridB{gb.minX, gb.minY, gb.invW, gb.invH};
-    A.slot_mp = cur_mp; A.th = th; A.nnratio = 0.f; A.mode = mode; A.checkOri = checkOri; A.nmatches = nmatches;
-    return launch_proj<false>(c, A, "search_proj_last");
+    A.slot_mp = cur_mp; A.th = th; A.mode = mode; A.checkOri = checkOri; A.nmatches = nmatches;
+    A.dmax = std::min(std::max(dist_th, 0) + 1, 256);               // best only: "if(bestDist<=TH_HIGH)" (:2140), bestDist starts at 256
+    return launch_win<1>(c, A, 1, n_last, "search_proj_last");
 }
 
 int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
@@ -548,13 +632,15 @@ int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint
                         const uint8_t* mp_obs, const uint8_t* mp_is_orb, eorb_grid_bounds gb, int32_t* frame_mp, float th,
                         float nnratio, int32_t* nmatches)
 {
-    ProjArgs A{};
-    A.kps = kps; A.n = n; A.desc = desc; A.stride = stride; A.is_orb = is_orb;
-    A.M = M; A.qkps = nullptr; A.q_is_orb = nullptr; A.valid = in_view; A.qf = (const float*)mp_f4; A.qlevel = level;
+    WinArgs A{};
+    A.kps2 = kps; A.n2 = n; A.cap2 = std::max(n, 1); A.desc2 = desc; A.dstride2 = stride; A.is_orb2 = is_orb;
+    A.nq = M; A.capq = std::max(M, 1); A.valid = in_view; A.qf = (const float*)mp_f4; A.qlevel = level;
     A.mp_desc = mp_desc; A.mp_obs = mp_obs; A.mp_is_orb = mp_is_orb;
     A.g = GridB{gb.minX, gb.minY, gb.invW, gb.invH};
-    A.slot_mp = frame_mp; A.th = th; A.nnratio = nnratio; A.mode = 0; A.checkOri = 0; A.nmatches = nmatches;
-    return launch_proj<true>(c, A, "search_proj_map");
+    A.slot_mp = frame_mp; A.th = th; A.nnratio = nnratio; A.nmatches = nmatches;
+    // the second best rejects only while "bestDist > ratio * bestDist2" (:134) can hold for some bestDist <= TH_HIGH
+    A.dmax = std::min(256, first_dist(TH_HIGH + 1, [&](int d) { return !((float)TH_HIGH > nnratio * (float)d); }));
+    return launch_win<2>(c, A, 1, M, "search_proj_map");
 }
 
 

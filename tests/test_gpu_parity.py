@@ -314,6 +314,81 @@ def test_search_by_projection_map_mixed_gate(oracle, fe, ctx):
     assert on > 10 and on_plain != on
 
 
+@pytest.mark.parametrize("wcap,ecap", [(2, 0), (0, 40), (1, 3)])
+def test_window_matchers_full_scan_path(oracle, fe, wcap, ecap):
+    """The two-phase window matchers keep a short candidate list per query; a query whose list (or whose frame pair's pool) overflows
+    is resolved by a full scan inside the sequential phase.  Tiny capacities force that path for all three matchers."""
+    c = fe.Context()
+    if wcap:
+        c.debug_option("win_list_cap", wcap)
+    if ecap:
+        c.debug_option("win_pool_cap", ecap)
+    k1, d1, k2, d2 = _two_frames(oracle, seed=27, shift=2)
+    rng = np.random.default_rng(6)
+    k1m, d1m, o1 = _mix(k1, d1, rng); k2m, d2m, o2 = _mix(k2, d2, rng, frac=(3, 5))
+    pm = np.stack([k1m["x"], k1m["y"]], axis=1)
+    on, om, opm = oracle.search_for_initialization(oracle.Frame(k1m, d1m, 240, 180, o1), oracle.Frame(k2m, d2m, 240, 180, o2), pm, 100, 0.9, True)
+    gn, gm, gpm = fe.ORBmatcher(0.9, True, c).SearchForInitialization(fe.FrameView(k1m, d1m, 240, 180, o1), fe.FrameView(k2m, d2m, 240, 180, o2), pm, 100)
+    assert on == gn and np.array_equal(om, gm) and np.array_equal(opm.view(np.uint32), gpm.view(np.uint32)) and on > 20
+    n1 = len(k1)
+    valid = (rng.uniform(size=n1) < 0.85).astype(np.uint8)
+    uv = np.stack([k1["x"] - 2 + rng.normal(0, 1, n1), k1["y"] + 2 + rng.normal(0, 1, n1)], axis=1).astype(np.float32)
+    mp_obs = (rng.uniform(size=n1) < 0.7).astype(np.uint8)
+    sf = oracle.OrbExtractor(1000, 1.2, 4).scale_factors
+    ls = sf[np.clip(k1["octave"], 0, 3)]
+    cur_mp = np.full(len(k2), -1, np.int32); cur_mp[::17] = -2; cur_mp[5::23] = -3
+    for mode in (0, 1, 2):
+        on, ocm = oracle.search_by_projection_last(oracle.Frame(k2, d2, 240, 180), oracle.Frame(k1, d1, 240, 180), valid, uv, d1, mp_obs, cur_mp, 15.0, ls, mode, True)
+        gn, gcm = fe.ORBmatcher(0.9, True, c).SearchByProjectionLast(fe.FrameView(k2, d2, 240, 180), fe.FrameView(k1, d1, 240, 180), valid, uv, d1, mp_obs, cur_mp, 15.0, ls, mode)
+        assert on == gn and np.array_equal(ocm, gcm) and on > 10
+    level = k1["octave"].astype(np.int32)
+    vc = rng.uniform(0.99, 1.0, n1).astype(np.float32)
+    fm = np.full(len(k2), -1, np.int32); fm[::19] = -2
+    for th in (1.0, 3.0):
+        on, ofm = oracle.search_by_projection_map(oracle.Frame(k2, d2, 240, 180), valid, uv, level, vc, d1, mp_obs, fm, th, 0.8, ls)
+        gn, gfm = fe.ORBmatcher(0.8, True, c).SearchByProjectionMap(fe.FrameView(k2, d2, 240, 180), valid, uv, level, vc, d1, mp_obs, fm, th, ls)
+        assert on == gn and np.array_equal(ofm, gfm)
+    c.close()
+
+
+def test_window_matchers_state_chains(oracle, fe, ctx):
+    """Repeated structure: many near-identical descriptors inside one window, so that queries steal each other's matches
+    (vnMatches21, :774-781) and skip candidates already matched at a smaller distance (:755) -- the state the sequential phase carries."""
+    rng = np.random.default_rng(12)
+    n = 600
+    base = synth.random_descriptors(6, seed=3)
+    kp = synth.random_keypoints(n, 240, 180, nlevels=1, seed=8); kp["octave"] = 0
+    kp["x"] = (100 + rng.uniform(0, 60, n)).astype(np.float32); kp["y"] = (60 + rng.uniform(0, 50, n)).astype(np.float32)
+
+    def noisy(seed):
+        r = np.random.default_rng(seed)
+        d = base[r.integers(0, len(base), n)].copy()
+        for i in range(n):
+            for b in r.choice(256, size=int(r.integers(0, 9)), replace=False):
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        return d
+    d1, d2 = noisy(1), noisy(2)
+    k2 = kp.copy(); k2["x"] += rng.normal(0, 2, n).astype(np.float32); k2["y"] += rng.normal(0, 2, n).astype(np.float32)
+    k2["angle"] = ((kp["angle"] + rng.normal(0, 4, n)) % 360).astype(np.float32)
+    pm = np.stack([kp["x"], kp["y"]], axis=1)
+    for ratio in (0.9, 1.0, 0.5):
+        on, om, _ = oracle.search_for_initialization(oracle.Frame(kp, d1, 240, 180), oracle.Frame(k2, d2, 240, 180), pm, 100, ratio, True)
+        gn, gm, _ = fe.ORBmatcher(ratio, True, ctx).SearchForInitialization(fe.FrameView(kp, d1, 240, 180), fe.FrameView(k2, d2, 240, 180), pm, 100)
+        assert on == gn and np.array_equal(om, gm)
+    valid = np.ones(n, np.uint8); uv = np.stack([kp["x"], kp["y"]], axis=1).astype(np.float32)
+    mp_obs = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    ls = np.ones(n, np.float32)
+    cur_mp = np.full(n, -1, np.int32)
+    on, ocm = oracle.search_by_projection_last(oracle.Frame(k2, d2, 240, 180), oracle.Frame(kp, d1, 240, 180), valid, uv, d1, mp_obs, cur_mp, 15.0, ls, 0, True)
+    gn, gcm = fe.ORBmatcher(0.9, True, ctx).SearchByProjectionLast(fe.FrameView(k2, d2, 240, 180), fe.FrameView(kp, d1, 240, 180), valid, uv, d1, mp_obs, cur_mp, 15.0, ls, 0)
+    assert on == gn and np.array_equal(ocm, gcm) and on > 50
+    lvl = np.zeros(n, np.int32); vc = np.full(n, 0.999, np.float32)
+    for ratio in (0.8, 1.0):
+        on, ofm = oracle.search_by_projection_map(oracle.Frame(k2, d2, 240, 180), valid, uv, lvl, vc, d1, mp_obs, cur_mp, 3.0, ratio, ls)
+        gn, gfm = fe.ORBmatcher(ratio, True, ctx).SearchByProjectionMap(fe.FrameView(k2, d2, 240, 180), valid, uv, lvl, vc, d1, mp_obs, cur_mp, 3.0, ls)
+        assert on == gn and np.array_equal(ofm, gfm)
+
+
 # ---- the batched HBM-resident pipeline -------------------------------------------------------------------------------
 def test_frontend_batch_matches_oracle_pipeline(oracle, fe):
     W, H, B, n = 240, 180, 3, 40000
