@@ -345,17 +345,32 @@ __global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
     }
 }
 
-// wave-wide two smallest keys (smaller = better); result in every lane
+// wave-wide minimum of a 32-bit value in every lane: row_shr 1 / 2 / 4 / 8 inside the 16-lane rows, row_bcast 15 / 31 across them
+// (lanes without a source keep their own value), then lane 63 holds the minimum
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+#define EORB_MIN_DPP(ctrl, rmask) x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, ctrl, rmask, 0xf, false))
+    EORB_MIN_DPP(0x111, 0xf); EORB_MIN_DPP(0x112, 0xf); EORB_MIN_DPP(0x114, 0xf); EORB_MIN_DPP(0x118, 0xf);
+    EORB_MIN_DPP(0x142, 0xa); EORB_MIN_DPP(0x143, 0xc);
+#undef EORB_MIN_DPP
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// wave-wide smallest 64-bit key (every lane gets it): minimum of the high words, then of the low words among the lanes that hold it
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t k)
+{
+    const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+    const uint32_t mh = wave_min_u32(hi);
+    const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((uint64_t)mh << 32) | ml;
+}
+
+// wave-wide two smallest keys of the lanes' (k0 <= k1) pairs; keys are unique; result in every lane
 __device__ __forceinline__ void wave_top2(uint64_t& k0, uint64_t& k1)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
-        const uint64_t lo = k0 < o0 ? k0 : o0;
-        const uint64_t hi = k0 < o0 ? o0 : k0;
-        const uint64_t s = k1 < o1 ? k1 : o1;
-        k0 = lo; k1 = hi < s ? hi : s;
-    }
+    const uint64_t b0 = wave_min_u64(k0);
+    const uint64_t b1 = wave_min_u64(k0 == b0 ? k1 : k0);
+    k0 = b0; k1 = b1;
 }
 
 constexpr int kWinLdsEntries = 6144;      // entries of a pair staged in LDS by phase 2 (the rest is read from global memory)

@@ -36,7 +36,7 @@ def test_library_contains_gfx950_code_object():
     data = open(_lib.build(), "rb").read()
     assert b"amdgcn-amd-amdhsa--gfx950" in data, "no gfx950 code object embedded in libeorb_fe.so"
     for kern in (b"ev_gather_kernel", b"ev_gather_raw_kernel", b"ev_count_kernel", b"ev_scan_kernel", b"ev_scatter_kernel", b"fast_cells_kernel", b"octree_kernel", b"brief_kernel",
-                 b"search_init_kernel", b"bf_knn2_kernel"):
+                 b"win_cand_kernel", b"win_resolve_kernel", b"bf_knn2_kernel"):
         assert kern in data, kern
 
 
