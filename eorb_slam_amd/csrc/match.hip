@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
     int16_t* m21 = (int16_t*)(match_at + cq);                         // c2: KIND 0 vnMatches21 (-1: none)  [cap1 < 32768]
     uint8_t* obs = (uint8_t*)(m21 + c2);                              // c2: KIND 1/2 "slot holds an observed map point"
     uint8_t* qobs = obs + c2;                                         // cq: KIND 1/2 mp_obs of the query's map point
+    unsigned int* claim = (unsigned int*)(((uintptr_t)(qobs + cq) + 3) & ~(uintptr_t)3);   // c2: earliest query of the round matching the candidate
     int32_t* M12 = A.matches12 ? A.matches12 + (size_t)pair * cq : nullptr;
     const uint64_t* gent = A.ent + (size_t)pair * A.ecap;
     const uint32_t total = min(A.total[pair], (uint32_t)A.ecap);
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
         if (KIND != 0) qobs[i] = A.mp_obs[i] != 0;
     }
     for (int i = tid; i < N2; i += blockDim.x) {
+        claim[i] = 0xFFFFFFFFu;
         if (KIND == 0) { st_a[i] = 0x7fffffff; m21[i] = -1; }
         else {
             // "if(F.getMapPoint(idx)) if(F.getMapPoint(idx)->Observations()>0) continue;" (:91-93, :2045-2047): slot values
@@ -420,80 +422,108 @@ __global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
     __syncthreads();
 
     if (wave == 0) {
+        // The queries are walked in order, 64 at a time (lane = query).  Every lane evaluates its query against the committed
+        // state; a query commits in this round only if no EARLIER query of the round changes a candidate it depends on.  The state
+        // only ever removes candidates (vMatchedDistance decreases, a slot turns "observed"), and a query's outcome depends on its
+        // best and second-best passing candidates alone: so query j must wait exactly when an earlier query of the round matches
+        // j's best or second-best candidate.  The round commits the conflict-free prefix (never empty: its first query has no
+        // predecessor) and the next round starts at the first conflicting query.  Committed queries of one round have distinct best
+        // candidates, so their updates are independent.
         int nm = 0;
         const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
         const uint8_t* D2 = A.desc2 + (size_t)pair * A.desc2_slice;
         const uint8_t* O2 = A.is_orb2 ? A.is_orb2 + (size_t)pair * A.cap2 : nullptr;
-        for (int qb = 0; qb < NQ; qb += 64) {
-            const uint32_t myc = (qb + lane < NQ) ? cnts[qb + lane] : 0u;
-            uint64_t act = __ballot(myc != 0u);
-            while (act) {
-                const int bit = __ffsll((unsigned long long)act) - 1;
-                act &= act - 1;
-                const int q = qb + bit;
-                const uint32_t c = (uint32_t)__shfl((int)myc, bit, 64);
+        auto passes = [&](uint64_t key) -> bool {
+            const int idx = (int)((key >> 8) & 0xffffffu);
+            const int dist = (int)(key >> 44);
+            return (KIND == 0) ? (st_a[idx] > dist)                     // "if(vMatchedDistance[i2]<=dist) continue;" :755
+                               : (obs[idx] == 0 && dist < 256);         // bestDist starts at 256, strict '<'
+        };
+        // outcome of a query from its two smallest passing keys: does it match its best candidate?
+        auto matched = [&](uint64_t k0, uint64_t k1) -> bool {
+            if (k0 == ~0ull) return false;
+            const int bestDist = (int)(k0 >> 44), bestLevel = (int)(k0 & 0xff) - 1;
+            if (KIND == 0) {
+                const int bestDist2 = (k1 == ~0ull) ? 0x7fffffff : (int)(k1 >> 44);
+                return bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio;       // :770-772
+            } else if (KIND == 2) {
+                int bestDist2 = 256, bestLevel2 = -1;
+                if (k1 != ~0ull) { bestDist2 = (int)(k1 >> 44); bestLevel2 = (int)(k1 & 0xff) - 1; }
+                if (bestDist > TH_HIGH) return false;                                              // :131-147
+                const bool reject = (bestLevel == bestLevel2) && ((float)bestDist > A.nnratio * (float)bestDist2);
+                return !reject && (bestLevel != bestLevel2 || (float)bestDist <= A.nnratio * (float)bestDist2);
+            } else {
+                return bestDist <= A.dist_th;                                                      // :2140 / :2271
+            }
+        };
+        // the greedy update of one matched query (one lane; distinct candidates across the lanes of a round)
+        auto commit = [&](int q, uint64_t k0, int& stolen) {
+            const int bestIdx = (int)((k0 >> 8) & 0xffffffu);
+            if (KIND == 0) {
+                const int old = m21[bestIdx];
+                if (old >= 0) { M12[old] = -1; stolen = 1; }                                       // :774-778
+                M12[q] = bestIdx; m21[bestIdx] = (int16_t)q; st_a[bestIdx] = (int)(k0 >> 44); match_at[q] = bestIdx;
+            } else {
+                st_a[bestIdx] = q; obs[bestIdx] = qobs[q];
+                if (KIND == 1) match_at[q] = bestIdx;
+            }
+        };
+        int pos = 0;
+        while (pos < NQ) {
+            const int q = pos + lane;
+            const uint32_t c = (q < NQ) ? cnts[q] : 0u;
+            const uint64_t over = __ballot(c == kWinOver);
+            const int limit = over ? (__ffsll((unsigned long long)over) - 1) : 64;
+            if (limit == 0) {
+                // the list of query `pos` overflowed: the wavefront scans the whole searched frame (global memory) for it
                 uint64_t k0 = ~0ull, k1 = ~0ull;
-                auto offer = [&](uint64_t key) {
-                    if (key == ~0ull) return;
-                    const int idx = (int)((key >> 8) & 0xffffffu);
-                    const int dist = (int)(key >> 44);
-                    const bool pass = (KIND == 0) ? (st_a[idx] > dist)                    // "if(vMatchedDistance[i2]<=dist) continue;" :755
-                                                  : (obs[idx] == 0 && dist < 256);        // bestDist starts at 256, strict '<'
-                    if (!pass) return;
-                    if (key < k0) { k1 = k0; k0 = key; }
-                    else if (key < k1) k1 = key;
-                };
-                if (c != kWinOver) {
-                    const uint32_t o = offs[q];
-                    for (uint32_t j = lane; j < c; j += 64) {
-                        const uint32_t e = o + j;
-                        offer(e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e]);
-                    }
-                } else {
-                    // the list overflowed: scan the whole searched frame (global memory) for this query
-                    const WinQuery Q = win_query<KIND>(A, pair, q);
-                    int cx0, cx1, cy0, cy1;
-                    if (Q.active && cell_range(A.g, Q.qx, Q.qy, Q.r, cx0, cx1, cy0, cy1)) {
-                        for (int i2 = lane; i2 < N2; i2 += 64) {
-                            const eorb_keypoint k = K2[i2];
-                            const bool isorb = O2 ? O2[i2] != 0 : true;
-                            uint64_t dd[4];
-                            load_desc32(D2 + (size_t)i2 * A.dstride2, dd[0], dd[1], dd[2], dd[3]);
-                            offer(win_key(Q, cx0, cx1, cy0, cy1, f2_info(k, isorb, A.g), k.x, k.y, dd, i2));
-                        }
+                const WinQuery Q = win_query<KIND>(A, pair, pos);
+                int cx0, cx1, cy0, cy1;
+                if (Q.active && cell_range(A.g, Q.qx, Q.qy, Q.r, cx0, cx1, cy0, cy1)) {
+                    for (int i2 = lane; i2 < N2; i2 += 64) {
+                        const eorb_keypoint k = K2[i2];
+                        const bool isorb = O2 ? O2[i2] != 0 : true;
+                        uint64_t dd[4];
+                        load_desc32(D2 + (size_t)i2 * A.dstride2, dd[0], dd[1], dd[2], dd[3]);
+                        const uint64_t key = win_key(Q, cx0, cx1, cy0, cy1, f2_info(k, isorb, A.g), k.x, k.y, dd, i2);
+                        if (key != ~0ull && passes(key)) { if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key; }
                     }
                 }
                 wave_top2(k0, k1);
-                if (k0 == ~0ull) continue;
-                const int bestDist = (int)(k0 >> 44), bestIdx = (int)((k0 >> 8) & 0xffffffu), bestLevel = (int)(k0 & 0xff) - 1;
-                if (KIND == 0) {
-                    const int bestDist2 = (k1 == ~0ull) ? 0x7fffffff : (int)(k1 >> 44);
-                    if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) {      // :770-772
-                        const int old = m21[bestIdx];
-                        if (old >= 0) nm--;                                                       // :774-778
-                        nm++;
-                        if (lane == 0) {
-                            if (old >= 0) M12[old] = -1;
-                            M12[q] = bestIdx; m21[bestIdx] = (int16_t)q; st_a[bestIdx] = bestDist; match_at[q] = bestIdx;
-                        }
-                    }
-                } else if (KIND == 2) {
-                    int bestDist2 = 256, bestLevel2 = -1;
-                    if (k1 != ~0ull) { bestDist2 = (int)(k1 >> 44); bestLevel2 = (int)(k1 & 0xff) - 1; }
-                    if (bestDist <= TH_HIGH) {                                                    // :131-147
-                        const bool reject = (bestLevel == bestLevel2) && ((float)bestDist > A.nnratio * (float)bestDist2);
-                        if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= A.nnratio * (float)bestDist2)) {
-                            nm++;
-                            if (lane == 0) { st_a[bestIdx] = q; obs[bestIdx] = qobs[q]; }
-                        }
-                    }
-                } else {
-                    if (bestDist <= A.dist_th) {                                                  // :2140 / :2271
-                        nm++;
-                        if (lane == 0) { st_a[bestIdx] = q; obs[bestIdx] = qobs[q]; match_at[q] = bestIdx; }
-                    }
+                if (matched(k0, k1)) {
+                    int stolen = 0;
+                    if (lane == 0) commit(pos, k0, stolen);
+                    stolen = __shfl(stolen, 0, 64);
+                    nm += 1 - stolen;
+                }
+                pos += 1;
+                continue;
+            }
+            // ---- evaluate (lane = query) ----
+            uint64_t k0 = ~0ull, k1 = ~0ull;
+            const bool live = lane < limit && c != 0u;
+            if (live) {
+                const uint32_t o = offs[q];
+                for (uint32_t j = 0; j < c; j++) {
+                    const uint32_t e = o + j;
+                    const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
+                    if (passes(key)) { if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key; }
                 }
             }
+            const bool mt = live && matched(k0, k1);
+            const int i0 = (int)((k0 >> 8) & 0xffffffu), i1 = (int)((k1 >> 8) & 0xffffffu);
+            // ---- claims: the earliest query of the round that changes each candidate ----
+            if (mt) atomicMin(&claim[i0], (unsigned int)lane);
+            bool conflict = false;
+            if (live) conflict = (k0 != ~0ull && claim[i0] < (unsigned int)lane) || (k1 != ~0ull && claim[i1] < (unsigned int)lane);
+            const uint64_t cm = __ballot(conflict);
+            const int ncommit = cm ? (__ffsll((unsigned long long)cm) - 1) : limit;
+            int stolen = 0;
+            const bool doit = mt && lane < ncommit;
+            if (doit) commit(q, k0, stolen);
+            if (mt) claim[i0] = 0xFFFFFFFFu;
+            nm += (int)__popcll(__ballot(doit)) - (int)__popcll(__ballot(stolen != 0));
+            pos += ncommit;
         }
         if (lane == 0) sh_nm[0] = nm;
     }
@@ -566,7 +596,7 @@ __global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
 static size_t win_cand_lds(int cap2, int wcap) { return ((size_t)cap2 * (32 + 4 + 4 + 4) + (size_t)4 * wcap * 8 + 15) & ~(size_t)15; }
 static size_t win_resolve_lds(int cap2, int capq)
 {
-    return ((size_t)kWinLdsEntries * 8 + (size_t)capq * (4 + 4 + 4 + 1) + (32 + 4) * 4 + (size_t)cap2 * (4 + 2 + 1) + 15) & ~(size_t)15;
+    return ((size_t)kWinLdsEntries * 8 + (size_t)capq * (4 + 4 + 4 + 1) + (32 + 4) * 4 + (size_t)cap2 * (4 + 2 + 1 + 4) + 4 + 15) & ~(size_t)15;
 }
 
 // smallest d in [lo, 256] for which pred(d) holds, else 257 (= keep every candidate)
@@ -595,7 +625,7 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     ProfScope ps(c, name);
-    const int qpb = 32;                    // queries per phase-1 workgroup (8 per wavefront)
+    const int qpb = npairs >= 8 ? 32 : 8;  // queries per phase-1 workgroup (a lone pair is spread over more workgroups)
     win_cand_kernel<KIND><<<dim3((nq_max + qpb - 1) / qpb, npairs), 256, lds1, c->stream>>>(A, qpb);
     win_resolve_kernel<KIND><<<npairs, 256, lds2, c->stream>>>(A);
     EORB_LAUNCH_CHECK(c, name);
