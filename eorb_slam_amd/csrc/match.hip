@@ -178,7 +178,7 @@ __device__ __forceinline__ int kp_level(const eorb_keypoint& k, bool isorb)
 // -- does not depend on it.  Two phases:
 //   win_cand_kernel     every (query, candidate) pair in parallel: one wavefront per query, lanes over the searched frame (staged in
 //                       LDS), window / level / type tests, distance; the candidates whose distance can still influence the outcome
-//                       (dist < dmax, see the launchers) are appended to the query's list: key = dist | cell | index | level, the
+//                       (dist < dmax, see the launchers) form the query's list, sorted by key = dist | cell | index | level: the
 //                       reference's candidate order (cell ix, cell iy, insertion index) rides in the key for the tie-breaks.
 //   win_resolve_kernel  one wavefront per frame pair walks the queries in order: the (short) list of a query is filtered by the
 //                       current state, the two smallest keys found by a wave reduction, the greedy update applied.  Everything it
@@ -339,7 +339,16 @@ __global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
             if (lane == 0) off = atomicAdd(&A.total[pair], n);
             off = (uint32_t)__shfl((int)off, 0, 64);
             if (off + n > (uint32_t)A.ecap) cnt = kWinOver;           // the pair's pool is full
-            else for (uint32_t j = lane; j < n; j += 64) ent[off + j] = wl[j];
+            else {
+                // the list leaves sorted by key (rank = number of smaller keys; keys are unique): phase 2 then stops at the first
+                // one or two candidates that pass its state filter instead of walking the whole list
+                for (uint32_t j = lane; j < n; j += 64) {
+                    const uint64_t kj = wl[j];
+                    uint32_t rank = 0;
+                    for (uint32_t i = 0; i < n; i++) rank += (wl[i] < kj) ? 1u : 0u;
+                    ent[off + rank] = kj;
+                }
+            }
         }
         if (lane == 0) { A.cnt[(size_t)pair * A.capq + q] = cnt; A.off[(size_t)pair * A.capq + q] = off; }
     }
@@ -504,10 +513,13 @@ __global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
             const bool live = lane < limit && c != 0u;
             if (live) {
                 const uint32_t o = offs[q];
-                for (uint32_t j = 0; j < c; j++) {
+                // the list is sorted: the first passing entries are the best and the second best
+                constexpr int need = (KIND == 1) ? 1 : 2;
+                int found = 0;
+                for (uint32_t j = 0; j < c && found < need; j++) {
                     const uint32_t e = o + j;
                     const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
-                    if (passes(key)) { if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key; }
+                    if (passes(key)) { if (found == 0) k0 = key; else k1 = key; found++; }
                 }
             }
             const bool mt = live && matched(k0, k1);
