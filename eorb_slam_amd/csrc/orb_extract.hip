@@ -33,10 +33,10 @@ struct DevGeom {
     int iniTh, minTh;
     int umax[16];
     float sf[kMaxLevels];
-    // octree working set: items 0 node pool, 1 / 2 the two (size, seq, node) lists, 3 / 4 the key ping-pong buffers, 5 the
-    // candidate points; each lives in LDS (offset into the dynamic LDS block) or, when the 160 KB do not hold it, in the
-    // (slice, level) block of a global scratch buffer (offset into that block)
-    int oct_in_lds[6], oct_off[6];
+    // octree working set: items 0 the two node arrays, 1 / 2 the two (size, seq, node) lists, 3 / 4 the key ping-pong buffers, 5 the
+    // candidate points, 6 the per-round arrays; each lives in LDS (offset into the dynamic LDS block) or, when the 160 KB do not hold
+    // it, in the (slice, level) block of a global scratch buffer (offset into that block)
+    int oct_in_lds[7], oct_off[7];
     int oct_lds_bytes, oct_gblock_bytes;
     int node_cap_max, vsp_cap_max, ncap_max;
 };
@@ -211,26 +211,64 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-// octree
-struct OctLds {
-    uint16_t* keys[2];
-    uint32_t* pts;        // LDS or global
-    uint16_t *x0, *x1, *y0, *y1, *start, *cnt, *next, *prev, *seq, *freel, *order;
-    uint8_t* flags;       // bit0 nomore, bit1 key buffer select
-    uint64_t* vsp[2];
-};
+// octree: ORBextractor::DistributeOctTree (:558-782) in data-parallel rounds.
+//
+// The reference walks a std::list of nodes: a full pass divides every expandable node in list order (children pushed to the FRONT,
+// parent erased); once "size + 3 * nToExpand > N" it divides the recorded (size, node) pairs largest first and stops the moment the
+// list reaches N nodes.  All divisions of one pass are independent of each other -- only the order of the resulting list, the
+// creation order of the children (tie-break of the size sort) and the stopping point depend on the processing order.  One round =
+//   1. the nodes to divide, in processing order (a compaction of the expandable nodes / the sorted size list);
+//   2. one wavefront per node: stable 4-way partition of its keys (DivideNode :500-556) into the other key buffer, child counts;
+//   3. prefix sums over the processing order: where the pass stops (largest-first phase), creation index of every child;
+//   4. the new list, written as an array: children in reverse creation order (what repeated push_front produces), then the
+//      surviving nodes in their old order.
+// The list IS the node array (node id = list position), rebuilt every round in a second array.  One workgroup per (slice, level).
+struct ONode { uint16_t x0, x1, y0, y1, start, cnt, seq; uint8_t flags, pad; };     // flags: bit0 bNoMore, bit1 key buffer
+static_assert(sizeof(ONode) == 16, "ONode is 16 bytes");
+constexpr int kOctThreads = 512;
 
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int oct_wave_incl_scan(int x)
+{   // row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 / 31
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 
-// bitonic sort (ascending) of n u64 items in LDS by one wavefront; np2 = next pow2 >= n, padded with ~0
-__device__ void wave_sort_u64(uint64_t* a, int n, int lane)
+// exclusive prefix sums of a[0..n) in place (block-wide, any n); returns the total.  ws: kOctThreads / 64 + 2 ints of LDS
+__device__ int oct_block_scan(int* a, int n, int* ws)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + tid;
+        const int v = i < n ? a[i] : 0;
+        const int incl = oct_wave_incl_scan(v);
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; w++) before += ws[w];
+        int tot = 0;
+        for (int w = 0; w < nw; w++) tot += ws[w];
+        if (i < n) a[i] = before + incl - v;
+        carry += tot;
+        __syncthreads();
+    }
+    return carry;
+}
+
+// bitonic sort (ascending) of n u64 items by the whole workgroup; padded with ~0 up to the next power of two
+__device__ void oct_block_sort_u64(uint64_t* a, int n)
 {
     int np2 = 1; while (np2 < n) np2 <<= 1;
-    for (int i = n + lane; i < np2; i += 64) a[i] = ~0ull;
+    for (int i = n + threadIdx.x; i < np2; i += blockDim.x) a[i] = ~0ull;
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < np2; i += 64) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
                 const int l = i ^ j;
                 if (l > i) {
                     const uint64_t ai = a[i], al = a[l];
@@ -243,206 +281,217 @@ __device__ void wave_sort_u64(uint64_t* a, int n, int lane)
     }
 }
 
-__global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ G, const int32_t* __restrict__ cell_cnt,
-                                                    const uint32_t* __restrict__ cell_cand, unsigned char* __restrict__ scratch_g,
-                                                    uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_cnt,
-                                                    int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky)
+__global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __restrict__ G, const int32_t* __restrict__ cell_cnt,
+                                                             const uint32_t* __restrict__ cell_cand, unsigned char* __restrict__ scratch_g,
+                                                             uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_cnt,
+                                                             int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky)
 {
     extern __shared__ unsigned char smem[];
-    const int lane = threadIdx.x;
+    __shared__ int s_ws[kOctThreads / 64 + 2];
+    __shared__ int s_m, s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kOctThreads / 64;
     const int slice = blockIdx.x / G->nlevels, level = blockIdx.x % G->nlevels;
     const LevelGeom& L = G->lv[level];
-    const int ncap = G->ncap_max, pool = L.node_cap, vcap = G->vsp_cap_max;
-    OctLds S;
-    {
-        // every item in LDS when the 160 KB hold it, otherwise in this (slice, level)'s block of the global scratch buffer: the
-        // workgroup is one wavefront on one CU, whose own stores are visible to its later loads after __syncthreads()
-        unsigned char* gblk = scratch_g + (size_t)blockIdx.x * G->oct_gblock_bytes;
-        auto item = [&](int k) -> unsigned char* { return (G->oct_in_lds[k] ? smem : gblk) + G->oct_off[k]; };
-        S.keys[0] = (uint16_t*)item(3); S.keys[1] = (uint16_t*)item(4);
-        S.vsp[0] = (uint64_t*)item(1); S.vsp[1] = (uint64_t*)item(2);
-        S.pts = (uint32_t*)item(5);
-        unsigned char* p = item(0);
-        const int pc = G->node_cap_max;
-        S.x0 = (uint16_t*)p; p += 2 * pc; S.x1 = (uint16_t*)p; p += 2 * pc;
-        S.y0 = (uint16_t*)p; p += 2 * pc; S.y1 = (uint16_t*)p; p += 2 * pc;
-        S.start = (uint16_t*)p; p += 2 * pc; S.cnt = (uint16_t*)p; p += 2 * pc;
-        S.next = (uint16_t*)p; p += 2 * pc; S.prev = (uint16_t*)p; p += 2 * pc;
-        S.seq = (uint16_t*)p; p += 2 * pc; S.freel = (uint16_t*)p; p += 2 * pc;
-        S.order = (uint16_t*)p; p += 2 * pc;
-        S.flags = (uint8_t*)p; p += pc;
-    }
-    auto raise = [&](int bit) { if (lane == 0) { atomicOr(err_flag, bit); atomicOr(sticky, bit); } };
+    const int ncap = G->ncap_max, pool = L.node_cap, vcap = G->vsp_cap_max, pc = G->node_cap_max;
+    // every item in LDS when the 160 KB hold it, otherwise in this (slice, level)'s block of the global scratch buffer: the
+    // workgroup sits on one CU, whose own stores are visible to its later loads after __syncthreads()
+    unsigned char* gblk = scratch_g + (size_t)blockIdx.x * G->oct_gblock_bytes;
+    auto item = [&](int k) -> unsigned char* { return (G->oct_in_lds[k] ? smem : gblk) + G->oct_off[k]; };
+    ONode* nodes[2] = {(ONode*)item(0), (ONode*)item(0) + pc};
+    uint64_t* vsp[2] = {(uint64_t*)item(1), (uint64_t*)item(2)};
+    uint16_t* keys[2] = {(uint16_t*)item(3), (uint16_t*)item(4)};
+    uint32_t* pts = (uint32_t*)item(5);
+    int* aux = (int*)item(6);                       // pc ints: scan array (ne | n2 << 16 per processed node / survivor flags)
+    uint16_t* P = (uint16_t*)(aux + pc);            // pc: nodes to divide, in processing order
+    uint8_t* dv = (uint8_t*)(P + pc);               // pc: node is divided in this round
+    uint64_t* cc = (uint64_t*)(((uintptr_t)(dv + pc) + 7) & ~(uintptr_t)7);       // pc: child counts of the processed nodes, 4 x 16 bits
     uint32_t* lkp = lvl_kp + (size_t)slice * G->kp_total + L.kp_off;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    constexpr uint16_t NIL = 0xFFFF;
+    auto raise = [&](int bit) { if (tid == 0) { atomicOr(err_flag, bit); atomicOr(sticky, bit); } };
 
     // ---- gather the level's candidates in cell order (vToDistributeKeys) ----
     int n = 0;
     {
         const int nc = L.nCols * L.nRows;
         for (int cidx = 0; cidx < nc; cidx++) {
-            const int cc = cell_cnt[(size_t)slice * G->ncells + L.cell_off + cidx];
+            const int ccnt = cell_cnt[(size_t)slice * G->ncells + L.cell_off + cidx];
             const uint32_t* src = cell_cand + ((size_t)slice * G->ncells + L.cell_off + cidx) * G->cell_cap;
-            for (int i = lane; i < cc; i += 64) {
-                if (n + i < ncap) { S.pts[n + i] = src[i]; S.keys[0][n + i] = (uint16_t)(n + i); }
-            }
-            n += cc;
+            for (int i = tid; i < ccnt; i += kOctThreads)
+                if (n + i < ncap) { pts[n + i] = src[i]; keys[0][n + i] = (uint16_t)(n + i); }
+            n += ccnt;
         }
         if (n > ncap) { raise(1); n = ncap; }
     }
     __syncthreads();
-    if (n == 0) { if (lane == 0) lvl_cnt[slice * G->nlevels + level] = 0; return; }
+    if (n == 0) { if (tid == 0) lvl_cnt[slice * G->nlevels + level] = 0; return; }
 
     const int N = L.nfeat;
     const int width = L.maxBX - L.minBX, height = L.maxBY - L.minBY;
     const int nIni = (int)roundf((float)width / (float)height);
     const float hX = (float)width / (float)nIni;
-    // free list
-    for (int i = lane; i < pool; i += 64) S.freel[i] = (uint16_t)(pool - 1 - i);
-    __syncthreads();
-    int nfree = pool, seqctr = 0, head = NIL, tail = NIL, lsize = 0;
-    bool overflow = false;
-
-    auto alloc_node = [&]() -> int {
-        if (nfree == 0) { overflow = true; return 0; }
-        nfree--;
-        return S.freel[nfree];
-    };
-    // ---- root nodes :562-590 (stable partition of the keys by root index) ----
-    int cur = 0;
+    int cur = 0, lsize = 0, seqctr = 0;
+    // ---- root nodes :562-603: stable partition of the keys by root index (wave 0), empty roots erased, singletons bNoMore ----
     {
         int off = 0;
         for (int r = 0; r < nIni; r++) {
             int c = 0;
-            for (int k0 = 0; k0 < n; k0 += 64) {
-                const int i = k0 + lane;
-                bool mine = false; uint16_t key = 0;
-                if (i < n) {
-                    key = S.keys[0][i];
-                    const float kx = (float)(S.pts[key] & 0xfff);
-                    int b = (int)(kx / hX);
-                    b = min(max(b, 0), nIni - 1);
-                    mine = (b == r);
+            if (wave == 0) {
+                for (int k0 = 0; k0 < n; k0 += 64) {
+                    const int i = k0 + lane;
+                    bool mine = false; uint16_t key = 0;
+                    if (i < n) {
+                        key = keys[0][i];
+                        const float kx = (float)(pts[key] & 0xfff);
+                        int b = (int)(kx / hX);
+                        b = min(max(b, 0), nIni - 1);
+                        mine = (b == r);
+                    }
+                    const uint64_t bal = __ballot(mine);
+                    if (mine) keys[1][off + c + __popcll(bal & lt_mask)] = key;
+                    c += __popcll(bal);
                 }
-                const uint64_t bal = __ballot(mine);
-                if (mine) S.keys[1][off + c + __popcll(bal & lt_mask)] = key;
-                c += __popcll(bal);
+                if (lane == 0) s_m = c;
             }
             __syncthreads();
-            if (c > 0) {                           // empty roots are erased (:598-599)
-                const int id = alloc_node();
-                if (lane == 0) {
-                    S.x0[id] = (uint16_t)(int)(hX * (float)r); S.x1[id] = (uint16_t)(int)(hX * (float)(r + 1));
-                    S.y0[id] = 0; S.y1[id] = (uint16_t)height;
-                    S.start[id] = (uint16_t)off; S.cnt[id] = (uint16_t)c;
-                    S.flags[id] = (uint8_t)((c == 1 ? 1 : 0) | 2);
-                    S.seq[id] = (uint16_t)seqctr;
-                    S.next[id] = NIL; S.prev[id] = (uint16_t)tail;      // push_back
-                    if (tail != NIL) S.next[tail] = (uint16_t)id;
+            c = s_m;
+            if (c > 0) {
+                if (tid == 0) {
+                    ONode nd;
+                    nd.x0 = (uint16_t)(int)(hX * (float)r); nd.x1 = (uint16_t)(int)(hX * (float)(r + 1));
+                    nd.y0 = 0; nd.y1 = (uint16_t)height;
+                    nd.start = (uint16_t)off; nd.cnt = (uint16_t)c; nd.seq = (uint16_t)seqctr;
+                    nd.flags = (uint8_t)((c == 1 ? 1 : 0) | 2); nd.pad = 0;
+                    nodes[0][lsize] = nd;                           // push_back
                 }
-                if (tail == NIL) head = id;
-                tail = id; lsize++; seqctr++;
-                __syncthreads();
+                lsize++; seqctr++;
             }
             off += c;
+            __syncthreads();
         }
-        cur = 1;
     }
-    (void)cur;
 
-    // DivideNode :500-556 + push_front of the non-empty children (:633-672).  Returns via refs.
-    int nvsp = 0;                     // entries in S.vsp[vw]
-    int vw = 0;                       // vsp buffer being written
-    auto divide = [&](int id, int& nToExpand) {
-        const int x0 = S.x0[id], x1 = S.x1[id], y0 = S.y0[id], y1 = S.y1[id];
-        const int start = S.start[id], cnt = S.cnt[id];
-        const int fl = S.flags[id];
-        const int sb = (fl >> 1) & 1;
-        const uint16_t* src = S.keys[sb]; uint16_t* dst = S.keys[sb ^ 1];
-        const int halfX = (int)ceilf((float)(x1 - x0) / 2), halfY = (int)ceilf((float)(y1 - y0) / 2);
-        const int midx = x0 + halfX, midy = y0 + halfY;
-        int c[4] = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < cnt; k0 += 64) {
-            const int i = k0 + lane;
-            int cls = -1;
-            if (i < cnt) {
-                const uint32_t p = S.pts[src[start + i]];
-                const int px = p & 0xfff, py = (p >> 12) & 0xfff;
-                cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
-            }
+    // One round: divide the nodes P[0..nP) (processing order).  cut: stop after the division that brings the list to N nodes
+    // (:741-757).  Returns through the references; vsp[vw] receives the children with more than one key, in creation order.
+    bool overflow = false;
+    int nvsp = 0, vw = 0;
+    auto round = [&](int nP, bool cut, int& nToExpand) {
+        const ONode* src = nodes[cur];
+        ONode* dst = nodes[cur ^ 1];
+        // 2. one wavefront per node: child counts, stable partition into the other key buffer (DivideNode :531-545)
+        for (int j = wave; j < nP; j += nwaves) {
+            const ONode nd = src[P[j]];
+            const int sb = (nd.flags >> 1) & 1;
+            const uint16_t* ks = keys[sb]; uint16_t* kd = keys[sb ^ 1];
+            const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+            const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
+            const int start = nd.start, cnt = nd.cnt;
+            int c[4] = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < cnt; k0 += 64) {
+                const int i = k0 + lane;
+                int cls = -1;
+                if (i < cnt) {
+                    const uint32_t p = pts[ks[start + i]];
+                    const int px = p & 0xfff, py = (p >> 12) & 0xfff;
+                    cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; q++) c[q] += __popcll(__ballot(cls == q));
-        }
-        int sbase[4]; sbase[0] = start; sbase[1] = sbase[0] + c[0]; sbase[2] = sbase[1] + c[1]; sbase[3] = sbase[2] + c[2];
-        int run[4] = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < cnt; k0 += 64) {
-            const int i = k0 + lane;
-            int cls = -1; uint16_t key = 0;
-            if (i < cnt) {
-                key = src[start + i];
-                const uint32_t p = S.pts[key];
-                const int px = p & 0xfff, py = (p >> 12) & 0xfff;
-                cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+                for (int q = 0; q < 4; q++) c[q] += __popcll(__ballot(cls == q));
             }
+            int sbase[4]; sbase[0] = start; sbase[1] = sbase[0] + c[0]; sbase[2] = sbase[1] + c[1]; sbase[3] = sbase[2] + c[2];
+            int run[4] = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < cnt; k0 += 64) {
+                const int i = k0 + lane;
+                int cls = -1; uint16_t key = 0;
+                if (i < cnt) {
+                    key = ks[start + i];
+                    const uint32_t p = pts[key];
+                    const int px = p & 0xfff, py = (p >> 12) & 0xfff;
+                    cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+                }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint64_t bal = __ballot(cls == q);
-                if (cls == q) dst[sbase[q] + run[q] + __popcll(bal & lt_mask)] = key;
-                run[q] += __popcll(bal);
+                for (int q = 0; q < 4; q++) {
+                    const uint64_t bal = __ballot(cls == q);
+                    if (cls == q) kd[sbase[q] + run[q] + __popcll(bal & lt_mask)] = key;
+                    run[q] += __popcll(bal);
+                }
             }
-        }
-        __syncthreads();
-        // children n1..n4 (x-low/y-low, x-high/y-low, x-low/y-high, x-high/y-high)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (c[q] == 0) continue;
-            const int cid = alloc_node();
             if (lane == 0) {
-                S.x0[cid] = (uint16_t)((q & 1) ? midx : x0); S.x1[cid] = (uint16_t)((q & 1) ? x1 : midx);
-                S.y0[cid] = (uint16_t)((q & 2) ? midy : y0); S.y1[cid] = (uint16_t)((q & 2) ? y1 : midy);
-                S.start[cid] = (uint16_t)sbase[q]; S.cnt[cid] = (uint16_t)c[q];
-                S.flags[cid] = (uint8_t)((c[q] == 1 ? 1 : 0) | ((sb ^ 1) << 1));
-                S.seq[cid] = (uint16_t)seqctr;
-                S.prev[cid] = NIL; S.next[cid] = (uint16_t)head;                 // push_front
-                if (head != NIL) S.prev[head] = (uint16_t)cid;
-                if (c[q] > 1 && nvsp < vcap)
-                    S.vsp[vw][nvsp] = ((uint64_t)c[q] << 32) | ((uint64_t)seqctr << 16) | (uint64_t)cid;
+                cc[j] = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);
+                aux[j] = ((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) | (((c[0] > 1) + (c[1] > 1) + (c[2] > 1) + (c[3] > 1)) << 16);
             }
-            if (head == NIL) tail = cid;
-            head = cid; lsize++; seqctr++;
-            if (c[q] > 1) { nToExpand++; if (nvsp < vcap) nvsp++; else overflow = true; }
+        }
+        if (tid == 0) s_m = nP;
+        __syncthreads();
+        // 3. prefix sums over the processing order: aux[j] = children (low half) / children with > 1 key (high half) before j
+        const int tot = oct_block_scan(aux, nP, s_ws);
+        if (cut) {
+            // list size after processing j = lsize + (children of 0..j) - (j + 1); the pass stops after the first j reaching N
+            for (int j = tid; j < nP; j += kOctThreads) {
+                const uint64_t cj = cc[j];
+                const int ne = ((cj & 0xffff) != 0) + (((cj >> 16) & 0xffff) != 0) + (((cj >> 32) & 0xffff) != 0) + ((cj >> 48) != 0);
+                if (lsize + (aux[j] & 0xffff) + ne - (j + 1) >= N) atomicMin(&s_m, j + 1);
+            }
+            __syncthreads();
+        }
+        const int m = s_m;
+        int C, n2tot;
+        if (m == nP) { C = tot & 0xffff; n2tot = tot >> 16; }
+        else { C = aux[m] & 0xffff; n2tot = aux[m] >> 16; }
+        // 4a. survivors: old nodes that are not divided keep their relative order behind the children
+        for (int i = tid; i < lsize; i += kOctThreads) dv[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < m; j += kOctThreads) dv[P[j]] = 1;
+        __syncthreads();
+        const int nsurv = lsize - m;
+        if (C + nsurv > pool || n2tot > vcap) { overflow = true; nToExpand = 0; return; }   // uniform: every thread sees the same numbers
+        // children first (they only need aux / cc / src), then the survivors' scan reuses aux
+        uint64_t* vout = vsp[vw];
+        for (int j = tid; j < m; j += kOctThreads) {
+            const ONode nd = src[P[j]];
+            const uint64_t cj = cc[j];
+            const int c[4] = {(int)(cj & 0xffff), (int)((cj >> 16) & 0xffff), (int)((cj >> 32) & 0xffff), (int)(cj >> 48)};
+            const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+            const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
+            const int sb = (nd.flags >> 1) & 1;
+            int k = aux[j] & 0xffff, k2 = aux[j] >> 16, sb0 = nd.start;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                           // n1..n4: x-low/y-low, x-high/y-low, x-low/y-high, x-high/y-high
+                if (c[q] > 0) {
+                    ONode ch;
+                    ch.x0 = (uint16_t)((q & 1) ? midx : nd.x0); ch.x1 = (uint16_t)((q & 1) ? nd.x1 : midx);
+                    ch.y0 = (uint16_t)((q & 2) ? midy : nd.y0); ch.y1 = (uint16_t)((q & 2) ? nd.y1 : midy);
+                    ch.start = (uint16_t)sb0; ch.cnt = (uint16_t)c[q]; ch.seq = (uint16_t)(seqctr + k);
+                    ch.flags = (uint8_t)((c[q] == 1 ? 1 : 0) | ((sb ^ 1) << 1)); ch.pad = 0;
+                    const int pos = C - 1 - k;                      // push_front in creation order
+                    dst[pos] = ch;
+                    if (c[q] > 1) { vout[k2] = ((uint64_t)c[q] << 32) | ((uint64_t)(uint16_t)(seqctr + k) << 16) | (uint64_t)pos; k2++; }
+                    k++;
+                }
+                sb0 += c[q];
+            }
         }
         __syncthreads();
-    };
-    auto erase = [&](int id) {
-        const int p = S.prev[id], nx = S.next[id];
+        for (int i = tid; i < lsize; i += kOctThreads) aux[i] = dv[i] ? 0 : 1;
         __syncthreads();
-        if (lane == 0) {
-            if (p != NIL) S.next[p] = (uint16_t)nx;
-            if (nx != NIL) S.prev[nx] = (uint16_t)p;
-            S.freel[nfree] = (uint16_t)id;
-        }
-        if (p == NIL) head = nx;
-        if (nx == NIL) tail = p;
-        nfree++; lsize--;
+        oct_block_scan(aux, lsize, s_ws);
+        for (int i = tid; i < lsize; i += kOctThreads) if (!dv[i]) dst[C + aux[i]] = src[i];
         __syncthreads();
+        seqctr += C; lsize = C + nsurv; cur ^= 1; nvsp = n2tot; nToExpand = n2tot;
     };
 
     bool finish = false;
     int guard = 0;
     while (!finish && !overflow && guard++ < 64) {
         const int prevSize = lsize;
+        // processing order of a full pass = list order of the expandable nodes (:618-686)
+        for (int i = tid; i < lsize; i += kOctThreads) aux[i] = (nodes[cur][i].flags & 1) ? 0 : 1;
+        __syncthreads();
+        const int nP = oct_block_scan(aux, lsize, s_ws);
+        for (int i = tid; i < lsize; i += kOctThreads) if (!(nodes[cur][i].flags & 1)) P[aux[i]] = (uint16_t)i;
+        __syncthreads();
         int nToExpand = 0;
-        nvsp = 0;
-        int lit = head;
-        while (lit != NIL && !overflow) {
-            const int nx = S.next[lit];
-            if (S.flags[lit] & 1) { lit = nx; continue; }
-            divide(lit, nToExpand);
-            erase(lit);
-            lit = nx;
-        }
+        if (nP > 0) round(nP, false, nToExpand);
+        if (overflow) break;
         if (lsize >= N || lsize == prevSize) {
             finish = true;
         } else if (lsize + nToExpand * 3 > N) {
@@ -450,16 +499,13 @@ __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ 
             while (!finish && !overflow && guard2++ < 4096) {
                 const int prevSize2 = lsize;
                 const int nprev = nvsp;
-                const int vr = vw;               // read (sort) this buffer, write children into the other
-                vw ^= 1; nvsp = 0;
-                wave_sort_u64(S.vsp[vr], nprev, lane);
-                for (int j = nprev - 1; j >= 0; j--) {
-                    const int id = (int)(S.vsp[vr][j] & 0xffff);
-                    int dummy = 0;
-                    divide(id, dummy);
-                    erase(id);
-                    if (lsize >= N || overflow) break;
-                }
+                // largest first: ascending sort of (size, creation order), walked from the back (:703-712)
+                oct_block_sort_u64(vsp[vw], nprev);
+                for (int j = tid; j < nprev; j += kOctThreads) P[j] = (uint16_t)(vsp[vw][nprev - 1 - j] & 0xffff);
+                vw ^= 1;
+                __syncthreads();
+                int dummy = 0;
+                if (nprev > 0) round(nprev, true, dummy);
                 if (lsize >= N || lsize == prevSize2) finish = true;
             }
         }
@@ -468,23 +514,20 @@ __global__ __launch_bounds__(64) void octree_kernel(const DevGeom* __restrict__ 
 
     // ---- retain the best point of each node, in list order (:760-780) ----
     {
-        int k = 0;
-        for (int lit = head; lit != NIL && k < pool; lit = S.next[lit]) { if (lane == 0) S.order[k] = (uint16_t)lit; k++; }
-        __syncthreads();
-        const int nout = min(k, L.kp_cap);
-        if (k > L.kp_cap) raise(4);
-        for (int i = lane; i < nout; i += 64) {
-            const int id = S.order[i];
-            const uint16_t* ks = S.keys[(S.flags[id] >> 1) & 1] + S.start[id];
-            const int cnt = S.cnt[id];
-            uint32_t best = S.pts[ks[0]];
+        const ONode* nd = nodes[cur];
+        const int nout = min(lsize, L.kp_cap);
+        if (lsize > L.kp_cap) raise(4);
+        for (int i = tid; i < nout; i += kOctThreads) {
+            const uint16_t* ks = keys[(nd[i].flags >> 1) & 1] + nd[i].start;
+            const int cnt = nd[i].cnt;
+            uint32_t best = pts[ks[0]];
             for (int q = 1; q < cnt; q++) {
-                const uint32_t p = S.pts[ks[q]];
+                const uint32_t p = pts[ks[q]];
                 if ((p >> 24) > (best >> 24)) best = p;
             }
             lkp[i] = best;
         }
-        if (lane == 0) lvl_cnt[slice * G->nlevels + level] = nout;
+        if (tid == 0) lvl_cnt[slice * G->nlevels + level] = nout;
     }
 }
 
@@ -870,20 +913,27 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
         ncap_max = std::max(ncap_max, L.cand_cap);
     }
     if (ncap_max >= 65535) return set_err(c, EORB_E_CAPACITY, "image too large for the 16-bit octree keys");
+    if (node_cap_max > 16000) return set_err(c, EORB_E_CAPACITY, "more than 16 000 features on one pyramid level");   // 16-bit packed child counters
     o.pyr_bytes = pyr; o.roi_bytes = roi; o.ncells = cells; o.cell_cap = cell_cap;
     o.cand_total = cand_total; o.kp_total = kp_total; o.max_out = kp_total;
     // octree working set: greedy placement into the 160 KB of LDS (most latency-critical first), the rest into a per-(slice,
     // level) block of global scratch (346x260 with 3 000 features on one level, VGA-class frames)
     if (c->dbg_pool_shrink > 0)                    // test hook: force node-pool overflows (sticky status of the *_dev paths)
         for (int l = 0; l < nlevels; l++) o.lv[l].node_cap = std::max(8, o.lv[l].node_cap - c->dbg_pool_shrink);
-    const size_t item_bytes[6] = {((size_t)node_cap_max * (11 * 2 + 1) + 15) & ~(size_t)15,
-                                  sizeof(uint64_t) * (size_t)vsp_cap_max, sizeof(uint64_t) * (size_t)vsp_cap_max,
+    // vsp lists are sorted with a bitonic network: capacity rounded up to a power of two
+    int vsp_pow2 = 1; while (vsp_pow2 < vsp_cap_max) vsp_pow2 <<= 1;
+    const size_t item_bytes[7] = {(size_t)2 * node_cap_max * 16,
+                                  sizeof(uint64_t) * (size_t)vsp_pow2, sizeof(uint64_t) * (size_t)vsp_pow2,
                                   (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15, (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15,
-                                  (sizeof(uint32_t) * (size_t)ncap_max + 15) & ~(size_t)15};
-    int oct_in_lds[6], oct_off[6];
+                                  (sizeof(uint32_t) * (size_t)ncap_max + 15) & ~(size_t)15,
+                                  ((size_t)node_cap_max * (4 + 2 + 1 + 8) + 8 + 15) & ~(size_t)15};
+    int oct_in_lds[7], oct_off[7];
     size_t lds = 0, gblock = 0;
-    const size_t lds_budget = c->dbg_force_global ? 0 : 156 * 1024;
-    for (int k = 0; k < 6; k++) {
+    const size_t lds_budget = c->dbg_force_global ? 0 : 150 * 1024;
+    // placement order: the per-round arrays and the node arrays first (touched by every step), then the size lists, keys, points
+    const int order[7] = {6, 0, 1, 2, 3, 4, 5};
+    for (int oi = 0; oi < 7; oi++) {
+        const int k = order[oi];
         if (lds + item_bytes[k] <= lds_budget) { oct_in_lds[k] = 1; oct_off[k] = (int)lds; lds += item_bytes[k]; }
         else { oct_in_lds[k] = 0; oct_off[k] = (int)gblock; gblock += item_bytes[k]; }
     }
@@ -950,7 +1000,7 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     }
     {
         ProfScope ps(c, "orb_octree");
-        octree_kernel<<<B * o.nlevels, 64, o.oct_lds, c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
+        octree_kernel<<<B * o.nlevels, kOctThreads, o.oct_lds, c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
                                                                     (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p,
                                                                     (int32_t*)c->lvl_cnt.p, err_flag, (int32_t*)c->status.p);
         EORB_LAUNCH_CHECK(c, "octree_kernel");
