@@ -956,7 +956,7 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
     EORB_HIP(c, hipMemcpy(o.geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
     if (!tabs.empty()) EORB_HIP(c, hipMemcpy(o.tabs.p, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice));
     EORB_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_pattern_31, 1024));
-    EORB_HIP(c, hipFuncSetAttribute((const void*)octree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    EORB_HIP(c, hipFuncSetAttribute((const void*)octree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     o.configured = true;
     return EORB_OK;
 }
