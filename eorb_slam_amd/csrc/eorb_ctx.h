@@ -97,6 +97,8 @@ struct eorb_ctx {
     // matcher workspaces
     eorb::DevBuf m_a, m_b, m_c, m_d, m_e, m_f, m_g, m_h, m_i, m_j;
     eorb::DevBuf win_ws;                 // candidate lists of the two-phase window matchers
+    eorb::DevBuf arena;                  // host-buffer entry points: all inputs / outputs of one call, one H2D and one D2H copy
+    void* dl_pinned = nullptr; size_t dl_cap = 0;      // pinned landing buffer of the D2H copy (the call synchronises before reading it)
     // pyramidal LK workspaces
     eorb::DevBuf klt_pyr, klt_der, klt_scratch;
     // DBoW2 vocabulary (device copy) for eorb_bow_transform

@@ -22,6 +22,7 @@ int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm
 int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out);
 int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H);
 int orb_err_flag(eorb_ctx* c, int B, int* flag);
+int orb_err_flag_to(eorb_ctx* c, int B, int32_t* d_dst);
 int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_idx2, int32_t* d_dist2);
 int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride,
                          const uint8_t* cur_is_orb, const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
@@ -129,6 +130,59 @@ static void prof_collect(eorb_ctx* c)
 
 static void free_buf(DevBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
+// Host-buffer entry points are called once per frame (src/Frame.cc:467-482, src/Tracking.cc:1420, EvImBuilder.cpp:1345): their
+// latency is launches and copies, not kernels.  A call lays ALL its inputs and outputs out in one device arena: the inputs are
+// packed into a pinned slot and cross PCIe in ONE copy (a pageable hipMemcpy2DAsync of a 346x260 image alone cost > 1 ms), the
+// outputs come back in ONE copy into a pinned landing buffer.
+struct Arena {
+    eorb_ctx* c;
+    size_t total = 0, in_end = 0;
+    struct Part { const void* src; size_t off, bytes; int rows; size_t row_bytes, stride; };
+    std::vector<Part> parts;
+    explicit Arena(eorb_ctx* cc) : c(cc) {}
+    size_t take(size_t bytes) { const size_t o = total; total = (total + std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return o; }
+    // inputs first (they form the prefix that is uploaded), then reserve() for device-only / output regions
+    size_t in(const void* h, size_t bytes) { const size_t o = take(bytes); if (h && bytes) parts.push_back({h, o, bytes, 0, 0, 0}); in_end = total; return o; }
+    size_t in2d(const void* h, int rows, size_t row_bytes, size_t stride)
+    {
+        const size_t o = take((size_t)rows * row_bytes);
+        if (stride == row_bytes) parts.push_back({h, o, (size_t)rows * row_bytes, 0, 0, 0});
+        else parts.push_back({h, o, 0, rows, row_bytes, stride});
+        in_end = total; return o;
+    }
+    size_t reserve(size_t bytes) { return take(bytes); }
+    template <typename T> T* dev(size_t off) const { return (T*)((char*)c->arena.p + off); }
+    int upload()
+    {
+        int rc = ensure(c, c->arena, total);
+        if (rc) return rc;
+        if (!in_end) return EORB_OK;
+        char* hp = (char*)pinned(c, in_end);
+        if (!hp) return set_err(c, EORB_E_HIP, "pinned alloc failed");
+        for (const Part& p : parts) {
+            if (p.rows) for (int r = 0; r < p.rows; r++) memcpy(hp + p.off + (size_t)r * p.row_bytes, (const char*)p.src + (size_t)r * p.stride, p.row_bytes);
+            else memcpy(hp + p.off, p.src, p.bytes);
+        }
+        EORB_HIP(c, hipMemcpyAsync(c->arena.p, hp, in_end, hipMemcpyHostToDevice, c->stream));
+        pinned_commit(c);
+        return EORB_OK;
+    }
+    // one D2H copy of arena[off, off + bytes) + stream sync; returns the host view of arena offset `off` (valid until the next call)
+    int download(size_t off, size_t bytes, const char** host)
+    {
+        if (c->dl_cap < bytes) {
+            if (c->dl_pinned) { hipHostFree(c->dl_pinned); c->dl_pinned = nullptr; c->dl_cap = 0; }
+            const size_t want = bytes + bytes / 2 + 4096;
+            if (hipHostMalloc(&c->dl_pinned, want, hipHostMallocDefault) != hipSuccess) { c->dl_pinned = nullptr; return set_err(c, EORB_E_HIP, "pinned alloc failed"); }
+            c->dl_cap = want;
+        }
+        EORB_HIP(c, hipMemcpyAsync(c->dl_pinned, (char*)c->arena.p + off, bytes, hipMemcpyDeviceToHost, c->stream));
+        EORB_HIP(c, hipStreamSynchronize(c->stream));
+        *host = (const char*)c->dl_pinned - off;
+        return EORB_OK;
+    }
+};
+
 }  // namespace eorb
 
 using namespace eorb;
@@ -167,9 +221,10 @@ void eorb_destroy(eorb_ctx* c)
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
-                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws};
+                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
+    if (c->dl_pinned) hipHostFree(c->dl_pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -269,37 +324,37 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
     hipSetDevice(c->device);
     int rc;
     const size_t npix = (size_t)W * H;
-    if ((rc = ensure(c, c->ev16, sizeof(eorb_event16) * std::max<size_t>(n, 1)))) return rc;
-    if ((rc = ensure(c, c->img_f32, sizeof(float) * npix))) return rc;
-    if ((rc = ensure(c, c->img_u8, npix))) return rc;
-    if ((rc = ensure(c, c->minmax, 64))) return rc;
+    static_assert(sizeof(eorb_raw_event) == sizeof(eorb_event16), "raw and packed events share the 16-byte slot");
+    std::vector<eorb_event16> packed;
     if (n && raw) {
         for (size_t i = 0; i < n; i++)
             if ((int)rawev[i].x >= c->lut_w || (int)rawev[i].y >= c->lut_h)       // the reference asserts (MyCalibrator.cpp:176)
                 return set_err(c, EORB_E_ARG, "ev2im_raw: event %zu at (%u,%u) lies outside the %dx%d maps", i, rawev[i].x, rawev[i].y,
                                c->lut_w, c->lut_h);
-        static_assert(sizeof(eorb_raw_event) == sizeof(eorb_event16), "raw and packed events share the 16-byte slot");
-        EORB_HIP(c, hipMemcpyAsync(c->ev16.p, rawev, sizeof(eorb_raw_event) * n, hipMemcpyHostToDevice, c->stream));
-        EORB_HIP(c, hipStreamSynchronize(c->stream));
     } else if (n) {
-        std::vector<eorb_event16> packed(n);
+        packed.resize(n);
         eorb_pack_events(ev, n, packed.data());
-        EORB_HIP(c, hipMemcpyAsync(c->ev16.p, packed.data(), sizeof(eorb_event16) * n, hipMemcpyHostToDevice, c->stream));
-        EORB_HIP(c, hipStreamSynchronize(c->stream));
     }
+    Arena A(c);
+    const size_t o_ev = A.in(raw ? (const void*)rawev : (const void*)packed.data(), sizeof(eorb_event16) * n);
+    // outputs, contiguous: min/max (encoded | decoded) | u8 image | f32 image
+    const size_t o_mm = A.reserve(64), o_u8 = A.reserve(npix), o_f32 = A.reserve(sizeof(float) * npix);
+    if ((rc = A.upload())) return rc;
     int64_t offs[2] = {0, (int64_t)n};
-    uint32_t* mm = (uint32_t*)c->minmax.p;
-    float* mmf = (float*)((char*)c->minmax.p + 16);
-    EORB_HIP(c, hipMemsetAsync(c->img_u8.p, 0, npix, c->stream));
-    rc = ev_accumulate_dev(c, c->ev16.p, raw, offs, 1, W, H, sigma, pol, mode_count, (float*)c->img_f32.p,
-                           (uint8_t*)c->img_u8.p, normalized, mm);
+    uint32_t* mm = A.dev<uint32_t>(o_mm);
+    float* mmf = (float*)((char*)mm + 16);
+    uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
+    float* d_f32 = A.dev<float>(o_f32);
+    if (out_u8) EORB_HIP(c, hipMemsetAsync(d_u8, 0, npix, c->stream));     // count images stay empty when max == min
+    rc = ev_accumulate_dev(c, A.dev<void>(o_ev), raw, offs, 1, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, mm);
     if (rc) return rc;
     if ((rc = ev_decode_minmax(c, mm, mmf, 1))) return rc;
-    float hmm[2];
-    EORB_HIP(c, hipMemcpyAsync(hmm, mmf, 8, hipMemcpyDeviceToHost, c->stream));
-    if (out_f32) EORB_HIP(c, hipMemcpyAsync(out_f32, c->img_f32.p, sizeof(float) * npix, hipMemcpyDeviceToHost, c->stream));
-    if (out_u8) EORB_HIP(c, hipMemcpyAsync(out_u8, c->img_u8.p, npix, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t end = out_f32 ? o_f32 + sizeof(float) * npix : (out_u8 ? o_u8 + npix : o_mm + 64);
+    const char* h;
+    if ((rc = A.download(o_mm, end - o_mm, &h))) return rc;
+    const float* hmm = (const float*)(h + o_mm + 16);
+    if (out_f32) memcpy(out_f32, h + o_f32, sizeof(float) * npix);
+    if (out_u8) memcpy(out_u8, h + o_u8, npix);
     if (minmax) { minmax[0] = hmm[0]; minmax[1] = hmm[1]; }
     if (is_u8) *is_u8 = mode_count ? (normalized && hmm[1] > hmm[0]) : (normalized != 0);
     return EORB_OK;
@@ -573,31 +628,32 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     if (stride < W) return set_err(c, EORB_E_ARG, "stride < width");
     hipSetDevice(c->device);
     int rc;
-    const int mo = o.max_out;
-    if ((rc = ensure(c, c->in_img, (size_t)W * H))) return rc;
-    if ((rc = ensure(c, c->out_kp, sizeof(eorb_keypoint) * (size_t)mo))) return rc;
-    if ((rc = ensure(c, c->m_a, 32 * (size_t)mo))) return rc;
-    if ((rc = ensure(c, c->m_b, (size_t)mo))) return rc;
-    if ((rc = ensure(c, c->out_n, 64))) return rc;
-    EORB_HIP(c, hipMemcpy2DAsync(c->in_img.p, W, img, stride, W, H, hipMemcpyHostToDevice, c->stream));
-    int32_t* dn = (int32_t*)c->out_n.p;
-    rc = orb_extract_dev(c, (const uint8_t*)c->in_img.p, W, (size_t)W * H, 1, lap0, lap1, want_desc, (eorb_keypoint*)c->out_kp.p,
-                         (uint8_t*)c->m_a.p, (uint8_t*)c->m_b.p, dn, dn + 1);
+    const size_t mo = (size_t)o.max_out;
+    Arena A(c);
+    const size_t o_img = A.in2d(img, H, (size_t)W, (size_t)stride);
+    // outputs, contiguous: {n, mono, flag, pad} | keypoints | descriptors | oob
+    const size_t o_n = A.reserve(16), o_kp = A.reserve(sizeof(eorb_keypoint) * mo), o_desc = A.reserve(32 * mo), o_oob = A.reserve(mo);
+    if ((rc = A.upload())) return rc;
+    int32_t* dn = A.dev<int32_t>(o_n);
+    rc = orb_extract_dev(c, A.dev<uint8_t>(o_img), W, (size_t)W * H, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp),
+                         A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob), dn, dn + 1);
     if (rc) return rc;
-    int hn[2];
-    EORB_HIP(c, hipMemcpyAsync(hn, dn, 8, hipMemcpyDeviceToHost, c->stream));
-    int flag = 0;
-    if ((rc = orb_err_flag(c, 1, &flag))) return rc;
-    if (flag) {
+    if ((rc = orb_err_flag_to(c, 1, dn + 2))) return rc;
+    // one copy back: counters always, the rest up to the caller's capacity
+    const size_t ncopy = std::min<size_t>(mo, (size_t)std::max(cap, 0));
+    const size_t end = !ncopy ? o_n + 16 : (oob ? o_oob + ncopy : ((want_desc && desc) ? o_desc + 32 * ncopy : (kps ? o_kp + sizeof(eorb_keypoint) * ncopy : o_n + 16)));
+    const char* h;
+    if ((rc = A.download(o_n, end - o_n, &h))) return rc;
+    const int32_t* hn = (const int32_t*)(h + o_n);
+    if (hn[2]) {
         hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream);       // reported here, not again by eorb_sync
-        return set_err(c, EORB_E_CAPACITY, "orb_extract: internal capacity exceeded (flag %d)", flag);
+        return set_err(c, EORB_E_CAPACITY, "orb_extract: internal capacity exceeded (flag %d)", hn[2]);
     }
     if (hn[0] > cap) return set_err(c, EORB_E_CAPACITY, "orb_extract: %d keypoints > caller capacity %d", hn[0], cap);
     if (hn[0] > 0) {
-        if (kps) EORB_HIP(c, hipMemcpyAsync(kps, c->out_kp.p, sizeof(eorb_keypoint) * hn[0], hipMemcpyDeviceToHost, c->stream));
-        if (want_desc && desc) EORB_HIP(c, hipMemcpyAsync(desc, c->m_a.p, 32 * (size_t)hn[0], hipMemcpyDeviceToHost, c->stream));
-        if (oob) EORB_HIP(c, hipMemcpyAsync(oob, c->m_b.p, hn[0], hipMemcpyDeviceToHost, c->stream));
-        EORB_HIP(c, hipStreamSynchronize(c->stream));
+        if (kps) memcpy(kps, h + o_kp, sizeof(eorb_keypoint) * (size_t)hn[0]);
+        if (want_desc && desc) memcpy(desc, h + o_desc, 32 * (size_t)hn[0]);
+        if (oob) memcpy(oob, h + o_oob, (size_t)hn[0]);
     }
     if (n_out) *n_out = hn[0];
     if (mono_index) *mono_index = hn[1];
@@ -620,7 +676,8 @@ static int tracked_common(eorb_ctx* c, const uint8_t* img, int W, int H, int str
     if ((rc = ensure(c, c->m_a, 32 * (size_t)std::max(n, o.max_out)))) return rc;
     if ((rc = ensure(c, c->m_b, (size_t)std::max(n, o.max_out)))) return rc;
     if ((rc = ensure(c, c->m_c, 32 * (size_t)n))) return rc;
-    EORB_HIP(c, hipMemcpy2DAsync(c->in_img.p, W, img, stride, W, H, hipMemcpyHostToDevice, c->stream));
+    if (stride == W) EORB_HIP(c, hipMemcpyAsync(c->in_img.p, img, (size_t)W * H, hipMemcpyHostToDevice, c->stream));
+    else EORB_HIP(c, hipMemcpy2DAsync(c->in_img.p, W, img, stride, W, H, hipMemcpyHostToDevice, c->stream));
     EORB_HIP(c, hipMemcpyAsync(c->out_kp.p, kps_in, sizeof(eorb_keypoint) * n, hipMemcpyHostToDevice, c->stream));
     if (ref) EORB_HIP(c, hipMemcpyAsync(c->m_c.p, ref, 32 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     if ((rc = orb_pyramid_blur_dev(c, (const uint8_t*)c->in_img.p, W))) return rc;
@@ -671,32 +728,29 @@ int eorb_search_for_initialization(eorb_ctx* c,
     if (n1 == 0) return EORB_OK;
     int rc;
     const int c1 = std::max(n1, 1), c2 = std::max(n2, 1);
-    if ((rc = up(c, c->m_a, kps1, sizeof(eorb_keypoint) * n1))) return rc;
-    if ((rc = up(c, c->m_b, desc1, (size_t)stride1 * n1))) return rc;
-    if ((rc = up(c, c->m_c, kps2, sizeof(eorb_keypoint) * n2))) return rc;
-    if ((rc = up(c, c->m_d, desc2, (size_t)stride2 * n2))) return rc;
-    if ((rc = up(c, c->m_e, is_orb1, is_orb1 ? n1 : 0))) return rc;
-    if ((rc = up(c, c->m_f, is_orb2, is_orb2 ? n2 : 0))) return rc;
-    if ((rc = up(c, c->m_g, prev_matched, prev_matched ? sizeof(float) * 2 * n1 : 0))) return rc;
-    if ((rc = ensure(c, c->m_h, sizeof(int32_t) * c1))) return rc;
+    Arena A(c);
     int32_t hn[2] = {n1, n2};
-    if ((rc = up(c, c->m_i, hn, 8))) return rc;
-    if ((rc = ensure(c, c->m_j, 16))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));       // hn is a stack variable
-    const int32_t* dn = (const int32_t*)c->m_i.p;
-    rc = search_init_dev(c, 1, (const eorb_keypoint*)c->m_a.p, dn, 0, (const uint8_t*)c->m_b.p, stride1, 0,
-                         is_orb1 ? (const uint8_t*)c->m_e.p : nullptr,
-                         (const eorb_keypoint*)c->m_c.p, dn + 1, 0, (const uint8_t*)c->m_d.p, stride2, 0,
-                         is_orb2 ? (const uint8_t*)c->m_f.p : nullptr, c1, c2, *gb,
-                         prev_matched ? (float*)c->m_g.p : nullptr, (int32_t*)c->m_h.p, windowSize, nnratio, checkOri,
-                         (int32_t*)c->m_j.p);
+    const size_t o_n = A.in(hn, 8);
+    const size_t o_k1 = A.in(kps1, sizeof(eorb_keypoint) * (size_t)n1), o_d1 = A.in(desc1, (size_t)stride1 * n1);
+    const size_t o_k2 = A.in(kps2, sizeof(eorb_keypoint) * (size_t)n2), o_d2 = A.in(desc2, (size_t)stride2 * n2);
+    const size_t o_o1 = A.in(is_orb1, is_orb1 ? n1 : 0), o_o2 = A.in(is_orb2, is_orb2 ? n2 : 0);
+    // outputs, contiguous: nmatches | matches12 | prev_matched (uploaded: it is in/out)
+    const size_t o_nm = A.in(nullptr, 16);
+    const size_t o_m = A.in(nullptr, sizeof(int32_t) * (size_t)c1);
+    const size_t o_pm = A.in(prev_matched, prev_matched ? sizeof(float) * 2 * (size_t)n1 : 0);
+    if ((rc = A.upload())) return rc;
+    const int32_t* dn = A.dev<int32_t>(o_n);
+    rc = search_init_dev(c, 1, A.dev<eorb_keypoint>(o_k1), dn, 0, A.dev<uint8_t>(o_d1), stride1, 0, is_orb1 ? A.dev<uint8_t>(o_o1) : nullptr,
+                         A.dev<eorb_keypoint>(o_k2), dn + 1, 0, A.dev<uint8_t>(o_d2), stride2, 0, is_orb2 ? A.dev<uint8_t>(o_o2) : nullptr,
+                         c1, c2, *gb, prev_matched ? A.dev<float>(o_pm) : nullptr, A.dev<int32_t>(o_m), windowSize, nnratio, checkOri,
+                         A.dev<int32_t>(o_nm));
     if (rc) return rc;
-    int nm = 0;
-    EORB_HIP(c, hipMemcpyAsync(matches12, c->m_h.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, c->stream));
-    if (prev_matched) EORB_HIP(c, hipMemcpyAsync(prev_matched, c->m_g.p, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(&nm, c->m_j.p, 4, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
-    if (nmatches) *nmatches = nm;
+    const size_t end = prev_matched ? o_pm + sizeof(float) * 2 * (size_t)n1 : o_m + sizeof(int32_t) * (size_t)n1;
+    const char* h;
+    if ((rc = A.download(o_nm, end - o_nm, &h))) return rc;
+    memcpy(matches12, h + o_m, sizeof(int32_t) * (size_t)n1);
+    if (prev_matched) memcpy(prev_matched, h + o_pm, sizeof(float) * 2 * (size_t)n1);
+    if (nmatches) *nmatches = *(const int32_t*)(h + o_nm);
     return EORB_OK;
 }
 
@@ -714,33 +768,28 @@ static int proj_last_common(eorb_ctx* c,
     if (nmatches) *nmatches = 0;
     if (n_last == 0 || n_cur == 0) return EORB_OK;
     int rc;
-    if ((rc = up(c, c->m_a, cur_kps, sizeof(eorb_keypoint) * n_cur))) return rc;
-    if ((rc = up(c, c->m_b, cur_desc, (size_t)cur_stride * n_cur))) return rc;
-    if ((rc = up(c, c->m_c, last_kps, sizeof(eorb_keypoint) * n_last))) return rc;
-    if ((rc = up(c, c->m_d, mp_desc, 32 * (size_t)n_last))) return rc;
-    if ((rc = up(c, c->m_e, cur_is_orb, cur_is_orb ? n_cur : 0))) return rc;
-    if ((rc = up(c, c->m_f, last_is_orb, last_is_orb ? n_last : 0))) return rc;
+    Arena A(c);
+    const size_t o_ck = A.in(cur_kps, sizeof(eorb_keypoint) * (size_t)n_cur), o_cd = A.in(cur_desc, (size_t)cur_stride * n_cur);
+    const size_t o_lk = A.in(last_kps, sizeof(eorb_keypoint) * (size_t)n_last), o_md = A.in(mp_desc, 32 * (size_t)n_last);
+    const size_t o_co = A.in(cur_is_orb, cur_is_orb ? n_cur : 0), o_lo = A.in(last_is_orb, last_is_orb ? n_last : 0);
     std::vector<float> f3(3 * (size_t)n_last);
     for (int i = 0; i < n_last; i++) { f3[3 * i] = uv[2 * i]; f3[3 * i + 1] = uv[2 * i + 1]; f3[3 * i + 2] = level_scale[i]; }
-    if ((rc = up(c, c->m_g, f3.data(), sizeof(float) * f3.size()))) return rc;
-    if ((rc = up(c, c->m_h, cur_mp, sizeof(int32_t) * n_cur))) return rc;
-    // valid | mp_obs packed behind each other
-    std::vector<uint8_t> vo(2 * (size_t)n_last);
-    memcpy(vo.data(), valid, n_last); memcpy(vo.data() + n_last, mp_obs, n_last);
-    if ((rc = up(c, c->m_i, vo.data(), vo.size()))) return rc;
-    if ((rc = ensure(c, c->m_j, 16))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
-    rc = search_proj_last_dev(c, (const eorb_keypoint*)c->m_a.p, n_cur, (const uint8_t*)c->m_b.p, cur_stride,
-                              cur_is_orb ? (const uint8_t*)c->m_e.p : nullptr, (const eorb_keypoint*)c->m_c.p, n_last,
-                              last_is_orb ? (const uint8_t*)c->m_f.p : nullptr, (const uint8_t*)c->m_i.p, (const float*)c->m_g.p,
-                              (const uint8_t*)c->m_d.p, (const uint8_t*)c->m_i.p + n_last, dist_th, *gb, (int32_t*)c->m_h.p, th,
-                              mode, checkOri, (int32_t*)c->m_j.p);
+    const size_t o_f3 = A.in(f3.data(), sizeof(float) * f3.size());
+    const size_t o_va = A.in(valid, n_last), o_ob = A.in(mp_obs, n_last);
+    // outputs, contiguous: nmatches | slots (in/out)
+    const size_t o_nm = A.in(nullptr, 16);
+    const size_t o_mp = A.in(cur_mp, sizeof(int32_t) * (size_t)n_cur);
+    if ((rc = A.upload())) return rc;
+    rc = search_proj_last_dev(c, A.dev<eorb_keypoint>(o_ck), n_cur, A.dev<uint8_t>(o_cd), cur_stride,
+                              cur_is_orb ? A.dev<uint8_t>(o_co) : nullptr, A.dev<eorb_keypoint>(o_lk), n_last,
+                              last_is_orb ? A.dev<uint8_t>(o_lo) : nullptr, A.dev<uint8_t>(o_va), A.dev<float>(o_f3),
+                              A.dev<uint8_t>(o_md), A.dev<uint8_t>(o_ob), dist_th, *gb, A.dev<int32_t>(o_mp), th,
+                              mode, checkOri, A.dev<int32_t>(o_nm));
     if (rc) return rc;
-    int nm = 0;
-    EORB_HIP(c, hipMemcpyAsync(cur_mp, c->m_h.p, sizeof(int32_t) * n_cur, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(&nm, c->m_j.p, 4, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
-    if (nmatches) *nmatches = nm;
+    const char* h;
+    if ((rc = A.download(o_nm, o_mp + sizeof(int32_t) * (size_t)n_cur - o_nm, &h))) return rc;
+    memcpy(cur_mp, h + o_mp, sizeof(int32_t) * (size_t)n_cur);
+    if (nmatches) *nmatches = *(const int32_t*)(h + o_nm);
     return EORB_OK;
 }
 
@@ -789,33 +838,25 @@ int eorb_search_by_projection_map(eorb_ctx* c,
     if (nmatches) *nmatches = 0;
     if (M == 0 || n == 0) return EORB_OK;
     int rc;
-    if ((rc = up(c, c->m_a, kps, sizeof(eorb_keypoint) * n))) return rc;
-    if ((rc = up(c, c->m_b, desc, (size_t)stride * n))) return rc;
-    if ((rc = up(c, c->m_c, is_orb, is_orb ? n : 0))) return rc;
-    if ((rc = up(c, c->m_d, mp_desc, 32 * (size_t)M))) return rc;
+    Arena A(c);
+    const size_t o_k = A.in(kps, sizeof(eorb_keypoint) * (size_t)n), o_d = A.in(desc, (size_t)stride * n), o_o = A.in(is_orb, is_orb ? n : 0);
+    const size_t o_md = A.in(mp_desc, 32 * (size_t)M);
     // per map point record: proj x, proj y, view cos, level scale (floats) | level (int) | in_view, obs, is_orb (bytes)
     std::vector<float> f4(4 * (size_t)M);
     for (int m = 0; m < M; m++) { f4[4 * m] = proj_xy[2 * m]; f4[4 * m + 1] = proj_xy[2 * m + 1]; f4[4 * m + 2] = view_cos[m]; f4[4 * m + 3] = level_scale[m]; }
-    if ((rc = up(c, c->m_e, f4.data(), sizeof(float) * f4.size()))) return rc;
-    if ((rc = up(c, c->m_f, level, sizeof(int32_t) * M))) return rc;
-    std::vector<uint8_t> b3(3 * (size_t)M);
-    for (int m = 0; m < M; m++) { b3[m] = in_view[m]; b3[M + m] = mp_obs[m]; b3[2 * M + m] = mp_is_orb ? mp_is_orb[m] : 1; }
-    if ((rc = up(c, c->m_g, b3.data(), b3.size()))) return rc;
-    if ((rc = up(c, c->m_h, frame_mp, sizeof(int32_t) * n))) return rc;
-    if ((rc = ensure(c, c->m_j, 16))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
-    const float* F = (const float*)c->m_e.p;
-    const uint8_t* Bp = (const uint8_t*)c->m_g.p;
-    rc = search_proj_map_dev(c, (const eorb_keypoint*)c->m_a.p, n, (const uint8_t*)c->m_b.p, stride,
-                             is_orb ? (const uint8_t*)c->m_c.p : nullptr, M, Bp, (const float4*)F, (const int32_t*)c->m_f.p,
-                             (const uint8_t*)c->m_d.p, Bp + M, Bp + 2 * M, *gb, (int32_t*)c->m_h.p, th, nnratio,
-                             (int32_t*)c->m_j.p);
+    const size_t o_f4 = A.in(f4.data(), sizeof(float) * f4.size()), o_lv = A.in(level, sizeof(int32_t) * (size_t)M);
+    const size_t o_iv = A.in(in_view, M), o_ob = A.in(mp_obs, M), o_mo = A.in(mp_is_orb, mp_is_orb ? M : 0);
+    const size_t o_nm = A.in(nullptr, 16);
+    const size_t o_fm = A.in(frame_mp, sizeof(int32_t) * (size_t)n);
+    if ((rc = A.upload())) return rc;
+    rc = search_proj_map_dev(c, A.dev<eorb_keypoint>(o_k), n, A.dev<uint8_t>(o_d), stride, is_orb ? A.dev<uint8_t>(o_o) : nullptr, M,
+                             A.dev<uint8_t>(o_iv), A.dev<float4>(o_f4), A.dev<int32_t>(o_lv), A.dev<uint8_t>(o_md), A.dev<uint8_t>(o_ob),
+                             mp_is_orb ? A.dev<uint8_t>(o_mo) : nullptr, *gb, A.dev<int32_t>(o_fm), th, nnratio, A.dev<int32_t>(o_nm));
     if (rc) return rc;
-    int nm = 0;
-    EORB_HIP(c, hipMemcpyAsync(frame_mp, c->m_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(&nm, c->m_j.p, 4, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
-    if (nmatches) *nmatches = nm;
+    const char* h;
+    if ((rc = A.download(o_nm, o_fm + sizeof(int32_t) * (size_t)n - o_nm, &h))) return rc;
+    memcpy(frame_mp, h + o_fm, sizeof(int32_t) * (size_t)n);
+    if (nmatches) *nmatches = *(const int32_t*)(h + o_nm);
     return EORB_OK;
 }
 
@@ -1217,15 +1258,16 @@ int eorb_hamming_bf_knn2(eorb_ctx* c, const uint8_t* q, int nq, const uint8_t* t
     if (nq == 0) return EORB_OK;
     hipSetDevice(c->device);
     int rc;
-    if ((rc = up(c, c->m_a, q, 32 * (size_t)nq))) return rc;
-    if ((rc = up(c, c->m_b, t, 32 * (size_t)nt))) return rc;
-    if ((rc = ensure(c, c->m_c, sizeof(int32_t) * 2 * (size_t)nq))) return rc;
-    if ((rc = ensure(c, c->m_d, sizeof(int32_t) * 2 * (size_t)nq))) return rc;
-    rc = bf_knn2_dev(c, (const uint8_t*)c->m_a.p, nq, (const uint8_t*)c->m_b.p, nt, (int32_t*)c->m_c.p, (int32_t*)c->m_d.p);
+    Arena A(c);
+    const size_t o_q = A.in(q, 32 * (size_t)nq), o_t = A.in(t, 32 * (size_t)nt);
+    const size_t o_idx = A.reserve(sizeof(int32_t) * 2 * (size_t)nq), o_dist = A.reserve(sizeof(int32_t) * 2 * (size_t)nq);
+    if ((rc = A.upload())) return rc;
+    rc = bf_knn2_dev(c, A.dev<uint8_t>(o_q), nq, A.dev<uint8_t>(o_t), nt, A.dev<int32_t>(o_idx), A.dev<int32_t>(o_dist));
     if (rc) return rc;
-    EORB_HIP(c, hipMemcpyAsync(idx2, c->m_c.p, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(dist2, c->m_d.p, sizeof(int32_t) * 2 * nq, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    const char* h;
+    if ((rc = A.download(o_idx, o_dist + sizeof(int32_t) * 2 * (size_t)nq - o_idx, &h))) return rc;
+    memcpy(idx2, h + o_idx, sizeof(int32_t) * 2 * (size_t)nq);
+    memcpy(dist2, h + o_dist, sizeof(int32_t) * 2 * (size_t)nq);
     return EORB_OK;
 }
 

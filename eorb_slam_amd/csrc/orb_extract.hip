@@ -1073,6 +1073,15 @@ int orb_tracked_dev(eorb_ctx* c, eorb_keypoint* d_kps, int n, int mode, const ui
     return EORB_OK;
 }
 
+// the flag of the last extraction of B slices, copied device-to-device next to the call's other outputs
+int orb_err_flag_to(eorb_ctx* c, int B, int32_t* d_dst)
+{
+    OrbState& o = c->orb;
+    const int32_t* err_flag = (const int32_t*)((char*)c->lvl_cnt.p + (size_t)B * o.nlevels * sizeof(int32_t));
+    EORB_HIP(c, hipMemcpyAsync(d_dst, err_flag, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    return EORB_OK;
+}
+
 int orb_err_flag(eorb_ctx* c, int B, int* flag)
 {
     OrbState& o = c->orb;
