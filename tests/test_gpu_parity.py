@@ -980,8 +980,11 @@ for (W, H, n, sigma, pol, seed) in ((240, 180, 300000, 1.0, False, 5), (240, 180
     ev = orc.undistort_events(raw, mx, my, W, H, True, 1.0)
     of, ou, omm = orc.ev2im_gauss(ev, W, H, sigma, pol, True)
     gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, pol, True, ctx=c, return_all=True)
-    assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)) and np.array_equal(ou, gu), (W, H, n, sigma, pol)
-    assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), (W, H, n, sigma, pol)
+    d = of.view(np.uint32) != gf.view(np.uint32)
+    what = (W, H, n, sigma, pol, "f32 px", int(d.sum()), "u8 px", int((ou != gu).sum()), "minmax", list(map(float, omm)), gmm.tolist(),
+            "tiles", sorted(set(zip((np.nonzero(d)[0] // 8).tolist(), (np.nonzero(d)[1] // 8).tolist())))[:8])
+    assert not d.any() and np.array_equal(ou, gu), what
+    assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), what
 print("nc4 ok")
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
