@@ -209,6 +209,158 @@ __global__ __launch_bounds__(64) void ev_scatter_kernel(const eorb_event16* __re
     }
 }
 
+// K1c, second form: the chunk's entries are SORTED BY TILE IN LDS first and leave the CU as contiguous runs (one run per tile: the
+// chunk's segment of that tile's list), so that a store instruction covers a few cache lines instead of up to 64 (the first form
+// is bound by the rate of its scattered 8-byte store requests, ~100 G/s).  One 4-wave workgroup per chunk (<= 2048 events); wave w
+// owns the w-th quarter of the chunk's events, whose tile ranges it keeps in registers.
+//   A  every wave counts its quarter's entries per tile (LDS atomics, its own row of cntw).
+//   B  per tile: exclusive prefix of the four rows (wave w's entries of a tile come after those of the waves before it) and an
+//      exclusive scan of the totals over the tiles: loff[t] = start of tile t's run inside the chunk's sorted order.
+//   C  every wave walks its sub-batches of 64 events in order; rank among the lanes of the same tile by ballot matching (tiles
+//      visited in parity classes, as in the first form) + the wave's running counter of that tile: sidx[slot] = event.  The
+//      counters are private to the wave: no barrier inside this phase.
+//   D  slot p of the sorted order -> (event, tile) -> the entry is rebuilt from the event (L2) and stored at the tile's run base +
+//      (p - loff[tile]): consecutive threads write consecutive entries of a run.
+constexpr int kScatWaves = 4;
+__device__ __forceinline__ int wave_incl_scan(int x);
+template <int R, bool POL>
+__global__ __launch_bounds__(256) void ev_scatter2_kernel(const eorb_event16* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                          BinParams P, int chunk_cap, const int64_t* __restrict__ slice_ebase,
+                                                          const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
+                                                          float* __restrict__ entries)
+{
+    extern __shared__ unsigned char sm2[];
+    __shared__ uint32_t s_wsum[kScatWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x;
+    const ChunkDesc cd = chunks[chunk];
+    const int NT = P.NT, NTp = (NT + 1) & ~1;
+    uint16_t* sidx = (uint16_t*)sm2;                                  // chunk_cap * R * R: event of every slot of the sorted order
+    uint16_t* cntw = sidx + (size_t)chunk_cap * R * R;                // kScatWaves * NTp
+    uint16_t* loff = cntw + kScatWaves * NTp;                         // NT + 1 (+ 1 pad)
+    uint32_t* gbase = (uint32_t*)(loff + NTp + 2);                    // NT: first entry of the tile's run in the global lists
+    for (int i = tid; i < kScatWaves * NTp / 2; i += 256) ((uint32_t*)cntw)[i] = 0u;
+    const eorb_event16* e = ev + cd.start;
+    // quarter of wave w: events [w * Q, (w + 1) * Q), Q a multiple of 64; S sub-batches of 64 (<= 8: chunk_cap <= 2048)
+    const int Q = (((cd.n + kScatWaves - 1) / kScatWaves) + 63) & ~63;
+    const int S = Q >> 6;
+    constexpr int SMAX = 8;
+    uint32_t rng[SMAX];                                               // tx0 | ty0 << 8 | (tx1 - tx0 + 1) << 16 | (ty1 - ty0 + 1) << 20; 0 = no entry
+    auto tile_range = [&](int k, int& tx0, int& tx1, int& ty0, int& ty1) -> bool {
+        if (P.raw) { uint32_t src, info; return ev_tile_range_raw(((const eorb_raw_event*)e)[k], P, tx0, tx1, ty0, ty1, src, info); }
+        return ev_tile_range(e[k], P, tx0, tx1, ty0, ty1);
+    };
+    __syncthreads();
+    // ---- A: ranges into registers, counts per (wave, tile) ----
+    uint32_t* cw32 = (uint32_t*)(cntw + wave * NTp);
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        rng[s] = 0u;
+        const int k = wave * Q + s * 64 + lane;
+        if (s < S && k < cd.n) {
+            int tx0, tx1, ty0, ty1;
+            if (tile_range(k, tx0, tx1, ty0, ty1) && tx1 >= tx0 && ty1 >= ty0) {
+                rng[s] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)(tx1 - tx0 + 1) << 16) | ((uint32_t)(ty1 - ty0 + 1) << 20);
+                for (int ty = ty0; ty <= ty1; ty++)
+                    for (int tx = tx0; tx <= tx1; tx++) {
+                        const int t = ty * P.TX + tx;
+                        atomicAdd(&cw32[t >> 1], 1u << (16 * (t & 1)));       // 16-bit counters, two per word (a quarter has <= 512 events)
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B: per tile the exclusive prefix over the waves; exclusive scan of the totals over the tiles ----
+    {
+        const int per = (NT + 255) / 256;                             // consecutive tiles of one thread
+        const int t0 = tid * per, t1 = min(t0 + per, NT);
+        uint32_t mine = 0;
+        for (int t = t0; t < t1; t++) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < kScatWaves; w++) { const uint32_t v = cntw[w * NTp + t]; cntw[w * NTp + t] = (uint16_t)run; run += v; }
+            loff[t] = (uint16_t)run;                                  // total of the tile, turned into its offset below
+            mine += run;
+            gbase[t] = tile_base[(size_t)cd.slice * NT + t] + segbase[(size_t)chunk * NT + t];
+        }
+        uint32_t incl = (uint32_t)wave_incl_scan((int)mine);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < wave; w++) before += s_wsum[w];
+        for (int t = t0; t < t1; t++) { const uint32_t v = loff[t]; loff[t] = (uint16_t)before; before += v; }
+        if (tid == 255) loff[NT] = (uint16_t)before;                  // (threads past the last tile carry the grand total)
+    }
+    __syncthreads();
+    // ---- C: stable ranks -> sidx ----
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint16_t* cw = cntw + wave * NTp;
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        if (s >= S) break;
+        const uint32_t rg = rng[s];
+        const int tx0 = rg & 0xff, ty0 = (rg >> 8) & 0xff, tx1 = tx0 + (int)((rg >> 16) & 0xf) - 1, ty1 = ty0 + (int)((rg >> 20) & 0xf) - 1;
+        const bool valid = rg != 0u;
+        const uint16_t kloc = (uint16_t)(wave * Q + s * 64 + lane);
+#pragma unroll
+        for (int cy = 0; cy < R; cy++) {
+#pragma unroll
+            for (int cx = 0; cx < R; cx++) {
+                // the tile of residue class (cx, cy) inside this event's tile range, if any
+                const int tx = tx0 + ((cx - tx0 % R) + R) % R;
+                const int ty = ty0 + ((cy - ty0 % R) + R) % R;
+                const bool has = valid && tx <= tx1 && ty <= ty1;
+                uint64_t m = __ballot(has);
+                if (m == 0ull) continue;
+                const int key = has ? ty * P.TX + tx : 0;
+                for (int b = 0; b < P.nbits; b++) {
+                    const bool bit = (key >> b) & 1;
+                    const uint64_t bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                if (has) {
+                    const int rank = __popcll(m & lt_mask);
+                    const uint32_t base = cw[key];
+                    sidx[(uint32_t)loff[key] + base + rank] = kloc;
+                    if (rank == 0) cw[key] = (uint16_t)(base + (uint32_t)__popcll(m));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- D: the sorted order leaves as contiguous runs ----
+    constexpr int ESZ = POL ? 4 : 2;
+    float* out = entries + (size_t)slice_ebase[cd.slice] * ESZ;
+    const int E = loff[NT];
+    for (int p = tid; p < E; p += 256) {
+        const int k = sidx[p];
+        int tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0;
+        float x, y, sg = 1.f;
+        if (P.raw) {
+            // entry = { sensor pixel | negative polarity << 31, xi | yi << 16 } in the float2 slot
+            const eorb_raw_event q = ((const eorb_raw_event*)e)[k];
+            uint32_t src = 0, info = 0;
+            ev_tile_range_raw(q, P, tx0, tx1, ty0, ty1, src, info);
+            x = __uint_as_float(src | (q.p ? 0u : 0x80000000u)); y = __uint_as_float(info);
+        } else {
+            const eorb_event16 q = e[k];
+            ev_tile_range(q, P, tx0, tx1, ty0, ty1);
+            x = q.x; y = q.y;
+            if (POL) sg = (__double_as_longlong(q.t) < 0) ? -1.0f : 1.0f;
+        }
+        // the tile of the event's range whose run holds slot p
+        int t = ty0 * P.TX + tx0;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int tt = ty * P.TX + tx;
+                if ((int)loff[tt] <= p && p < (int)loff[tt + 1]) t = tt;
+            }
+        const size_t pos = (size_t)gbase[t] + (uint32_t)(p - (int)loff[t]);
+        if (POL) { float4 v = make_float4(x, y, sg, 0.f); *(float4*)(out + pos * 4) = v; }
+        else { float2 v = make_float2(x, y); *(float2*)(out + pos * 2) = v; }
+    }
+}
+
 // Heaviest-first launch order for K2 (longest-processing-time-first): event data is spatially concentrated (on the reference's
 // `shapes` sequences one tile holds ~6 % of a slice's entries), and a workgroup that starts its long tile late is the tail of the
 // launch.  Bucket sort of the (slice, tile) work items by a 2-bits-per-octave log weight.
@@ -1284,7 +1436,9 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     // loop (72 us on MI355X) but eight waves side by side
     const int64_t nev_all = h_offsets[B] - h_offsets[0];
     const int64_t per_slice = nev_all / B;
-    const int chunk = per_slice >= (int64_t)1 << 17 ? kChunk : (per_slice >= (int64_t)1 << 14 ? 1024 : 256);
+    static const int scat_form = [] { const char* e = getenv("EORB_SCATTER"); return e ? atoi(e) : 2; }();      // 1: first form (A/B runs)
+    const int chunk_big = scat_form == 1 ? kChunk : 2048;
+    const int chunk = per_slice >= (int64_t)1 << 17 ? chunk_big : (per_slice >= (int64_t)1 << 14 ? 1024 : 256);
     std::vector<ChunkDesc> cds;
     std::vector<int> slice_c0(B + 1);
     std::vector<int64_t> slice_eb(B);
@@ -1380,7 +1534,11 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         if (nchunks) ev_count_kernel<<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, P, d_segcnt);
         ev_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
         if (nchunks) {
-#define LAUNCH_BIN(RR, PP) ev_scatter_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, d_slice_eb, d_segbase, d_tile_base, en)
+            const int NTp = (NT + 1) & ~1;
+            const size_t lds2 = ((size_t)chunk * R * R * 2 + (size_t)kScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
+            const bool form2 = scat_form != 1 && lds2 <= 64 * 1024 && TX < 256 && TY < 256;
+#define LAUNCH_BIN(RR, PP) do { if (form2) ev_scatter2_kernel<RR, PP><<<nchunks, 256, lds2, c->stream>>>(d_ev, d_chunks, P, chunk, d_slice_eb, d_segbase, d_tile_base, en); \
+                                else ev_scatter_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, d_slice_eb, d_segbase, d_tile_base, en); } while (0)
             const bool wide = pol && !raw;                       // raw entries keep the polarity in the sensor-pixel word
             if (R == 1) { if (wide) LAUNCH_BIN(1, true); else LAUNCH_BIN(1, false); }
             else if (R == 2) { if (wide) LAUNCH_BIN(2, true); else LAUNCH_BIN(2, false); }
