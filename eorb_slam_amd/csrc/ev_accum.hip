@@ -221,50 +221,64 @@ __global__ __launch_bounds__(64) void ev_scatter_kernel(const eorb_event16* __re
 //      counters are private to the wave: no barrier inside this phase.
 //   D  slot p of the sorted order -> (event, tile) -> the entry is rebuilt from the event (L2) and stored at the tile's run base +
 //      (p - loff[tile]): consecutive threads write consecutive entries of a run.
-constexpr int kScatWaves = 4;
+constexpr int kScatWaves = 8;
 __device__ __forceinline__ int wave_incl_scan(int x);
-template <int R, bool POL>
-__global__ __launch_bounds__(256) void ev_scatter2_kernel(const eorb_event16* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
-                                                          BinParams P, int chunk_cap, const int64_t* __restrict__ slice_ebase,
+template <int R>
+__global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb_event16* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                          BinParams P, int chunk_cap, int ko, const int64_t* __restrict__ slice_ebase,
                                                           const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
-                                                          float* __restrict__ entries)
+                                                          uint2* __restrict__ entries)
 {
     extern __shared__ unsigned char sm2[];
     __shared__ uint32_t s_wsum[kScatWaves];
+    constexpr int NTHR = 64 * kScatWaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
     const ChunkDesc cd = chunks[chunk];
     const int NT = P.NT, NTp = (NT + 1) & ~1;
-    uint16_t* sidx = (uint16_t*)sm2;                                  // chunk_cap * R * R: event of every slot of the sorted order
+    uint2* pay = (uint2*)sm2;                                         // chunk_cap: the 8-byte entry of every event
+    uint16_t* prng = (uint16_t*)(pay + chunk_cap);                    // chunk_cap: first tile of the event's range, tx0 | ty0 << 8
+    uint16_t* sidx = prng + chunk_cap;                                // chunk_cap * R * R: slot of the sorted order -> event | dx << 11 | dy << 13
     uint16_t* cntw = sidx + (size_t)chunk_cap * R * R;                // kScatWaves * NTp
     uint16_t* loff = cntw + kScatWaves * NTp;                         // NT + 1 (+ 1 pad)
     uint32_t* gbase = (uint32_t*)(loff + NTp + 2);                    // NT: first entry of the tile's run in the global lists
-    for (int i = tid; i < kScatWaves * NTp / 2; i += 256) ((uint32_t*)cntw)[i] = 0u;
+    for (int i = tid; i < kScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
     const eorb_event16* e = ev + cd.start;
-    // quarter of wave w: events [w * Q, (w + 1) * Q), Q a multiple of 64; S sub-batches of 64 (<= 8: chunk_cap <= 2048)
+    // share of wave w: events [w * Q, (w + 1) * Q), Q a multiple of 64; S sub-batches of 64 (<= 4: chunk_cap <= 2048)
     const int Q = (((cd.n + kScatWaves - 1) / kScatWaves) + 63) & ~63;
     const int S = Q >> 6;
-    constexpr int SMAX = 8;
+    constexpr int SMAX = 4;
     uint32_t rng[SMAX];                                               // tx0 | ty0 << 8 | (tx1 - tx0 + 1) << 16 | (ty1 - ty0 + 1) << 20; 0 = no entry
-    auto tile_range = [&](int k, int& tx0, int& tx1, int& ty0, int& ty1) -> bool {
-        if (P.raw) { uint32_t src, info; return ev_tile_range_raw(((const eorb_raw_event*)e)[k], P, tx0, tx1, ty0, ty1, src, info); }
-        return ev_tile_range(e[k], P, tx0, tx1, ty0, ty1);
-    };
     __syncthreads();
-    // ---- A: ranges into registers, counts per (wave, tile) ----
+    // ---- A: entries into LDS, tile ranges into registers, counts per (wave, tile) ----
     uint32_t* cw32 = (uint32_t*)(cntw + wave * NTp);
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         rng[s] = 0u;
         const int k = wave * Q + s * 64 + lane;
         if (s < S && k < cd.n) {
-            int tx0, tx1, ty0, ty1;
-            if (tile_range(k, tx0, tx1, ty0, ty1) && tx1 >= tx0 && ty1 >= ty0) {
+            int tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0;
+            bool ok;
+            uint2 pl;
+            if (P.raw) {
+                // entry = { sensor pixel | negative polarity << 31, xi | yi << 16 }
+                const eorb_raw_event q = ((const eorb_raw_event*)e)[k];
+                uint32_t src = 0, info = 0;
+                ok = ev_tile_range_raw(q, P, tx0, tx1, ty0, ty1, src, info);
+                pl = make_uint2(src | (q.p ? 0u : 0x80000000u), info);
+            } else {
+                const eorb_event16 q = e[k];
+                ok = ev_tile_range(q, P, tx0, tx1, ty0, ty1);
+                pl = make_uint2(__float_as_uint(q.x), __float_as_uint(q.y));
+            }
+            pay[k] = pl;
+            prng[k] = (uint16_t)((tx0 & 0xff) | ((ty0 & 0xff) << 8));
+            if (ok && tx1 >= tx0 && ty1 >= ty0) {
                 rng[s] = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)(tx1 - tx0 + 1) << 16) | ((uint32_t)(ty1 - ty0 + 1) << 20);
                 for (int ty = ty0; ty <= ty1; ty++)
                     for (int tx = tx0; tx <= tx1; tx++) {
                         const int t = ty * P.TX + tx;
-                        atomicAdd(&cw32[t >> 1], 1u << (16 * (t & 1)));       // 16-bit counters, two per word (a quarter has <= 512 events)
+                        atomicAdd(&cw32[t >> 1], 1u << (16 * (t & 1)));       // 16-bit counters, two per word (a share has <= 256 events)
                     }
             }
         }
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(256) void ev_scatter2_kernel(const eorb_event16* __
     __syncthreads();
     // ---- B: per tile the exclusive prefix over the waves; exclusive scan of the totals over the tiles ----
     {
-        const int per = (NT + 255) / 256;                             // consecutive tiles of one thread
+        const int per = (NT + NTHR - 1) / NTHR;                       // consecutive tiles of one thread
         const int t0 = tid * per, t1 = min(t0 + per, NT);
         uint32_t mine = 0;
         for (int t = t0; t < t1; t++) {
@@ -289,12 +303,15 @@ __global__ __launch_bounds__(256) void ev_scatter2_kernel(const eorb_event16* __
         uint32_t before = incl - mine;
         for (int w = 0; w < wave; w++) before += s_wsum[w];
         for (int t = t0; t < t1; t++) { const uint32_t v = loff[t]; loff[t] = (uint16_t)before; before += v; }
-        if (tid == 255) loff[NT] = (uint16_t)before;                  // (threads past the last tile carry the grand total)
+        if (tid == NTHR - 1) loff[NT] = (uint16_t)before;             // (threads past the last tile carry the grand total)
     }
     __syncthreads();
     // ---- C: stable ranks -> sidx ----
+    if (ko & 4) return;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint16_t* cw = cntw + wave * NTp;
+    const int txr = (P.TX + R - 1) / R;
+    int mbits = 1; while ((1 << mbits) < txr * ((P.TY + R - 1) / R)) mbits++;
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         if (s >= S) break;
@@ -313,51 +330,36 @@ __global__ __launch_bounds__(256) void ev_scatter2_kernel(const eorb_event16* __
                 uint64_t m = __ballot(has);
                 if (m == 0ull) continue;
                 const int key = has ? ty * P.TX + tx : 0;
-                for (int b = 0; b < P.nbits; b++) {
-                    const bool bit = (key >> b) & 1;
+                // lanes of the same tile: inside one parity class a tile is identified by (tx / R, ty / R) -- fewer bits to match
+                const int mkey = has ? (ty / R) * txr + (tx / R) : 0;
+                for (int b = 0; b < mbits; b++) {
+                    const bool bit = (mkey >> b) & 1;
                     const uint64_t bal = __ballot(bit);
                     m &= bit ? bal : ~bal;
                 }
                 if (has) {
                     const int rank = __popcll(m & lt_mask);
                     const uint32_t base = cw[key];
-                    sidx[(uint32_t)loff[key] + base + rank] = kloc;
+                    sidx[(uint32_t)loff[key] + base + rank] = (uint16_t)(kloc | ((tx - tx0) << 11) | ((ty - ty0) << 13));
                     if (rank == 0) cw[key] = (uint16_t)(base + (uint32_t)__popcll(m));
                 }
             }
         }
     }
     __syncthreads();
-    // ---- D: the sorted order leaves as contiguous runs ----
-    constexpr int ESZ = POL ? 4 : 2;
-    float* out = entries + (size_t)slice_ebase[cd.slice] * ESZ;
+    // ---- D: the sorted order leaves as contiguous runs: consecutive threads write consecutive entries of a tile's run ----
+    if (ko & 2) return;
+    uint2* out = entries + (size_t)slice_ebase[cd.slice];
     const int E = loff[NT];
-    for (int p = tid; p < E; p += 256) {
-        const int k = sidx[p];
-        int tx0 = 1, tx1 = 0, ty0 = 1, ty1 = 0;
-        float x, y, sg = 1.f;
-        if (P.raw) {
-            // entry = { sensor pixel | negative polarity << 31, xi | yi << 16 } in the float2 slot
-            const eorb_raw_event q = ((const eorb_raw_event*)e)[k];
-            uint32_t src = 0, info = 0;
-            ev_tile_range_raw(q, P, tx0, tx1, ty0, ty1, src, info);
-            x = __uint_as_float(src | (q.p ? 0u : 0x80000000u)); y = __uint_as_float(info);
-        } else {
-            const eorb_event16 q = e[k];
-            ev_tile_range(q, P, tx0, tx1, ty0, ty1);
-            x = q.x; y = q.y;
-            if (POL) sg = (__double_as_longlong(q.t) < 0) ? -1.0f : 1.0f;
-        }
-        // the tile of the event's range whose run holds slot p
-        int t = ty0 * P.TX + tx0;
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) {
-                const int tt = ty * P.TX + tx;
-                if ((int)loff[tt] <= p && p < (int)loff[tt + 1]) t = tt;
-            }
+    for (int p = tid; p < E; p += NTHR) {
+        const uint32_t sv = sidx[p];
+        const int k = sv & 0x7ff;
+        const uint32_t r0 = prng[k];
+        const int t = ((int)(r0 >> 8) + (int)((sv >> 13) & 3)) * P.TX + (int)(r0 & 0xff) + (int)((sv >> 11) & 3);
+        const uint2 v = pay[k];
         const size_t pos = (size_t)gbase[t] + (uint32_t)(p - (int)loff[t]);
-        if (POL) { float4 v = make_float4(x, y, sg, 0.f); *(float4*)(out + pos * 4) = v; }
-        else { float2 v = make_float2(x, y); *(float2*)(out + pos * 2) = v; }
+        if (ko & 1) { if (v.x == 0x12345u && pos == 77) out[0] = v; continue; }
+        out[pos] = v;
     }
 }
 
@@ -1535,9 +1537,11 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         ev_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
         if (nchunks) {
             const int NTp = (NT + 1) & ~1;
-            const size_t lds2 = ((size_t)chunk * R * R * 2 + (size_t)kScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
-            const bool form2 = scat_form != 1 && lds2 <= 64 * 1024 && TX < 256 && TY < 256;
-#define LAUNCH_BIN(RR, PP) do { if (form2) ev_scatter2_kernel<RR, PP><<<nchunks, 256, lds2, c->stream>>>(d_ev, d_chunks, P, chunk, d_slice_eb, d_segbase, d_tile_base, en); \
+            const size_t lds2 = ((size_t)chunk * 8 + (size_t)chunk * 2 + (size_t)chunk * R * R * 2 + (size_t)kScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
+            static const int scat_ko = [] { const char* e = getenv("EORB_SCAT_KO"); return e ? atoi(e) : 0; }();
+            // (float events with polarity carry 16-byte entries: first form)
+            const bool form2 = scat_form != 1 && !(pol && !raw) && lds2 <= 64 * 1024 && TX < 256 && TY < 256;
+#define LAUNCH_BIN(RR, PP) do { if (form2) ev_scatter2_kernel<RR><<<nchunks, 64 * kScatWaves, lds2, c->stream>>>(d_ev, d_chunks, P, chunk, scat_ko, d_slice_eb, d_segbase, d_tile_base, (uint2*)en); \
                                 else ev_scatter_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, d_slice_eb, d_segbase, d_tile_base, en); } while (0)
             const bool wide = pol && !raw;                       // raw entries keep the polarity in the sensor-pixel word
             if (R == 1) { if (wide) LAUNCH_BIN(1, true); else LAUNCH_BIN(1, false); }
