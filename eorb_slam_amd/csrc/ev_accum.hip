@@ -793,6 +793,7 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
         S.sg = (w0 >> 31) ? -1.0f : 1.0f;
         // float index of the table value that falls on tile row 0 of column c: row (ty0 - yi + h) of stamp column (tx0 + c - xi + h)
         const int base = (int)__umul24(w0 & 0x7fffffffu, (uint32_t)P.stamp_stride) + (ty0 - yi + h);
+        const bool halfA = b0 <= 3, halfB = b1 >= 4;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
             const int cc = wave - 1 + k * NW;
@@ -800,8 +801,11 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
             // byte offset from the start of the front padding (scalar base + 32-bit lane offset: no 64-bit address arithmetic);
             // a column outside the rectangle reads the 8 zeros there
             const uint32_t off = in ? (uint32_t)(base + kStampPad + (int)__umul24((uint32_t)(tx0 + cc - xi + h), (uint32_t)SWP)) << 2 : 0u;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.c[k][0]) : "v"(off), "s"(tab0) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(S.c[k][1]) : "v"(off), "s"(tab0) : "memory");
+            // a half of the column (tile rows 0-3 / 4-7) that lies outside the rectangle reads the zeros too: 57 % of the entries
+            // touch one half of their tile only, and lanes that share an address share the request
+            const uint32_t offA = halfA ? off : 0u, offB = halfB ? off : 0u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.c[k][0]) : "v"(offA), "s"(tab0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(S.c[k][1]) : "v"(offB), "s"(tab0) : "memory");
         }
     };
     // wait until all but the n youngest loads have landed; the "+v" operands keep the uses of the set / entry behind the wait
