@@ -11,6 +11,8 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -23,7 +25,7 @@ struct Error : std::runtime_error {
     Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 
-// one context per calling thread (the ABI's threading contract)
+// one context per calling thread AT A TIME (the ABI's threading contract)
 class Context {
 public:
     explicit Context(int device = 0, void* hipStream = nullptr) {
@@ -35,11 +37,74 @@ public:
     Context& operator=(const Context&) = delete;
     eorb_ctx* get() const { return h_; }
     void check(int rc) const { if (rc != EORB_OK) throw Error(rc, eorb_last_error(h_)); }
+    unsigned maps_epoch = 0, voc_epoch = 0;          // which shared state of the pool this context has loaded
 private:
     eorb_ctx* h_ = nullptr;
 };
 
-inline Context& thread_context() { thread_local Context c; return c; }
+// Warm contexts shared by the threads of the process.  The reference calls the converters from long-lived tracker threads AND
+// from four transient std::threads per motion-compensated image (src/Event/EvImBuilder.cpp:1165-1193): a context per thread
+// would be created (device workspaces, pinned staging) and destroyed on every dispatch.  A thread borrows a context on its first
+// call and hands it back when it exits; state that the reference keeps in process-wide objects (the calibrator's undistortion maps,
+// the vocabulary) is recorded in the pool and loaded into a borrowed context that has not seen its current version yet.
+class ContextPool {
+public:
+    static ContextPool& instance() { static ContextPool p; return p; }
+    Context* acquire() {
+        Context* c = nullptr;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (!free_.empty()) { c = free_.back(); free_.pop_back(); }
+        }
+        if (!c) {
+            std::unique_ptr<Context> n(new Context());
+            c = n.get();
+            std::lock_guard<std::mutex> g(m_);
+            all_.push_back(std::move(n));
+        }
+        sync_state(*c);
+        return c;
+    }
+    void release(Context* c) { std::lock_guard<std::mutex> g(m_); free_.push_back(c); }
+    size_t created() const { std::lock_guard<std::mutex> g(m_); return all_.size(); }
+    // process-wide state
+    void set_maps(const std::vector<float>& mapX, const std::vector<float>& mapY, int LW, int LH, bool check) {
+        std::lock_guard<std::mutex> g(m_);
+        mapX_ = mapX; mapY_ = mapY; LW_ = LW; LH_ = LH; check_ = check; maps_epoch_++;
+    }
+    struct Voc { int L = 0; std::vector<int32_t> childOff, childIds, wordId; std::vector<uint8_t> nodeDesc; std::vector<double> weight; };
+    void set_vocabulary(Voc v) { std::lock_guard<std::mutex> g(m_); voc_ = std::move(v); voc_epoch_++; }
+    void sync_state(Context& c) {
+        std::lock_guard<std::mutex> g(m_);
+        if (c.maps_epoch != maps_epoch_) {
+            c.check(eorb_set_undistort_maps(c.get(), mapX_.data(), mapY_.data(), LW_, LH_, check_));
+            c.maps_epoch = maps_epoch_;
+        }
+        if (c.voc_epoch != voc_epoch_) {
+            c.check(eorb_bow_set_vocabulary(c.get(), (int)voc_.childOff.size() - 1, voc_.L, voc_.childOff.data(), voc_.childIds.data(),
+                                            voc_.nodeDesc.data(), voc_.wordId.data(), voc_.weight.data()));
+            c.voc_epoch = voc_epoch_;
+        }
+    }
+private:
+    mutable std::mutex m_;
+    std::vector<std::unique_ptr<Context>> all_;
+    std::vector<Context*> free_;
+    std::vector<float> mapX_, mapY_; int LW_ = 0, LH_ = 0; bool check_ = true; unsigned maps_epoch_ = 0;
+    Voc voc_; unsigned voc_epoch_ = 0;
+};
+
+// the calling thread's context: borrowed from the pool for the lifetime of the thread
+inline Context& thread_context() {
+    struct Lease {
+        Context* c;
+        Lease() : c(ContextPool::instance().acquire()) {}
+        ~Lease() { ContextPool::instance().release(c); }
+    };
+    thread_local Lease lease;
+    ContextPool::instance().sync_state(*lease.c);        // (a long-lived thread picks up maps / vocabulary set after it started)
+    return *lease.c;
+}
 
 // minimal stand-ins for cv::Mat (CV_8UC1 / CV_32FC1) and cv::KeyPoint
 template <typename T> struct Mat_ {
@@ -94,8 +159,7 @@ struct EvImConverter {
 struct EventDataStore {
     // MyCalibrator::mUndistMapX / mUndistMapY (LH x LW floats each) for this thread's context
     static void setUndistortMaps(const std::vector<float>& mapX, const std::vector<float>& mapY, int LW, int LH, bool checkInImage) {
-        auto& c = eorb_host::thread_context();
-        c.check(eorb_set_undistort_maps(c.get(), mapX.data(), mapY.data(), LW, LH, checkInImage));
+        eorb_host::ContextPool::instance().set_maps(mapX, mapY, LW, LH, checkInImage);      // every context of the process
     }
     // getline + parseLine + isComment over a text buffer (:80-92); throws eorb_host::Error for a line outside the grammar
     static std::vector<eorb_raw_event> parseText(const std::string& text) {
@@ -262,9 +326,10 @@ public:
     ORBVocabulary(int L, const std::vector<int32_t>& childOff, const std::vector<int32_t>& childIds, const eorb_host::Mat8& nodeDesc,
                   const std::vector<int32_t>& wordId, const std::vector<double>& weight, int weighting = 0, int norm = 1)
         : weighting_(weighting), norm_(norm) {
-        auto& c = eorb_host::thread_context();
-        c.check(eorb_bow_set_vocabulary(c.get(), (int)childOff.size() - 1, L, childOff.data(), childIds.data(), nodeDesc.ptr(),
-                                        wordId.data(), weight.data()));
+        eorb_host::ContextPool::Voc v;
+        v.L = L; v.childOff = childOff; v.childIds = childIds; v.wordId = wordId; v.weight = weight;
+        v.nodeDesc.assign(nodeDesc.ptr(), nodeDesc.ptr() + (size_t)nodeDesc.rows * nodeDesc.cols);
+        eorb_host::ContextPool::instance().set_vocabulary(std::move(v));                    // every context of the process
     }
     // transform(vCurrentDesc, mBowVec, mFeatVec, levelsup) (Frame::ComputeBoW)
     void transform(const eorb_host::Mat8& desc, std::vector<std::pair<uint32_t, double>>& bowVec, ORBmatcher::FeatureVector& featVec,

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = r'''
 #include "eorb_slam_amd/host/eorb_host.hpp"
 #include <cstdio>
+#include <thread>
 int main(int argc, char** argv) {
     if (argc < 2) { std::puts("linked"); return 0; }          // link check only (no GPU touched)
     try {
@@ -41,7 +42,24 @@ int main(int argc, char** argv) {
         eorb_host::Mat8 d(5, 32); for (int i = 0; i < 5 * 32; i++) d.ptr()[i] = (unsigned char)(i * 7 + (i / 32 == 3 ? 1 : 0));
         auto best = ORB_SLAM3::ComputeDistinctiveDescriptors(d, std::vector<int32_t>{0, 5});
         std::printf("raw=%zu kept=%zu same=%d best=%d\n", raw.size(), evs.size(), (int)same, best[0]);
-        return (mono == 0 && m1 == -1 && same && best[0] >= 0 && best[0] < 5) ? 0 : 1;
+        // transient threads (EvImBuilder.cpp:1165-1193 starts four per motion-compensated image) borrow warm contexts: three rounds
+        // of four threads must not create more than four contexts beyond the main thread's, and they see the maps set above
+        bool pool_ok = true;
+        for (int round = 0; round < 3; round++) {
+            std::vector<std::thread> th; std::vector<int> okv(4, 0);
+            for (int t = 0; t < 4; t++) th.emplace_back([&, t] {
+                eorb_host::Mat8 c8; eorb_host::Mat32f c32;
+                EORB_SLAM::EvImConverter::ev2im_gauss_raw(raw, 240, 180, 1.0f, true, false, c8, c32);
+                bool s2 = true;
+                for (int i = 0; i < 240 * 180 && s2; i++) s2 = c32.ptr()[i] == b32.ptr()[i];
+                okv[t] = s2;
+            });
+            for (auto& x : th) x.join();
+            for (int v : okv) pool_ok = pool_ok && v;
+        }
+        const size_t made = eorb_host::ContextPool::instance().created();
+        std::printf("pool contexts=%zu ok=%d\n", made, (int)pool_ok);
+        return (mono == 0 && m1 == -1 && same && best[0] >= 0 && best[0] < 5 && pool_ok && made <= 5) ? 0 : 1;
     } catch (const eorb_host::Error& e) { std::printf("error %d: %s\n", e.code, e.what()); return 2; }
 }
 '''
@@ -54,7 +72,7 @@ def _build(tmp):
     open(src, "w").write(SRC)
     libdir = os.path.dirname(lib)
     p = subprocess.run(["g++", "-std=c++14", "-Wall", "-I", ROOT, src, "-o", exe, "-L", libdir, "-leorb_fe",
-                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-pthread"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     return exe
 

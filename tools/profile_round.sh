@@ -1,13 +1,23 @@
 #!/bin/bash
-# usage: final_prof.sh <tag>  -> gpurun_out/<tag>_{bench.json,bench_float.json,kernel_stats.csv,pmc_traffic.txt}
+# usage: tools/profile_round.sh <tag>  (on the GPU box)
+#   -> gpurun_out/<tag>_{bench.json,bench_float.json,kernel_stats.csv,pmc_traffic.txt} for the default workload (w2) and
+#      gpurun_out/<tag>_{w1,w3,w4}_{bench.json,kernel_stats.csv}
 tag=$1
 R=$PWD
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || { tail -5 gpurun_out/${tag}_bench.err; exit 1; }
 python bench.py --input float --cpu-slices 0 > gpurun_out/${tag}_bench_float.json 2>> gpurun_out/${tag}_bench.err
+for w in w1 w3 w4; do
+  python bench.py --workload $w > gpurun_out/${tag}_${w}_bench.json 2>> gpurun_out/${tag}_bench.err || { tail -5 gpurun_out/${tag}_bench.err; exit 1; }
+done
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/st /tmp/f1 /tmp/f2
 rocprofv3 --kernel-trace --stats -d /tmp/st -o st --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-slices 0 --no-prof > /tmp/st.log 2>&1 || { tail -5 /tmp/st.log; exit 1; }
 cp $(find /tmp/st -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${tag}_kernel_stats.csv
+for w in w1 w3 w4; do
+  rm -rf /tmp/st_$w
+  rocprofv3 --kernel-trace --stats -d /tmp/st_$w -o st --output-format csv -- python3 $R/bench.py --workload $w --steps 5 --warmup 2 --cpu-slices 0 --no-prof --latency-calls 0 > /tmp/st_$w.log 2>&1 || { tail -5 /tmp/st_$w.log; exit 1; }
+  cp $(find /tmp/st_$w -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${tag}_${w}_kernel_stats.csv
+done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/f1 -o f1 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-slices 0 --no-prof > /tmp/f1.log 2>&1 || { tail -5 /tmp/f1.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/f2 -o f2 --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-slices 0 --no-prof > /tmp/f2.log 2>&1 || { tail -5 /tmp/f2.log; exit 1; }
 cd $R
