@@ -175,6 +175,121 @@ __device__ __forceinline__ void dev_dsincos(double x, double* sn, double* cs)
     }
 }
 
+// ---- tanf / atanf / atan2f: glibc's float algorithms (s_tanf.c + k_tanf.c with the sincosf.h double reduction; s_atanf.c;
+// e_atan2f.c), the operation sequences of oracle/orc_math.c written independently here; needed by KannalaBrandt8::unproject /
+// project (src/CameraModels/KannalaBrandt8.cpp:87-190).  Checked against the oracle over their whole domains by
+// eorb_selfcheck_math (which = 3, 4, 5), the oracle against the host glibc exhaustively (oracle/check_libm.c).
+__device__ __forceinline__ float dev_ktanf(float x, float y, int iy)
+{
+    const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f, T4 = 8.8632395491e-03f,
+                T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f, T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f,
+                T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f, T12 = 2.5907305826e-05f;
+    const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {
+        if ((int)x == 0) {
+            if ((ix | (iy + 1)) == 0) return 1.0f / fabsf(x);
+            return (iy == 1) ? x : -1.0f / x;
+        }
+    }
+    if (ix >= 0x3f2ca140) {
+        if (hx < 0) { x = -x; y = -y; }
+        const float z0 = pio4 - x;
+        const float w0 = pio4lo - y;
+        x = z0 + w0; y = 0.0f;
+        if (fabsf(x) < 0x1p-13f) return (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x);
+    }
+    float z = x * x;
+    float w = z * z;
+    float r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    float v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T0 * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    z = __uint_as_float(__float_as_uint(w) & 0xfffff000u);
+    v = r - (z - x);
+    const float a = -1.0f / w;
+    const float t = __uint_as_float(__float_as_uint(a) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+__device__ __forceinline__ float dev_tanf(float x)             // |x| < 120
+{
+    const int ix = (int)(__float_as_uint(x) & 0x7fffffffu);
+    if (ix <= 0x3f490fda) return dev_ktanf(x, 0.0f, 1);
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double xd = (double)x;
+    const double rr = xd * hpi_inv;
+    const int n = ((int)rr + 0x800000) >> 24;
+    const double xr = xd - (double)n * hpi;
+    const float y0 = (float)xr;
+    const float y1 = (float)(xr - (double)y0);
+    return dev_ktanf(y0, y1, 1 - ((n & 1) << 1));
+}
+__device__ __forceinline__ float dev_atanf(float x)
+{
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff;
+    int id;
+    float hi = 0.f, lo = 0.f;
+    if (ix >= 0x4c000000) {
+        if (ix > 0x7f800000) return x + x;
+        return (hx > 0) ? 1.5707962513e+00f + 7.5497894159e-08f : -1.5707962513e+00f - 7.5497894159e-08f;
+    }
+    if (ix < 0x3ee00000) {
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; hi = 4.6364760399e-01f; lo = 5.0121582440e-09f; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; hi = 7.8539812565e-01f; lo = 3.7748947079e-08f; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; hi = 9.8279368877e-01f; lo = 3.4473217170e-08f; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; hi = 1.5707962513e+00f; lo = 7.5497894159e-08f; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return (hx < 0) ? -r : r;
+}
+__device__ __forceinline__ float dev_atan2f(float y, float x)
+{
+    const float pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, tiny = 1.0e-30f;
+    const int hx = (int)__float_as_uint(x), ix = hx & 0x7fffffff, hy = (int)__float_as_uint(y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return dev_atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) { if (m < 2) return y; return (m == 2) ? pi + tiny : -pi - tiny; }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) { return (m == 0) ? pi_o_4 + tiny : (m == 1) ? -pi_o_4 - tiny : (m == 2) ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny; }
+        return (m == 0) ? 0.0f : (m == 1) ? -0.0f : (m == 2) ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = dev_atanf(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return __uint_as_float(__float_as_uint(z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
+
 __device__ __forceinline__ int dev_cvround(float v) { return __float2int_rn(v); }
 
 // popcount of a 256-bit XOR: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2360-2378)

@@ -14,9 +14,9 @@ int ev_decode_minmax(eorb_ctx* c, const uint32_t* d_enc, float* d_out, int B);
 int ev_divcheck(eorb_ctx* c, float lo, float hi, float sigma, unsigned long long* bad_out);
 int ev_diag_read(unsigned long long* out16);
 int ev_trace_read(unsigned long long* out, int n);
-int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], double angle,
+int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const eorb_camera* cam, double angle,
                     const double axis[3], const double tt[3], float medDepth, const float* d_depth);
-int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], const float* params, int nparams);
+int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const eorb_camera* cam, const float* params, int nparams);
 int ev_focus_dev(eorb_ctx* c, const float* d_img, int W, int H, float* d_out);
 int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm, uint8_t* d_out);
 int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out);
@@ -472,7 +472,7 @@ int eorb_ev2im_raw(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int W, int 
 }
 
 // ---- motion-compensated accumulation (f1) ----
-static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, int se3, double angle, const double* axis,
+static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_camera* cam, int se3, double angle, const double* axis,
                       const double* t, float medDepth, const float* depth, const float* params, int nparams, int W, int H,
                       float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
 {
@@ -502,9 +502,9 @@ static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pi
         d_depth = (const float*)c->m_b.p;
     }
     EORB_HIP(c, hipStreamSynchronize(c->stream));
-    const float camv[4] = {cam->fx, cam->fy, cam->cx, cam->cy};
-    if (se3) rc = ev_warp_se3_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, camv, angle, axis, t, medDepth, d_depth);
-    else rc = ev_warp_se2_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, camv, params, nparams);
+    if (cam->model != 0 && cam->model != 1) return set_err(c, EORB_E_ARG, "ev2mci: camera model %d unknown", cam->model);
+    if (se3) rc = ev_warp_se3_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, cam, angle, axis, t, medDepth, d_depth);
+    else rc = ev_warp_se2_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, cam, params, nparams);
     if (rc) return rc;
     int64_t offs[2] = {0, (int64_t)n};
     uint32_t* mm = (uint32_t*)c->minmax.p;
@@ -522,19 +522,36 @@ static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pi
     return EORB_OK;
 }
 
-int eorb_ev2mci_se3(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, double angle, const double axis[3],
-                    const double t[3], float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol,
-                    int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+static eorb_camera pinhole_cam(const eorb_pinhole* p) { eorb_camera c{}; if (p) { c.fx = p->fx; c.fy = p->fy; c.cx = p->cx; c.cy = p->cy; } return c; }
+
+int eorb_ev2mci_se3_cam(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_camera* cam, double angle, const double axis[3],
+                        const double t[3], float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol,
+                        int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
 {
     if (c && (!axis || !t)) return set_err(c, EORB_E_ARG, "ev2mci_se3: null pose");
     return mci_common(c, ev, n, cam, 1, angle, axis, t, medDepth, depth_per_event, nullptr, 0, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
 }
 
-int eorb_ev2mci_se2(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, const float* params2D, int nparams,
-                    int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+int eorb_ev2mci_se2_cam(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_camera* cam, const float* params2D, int nparams,
+                        int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
 {
     if (c && (!params2D || nparams < 3)) return set_err(c, EORB_E_ARG, "ev2mci_se2: need at least 3 parameters");
     return mci_common(c, ev, n, cam, 0, 0.0, nullptr, nullptr, 0.f, nullptr, params2D, nparams, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+}
+
+int eorb_ev2mci_se3(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, double angle, const double axis[3],
+                    const double t[3], float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol,
+                    int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    const eorb_camera cc = pinhole_cam(cam);
+    return eorb_ev2mci_se3_cam(c, ev, n, cam ? &cc : nullptr, angle, axis, t, medDepth, depth_per_event, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+}
+
+int eorb_ev2mci_se2(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinhole* cam, const float* params2D, int nparams,
+                    int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
+    const eorb_camera cc = pinhole_cam(cam);
+    return eorb_ev2mci_se2_cam(c, ev, n, cam ? &cc : nullptr, params2D, nparams, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
 }
 
 int eorb_measure_image_focus(eorb_ctx* c, const float* img, int W, int H, float* focus)
@@ -579,7 +596,7 @@ int eorb_selfcheck_division(eorb_ctx* c, float lo, float hi, float sigma, uint64
 
 int eorb_selfcheck_math(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, uint64_t* hash)
 {
-    if (!c || !hash || which < 0 || which > 2 || hi_bits < lo_bits) return c ? set_err(c, EORB_E_ARG, "selfcheck_math: bad arguments") : EORB_E_ARG;
+    if (!c || !hash || which < 0 || which > 5 || hi_bits < lo_bits) return c ? set_err(c, EORB_E_ARG, "selfcheck_math: bad arguments") : EORB_E_ARG;
     hipSetDevice(c->device);
     unsigned long long h = 0;
     int rc = ev_mathhash(c, which, lo_bits, hi_bits, &h);

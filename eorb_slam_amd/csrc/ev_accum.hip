@@ -994,8 +994,36 @@ __global__ void ev_decode_minmax_kernel(const uint32_t* mm, float* out, int B)
 // Motion-compensated accumulation: ev2mci_gg_f (src/Event/EventConversion.cc:280-531) = a per-event warp
 // followed by exactly the ev2im_gauss splat.  The warp kernels rewrite (x, y) of the 16-byte records; the splat is the
 // pipeline above.
+// GeometricCamera of the warp: model 0 = Pinhole (CameraModels/Pinhole.cpp:30-62), 1 = KannalaBrandt8 (KannalaBrandt8.cpp:87-190)
+struct WarpCam { int model; float fx, fy, cx, cy, k0, k1, k2, k3, precision; };
+
+// pCamera->unproject(cv::Point2f) -> (X, Y, 1)
+__device__ __forceinline__ void cam_unproject(const WarpCam& c, float x, float y, float& X, float& Y)
+{
+    const float pwx = (x - c.cx) / c.fx, pwy = (y - c.cy) / c.fy;
+    if (c.model == 0) { X = pwx; Y = pwy; return; }
+    // Newton iterations on theta, all in float (:164-187)
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf((float)(-3.1415926535897932384626433832795 / 2.f), theta_d), (float)(3.1415926535897932384626433832795 / 2.f));
+    if ((double)theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0_theta2 = c.k0 * theta2, k1_theta4 = c.k1 * theta4;
+            const float k2_theta6 = c.k2 * theta6, k3_theta8 = c.k3 * theta8;
+            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < c.precision) break;
+        }
+        scale = dev_tanf(theta) / theta_d;
+    }
+    X = pwx * scale; Y = pwy * scale;
+}
+
 struct WarpSE3 {
-    float fx, fy, cx, cy;
+    WarpCam cam;
     double angle, ax, ay, az, tx, ty, tz;
     float medDepth;
 };
@@ -1010,7 +1038,8 @@ __global__ void ev_warp_se3_kernel(const eorb_event16* __restrict__ in, eorb_eve
     const double invDT = 1.0 / DT;
     const eorb_event16 e = in[k];
     const double etRate = (t1 - fabs(e.t)) * invDT;
-    const float X = (e.x - P.cx) / P.fx, Y = (e.y - P.cy) / P.fy;          // Pinhole::unproject (float)
+    float X, Y;
+    cam_unproject(P.cam, e.x, e.y, X, Y);
     const double Pv[3] = {(double)X, (double)Y, 1.0};
     const double a = P.angle * etRate;
     double sn, c;
@@ -1036,14 +1065,28 @@ __global__ void ev_warp_se3_kernel(const eorb_event16* __restrict__ in, eorb_eve
         const double acc = a0 + (a1 + a2);
         np[i] = acc + tt[i] * etRate;
     }
-    const double u = (double)P.fx * np[0] / np[2] + (double)P.cx;            // Pinhole::project(Eigen::Vector3d)
-    const double v = (double)P.fy * np[1] / np[2] + (double)P.cy;
+    double u, v;
+    if (P.cam.model == 0) {
+        u = (double)P.cam.fx * np[0] / np[2] + (double)P.cam.cx;            // Pinhole::project(Eigen::Vector3d)
+        v = (double)P.cam.fy * np[1] / np[2] + (double)P.cam.cy;
+    } else {
+        // KannalaBrandt8::project(Eigen::Vector3d) (:111-133): atan2f / sqrtf on the float-converted arguments, the rest in double
+        const double x2_plus_y2 = np[0] * np[0] + np[1] * np[1];
+        const double theta = (double)dev_atan2f(sqrtf((float)x2_plus_y2), (float)np[2]);
+        const double psi = (double)dev_atan2f((float)np[1], (float)np[0]);
+        const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+        const double r = theta + (double)P.cam.k0 * theta3 + (double)P.cam.k1 * theta5 + (double)P.cam.k2 * theta7 + (double)P.cam.k3 * theta9;
+        double ps, pc;
+        dev_dsincos(psi, &ps, &pc);
+        u = (double)P.cam.fx * r * pc + (double)P.cam.cx;
+        v = (double)P.cam.fy * r * ps + (double)P.cam.cy;
+    }
     eorb_event16 o = e;
     o.x = (float)u; o.y = (float)v;
     out[k] = o;
 }
 
-struct WarpSE2 { float fx, fy, cx, cy, p0, p1, p2, sc; };
+struct WarpSE2 { WarpCam cam; float p0, p1, p2, sc; };
 
 __global__ void ev_warp_se2_kernel(const eorb_event16* __restrict__ in, eorb_event16* __restrict__ out, int n, WarpSE2 P)
 {
@@ -1056,7 +1099,8 @@ __global__ void ev_warp_se2_kernel(const eorb_event16* __restrict__ in, eorb_eve
     const float scDiff = 1.f - P.sc;
     const eorb_event16 e = in[k];
     const float tk = (float)(t1 - fabs(e.t));
-    const float X = (e.x - P.cx) / P.fx, Y = (e.y - P.cy) / P.fy;
+    float X, Y;
+    cam_unproject(P.cam, e.x, e.y, X, Y);
     const float theta_k = tk * omega0;
     const float currSc = scDiff * (1 - tk * invDT) + P.sc;
     float sn, cs;
@@ -1064,26 +1108,44 @@ __global__ void ev_warp_se2_kernel(const eorb_event16* __restrict__ in, eorb_eve
     const float xp = currSc * (X * cs - Y * sn) + vx0 * tk;
     const float yp = currSc * (X * sn + Y * cs) + vy0 * tk;
     eorb_event16 o = e;
-    o.x = P.fx * xp / 1.f + P.cx;                                            // Pinhole::project(cv::Point3f)
-    o.y = P.fy * yp / 1.f + P.cy;
+    if (P.cam.model == 0) {
+        o.x = P.cam.fx * xp / 1.f + P.cam.cx;                                // Pinhole::project(cv::Point3f)
+        o.y = P.cam.fy * yp / 1.f + P.cam.cy;
+    } else {
+        // KannalaBrandt8::project(cv::Point3f(xp, yp, 1.f)) (:87-103), float throughout
+        const float x2_plus_y2 = xp * xp + yp * yp;
+        const float theta = dev_atan2f(sqrtf(x2_plus_y2), 1.f);
+        const float psi = dev_atan2f(yp, xp);
+        const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+        const float r = theta + P.cam.k0 * theta3 + P.cam.k1 * theta5 + P.cam.k2 * theta7 + P.cam.k3 * theta9;
+        float ps, pc;
+        dev_sincosf(psi, &ps, &pc);
+        o.x = P.cam.fx * r * pc + P.cam.cx;
+        o.y = P.cam.fy * r * ps + P.cam.cy;
+    }
     out[k] = o;
 }
 
-int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], double angle,
+static WarpCam warp_cam(const eorb_camera* cam)
+{
+    return WarpCam{cam->model, cam->fx, cam->fy, cam->cx, cam->cy, cam->k[0], cam->k[1], cam->k[2], cam->k[3], cam->precision};
+}
+
+int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const eorb_camera* cam, double angle,
                     const double axis[3], const double tt[3], float medDepth, const float* d_depth)
 {
     if (n <= 0) return EORB_OK;
-    WarpSE3 P{cam[0], cam[1], cam[2], cam[3], angle, axis[0], axis[1], axis[2], tt[0], tt[1], tt[2], medDepth};
+    WarpSE3 P{warp_cam(cam), angle, axis[0], axis[1], axis[2], tt[0], tt[1], tt[2], medDepth};
     ProfScope ps(c, "ev_warp_se3");
     ev_warp_se3_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d_in, d_out, n, P, d_depth);
     EORB_LAUNCH_CHECK(c, "ev_warp_se3_kernel");
     return EORB_OK;
 }
 
-int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const float cam[4], const float* params, int nparams)
+int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const eorb_camera* cam, const float* params, int nparams)
 {
     if (n <= 0) return EORB_OK;
-    WarpSE2 P{cam[0], cam[1], cam[2], cam[3], params[0], params[1], params[2], nparams > 3 ? params[3] : 1.f};
+    WarpSE2 P{warp_cam(cam), params[0], params[1], params[2], nparams > 3 ? params[3] : 1.f};
     ProfScope ps(c, "ev_warp_se2");
     ev_warp_se2_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(d_in, d_out, n, P);
     EORB_LAUNCH_CHECK(c, "ev_warp_se2_kernel");
@@ -1603,8 +1665,28 @@ __global__ void ev_mathhash_kernel(int which, uint32_t lo_bits, uint32_t hi_bits
         const float x = __uint_as_float(ub);
         float y;
         if (which == 0) y = dev_expf_nonpos<true>(-x, tab);
+        else if (which == 3) y = dev_tanf(x);
+        else if (which == 4) y = dev_atanf(x);
         else { float sn, cs; dev_sincosf(x, &sn, &cs); y = (which == 1) ? sn : cs; }
         h += (((unsigned long long)ub * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)__float_as_uint(y)) * 0xC2B2AE3D27D4EB4Full;
+    }
+    atomicAdd(out, h);
+}
+
+// atan2f over generated (y, x) pairs first .. first + count - 1 (the generator of oracle/orc_math.c: orc_atan2_pair)
+__global__ void ev_atan2hash_kernel(unsigned long long first, unsigned long long count, unsigned long long* out)
+{
+    unsigned long long h = 0;
+    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < count; j += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long i = first + j;
+        unsigned long long s = (i + 1) * 0x9E3779B97F4A7C15ull;
+        s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32;
+        float y, x;
+        if (i & 1) { y = (float)((int)(s & 0xffff) - 32768) / 97.0f; x = (float)((int)((s >> 20) & 0xffff) - 32768) / 89.0f; }
+        else { y = __uint_as_float((uint32_t)s); x = __uint_as_float((uint32_t)(s >> 32)); }
+        if (y != y || x != x) continue;
+        const uint32_t rb = __float_as_uint(dev_atan2f(y, x));
+        h += ((i * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)rb) * 0xC2B2AE3D27D4EB4Full;
     }
     atomicAdd(out, h);
 }
@@ -1614,7 +1696,9 @@ int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsi
     int rc;
     if ((rc = ensure(c, c->minmax, 64))) return rc;
     EORB_HIP(c, hipMemsetAsync(c->minmax.p, 0, 8, c->stream));
-    ev_mathhash_kernel<<<2048, 256, 0, c->stream>>>(which, lo_bits, hi_bits, (unsigned long long*)c->minmax.p);
+    if (which == 5) ev_atan2hash_kernel<<<2048, 256, 0, c->stream>>>((unsigned long long)lo_bits << 20, ((unsigned long long)(hi_bits - lo_bits) + 1) << 20,
+                                                                     (unsigned long long*)c->minmax.p);      // pairs [lo << 20, (hi + 1) << 20)
+    else ev_mathhash_kernel<<<2048, 256, 0, c->stream>>>(which, lo_bits, hi_bits, (unsigned long long*)c->minmax.p);
     EORB_LAUNCH_CHECK(c, "ev_mathhash_kernel");
     EORB_HIP(c, hipMemcpyAsync(out, c->minmax.p, 8, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));

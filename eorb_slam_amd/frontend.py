@@ -194,14 +194,14 @@ class EvImConverter:
     def ev2mci_gg_f_se3(vEvData, cam, angle, axis, t, medDepth, imWidth, imHeight, sigma=1.0, pol=False, normalized=False,
                         depth_per_event=None, ctx=None):
         """ev2mci_gg_f(evs, pCamera, Tcw, medDepth | depth map, ...) (src/Event/EventConversion.cc:280-360, 451-531); cam =
-        (fx, fy, cx, cy); angle/axis = AngleAxisd(R(Tcw)), t = translation.  Returns (f32 image, u8 image|None, minmax)."""
+        (fx, fy, cx, cy) for a Pinhole, (fx, fy, cx, cy, k1, k2, k3, k4) for a KannalaBrandt8 camera; angle/axis = AngleAxisd(R(Tcw)), t = translation.  Returns (f32 image, u8 image|None, minmax)."""
         ctx = ctx or default_context()
         ev = np.ascontiguousarray(vEvData, EVENT_DTYPE)
         ax = np.ascontiguousarray(axis, np.float64); tt = np.ascontiguousarray(t, np.float64)
         dp = None if depth_per_event is None else np.ascontiguousarray(depth_per_event, np.float32)
         f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8); mm = np.zeros(2, np.float32)
-        pc = _lib.Pinhole(*cam)
-        ctx.check(ctx.L.eorb_ev2mci_se3(ctx.h, _p(ev), len(ev), C.byref(pc), float(angle), _p(ax), _p(tt), float(medDepth), _p(dp),
+        pc = _lib.camera(cam)
+        ctx.check(ctx.L.eorb_ev2mci_se3_cam(ctx.h, _p(ev), len(ev), C.byref(pc), float(angle), _p(ax), _p(tt), float(medDepth), _p(dp),
                                         imWidth, imHeight, float(sigma), int(pol), int(normalized), _p(f32), _p(u8), _p(mm)))
         return f32, (u8 if (normalized and len(ev)) else None), mm
 
@@ -212,8 +212,8 @@ class EvImConverter:
         ev = np.ascontiguousarray(vEvData, EVENT_DTYPE)
         pr = np.ascontiguousarray(params2D, np.float32)
         f32 = np.empty((imHeight, imWidth), np.float32); u8 = np.zeros((imHeight, imWidth), np.uint8); mm = np.zeros(2, np.float32)
-        pc = _lib.Pinhole(*cam)
-        ctx.check(ctx.L.eorb_ev2mci_se2(ctx.h, _p(ev), len(ev), C.byref(pc), _p(pr), len(pr), imWidth, imHeight, float(sigma),
+        pc = _lib.camera(cam)
+        ctx.check(ctx.L.eorb_ev2mci_se2_cam(ctx.h, _p(ev), len(ev), C.byref(pc), _p(pr), len(pr), imWidth, imHeight, float(sigma),
                                         int(pol), int(normalized), _p(f32), _p(u8), _p(mm)))
         return f32, (u8 if (normalized and len(ev)) else None), mm
 

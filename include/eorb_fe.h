@@ -163,6 +163,15 @@ int eorb_ev2mci_se3(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eorb_pi
 /* replaces the SE2 overload (params2D = {omega, vx, vy[, scale]}), src/Event/EventConversion.cc:363-448 */
 int eorb_ev2mci_se2(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eorb_pinhole* cam, const float* params2D, int nparams,
                     int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+/* GeometricCamera of the motion-compensated images: model 0 = Pinhole (fx, fy, cx, cy), 1 = KannalaBrandt8 (+ k[0..3] =
+ * mvParameters[4..7], precision = KB8_DEF_PRECISION 1e-6: include/CameraModels/KannalaBrandt8.h:36; the MVSEC configuration,
+ * Examples/Event/EvMVSEC_ETHZ.yaml:54-67).  unproject / project follow src/CameraModels/KannalaBrandt8.cpp:87-190. */
+typedef struct { int model; float fx, fy, cx, cy; float k[4]; float precision; } eorb_camera;
+int eorb_ev2mci_se3_cam(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eorb_camera* cam, double angle,
+                        const double axis[3], const double t[3], float medDepth, const float* depth_per_event,
+                        int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+int eorb_ev2mci_se2_cam(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eorb_camera* cam, const float* params2D, int nparams,
+                        int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
 /* replaces EvImConverter::measureImageFocus (src/Event/EventConversion.cc:74-111) */
 int eorb_measure_image_focus(eorb_ctx* ctx, const float* img, int W, int H, float* focus);
 /* replaces cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) at src/Event/EvImBuilder.cpp:976,1055,1076,1140 */

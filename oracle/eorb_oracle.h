@@ -65,11 +65,18 @@ typedef struct {
 float orc_expf(float x);            /* glibc>=2.28 expf algorithm, strict IEEE double, no FMA   */
 float orc_sinf(float x);            /* glibc>=2.28 sinf algorithm (valid for |x| < 120)         */
 float orc_cosf(float x);
+float orc_tanf(float x);            /* glibc>=2.28 tanf (valid for |x| < 120)                   */
+float orc_atanf(float x);           /* glibc atanf / atan2f (fdlibm float)                      */
+float orc_atan2f(float y, float x);
 float orc_fast_atan2(float y, float x);   /* OpenCV 3.4 cv::fastAtan2 polynomial, degrees     */
 int   orc_cvround(double v);              /* cvRound: round-half-to-even                        */
 /* order-independent 64-bit hash of f over every float whose bit pattern is in [lo_bits, hi_bits] (which: 0 expf(-x),
- * 1 sinf(x), 2 cosf(x)); the device computes the same hash of its own functions (eorb_selfcheck_math). */
+ * 1 sinf(x), 2 cosf(x), 3 tanf(x), 4 atanf(x)); the device computes the same hash of its own functions (eorb_selfcheck_math). */
 uint64_t orc_math_hash(int which, uint32_t lo_bits, uint32_t hi_bits);
+/* atan2f over the generated pairs first .. first + count - 1 (orc_atan2_pair: every other pair raw bit patterns, the others small
+ * rationals); which = 5 of eorb_selfcheck_math */
+void orc_atan2_pair(uint64_t i, float* y, float* x);
+uint64_t orc_atan2_hash(uint64_t first, uint64_t count);
 
 /* ---- event accumulation: src/Event/EventConversion.cc ------------------------------------ */
 
@@ -107,6 +114,19 @@ size_t orc_undistort_events(const orc_raw_event* raw, size_t n, const float* map
 long orc_parse_events_text(const char* text, size_t nbytes, orc_raw_event* out, size_t cap);
 
 typedef struct { float fx, fy, cx, cy; } orc_pinhole;          /* Pinhole::mvParameters (float), CameraModels/Pinhole.cpp */
+/* GeometricCamera: model 0 = Pinhole, 1 = KannalaBrandt8 (mvParameters[4..7] = k1..k4, precision = KB8_DEF_PRECISION 1e-6) */
+typedef struct { int model; float fx, fy, cx, cy; float k[4]; float precision; } orc_camera;
+void orc_mci_warp_se3_cam(const orc_event* ev, size_t n, const orc_camera* cam, double angle, const double axis[3],
+                          const double tt[3], float medDepth, const float* depth_per_event, float* uv_out);
+void orc_mci_warp_se2_cam(const orc_event* ev, size_t n, const orc_camera* cam, const float* params2D, int nparams, float* uv_out);
+int orc_ev2mci_se3_cam(const orc_event* ev, size_t n, const orc_camera* cam, double angle, const double axis[3], const double tt[3],
+                       float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol, int normalized,
+                       float* out_f32, uint8_t* out_u8, float* minmax);
+int orc_ev2mci_se2_cam(const orc_event* ev, size_t n, const orc_camera* cam, const float* params2D, int nparams,
+                       int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
+/* sinf / cosf for any finite angle of interest here (|x| < 120; negative arguments by symmetry) */
+float orc_sinf_any(float x);
+float orc_cosf_any(float x);
 
 /* per-event warp of ev2mci_gg_f(evs, cam, Tcw, medDepth, ...) (:304-335): angle/axis = Eigen::AngleAxisd(R) and tt = t of
  * Tcw, computed by the caller (host, once per call).  depth_per_event != NULL replaces medDepth per event (depth-map

@@ -27,6 +27,23 @@ class Pinhole(C.Structure):
     _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("model", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("k", C.c_float * 4), ("precision", C.c_float)]
+
+
+def _camera(cam):
+    """(fx, fy, cx, cy) -> Pinhole; (fx, fy, cx, cy, k1, k2, k3, k4[, precision]) -> KannalaBrandt8"""
+    c = Camera()
+    c.fx, c.fy, c.cx, c.cy = [float(v) for v in cam[:4]]
+    if len(cam) > 4:
+        c.model = 1
+        for i in range(4):
+            c.k[i] = float(cam[4 + i])
+        c.precision = float(cam[8]) if len(cam) > 8 else 1e-6
+    return c
+
+
 class GridBounds(C.Structure):
     _fields_ = [("minX", C.c_float), ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float),
                 ("invW", C.c_float), ("invH", C.c_float)]
@@ -57,6 +74,10 @@ def lib(fast=False):
     L.orc_fast_atan2.restype = cf; L.orc_fast_atan2.argtypes = [cf, cf]
     L.orc_cvround.restype = ci; L.orc_cvround.argtypes = [C.c_double]
     L.orc_math_hash.restype = C.c_uint64; L.orc_math_hash.argtypes = [ci, C.c_uint32, C.c_uint32]
+    L.orc_atan2_hash.restype = C.c_uint64; L.orc_atan2_hash.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_tanf.restype = cf; L.orc_tanf.argtypes = [cf]
+    L.orc_atanf.restype = cf; L.orc_atanf.argtypes = [cf]
+    L.orc_atan2f.restype = cf; L.orc_atan2f.argtypes = [cf, cf]
     L.orc_ev2im.restype = ci
     L.orc_ev2im.argtypes = [vp, C.c_size_t, ci, ci, ci, ci, vp, vp, vp]
     L.orc_ev2im_gauss.restype = ci
@@ -71,6 +92,10 @@ def lib(fast=False):
     L.orc_ev2mci_se3.argtypes = [vp, C.c_size_t, C.POINTER(Pinhole), cd, vp, vp, cf, vp, ci, ci, cf, ci, ci, vp, vp, vp]
     L.orc_ev2mci_se2.restype = ci
     L.orc_ev2mci_se2.argtypes = [vp, C.c_size_t, C.POINTER(Pinhole), vp, ci, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.orc_ev2mci_se3_cam.restype = ci
+    L.orc_ev2mci_se3_cam.argtypes = [vp, C.c_size_t, C.POINTER(Camera), cd, vp, vp, cf, vp, ci, ci, cf, ci, ci, vp, vp, vp]
+    L.orc_ev2mci_se2_cam.restype = ci
+    L.orc_ev2mci_se2_cam.argtypes = [vp, C.c_size_t, C.POINTER(Camera), vp, ci, ci, ci, cf, ci, ci, vp, vp, vp]
     L.orc_measure_image_focus.restype = cf; L.orc_measure_image_focus.argtypes = [vp, ci, ci]
     L.orc_cv_normalize_minmax_u8.restype = None; L.orc_cv_normalize_minmax_u8.argtypes = [vp, C.c_size_t, vp]
     L.orc_normalize_u8.restype = None
@@ -403,8 +428,8 @@ def ev2mci_se3(ev, cam, angle, axis, tt, medDepth, W, H, sigma=1.0, pol=False, n
     ax = np.ascontiguousarray(axis, np.float64); t = np.ascontiguousarray(tt, np.float64)
     dp = None if depth is None else np.ascontiguousarray(depth, np.float32)
     f32 = np.empty((H, W), np.float32); u8 = np.zeros((H, W), np.uint8); mm = np.zeros(2, np.float32)
-    pc = Pinhole(*cam)
-    r = lib().orc_ev2mci_se3(_p(ev), len(ev), C.byref(pc), float(angle), _p(ax), _p(t), float(medDepth), _p(dp), W, H,
+    pc = _camera(cam)
+    r = lib().orc_ev2mci_se3_cam(_p(ev), len(ev), C.byref(pc), float(angle), _p(ax), _p(t), float(medDepth), _p(dp), W, H,
                              float(sigma), int(pol), int(normalized), _p(f32), _p(u8), _p(mm))
     return f32, (u8 if r else None), mm
 
@@ -413,8 +438,8 @@ def ev2mci_se2(ev, cam, params2D, W, H, sigma=1.0, pol=False, normalized=False):
     ev = np.ascontiguousarray(ev, EVENT_DTYPE)
     pr = np.ascontiguousarray(params2D, np.float32)
     f32 = np.empty((H, W), np.float32); u8 = np.zeros((H, W), np.uint8); mm = np.zeros(2, np.float32)
-    pc = Pinhole(*cam)
-    r = lib().orc_ev2mci_se2(_p(ev), len(ev), C.byref(pc), _p(pr), len(pr), W, H, float(sigma), int(pol), int(normalized),
+    pc = _camera(cam)
+    r = lib().orc_ev2mci_se2_cam(_p(ev), len(ev), C.byref(pc), _p(pr), len(pr), W, H, float(sigma), int(pol), int(normalized),
                              _p(f32), _p(u8), _p(mm))
     return f32, (u8 if r else None), mm
 

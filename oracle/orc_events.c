@@ -97,15 +97,62 @@ int orc_ev2im_gauss(const orc_event* ev, size_t n, int W, int H, float sigma, in
 }
 
 /* ---- motion-compensated accumulation: EventConversion.cc:280-531 ------------------------------------------------- */
-/* Pinhole::unproject (CameraModels/Pinhole.cpp:59-62), float */
-static inline void pin_unproject(const orc_pinhole* c, float x, float y, float* X, float* Y)
+/* KannalaBrandt8::unproject (src/CameraModels/KannalaBrandt8.cpp:163-190): Newton iterations on theta in float, std::tan(float) */
+static void kb8_unproject(const orc_camera* c, float x, float y, float* X, float* Y)
 {
-    *X = (x - c->cx) / c->fx;
-    *Y = (y - c->cy) / c->fy;
+    const float pwx = (x - c->cx) / c->fx, pwy = (y - c->cy) / c->fy;
+    float scale = 1.f;
+    float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+    theta_d = fminf(fmaxf((float)(-3.1415926535897932384626433832795 / 2.f), theta_d), (float)(3.1415926535897932384626433832795 / 2.f));
+    if ((double)theta_d > 1e-8) {
+        float theta = theta_d;
+        for (int j = 0; j < 10; j++) {
+            const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+            const float k0_theta2 = c->k[0] * theta2, k1_theta4 = c->k[1] * theta4;
+            const float k2_theta6 = c->k[2] * theta6, k3_theta8 = c->k[3] * theta8;
+            const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                                    (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+            theta = theta - theta_fix;
+            if (fabsf(theta_fix) < c->precision) break;
+        }
+        scale = orc_tanf(theta) / theta_d;
+    }
+    *X = pwx * scale; *Y = pwy * scale;
+}
+/* KannalaBrandt8::project(cv::Point3f) (:87-103); cos / sin of the float angle resolve to the float overloads (<math.h> of
+ * libstdc++ is reached through opencv2/opencv.hpp -> flann/lsh_table.h: unpinned, as for the other libm calls) */
+static void kb8_project_f(const orc_camera* c, float X, float Y, float Z, float* u, float* v)
+{
+    const float x2_plus_y2 = X * X + Y * Y;
+    const float theta = orc_atan2f(sqrtf(x2_plus_y2), Z);
+    const float psi = orc_atan2f(Y, X);
+    const float theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const float r = theta + c->k[0] * theta3 + c->k[1] * theta5 + c->k[2] * theta7 + c->k[3] * theta9;
+    *u = c->fx * r * orc_cosf_any(psi) + c->cx;
+    *v = c->fy * r * orc_sinf_any(psi) + c->cy;
+}
+/* KannalaBrandt8::project(Eigen::Vector3d) (:111-133): atan2f / sqrtf on the float-converted arguments, the polynomial and
+ * cos / sin in double */
+static void kb8_project_d(const orc_camera* c, const double P[3], double* u, double* v)
+{
+    const double x2_plus_y2 = P[0] * P[0] + P[1] * P[1];
+    const double theta = (double)orc_atan2f(sqrtf((float)x2_plus_y2), (float)P[2]);
+    const double psi = (double)orc_atan2f((float)P[1], (float)P[0]);
+    const double theta2 = theta * theta, theta3 = theta * theta2, theta5 = theta3 * theta2, theta7 = theta5 * theta2, theta9 = theta7 * theta2;
+    const double r = theta + (double)c->k[0] * theta3 + (double)c->k[1] * theta5 + (double)c->k[2] * theta7 + (double)c->k[3] * theta9;
+    *u = (double)c->fx * r * orc_dcos(psi) + (double)c->cx;
+    *v = (double)c->fy * r * orc_dsin(psi) + (double)c->cy;
 }
 
 void orc_mci_warp_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, double angle, const double axis[3],
                       const double tt[3], float medDepth, const float* depth_per_event, float* uv)
+{
+    const orc_camera c = {0, cam->fx, cam->fy, cam->cx, cam->cy, {0.f, 0.f, 0.f, 0.f}, 0.f};
+    orc_mci_warp_se3_cam(ev, n, &c, angle, axis, tt, medDepth, depth_per_event, uv);
+}
+
+void orc_mci_warp_se3_cam(const orc_event* ev, size_t n, const orc_camera* cam, double angle, const double axis[3],
+                          const double tt[3], float medDepth, const float* depth_per_event, float* uv)
 {
     if (n == 0) return;
     const double t1 = ev[n - 1].ts;
@@ -114,7 +161,8 @@ void orc_mci_warp_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, dou
     for (size_t k = 0; k < n; k++) {
         const double etRate = (t1 - ev[k].ts) * invDT;
         float X, Y;
-        pin_unproject(cam, ev[k].x, ev[k].y, &X, &Y);
+        if (cam->model == 1) kb8_unproject(cam, ev[k].x, ev[k].y, &X, &Y);
+        else { X = (ev[k].x - cam->cx) / cam->fx; Y = (ev[k].y - cam->cy) / cam->fy; }       /* Pinhole::unproject (Pinhole.cpp:59-62) */
         const double P[3] = { (double)X, (double)Y, (double)1.f };
         /* Eigen::AngleAxisd(omega.angle()*etRate, omega.axis()).toRotationMatrix() */
         const double a = angle * etRate;
@@ -139,14 +187,23 @@ void orc_mci_warp_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, dou
             const double acc = a0 + (a1 + a2);
             np[i] = acc + tt[i] * etRate;
         }
-        /* Pinhole::project(Eigen::Vector3d) :41-47 */
-        const double u = (double)cam->fx * np[0] / np[2] + (double)cam->cx;
-        const double v = (double)cam->fy * np[1] / np[2] + (double)cam->cy;
+        double u, v;
+        if (cam->model == 1) kb8_project_d(cam, np, &u, &v);
+        else {                                         /* Pinhole::project(Eigen::Vector3d) :41-47 */
+            u = (double)cam->fx * np[0] / np[2] + (double)cam->cx;
+            v = (double)cam->fy * np[1] / np[2] + (double)cam->cy;
+        }
         uv[2 * k] = (float)u; uv[2 * k + 1] = (float)v;
     }
 }
 
 void orc_mci_warp_se2(const orc_event* ev, size_t n, const orc_pinhole* cam, const float* params2D, int nparams, float* uv)
+{
+    const orc_camera c = {0, cam->fx, cam->fy, cam->cx, cam->cy, {0.f, 0.f, 0.f, 0.f}, 0.f};
+    orc_mci_warp_se2_cam(ev, n, &c, params2D, nparams, uv);
+}
+
+void orc_mci_warp_se2_cam(const orc_event* ev, size_t n, const orc_camera* cam, const float* params2D, int nparams, float* uv)
 {
     if (n == 0) return;
     const double t1 = ev[n - 1].ts;
@@ -159,16 +216,19 @@ void orc_mci_warp_se2(const orc_event* ev, size_t n, const orc_pinhole* cam, con
     for (size_t k = 0; k < n; k++) {
         const float tk = (float)(t1 - ev[k].ts);
         float X, Y;
-        pin_unproject(cam, ev[k].x, ev[k].y, &X, &Y);
+        if (cam->model == 1) kb8_unproject(cam, ev[k].x, ev[k].y, &X, &Y);
+        else { X = (ev[k].x - cam->cx) / cam->fx; Y = (ev[k].y - cam->cy) / cam->fy; }
         const float Z = 1.f;
         const float theta_k = tk * omega0;
         const float currSc = scDiff * (1 - tk * invDT) + sc;
         const float cs = orc_cosf(theta_k), sn = orc_sinf(theta_k);
         const float xp = currSc * (X * cs - Y * sn) + vx0 * tk;
         const float yp = currSc * (X * sn + Y * cs) + vy0 * tk;
-        /* Pinhole::project(cv::Point3f) :30-33 */
-        uv[2 * k] = cam->fx * xp / Z + cam->cx;
-        uv[2 * k + 1] = cam->fy * yp / Z + cam->cy;
+        if (cam->model == 1) kb8_project_f(cam, xp, yp, Z, &uv[2 * k], &uv[2 * k + 1]);
+        else {                                         /* Pinhole::project(cv::Point3f) :30-33 */
+            uv[2 * k] = cam->fx * xp / Z + cam->cx;
+            uv[2 * k + 1] = cam->fy * yp / Z + cam->cy;
+        }
     }
 }
 
@@ -186,13 +246,21 @@ int orc_ev2mci_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, double
                    float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol, int normalized,
                    float* out_f32, uint8_t* out_u8, float* minmax)
 {
+    const orc_camera c = {0, cam->fx, cam->fy, cam->cx, cam->cy, {0.f, 0.f, 0.f, 0.f}, 0.f};
+    return orc_ev2mci_se3_cam(ev, n, &c, angle, axis, tt, medDepth, depth_per_event, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+}
+
+int orc_ev2mci_se3_cam(const orc_event* ev, size_t n, const orc_camera* cam, double angle, const double axis[3], const double tt[3],
+                       float medDepth, const float* depth_per_event, int W, int H, float sigma, int pol, int normalized,
+                       float* out_f32, uint8_t* out_u8, float* minmax)
+{
     if (n == 0) {                       /* "no events": returns the zero CV_32FC1 image (:292-295) */
         memset(out_f32, 0, sizeof(float) * (size_t)W * H);
         if (minmax) { minmax[0] = 0.f; minmax[1] = -1000000.0f; }
         return 0;
     }
     float* uv = (float*)malloc(sizeof(float) * 2 * n);
-    orc_mci_warp_se3(ev, n, cam, angle, axis, tt, medDepth, depth_per_event, uv);
+    orc_mci_warp_se3_cam(ev, n, cam, angle, axis, tt, medDepth, depth_per_event, uv);
     int r = mci_splat(ev, n, uv, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
     free(uv);
     return r;
@@ -201,13 +269,20 @@ int orc_ev2mci_se3(const orc_event* ev, size_t n, const orc_pinhole* cam, double
 int orc_ev2mci_se2(const orc_event* ev, size_t n, const orc_pinhole* cam, const float* params2D, int nparams,
                    int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
 {
+    const orc_camera c = {0, cam->fx, cam->fy, cam->cx, cam->cy, {0.f, 0.f, 0.f, 0.f}, 0.f};
+    return orc_ev2mci_se2_cam(ev, n, &c, params2D, nparams, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
+}
+
+int orc_ev2mci_se2_cam(const orc_event* ev, size_t n, const orc_camera* cam, const float* params2D, int nparams,
+                       int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax)
+{
     if (n == 0) {
         memset(out_f32, 0, sizeof(float) * (size_t)W * H);
         if (minmax) { minmax[0] = 0.f; minmax[1] = -1000000.0f; }
         return 0;
     }
     float* uv = (float*)malloc(sizeof(float) * 2 * n);
-    orc_mci_warp_se2(ev, n, cam, params2D, nparams, uv);
+    orc_mci_warp_se2_cam(ev, n, cam, params2D, nparams, uv);
     int r = mci_splat(ev, n, uv, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
     free(uv);
     return r;

@@ -15,6 +15,11 @@
  *           there) and on every float in [-32, 0).
  *   sinf/cosf : glibc >= 2.28 s_sinf.c / s_cosf.c / sincosf.h (fast path |x| < 120).
  *           Host glibc 2.35 agrees on all 189 792 257 floats in [2^-20, 6.5].
+ *   tanf  : glibc >= 2.28 s_tanf.c (|x| <= pi/4: kernel; else the double reduction of sincosf.h, the reduced argument split into
+ *           float hi + lo) + k_tanf.c (fdlibm float kernel with glibc's early return for |pi/4 - x| < 2^-13).
+ *           Host glibc 2.35 agrees on all 2 150 419 662 floats in [-2.35, 2.35] (the domain KannalaBrandt8::unproject needs).
+ *   atanf / atan2f : glibc s_atanf.c / e_atan2f.c (fdlibm float).  Host glibc 2.35 agrees on all 2 139 095 040 positive
+ *           floats (atanf is odd) and on 398 439 896 pseudo-random / structured (y, x) pairs.
  * OpenCV restatements: cvRound (round half to even), cv::fastAtan2 (mathfuncs_core, 3.4.x).
  */
 #include "eorb_oracle.h"
@@ -135,6 +140,10 @@ float orc_cosf(float y)
     return (float)sincos_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
 }
 
+/* the fast path is glibc's for every |x| < 120, either sign (psi = atan2f(y, x) of KannalaBrandt8::project is in [-pi, pi]) */
+float orc_sinf_any(float x) { return orc_sinf(x); }
+float orc_cosf_any(float x) { return orc_cosf(x); }
+
 /* cv::fastAtan2 (OpenCV 3.4 modules/core/src/mathfuncs_core.simd.hpp atan_f32), SURVEY App.B H10 */
 float orc_fast_atan2(float y, float x)
 {
@@ -160,12 +169,149 @@ float orc_fast_atan2(float y, float x)
     return a;
 }
 
+/* ---- tanf / atanf / atan2f (KannalaBrandt8::project / unproject, src/CameraModels/KannalaBrandt8.cpp:87-190) ---- */
+static inline float asf32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static const float kT[13] = {
+  3.3333334327e-01f, 1.3333334029e-01f, 5.3968254477e-02f, 2.1869488060e-02f, 8.8632395491e-03f, 3.5920790397e-03f,
+  1.4562094584e-03f, 5.8804126456e-04f, 2.4646313977e-04f, 7.8179444245e-05f, 7.1407252108e-05f, -1.8558637748e-05f, 2.5907305826e-05f };
+static float k_tanf(float x, float y, int iy)
+{
+    const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    float z, r, v, w, s;
+    int32_t hx = (int32_t)asu32(x), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {                                   /* |x| < 2^-13 */
+        if ((int)x == 0) {
+            if ((ix | (iy + 1)) == 0) return 1.0f / fabsf(x);
+            else return (iy == 1) ? x : -1.0f / x;
+        }
+    }
+    if (ix >= 0x3f2ca140) {                                  /* |x| >= 0.6744 */
+        if (hx < 0) { x = -x; y = -y; }
+        z = pio4 - x;
+        w = pio4lo - y;
+        x = z + w; y = 0.0f;
+        if (fabsf(x) < 0x1p-13f) return (float)((1 - ((hx >> 30) & 2)) * iy) * (1.0f - (float)(2 * iy) * x);
+    }
+    z = x * x;
+    w = z * z;
+    r = kT[1] + w * (kT[3] + w * (kT[5] + w * (kT[7] + w * (kT[9] + w * kT[11]))));
+    v = z * (kT[2] + w * (kT[4] + w * (kT[6] + w * (kT[8] + w * (kT[10] + w * kT[12])))));
+    s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += kT[0] * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    {   /* -1 / (x + r), accurately */
+        float a, t;
+        z = asf32(asu32(w) & 0xfffff000u);
+        v = r - (z - x);
+        t = a = -1.0f / w;
+        t = asf32(asu32(t) & 0xfffff000u);
+        s = 1.0f + t * z;
+        return t + a * (s + t * v);
+    }
+}
+float orc_tanf(float x)                                      /* |x| < 120 */
+{
+    int32_t hx = (int32_t)asu32(x), ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda) return k_tanf(x, 0.0f, 1);
+    int n;
+    const double xr = reduce_fast((double)x, &n);
+    const float y0 = (float)xr;
+    const float y1 = (float)(xr - (double)y0);
+    return k_tanf(y0, y1, 1 - ((n & 1) << 1));
+}
+float orc_atanf(float x)
+{
+    static const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    static const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    static const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f,
+      -7.6918758452e-02f, 6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    float w, s1, s2, z;
+    int32_t hx = (int32_t)asu32(x), ix = hx & 0x7fffffff, id;
+    if (ix >= 0x4c000000) {                                  /* |x| >= 2^25 */
+        if (ix > 0x7f800000) return x + x;
+        return (hx > 0) ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {                                   /* |x| < 0.4375 */
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    z = x * x;
+    w = z * z;
+    s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return (hx < 0) ? -z : z;
+}
+float orc_atan2f(float y, float x)
+{
+    const float pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, tiny = 1.0e-30f;
+    float z;
+    int32_t hx = (int32_t)asu32(x), ix = hx & 0x7fffffff, hy = (int32_t)asu32(y), iy = hy & 0x7fffffff, k, m;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return orc_atanf(y);
+    m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) { switch (m) { case 0: case 1: return y; case 2: return pi + tiny; default: return -pi - tiny; } }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) { switch (m) { case 0: return pi_o_4 + tiny; case 1: return -pi_o_4 - tiny;
+                                            case 2: return 3.0f * pi_o_4 + tiny; default: return -3.0f * pi_o_4 - tiny; } }
+        else { switch (m) { case 0: return 0.0f; case 1: return -0.0f; case 2: return pi + tiny; default: return -pi - tiny; } }
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    k = (iy - ix) >> 23;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = orc_atanf(fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return asf32(asu32(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+/* the (y, x) pair number i of the atan2f self-check (device and oracle generate the same pairs) */
+void orc_atan2_pair(uint64_t i, float* y, float* x)
+{
+    uint64_t s = (i + 1) * 0x9E3779B97F4A7C15ull;
+    s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32;
+    if (i & 1) { *y = (float)((int32_t)(s & 0xffff) - 32768) / 97.0f; *x = (float)((int32_t)((s >> 20) & 0xffff) - 32768) / 89.0f; }
+    else { *y = asf32((uint32_t)s); *x = asf32((uint32_t)(s >> 32)); }
+}
+uint64_t orc_atan2_hash(uint64_t first, uint64_t count)
+{
+    uint64_t h = 0;
+    for (uint64_t i = first; i < first + count; i++) {
+        float y, x; orc_atan2_pair(i, &y, &x);
+        if (y != y || x != x) continue;
+        const uint32_t rb = asu32(orc_atan2f(y, x));
+        h += ((i * 0x9E3779B97F4A7C15ull) ^ (uint64_t)rb) * 0xC2B2AE3D27D4EB4Full;
+    }
+    return h;
+}
+
 uint64_t orc_math_hash(int which, uint32_t lo_bits, uint32_t hi_bits)
 {
     uint64_t h = 0;
     for (uint64_t u = lo_bits; u <= hi_bits; u++) {
         uint32_t ub = (uint32_t)u; float x; memcpy(&x, &ub, 4);
-        float y = which == 0 ? orc_expf(-x) : (which == 1 ? orc_sinf(x) : orc_cosf(x));
+        float y = which == 0 ? orc_expf(-x) : (which == 1 ? orc_sinf(x) : (which == 2 ? orc_cosf(x) : (which == 3 ? orc_tanf(x) : orc_atanf(x))));
         uint32_t yb; memcpy(&yb, &y, 4);
         h += (((uint64_t)ub * 0x9E3779B97F4A7C15ull) ^ (uint64_t)yb) * 0xC2B2AE3D27D4EB4Full;
     }

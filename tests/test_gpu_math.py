@@ -22,6 +22,12 @@ def test_reciprocal_fma_quotient_is_ieee_exact(sigma):
     (0, 2.0 ** -30, 104.0),      # exp(-x) for every float x in [2^-30, 104]: 307 232 769 inputs
     (1, 2.0 ** -20, 6.5),        # sin(x), every float in [2^-20, 6.5]: 189 792 257 inputs
     (2, 2.0 ** -20, 6.5),        # cos(x)
+    (1, -2.0 ** -20, -6.5),      # the negative half (psi = atan2f(y, x) of KannalaBrandt8::project lies in [-pi, pi])
+    (2, -2.0 ** -20, -6.5),
+    (3, 2.0 ** -14, 2.35),       # tan(x) as used by KannalaBrandt8::unproject: every float in [2^-14, 2.35] (127 M inputs) ...
+    (3, -2.0 ** -14, -2.35),     # ... and their negatives
+    (4, 2.0 ** -12, 4096.0),     # atan(x), every float in [2^-12, 4096]
+    (4, -2.0 ** -12, -4096.0),
 ])
 def test_device_math_equals_oracle_on_every_input(oracle, which, lo, hi):
     import numpy as np
@@ -31,5 +37,18 @@ def test_device_math_equals_oracle_on_every_input(oracle, which, lo, hi):
     ctx = frontend.Context()
     got = C.c_uint64(0)
     ctx.check(ctx.L.eorb_selfcheck_math(ctx.h, which, lob, hib, C.byref(got)))
+    ctx.close()
+    assert got.value == want
+
+
+def test_device_atan2f_equals_oracle_on_generated_pairs(oracle):
+    """atan2f has two arguments: 2^26 generated (y, x) pairs (every other one raw bit patterns: all exponent combinations, infinities,
+    zeros; the rest small rationals as image coordinates give), the same generator on both sides."""
+    from eorb_slam_amd import frontend
+    L = oracle.lib(fast=True)
+    want = L.orc_atan2_hash(0, 64 << 20)
+    ctx = frontend.Context()
+    got = C.c_uint64(0)
+    ctx.check(ctx.L.eorb_selfcheck_math(ctx.h, 5, 0, 63, C.byref(got)))
     ctx.close()
     assert got.value == want

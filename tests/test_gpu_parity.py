@@ -1246,6 +1246,40 @@ def test_ev2mci_se3(oracle, fe, ctx, n, pol):
                 assert np.array_equal(ou, gu)
 
 
+# the MVSEC configuration's camera (Examples/Event/EvMVSEC_ETHZ.yaml:54-67): KannalaBrandt8 on 346x260
+MVSEC_KB8 = (226.38018519795807, 226.15002947047415, 173.6470807871759, 133.73271487507847,
+             -0.048031442223833355, 0.011330957517194437, -0.055378166304281135, 0.021500973881459395)
+
+
+@pytest.mark.parametrize("n,pol", [(20000, False), (6000, True), (1, False)])
+def test_ev2mci_kannala_brandt8(oracle, fe, ctx, n, pol):
+    """ev2mci_gg_f with the fisheye camera: KannalaBrandt8::unproject (Newton iterations + tanf) and project (atan2f, sqrtf; double
+    polynomial + double cos / sin for the SE3 form, float throughout for the SE2 form), src/CameraModels/KannalaBrandt8.cpp:87-190."""
+    W, H = 346, 260
+    ev = synth.random_events(n, W, H, seed=90 + n, frac=True)
+    ev["ts"] = np.sort(ev["ts"])
+    axis = np.array([0.2, -0.1, 0.97], np.float64); axis /= np.linalg.norm(axis)
+    t = np.array([0.02, -0.01, 0.004])
+    depth = np.random.default_rng(2).uniform(0.8, 2.5, n).astype(np.float32)
+    for kw in (dict(medDepth=1.4, depth=None), dict(medDepth=1.0, depth=depth)):
+        for normalized in (False, True):
+            of, ou, omm = oracle.ev2mci_se3(ev, MVSEC_KB8, 0.045, axis, t, kw["medDepth"], W, H, 1.0, pol, normalized, depth=kw["depth"])
+            gf, gu, gmm = fe.EvImConverter.ev2mci_gg_f_se3(ev, MVSEC_KB8, 0.045, axis, t, kw["medDepth"], W, H, 1.0, pol, normalized,
+                                                          depth_per_event=kw["depth"], ctx=ctx)
+            assert _same_bits(of, gf) and _same_bits(omm, gmm)
+            if normalized:
+                assert np.array_equal(ou, gu)
+    for params in ([0.03, 0.004, -0.003], [-0.02, 0.002, 0.001, 0.96]):
+        of, _, omm = oracle.ev2mci_se2(ev, MVSEC_KB8, params, W, H, 1.0, pol, False)
+        gf, _, gmm = fe.EvImConverter.ev2mci_gg_f_se2(ev, MVSEC_KB8, params, W, H, 1.0, pol, False, ctx=ctx)
+        assert _same_bits(of, gf) and _same_bits(omm, gmm)
+    if n > 1:
+        # the fisheye model matters: the same events through a pinhole with the same focal lengths give another image
+        pf, _, _ = oracle.ev2mci_se3(ev, MVSEC_KB8[:4], 0.045, axis, t, 1.4, W, H, 1.0, pol, False)
+        of, _, _ = oracle.ev2mci_se3(ev, MVSEC_KB8, 0.045, axis, t, 1.4, W, H, 1.0, pol, False)
+        assert not _same_bits(pf, of)
+
+
 def test_ev2mci_se2_and_focus_contest(oracle, fe, ctx):
     """The reconstruction contest of EvImBuilder::generateMCImage (EvImBuilder.cpp:1146-1247): event histogram vs SE3 vs SE2
     reconstructions, each scored by measureImageFocus and normalised with cv::normalize; best focus wins."""

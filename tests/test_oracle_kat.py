@@ -311,3 +311,38 @@ def test_pyr_lk_known_answers(oracle):
     a = oracle.calc_optical_flow_pyr_lk(img1, img2, pts, None, 23, 2, 10, 0.03, 0)
     b = oracle.calc_optical_flow_pyr_lk(img1, img2, pts, None, 23, 6, 10, 0.03, 0)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_kannala_brandt8_known_answers(oracle):
+    """tanf / atanf / atan2f restatements against exactly representable answers and the host libm on spot values (the exhaustive
+    comparison is oracle/check_libm.c), and the warp's unproject -> project round trip with no motion."""
+    import math
+    L = oracle.lib()
+    assert L.orc_atanf(1.0) == np.float32(math.pi / 4) and L.orc_atan2f(1.0, 1.0) == np.float32(math.pi / 4)
+    assert L.orc_atan2f(0.0, -1.0) == np.float32(math.pi) and L.orc_atan2f(-1.0, 0.0) == np.float32(-math.pi / 2)
+    assert L.orc_tanf(0.0) == 0.0 and L.orc_atanf(0.0) == 0.0
+    rng = np.random.default_rng(3)
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")                      # the host glibc (numpy's float32 loops are its own SIMD code, not libm)
+    for f in (libm.tanf, libm.atanf):
+        f.restype = C.c_float; f.argtypes = [C.c_float]
+    libm.atan2f.restype = C.c_float; libm.atan2f.argtypes = [C.c_float, C.c_float]
+    for x in rng.uniform(-2.3, 2.3, 2000).astype(np.float32):
+        assert L.orc_tanf(float(x)) == libm.tanf(float(x)), x
+        assert L.orc_atanf(float(x)) == libm.atanf(float(x)), x
+    ys = rng.normal(0, 50, 2000).astype(np.float32); xs = rng.normal(0, 50, 2000).astype(np.float32)
+    for y, x in zip(ys, xs):
+        assert L.orc_atan2f(float(y), float(x)) == libm.atan2f(float(y), float(x)), (y, x)
+    # identity motion (angle 0, t 0, depth 1): every event must come back to its own pixel up to the float round trip
+    from tests.test_gpu_parity import MVSEC_KB8
+    W, H = 346, 260
+    ev = np.zeros(400, __import__("eorb_slam_amd.synth", fromlist=["EVENT_DTYPE"]).EVENT_DTYPE)
+    ev["x"] = rng.uniform(5, W - 5, 400).astype(np.float32); ev["y"] = rng.uniform(5, H - 5, 400).astype(np.float32)
+    ev["ts"] = np.arange(400) * 1e-5
+    uv = np.zeros((400, 2), np.float32)
+    cam = oracle._camera(MVSEC_KB8)
+    L.orc_mci_warp_se3_cam.restype = None
+    L.orc_mci_warp_se3_cam(ev.ctypes.data_as(C.c_void_p), C.c_size_t(400), C.byref(cam), C.c_double(0.0),
+                           np.array([0.0, 0.0, 1.0]).ctypes.data_as(C.c_void_p), np.zeros(3).ctypes.data_as(C.c_void_p),
+                           C.c_float(1.0), None, uv.ctypes.data_as(C.c_void_p))
+    assert np.abs(uv[:, 0] - ev["x"]).max() < 2e-3 and np.abs(uv[:, 1] - ev["y"]).max() < 2e-3
