@@ -13,7 +13,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 orc.build()
 ctx = fe.Context()
 NAMES = ["test_bf_knn2", "test_search_for_initialization", "test_search_for_initialization_mixed_gate", "test_search_by_projection_last",
-         "test_search_by_projection_map", "test_tracked_descriptors_and_level_assignment", "test_search_by_bow", "test_search_by_bow_keyframes",
+         "test_search_by_projection_map", "test_search_by_projection_last_mixed_gate", "test_search_by_projection_map_mixed_gate",
+         "test_window_matchers_state_chains", "test_ev2mci_kannala_brandt8", "test_unsynced_ragged_batches_keep_their_own_tables", "test_tracked_descriptors_and_level_assignment", "test_search_by_bow", "test_search_by_bow_keyframes",
          "test_search_for_triangulation", "test_kf_radius_match_fuse_sim3", "test_search_by_projection_keyframe", "test_bow_transform",
          "test_klt_pyr_lk", "test_hamming_window_match", "test_distinctive_descriptors", "test_frontend_batch_matches_oracle_pipeline",
          "test_ev2im_gauss_bit_exact", "test_ev2im_gauss_shapes_lut", "test_ev2im_gauss_hot_pixel_order", "test_frontend_batch_ragged_and_empty_slices",
