@@ -225,7 +225,7 @@ constexpr int kScatWaves = 8;
 __device__ __forceinline__ int wave_incl_scan(int x);
 template <int R>
 __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb_event16* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
-                                                          BinParams P, int chunk_cap, int ko, const int64_t* __restrict__ slice_ebase,
+                                                          BinParams P, int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                           const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
                                                           uint2* __restrict__ entries)
 {
@@ -307,7 +307,6 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
     }
     __syncthreads();
     // ---- C: stable ranks -> sidx ----
-    if (ko & 4) return;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint16_t* cw = cntw + wave * NTp;
     const int txr = (P.TX + R - 1) / R;
@@ -348,7 +347,6 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
     }
     __syncthreads();
     // ---- D: the sorted order leaves as contiguous runs: consecutive threads write consecutive entries of a tile's run ----
-    if (ko & 2) return;
     uint2* out = entries + (size_t)slice_ebase[cd.slice];
     const int E = loff[NT];
     for (int p = tid; p < E; p += NTHR) {
@@ -358,7 +356,6 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
         const int t = ((int)(r0 >> 8) + (int)((sv >> 13) & 3)) * P.TX + (int)(r0 & 0xff) + (int)((sv >> 11) & 3);
         const uint2 v = pay[k];
         const size_t pos = (size_t)gbase[t] + (uint32_t)(p - (int)loff[t]);
-        if (ko & 1) { if (v.x == 0x12345u && pos == 77) out[0] = v; continue; }
         out[pos] = v;
     }
 }
@@ -1604,10 +1601,9 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         if (nchunks) {
             const int NTp = (NT + 1) & ~1;
             const size_t lds2 = ((size_t)chunk * 8 + (size_t)chunk * 2 + (size_t)chunk * R * R * 2 + (size_t)kScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
-            static const int scat_ko = [] { const char* e = getenv("EORB_SCAT_KO"); return e ? atoi(e) : 0; }();
             // (float events with polarity carry 16-byte entries: first form)
             const bool form2 = scat_form != 1 && !(pol && !raw) && lds2 <= 64 * 1024 && TX < 256 && TY < 256;
-#define LAUNCH_BIN(RR, PP) do { if (form2) ev_scatter2_kernel<RR><<<nchunks, 64 * kScatWaves, lds2, c->stream>>>(d_ev, d_chunks, P, chunk, scat_ko, d_slice_eb, d_segbase, d_tile_base, (uint2*)en); \
+#define LAUNCH_BIN(RR, PP) do { if (form2) ev_scatter2_kernel<RR><<<nchunks, 64 * kScatWaves, lds2, c->stream>>>(d_ev, d_chunks, P, chunk, d_slice_eb, d_segbase, d_tile_base, (uint2*)en); \
                                 else ev_scatter_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, d_slice_eb, d_segbase, d_tile_base, en); } while (0)
             const bool wide = pol && !raw;                       // raw entries keep the polarity in the sensor-pixel word
             if (R == 1) { if (wide) LAUNCH_BIN(1, true); else LAUNCH_BIN(1, false); }
