@@ -746,8 +746,12 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     // pixel, same logical group) spread over all banks; a value wave's store (lane = slot, one pixel) stays 64 consecutive words.
     __shared__ __attribute__((aligned(16))) float vals[2][64 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // One tile per workgroup when the tiles carry real work (the hardware then balances the heaviest-first order dynamically).  When
+    // they are nearly empty (2 000-event slices leave most of their 690 tiles with a handful of entries) the launch rate of the
+    // workgroups is the cost: the host then starts fewer workgroups and each walks the order with stride gridDim.x.
+    for (int item = blockIdx.x; item < P.total; item += gridDim.x) {
     bool any_ok = false;                             // (wave 1) some entry of the tile touches an in-image pixel
-    const int logical = order[blockIdx.x];
+    const int logical = order[item];
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
     const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
@@ -902,6 +906,20 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
         iteration(t, S0, S1);
         if (t + 1 < nbatch + 1) iteration(t + 1, S1, S0);
     }
+    // The loads issued from the inline asm run ahead of the batches (entry of batch t + 3, columns of batch t + 2): the last ones are
+    // still in flight here, and the compiler, which takes an asm's outputs as written when the asm ends, is free to reuse their target
+    // registers from now on.  A late return would then overwrite whatever lives there (the flag below, the next tile's addresses).
+    // Drain them while the registers are still theirs.
+    if (wave >= 1) {
+        if constexpr (NC == 2)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0.c[0][0]), "+v"(S0.c[0][1]), "+v"(S0.c[1][0]), "+v"(S0.c[1][1]), "+v"(S0.E),
+                         "+v"(S1.c[0][0]), "+v"(S1.c[0][1]), "+v"(S1.c[1][0]), "+v"(S1.c[1][1]), "+v"(S1.E) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0.c[0][0]), "+v"(S0.c[0][1]), "+v"(S0.c[1][0]), "+v"(S0.c[1][1]),
+                         "+v"(S0.c[2][0]), "+v"(S0.c[2][1]), "+v"(S0.c[3][0]), "+v"(S0.c[3][1]), "+v"(S0.E),
+                         "+v"(S1.c[0][0]), "+v"(S1.c[0][1]), "+v"(S1.c[1][0]), "+v"(S1.c[1][1]),
+                         "+v"(S1.c[2][0]), "+v"(S1.c[2][1]), "+v"(S1.c[3][0]), "+v"(S1.c[3][1]), "+v"(S1.E) :: "memory");
+    }
 #ifdef EORB_DIAG
     if (nbatch > 1000 && lane == 0) {
         const unsigned long long tot = __builtin_readcyclecounter() - d_t0;
@@ -915,7 +933,7 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     // the flag of wave 1 travels through the (now free) list buffer
     if (wave == 1) { const bool f = __any(any_ok); if (lane == 0) vals[0][0] = f ? 1.0f : 0.0f; }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave == 0) {
     const bool tile_ok = vals[0][0] != 0.0f;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = tx0 + lx, py = ty0 + ly;
@@ -935,6 +953,9 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     if (lane == 0) {
         atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
         atomicMax(&minmax_enc[slice * 2 + 1], enc_f32(vmax));
+    }
+    }
+    if (gridDim.x < (unsigned)P.total) __syncthreads();      // (several tiles per workgroup: the list buffer is free for the next one)
     }
 }
 
@@ -1629,7 +1650,9 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             const int NC = nc_env == 2 || nc_env == 4 ? nc_env : (nb >= 32768 ? 4 : 2);
             const int rthreads = 64 * (1 + 8 / NC);
             const uint2* en2 = (const uint2*)c->entries.p;
-#define LAUNCH_R(PP, CC) ev_gather_raw_kernel<PP, CC><<<nb, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc)
+            // nearly empty tiles (fewer than one 64-entry batch per tile on average): ~20 workgroups per CU walk the order
+            const int ngrid = (nev * dup < (int64_t)nb * 64) ? std::min(nb, 20 * 256) : nb;
+#define LAUNCH_R(PP, CC) ev_gather_raw_kernel<PP, CC><<<ngrid, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc)
             if (pol) { if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
             else { if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
 #undef LAUNCH_R
