@@ -759,6 +759,14 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     const int h = P.h, SWP = P.stamp_colstride;
     const int nent = (int)tile_cnt[logical];
     const int nbatch = (nent + 63) >> 6;
+    if (nent == 0) {
+        // nothing touches the tile: zeros, and no offer to the running extremes (max stays -1e6, min 0: resolveMinMaxVals :32-39)
+        if (wave == 0) {
+            const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+            if (px < P.W && py < P.H) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = 0.0f;
+        }
+        continue;
+    }
     const uint2* list = entries + (size_t)slice_ebase[slice] + tile_base[logical];
     constexpr int kRowFloats = 8 * 64;
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
