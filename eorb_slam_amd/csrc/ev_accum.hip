@@ -85,13 +85,36 @@ __global__ __launch_bounds__(256) void ev_count_kernel(const eorb_event16* __res
     for (int i = threadIdx.x; i < NT; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
     const eorb_event16* e = ev + cd.start;
-    for (int k = threadIdx.x; k < cd.n; k += blockDim.x) {
-        int tx0, tx1, ty0, ty1;
-        uint32_t src, info;
-        if (P.raw ? ev_tile_range_raw(((const eorb_raw_event*)e)[k], P, tx0, tx1, ty0, ty1, src, info)
-                  : ev_tile_range(e[k], P, tx0, tx1, ty0, ty1))
-            for (int ty = ty0; ty <= ty1; ty++)
-                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&cnt[ty * P.TX + tx], 1u);
+    if (P.raw) {
+        // eight events per thread and round: all event loads, then all map lookups, then the counting (the chain event -> map entry
+        // -> tile range is latency; the loads of the round are in flight together)
+        constexpr int U = 8;
+        for (int k0 = threadIdx.x; k0 < cd.n; k0 += blockDim.x * U) {
+            uint32_t xy[U]; uint32_t info[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)&((const eorb_raw_event*)e)[k] : 0xffffffffu; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int x = (int)(xy[u] & 0xffff), y = (int)(xy[u] >> 16);
+                const bool ok = x < P.LW && y < P.LH;
+                info[u] = ok ? P.src_info[(uint32_t)y * (uint32_t)P.LW + x] : 0x80008000u;      // (-32768, -32768): touches no tile
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int xi = (int)(int16_t)(info[u] & 0xffff), yi = (int)(int16_t)(info[u] >> 16);
+                const int tx0 = max((xi - P.h) >> 3, 0), tx1 = min((xi + P.h) >> 3, P.TX - 1);
+                const int ty0 = max((yi - P.h) >> 3, 0), ty1 = min((yi + P.h) >> 3, P.TY - 1);
+                for (int ty = ty0; ty <= ty1; ty++)
+                    for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&cnt[ty * P.TX + tx], 1u);
+            }
+        }
+    } else {
+        for (int k = threadIdx.x; k < cd.n; k += blockDim.x) {
+            int tx0, tx1, ty0, ty1;
+            if (ev_tile_range(e[k], P, tx0, tx1, ty0, ty1))
+                for (int ty = ty0; ty <= ty1; ty++)
+                    for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&cnt[ty * P.TX + tx], 1u);
+        }
     }
     __syncthreads();
     uint16_t* sc = segcnt + (size_t)blockIdx.x * NT;
@@ -252,6 +275,22 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
     __syncthreads();
     // ---- A: entries into LDS, tile ranges into registers, counts per (wave, tile) ----
     uint32_t* cw32 = (uint32_t*)(cntw + wave * NTp);
+    // (raw events: the event loads of all sub-batches first, then the map lookups, then the LDS work -- the chain event -> map
+    // entry -> range is latency, so the loads of the share are in flight together)
+    uint2 rq[SMAX]; uint32_t rinfo[SMAX];
+    if (P.raw) {
+#pragma unroll
+        for (int s = 0; s < SMAX; s++) {
+            const int k = wave * Q + s * 64 + lane;
+            rq[s] = (s < S && k < cd.n) ? *(const uint2*)&((const eorb_raw_event*)e)[k] : make_uint2(0xffffffffu, 0u);
+        }
+#pragma unroll
+        for (int s = 0; s < SMAX; s++) {
+            const int x = (int)(rq[s].x & 0xffff), y = (int)(rq[s].x >> 16);
+            const bool in = x < P.LW && y < P.LH;
+            rinfo[s] = in ? P.src_info[(uint32_t)y * (uint32_t)P.LW + x] : 0u;
+        }
+    }
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         rng[s] = 0u;
@@ -262,10 +301,15 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
             uint2 pl;
             if (P.raw) {
                 // entry = { sensor pixel | negative polarity << 31, xi | yi << 16 }
-                const eorb_raw_event q = ((const eorb_raw_event*)e)[k];
-                uint32_t src = 0, info = 0;
-                ok = ev_tile_range_raw(q, P, tx0, tx1, ty0, ty1, src, info);
-                pl = make_uint2(src | (q.p ? 0u : 0x80000000u), info);
+                const int x = (int)(rq[s].x & 0xffff), y = (int)(rq[s].x >> 16);
+                ok = x < P.LW && y < P.LH;
+                const uint32_t src = ok ? (uint32_t)y * (uint32_t)P.LW + x : 0u, info = rinfo[s];
+                if (ok) {
+                    const int xi = (int)(int16_t)(info & 0xffff), yi = (int)(int16_t)(info >> 16);
+                    tx0 = max((xi - P.h) >> 3, 0); tx1 = min((xi + P.h) >> 3, P.TX - 1);
+                    ty0 = max((yi - P.h) >> 3, 0); ty1 = min((yi + P.h) >> 3, P.TY - 1);
+                }
+                pl = make_uint2(src | (rq[s].y ? 0u : 0x80000000u), info);
             } else {
                 const eorb_event16 q = e[k];
                 ok = ev_tile_range(q, P, tx0, tx1, ty0, ty1);
