@@ -97,7 +97,8 @@ void        eorb_destroy(eorb_ctx* ctx);
  * The host-buffer entry points report the same condition from the call itself (eorb_orb_extract). */
 int         eorb_sync(eorb_ctx* ctx);
 /* test hooks, not part of the reference's interface: "octree_pool_shrink" (n > 0: shrink the octree node pool by n at the
- * next configure, to force the overflow path), "octree_force_global" (1: keep the whole octree working set in global memory) */
+ * next configure, to force the overflow path), "octree_force_global" (1: keep the whole octree working set in global memory), "win_list_cap" / "win_pool_cap" (window matchers:
+ * candidate list capacity per query / pool per pair, to force the full-scan path) */
 int         eorb_debug_option(eorb_ctx* ctx, const char* name, int value);
 const char* eorb_last_error(eorb_ctx* ctx);
 const char* eorb_version(void);
