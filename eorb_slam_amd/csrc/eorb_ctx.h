@@ -85,7 +85,7 @@ struct eorb_ctx {
     std::vector<eorb::ProfEntry> profs;
 
     // accumulation workspaces
-    eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order;
+    eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order, order_hist;
     // raw sensor events: undistortion maps (float2 per sensor pixel) and the tables derived from them
     eorb::DevBuf lut, src_info, stamps;
     int lut_w = 0, lut_h = 0, lut_check = 1;

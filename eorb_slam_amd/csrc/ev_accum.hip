@@ -407,25 +407,46 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
 // Heaviest-first launch order for K2 (longest-processing-time-first): event data is spatially concentrated (on the reference's
 // `shapes` sequences one tile holds ~6 % of a slice's entries), and a workgroup that starts its long tile late is the tail of the
 // launch.  Bucket sort of the (slice, tile) work items by a 2-bits-per-octave log weight.
-__global__ __launch_bounds__(1024) void ev_tile_order_kernel(const uint32_t* __restrict__ weight, int total, int32_t* __restrict__ order)
+__device__ __forceinline__ int ev_weight_bucket(uint32_t w)
+{
+    if (w == 0) return 63;
+    const int lg = 31 - __clz(w);                                  // floor(log2 w)
+    const int half = (lg > 0) ? (int)((w >> (lg - 1)) & 1u) : 0;
+    return 62 - min(62, 2 * lg + half);                            // 0 = heaviest
+}
+constexpr int kOrderItems = 4096;       // work items per workgroup of the two kernels below
+// (1) bucket histogram of every block of kOrderItems work items
+__global__ __launch_bounds__(1024) void ev_tile_hist_kernel(const uint32_t* __restrict__ weight, int total, uint32_t* __restrict__ blk_hist)
 {
     __shared__ uint32_t hist[64];
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
-    auto bucket = [](uint32_t w) -> int {
-        if (w == 0) return 63;
-        const int lg = 31 - __clz(w);                                  // floor(log2 w)
-        const int half = (lg > 0) ? (int)((w >> (lg - 1)) & 1u) : 0;
-        return 62 - min(62, 2 * lg + half);                            // 0 = heaviest
-    };
-    for (int i = threadIdx.x; i < total; i += blockDim.x) atomicAdd(&hist[bucket(weight[i])], 1u);
+    const int i0 = blockIdx.x * kOrderItems, i1 = min(i0 + kOrderItems, total);
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) atomicAdd(&hist[ev_weight_bucket(weight[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) blk_hist[blockIdx.x * 64 + threadIdx.x] = hist[threadIdx.x];
+}
+// (2) a block's items of bucket b go behind all heavier buckets and behind the bucket-b items of the blocks before it
+__global__ __launch_bounds__(1024) void ev_tile_order_kernel(const uint32_t* __restrict__ weight, int total, const uint32_t* __restrict__ blk_hist,
+                                                             int32_t* __restrict__ order)
+{
+    __shared__ uint32_t tot[64], before[64], cur[64];
+    if (threadIdx.x < 64) tot[threadIdx.x] = before[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < (int)gridDim.x * 64; k += blockDim.x) {
+        const uint32_t v = blk_hist[k];
+        if (!v) continue;
+        atomicAdd(&tot[k & 63], v);
+        if ((k >> 6) < (int)blockIdx.x) atomicAdd(&before[k & 63], v);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int b = 0; b < 64; b++) { const uint32_t n = hist[b]; hist[b] = run; run += n; }
+        for (int b = 0; b < 64; b++) { cur[b] = run + before[b]; run += tot[b]; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < total; i += blockDim.x) order[atomicAdd(&hist[bucket(weight[i])], 1u)] = i;
+    const int i0 = blockIdx.x * kOrderItems, i1 = min(i0 + kOrderItems, total);
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) order[atomicAdd(&cur[ev_weight_bucket(weight[i])], 1u)] = i;
 }
 
 // wave-wide inclusive prefix sum without LDS round trips: row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 / 31
@@ -1684,7 +1705,12 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             else { if (wide) LAUNCH_BIN(3, true); else LAUNCH_BIN(3, false); }
 #undef LAUNCH_BIN
         }
-        ev_tile_order_kernel<<<1, 1024, 0, c->stream>>>(d_tile_cnt, nb, d_order);
+        {
+            const int nblk = (nb + kOrderItems - 1) / kOrderItems;
+            if ((rc = ensure(c, c->order_hist, sizeof(uint32_t) * 64 * (size_t)nblk))) return rc;
+            ev_tile_hist_kernel<<<nblk, 1024, 0, c->stream>>>(d_tile_cnt, nb, (uint32_t*)c->order_hist.p);
+            ev_tile_order_kernel<<<nblk, 1024, 0, c->stream>>>(d_tile_cnt, nb, (const uint32_t*)c->order_hist.p, d_order);
+        }
         EORB_LAUNCH_CHECK(c, "ev_bin kernels");
     }
     {
