@@ -253,6 +253,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "octree_force_global")) { c->dbg_force_global = value; return EORB_OK; }
     if (!strcmp(name, "win_list_cap")) { c->dbg_win_wcap = value; return EORB_OK; }
     if (!strcmp(name, "win_pool_cap")) { c->dbg_win_ecap = value; return EORB_OK; }
+    if (!strcmp(name, "gather_form")) { c->dbg_gather_form = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
 

@@ -1032,6 +1032,76 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     }
 }
 
+// K2s: the same gather for launches whose tiles are nearly empty (the 2 000-event slices of the live event path leave a tile about
+// nine entries).  K2r's pipeline costs a tile several memory round trips and two barriers whatever its list holds; here ONE wave
+// owns a tile, without LDS and without barriers (32 waves per CU hide each other's latency): lane = pixel, the tile's entries are
+// read 64 at a time (lane = entry) and handed round by v_readlane, and every lane reads its own tap of the entry's stamp -- the
+// 8 x 8 window of a stamp is 8 runs of 8 consecutive floats -- and adds it if the stamp reaches its pixel.  Adds are in list order;
+// a lane the stamp does not reach keeps its value, which is what K2r's + 0.0f does.
+constexpr int kSparseWaves = 4;
+template <bool POL>
+__global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(const int64_t* __restrict__ slice_ebase, GatherParams P, int per_wave,
+                                                                            const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_base,
+                                                                            const uint2* __restrict__ entries, float* __restrict__ img,
+                                                                            uint32_t* __restrict__ minmax_enc)
+{
+    const int lane = threadIdx.x & 63;
+    const int first = (blockIdx.x * kSparseWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * per_wave;
+    const int SW = 2 * P.h + 1, SWP = P.stamp_colstride;
+    for (int logical = first; logical < min(first + per_wave, P.total); logical++) {
+        const int slice = logical / P.NT, tile = logical - slice * P.NT;
+        const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
+        const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+        const bool inimg = px < P.W && py < P.H;
+        float* const dst = img + (size_t)slice * P.W * P.H + (size_t)py * P.W + px;
+        const int nent = (int)tile_cnt[logical];
+        if (nent == 0) { if (inimg) *dst = 0.0f; continue; }      // no offer to the running extremes (resolveMinMaxVals :32-39)
+        const uint2* list = entries + (size_t)slice_ebase[slice] + tile_base[logical];
+        float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
+        bool touched = false;                                   // this (in-image) pixel was reached by some stamp
+        for (int e0 = 0; e0 < nent; e0 += 64) {
+            const int cnt = min(64, nent - e0);
+            const uint2 mine = list[e0 + min(lane, cnt - 1)];
+            constexpr int U = 8;
+            for (int k0 = 0; k0 < cnt; k0 += U) {
+                float v[U]; bool in[U]; uint32_t sgn[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = min(k0 + u, cnt - 1);
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, k), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, k);
+                    const int xi = (int)(int16_t)(w1 & 0xffff), yi = (int)(int16_t)(w1 >> 16);
+                    const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
+                    in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
+                    sgn[u] = w0 & 0x80000000u;
+                    const uint32_t off = (w0 & 0x7fffffffu) * (uint32_t)P.stamp_stride + i * (uint32_t)SWP + j;
+                    v[u] = in[u] ? P.stamps[off] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (in[u]) {
+                        acc = acc + (POL ? __uint_as_float(__float_as_uint(v[u]) ^ sgn[u]) : v[u]);
+                        if (POL) { vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); }
+                        touched = true;
+                    }
+            }
+        }
+        // as in K2r: without polarity a tile some stamp reaches inside the image offers its pixels' values (0 where nothing was added)
+        const bool tile_ok = __any(touched);
+        if (!POL && tile_ok) vmax = fmaxf(vmax, acc);
+        if (inimg) *dst = acc;
+        else { vmax = -1000000.0f; vmin = 0.0f; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+            vmin = fminf(vmin, __shfl_xor(vmin, d, 64));
+        }
+        if (lane == 0) {
+            atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
+            atomicMax(&minmax_enc[slice * 2 + 1], enc_f32(vmax));
+        }
+    }
+}
+
 // exhaustive self-check helper: IEEE quotient vs the reciprocal/fma sequence used above
 __global__ void ev_divcheck_kernel(uint32_t lo_bits, uint32_t hi_bits, float norm, float rcp, unsigned long long* bad)
 {
@@ -1684,6 +1754,8 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
     }
+    // nearly empty tiles (fewer than one 64-entry batch per tile on average) of raw events with a Gaussian stamp: K2s, a wave per tile
+    const bool sparse = raw && !mode_count && (c->dbg_gather_form == 2 || (c->dbg_gather_form == 0 && nev * dup < (int64_t)nb * 64));
     {
         BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
@@ -1705,7 +1777,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             else { if (wide) LAUNCH_BIN(3, true); else LAUNCH_BIN(3, false); }
 #undef LAUNCH_BIN
         }
-        {
+        if (!sparse) {
             const int nblk = (nb + kOrderItems - 1) / kOrderItems;
             if ((rc = ensure(c, c->order_hist, sizeof(uint32_t) * 64 * (size_t)nblk))) return rc;
             ev_tile_hist_kernel<<<nblk, 1024, 0, c->stream>>>(d_tile_cnt, nb, (uint32_t*)c->order_hist.p);
@@ -1720,7 +1792,14 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         const int mode = mode_count ? 2 : ((G.div_is_pow2 && G.fast_norm) ? 1 : 0);
         const float* en = (const float*)c->entries.p;
 #define LAUNCH_G(PP, MM, RR) ev_gather_kernel<PP, MM, RR><<<nb, gthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en, d_f32, d_minmax_enc)
-        if (raw && mode != 2) {
+        if (sparse) {
+            const uint2* en2 = (const uint2*)c->entries.p;
+            // large launches: 8 consecutive work items per wave (a wave per item leaves the launch bound by workgroup dispatch)
+            const int per_wave = nb >= 65536 ? 8 : 1;
+            const int grid = (nb + kSparseWaves * per_wave - 1) / (kSparseWaves * per_wave);
+            if (pol) ev_gather_sparse_kernel<true><<<grid, 64 * kSparseWaves, 0, c->stream>>>(d_slice_eb, G, per_wave, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);
+            else ev_gather_sparse_kernel<false><<<grid, 64 * kSparseWaves, 0, c->stream>>>(d_slice_eb, G, per_wave, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);
+        } else if (raw && mode != 2) {
             // the add wave + four value waves with two tile columns each (shortest chain per batch), or -- when the launch has
             // enough tiles to keep every SIMD busy anyway -- two value waves with four columns each (the rectangle arithmetic is
             // done once per four columns: fewest instructions per batch)

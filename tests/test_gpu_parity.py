@@ -930,12 +930,16 @@ def test_polarity_extremes_of_one_sided_images(oracle, fe, ctx):
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), mm.view(np.uint32))
 
 
-def test_raw_accumulation_random_sweep(oracle, fe, ctx):
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_raw_accumulation_random_sweep(oracle, fe, form):
     """A seeded sweep over image sizes that are not multiples of the tile, stamps of 3x3 ... 17x17 taps, polarity, maps that throw
     pixels out of the image with and without checkInImage, event counts on the 64-entry batch boundaries and hot pixels
-    (tests/fuzz/fuzz_raw.py runs the long version)."""
+    (tests/fuzz/fuzz_raw.py runs the long version).  form: the gather kernel -- chosen by the batch's shape (0), the pipelined
+    workgroup per tile whatever the shape (1), the wave per tile whatever the shape (2)."""
+    ctx = fe.Context()
+    ctx.debug_option("gather_form", form)
     rng = np.random.default_rng(2024)
-    for case in range(80):
+    for case in range(80 if form == 0 else 50):
         W, H = [(240, 180), (346, 260), (64, 48), (33, 17), (100, 9), (16, 16), (250, 131)][rng.integers(0, 7)]
         LW, LH = W + int(rng.integers(0, 5)), H + int(rng.integers(0, 5))
         sigma = float([0.21, 0.4, 0.5, 0.8, 1.0, 1.0, 1.3, 1.7, 2.0, 2.5][rng.integers(0, 10)])
@@ -956,9 +960,10 @@ def test_raw_accumulation_random_sweep(oracle, fe, ctx):
         ev = oracle.undistort_events(raw, mx, my, W, H, check, 1.0)
         of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, pol, True)
         gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, pol, True, ctx=ctx, return_all=True)
-        what = dict(case=case, W=W, H=H, sigma=sigma, pol=pol, check=check, n=n)
+        what = dict(case=case, W=W, H=H, sigma=sigma, pol=pol, check=check, n=n, form=form)
         assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)) and np.array_equal(ou, gu), what
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), what
+    ctx.close()
 
 
 def test_raw_gather_four_column_variant(oracle):
