@@ -68,8 +68,8 @@ struct OrbState {
     int cand_total = 0;      // per slice: sum of cand_cap
     int kp_total = 0;        // per slice: sum of kp_cap  (= eorb_orb_max_keypoints)
     int max_out = 0;
-    int oct_lds = 0;         // dynamic LDS bytes of the octree kernel
-    int oct_scratch = 0;     // per (slice,level) global scratch ints
+    int oct_lds[2] = {0, 0};       // dynamic LDS bytes of the octree kernel, per placement (single frames / many workgroups)
+    int oct_scratch[2] = {0, 0};   // per (slice, level) global scratch bytes
     DevBuf tabs;             // resize tables (short/int), level geometry, pattern, umax
     DevBuf geom;
 };

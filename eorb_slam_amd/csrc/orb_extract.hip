@@ -36,8 +36,10 @@ struct DevGeom {
     // octree working set: items 0 the two node arrays, 1 / 2 the two (size, seq, node) lists, 3 / 4 the key ping-pong buffers, 5 the
     // candidate points, 6 the per-round arrays; each lives in LDS (offset into the dynamic LDS block) or, when the 160 KB do not hold
     // it, in the (slice, level) block of a global scratch buffer (offset into that block)
-    int oct_in_lds[7], oct_off[7];
-    int oct_lds_bytes, oct_gblock_bytes;
+    // octree working set, two placements: [0] as much as the LDS holds (one workgroup per CU: single frames), [1] at most half of
+    // it (two workgroups per CU: launches with more workgroups than CUs)
+    int oct_in_lds[2][7], oct_off[2][7];
+    int oct_lds_bytes[2], oct_gblock_bytes[2];
     int node_cap_max, vsp_cap_max, ncap_max;
 };
 
@@ -284,7 +286,7 @@ __device__ void oct_block_sort_u64(uint64_t* a, int n)
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __restrict__ G, const int32_t* __restrict__ cell_cnt,
                                                              const uint32_t* __restrict__ cell_cand, unsigned char* __restrict__ scratch_g,
                                                              uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_cnt,
-                                                             int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky)
+                                                             int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky, int placement)
 {
     extern __shared__ unsigned char smem[];
     __shared__ int s_ws[kOctThreads / 64 + 2];
@@ -295,8 +297,8 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     const int ncap = G->ncap_max, pool = L.node_cap, vcap = G->vsp_cap_max, pc = G->node_cap_max;
     // every item in LDS when the 160 KB hold it, otherwise in this (slice, level)'s block of the global scratch buffer: the
     // workgroup sits on one CU, whose own stores are visible to its later loads after __syncthreads()
-    unsigned char* gblk = scratch_g + (size_t)blockIdx.x * G->oct_gblock_bytes;
-    auto item = [&](int k) -> unsigned char* { return (G->oct_in_lds[k] ? smem : gblk) + G->oct_off[k]; };
+    unsigned char* gblk = scratch_g + (size_t)blockIdx.x * G->oct_gblock_bytes[placement];
+    auto item = [&](int k) -> unsigned char* { return (G->oct_in_lds[placement][k] ? smem : gblk) + G->oct_off[placement][k]; };
     ONode* nodes[2] = {(ONode*)item(0), (ONode*)item(0) + pc};
     uint64_t* vsp[2] = {(uint64_t*)item(1), (uint64_t*)item(2)};
     uint16_t* keys[2] = {(uint16_t*)item(3), (uint16_t*)item(4)};
@@ -927,18 +929,23 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
                                   (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15, (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15,
                                   (sizeof(uint32_t) * (size_t)ncap_max + 15) & ~(size_t)15,
                                   ((size_t)node_cap_max * (4 + 2 + 1 + 8) + 8 + 15) & ~(size_t)15};
-    int oct_in_lds[7], oct_off[7];
-    size_t lds = 0, gblock = 0;
-    const size_t lds_budget = c->dbg_force_global ? 0 : 150 * 1024;
+    int oct_in_lds[2][7], oct_off[2][7];
     // placement order: the per-round arrays and the node arrays first (touched by every step), then the size lists, keys, points
     const int order[7] = {6, 0, 1, 2, 3, 4, 5};
-    for (int oi = 0; oi < 7; oi++) {
-        const int k = order[oi];
-        if (lds + item_bytes[k] <= lds_budget) { oct_in_lds[k] = 1; oct_off[k] = (int)lds; lds += item_bytes[k]; }
-        else { oct_in_lds[k] = 0; oct_off[k] = (int)gblock; gblock += item_bytes[k]; }
+    static const int budget_kb = [] { const char* e = getenv("EORB_OCT_BUDGET_KB"); return e ? atoi(e) : 150; }();      // (A/B runs)
+    for (int v = 0; v < 2; v++) {
+        // measured on 1 024 frames of 240x180 / 400 features: 344 us with 150 KB per workgroup, 211 us with 76 KB, 253 us with the
+        // whole working set in global memory; a single frame per call is 5 % faster with everything in LDS
+        const size_t lds_budget = c->dbg_force_global ? 0 : (v == 0 ? (size_t)budget_kb * 1024 : std::min<size_t>((size_t)budget_kb, 76) * 1024);
+        size_t lds = 0, gblock = 0;
+        for (int oi = 0; oi < 7; oi++) {
+            const int k = order[oi];
+            if (lds + item_bytes[k] <= lds_budget) { oct_in_lds[v][k] = 1; oct_off[v][k] = (int)lds; lds += item_bytes[k]; }
+            else { oct_in_lds[v][k] = 0; oct_off[v][k] = (int)gblock; gblock += item_bytes[k]; }
+        }
+        o.oct_lds[v] = (int)lds;
+        o.oct_scratch[v] = (int)gblock;
     }
-    o.oct_lds = (int)lds;
-    o.oct_scratch = (int)gblock;
 
     DevGeom g{};
     memcpy(g.lv, o.lv, sizeof(o.lv));
@@ -948,7 +955,7 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
     g.minTh = std::min(std::max(p->minThFAST, 0), 255);
     memcpy(g.umax, o.umax, sizeof(o.umax)); memcpy(g.sf, o.sf, sizeof(o.sf));
     memcpy(g.oct_in_lds, oct_in_lds, sizeof(oct_in_lds)); memcpy(g.oct_off, oct_off, sizeof(oct_off));
-    g.oct_lds_bytes = (int)lds; g.oct_gblock_bytes = (int)gblock;
+    for (int v = 0; v < 2; v++) { g.oct_lds_bytes[v] = o.oct_lds[v]; g.oct_gblock_bytes[v] = o.oct_scratch[v]; }
     g.node_cap_max = node_cap_max; g.vsp_cap_max = vsp_cap_max; g.ncap_max = ncap_max;
     int rc;
     if ((rc = ensure(c, o.geom, sizeof(DevGeom)))) return rc;
@@ -973,7 +980,8 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     if ((rc = ensure(c, c->blur, nb * o.roi_bytes))) return rc;
     if ((rc = ensure(c, c->cell_cnt, nb * o.ncells * sizeof(int32_t)))) return rc;
     if ((rc = ensure(c, c->cell_cand, nb * o.ncells * (size_t)o.cell_cap * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(c, c->oct_scratch, nb * o.nlevels * (size_t)o.oct_scratch))) return rc;   // octree items that do not fit the LDS
+    const int placement = B * o.nlevels > 256 ? 1 : 0;                                         // more workgroups than CUs: two per CU
+    if ((rc = ensure(c, c->oct_scratch, nb * o.nlevels * (size_t)o.oct_scratch[placement]))) return rc;   // octree items that do not fit the LDS
     if ((rc = ensure(c, c->lvl_kp, nb * o.kp_total * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, c->lvl_cnt, nb * o.nlevels * sizeof(int32_t) + 64))) return rc;
     if ((rc = ensure(c, c->kp_angle, nb * o.kp_total * sizeof(float)))) return rc;
@@ -1000,9 +1008,9 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     }
     {
         ProfScope ps(c, "orb_octree");
-        octree_kernel<<<B * o.nlevels, kOctThreads, o.oct_lds, c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
+        octree_kernel<<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
                                                                     (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p,
-                                                                    (int32_t*)c->lvl_cnt.p, err_flag, (int32_t*)c->status.p);
+                                                                    (int32_t*)c->lvl_cnt.p, err_flag, (int32_t*)c->status.p, placement);
         EORB_LAUNCH_CHECK(c, "octree_kernel");
     }
     {
