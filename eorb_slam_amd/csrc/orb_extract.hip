@@ -55,10 +55,17 @@ __global__ void pyr_level0_kernel(const uint8_t* __restrict__ img, int stride, s
     const int n = L.bw * L.bh;
     uint8_t* dst = pyr + (size_t)slice * G->pyr_bytes + L.buf_off;
     const uint8_t* src = img + (size_t)slice * slice_bytes;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int y = i / L.bw, x = i - y * L.bw;
-        const int sy = reflect101(y - G->edge, L.h), sx = reflect101(x - G->edge, L.w);
-        dst[i] = src[(size_t)sy * stride + sx];
+    // four destination bytes per thread (level buffers start on 64-byte boundaries; the tail of the last word is padding)
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += gridDim.x * blockDim.x) {
+        int y = (i4 * 4) / L.bw, x = i4 * 4 - y * L.bw;
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sy = reflect101(min(y, L.bh - 1) - G->edge, L.h), sx = reflect101(x - G->edge, L.w);
+            w |= (uint32_t)src[(size_t)sy * stride + sx] << (8 * k);
+            if (++x == L.bw) { x = 0; y++; }
+        }
+        ((uint32_t*)dst)[i4] = w;
     }
 }
 
@@ -994,7 +1001,7 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
         ProfScope ps(c, "orb_pyr");
         EORB_HIP(c, hipMemsetAsync(err_flag, 0, sizeof(int32_t), c->stream));
         const int n0 = o.lv[0].bw * o.lv[0].bh;
-        pyr_level0_kernel<<<dim3((n0 + 255) / 256, B), 256, 0, c->stream>>>(d_img, img_stride, img_slice_bytes, G, pyr);
+        pyr_level0_kernel<<<dim3((n0 / 4 + 256) / 256, B), 256, 0, c->stream>>>(d_img, img_stride, img_slice_bytes, G, pyr);
         for (int l = 1; l < o.nlevels; l++) {
             const int n = o.lv[l].bw * o.lv[l].bh;
             pyr_resize_kernel<<<dim3((n + 255) / 256, B), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
