@@ -1,4 +1,4 @@
-"""Randomised parity sweep of the raw-event accumulation (ev_gather_raw_kernel + binning) against the CPU oracle: image sizes that are
+"""Randomised parity sweep of the raw-event accumulation (ev_gather_raw_kernel / ev_gather_sparse_kernel + binning) against the CPU oracle: image sizes that are
 not multiples of the tile, sigmas up to the 17x17 stamp, polarity, maps that throw pixels out of the image with and without
 checkInImage, event counts on the 64-entry batch boundaries, hot pixels.  Run on the GPU box: python tests/fuzz/fuzz_raw.py [cases] [seed]"""
 import os, sys, time
@@ -35,6 +35,8 @@ for case in range(ncase):
         raw["x"][:k] = rng.integers(0, LW, k); raw["y"][:k] = rng.integers(0, LH, k)
         rng.shuffle(raw)
     raw["p"] = rng.integers(0, 2, n); raw["t"] = np.arange(n) * 1e-6
+    form = int(rng.integers(0, 3))                                                # gather kernel: by shape / workgroup per tile / wave per tile
+    c.debug_option("gather_form", form)
     fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=c)
     ev = orc.undistort_events(raw, mx, my, W, H, check, 1.0)
     of, ou, omm = orc.ev2im_gauss(ev, W, H, sigma, pol, True)
@@ -47,7 +49,7 @@ for case in range(ncase):
             np.array_equal(np.asarray(omm, np.float32).view(np.uint32), hmm.view(np.uint32))
     if not ok:
         bad += 1
-        print("MISMATCH case", case, dict(W=W, H=H, LW=LW, LH=LH, sigma=sigma, pol=pol, check=check, n=n, mode=int(mode)),
+        print("MISMATCH case", case, dict(W=W, H=H, LW=LW, LH=LH, sigma=sigma, pol=pol, check=check, n=n, mode=int(mode), form=form),
               "pixels", int((of.view(np.uint32) != gf.view(np.uint32)).sum()), "minmax", omm, gmm, flush=True)
     if case % 25 == 24:
         print("case", case + 1, "bad", bad, "%.0f s" % (time.time() - t0), flush=True)
