@@ -502,13 +502,18 @@ def run_frames(env):
             one()
 
     def arm():
-        if not a.no_prof:
-            c.prof_reset(); c.prof_enable(True)
         st["nk"].clear(); st["nm"].clear()
     dt = timed_steps(env, step, arm)
+    nk, nm = list(st["nk"]), list(st["nm"])
+    # the per-kernel times come from a second pass over the same steps: with one frame per call the profiling scopes (two event
+    # records per kernel group) are a visible share of a call, and the value above is the product's, not the profiler's
     prof = {}
     if not a.no_prof:
+        c.prof_reset(); c.prof_enable(True)
+        for _ in range(a.steps):
+            step()
         c.prof_enable(False); prof = c.prof_results()
+    st["nk"], st["nm"] = nk, nm
     out = None
     if rank == 0:
         K = float(np.mean(st["nk"]))
@@ -522,7 +527,8 @@ def run_frames(env):
             bfb = (2000 + 2000) * 32 + 2000 * 16.0
             r, per_step = roofline_of(prof, a.steps, lambda k: bfb if k.startswith("bf_") else ext_bytes, 1)
             r["note"] = ("one frame per call: the working set (< 1 MB) lives in L2 / Infinity Cache and every kernel is launch- or "
-                         "latency-bound; the HBM fraction is reported as the contract asks")
+                         "latency-bound; the HBM fraction is reported as the contract asks; kernel times from a second, profiled "
+                         "pass over the same steps")
             out["roofline"] = r
             out["kernels_ms_per_step"] = per_step
         if ncpu > 0 and world == 1:

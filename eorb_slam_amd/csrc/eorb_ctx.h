@@ -83,6 +83,7 @@ struct eorb_ctx {
     std::string err;
     bool prof = false;
     std::vector<eorb::ProfEntry> profs;
+    std::vector<hipEvent_t> ev_pool;
 
     // accumulation workspaces
     eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order, order_hist;

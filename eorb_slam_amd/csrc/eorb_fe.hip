@@ -104,7 +104,9 @@ ProfScope::ProfScope(eorb_ctx* cc, const char* name) : c(cc), idx(-1)
     if (!c->prof) return;
     for (size_t i = 0; i < c->profs.size(); i++) if (c->profs[i].name == name) { idx = (int)i; break; }
     if (idx < 0) { c->profs.emplace_back(); c->profs.back().name = name; idx = (int)c->profs.size() - 1; }
-    hipEventCreate(&a); hipEventCreate(&b);
+    // events come from a pool (creating a pair costs several microseconds: visible on the one-frame-per-call paths)
+    auto take = [&](hipEvent_t& e) { if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else hipEventCreate(&e); };
+    take(a); take(b);
     hipEventRecord(a, c->stream);
 }
 ProfScope::~ProfScope()
@@ -115,14 +117,14 @@ ProfScope::~ProfScope()
     c->profs[idx].launches++;
 }
 
-static void prof_collect(eorb_ctx* c)
+void prof_collect(eorb_ctx* c)
 {
     for (auto& p : c->profs) {
         for (auto& ev : p.pending) {
             hipEventSynchronize(ev.second);
             float ms = 0; hipEventElapsedTime(&ms, ev.first, ev.second);
             p.total_ms += ms;
-            hipEventDestroy(ev.first); hipEventDestroy(ev.second);
+            c->ev_pool.push_back(ev.first); c->ev_pool.push_back(ev.second);
         }
         p.pending.clear();
     }
@@ -178,6 +180,7 @@ struct Arena {
         }
         EORB_HIP(c, hipMemcpyAsync(c->dl_pinned, (char*)c->arena.p + off, bytes, hipMemcpyDeviceToHost, c->stream));
         EORB_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->prof) prof_collect(c);               // the stream is idle: the scopes' events go back to the pool
         *host = (const char*)c->dl_pinned - off;
         return EORB_OK;
     }
@@ -224,6 +227,7 @@ void eorb_destroy(eorb_ctx* c)
                       &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->dl_pinned) hipHostFree(c->dl_pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
