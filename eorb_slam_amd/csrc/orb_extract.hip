@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restri
 {
     __shared__ uint8_t tile[(kCellMax + 6) * (kCellMax + 8)];
     __shared__ uint8_t smap[(kCellMax + 2) * (kCellMax + 2)];
-    __shared__ int s_wbase[4];
+    __shared__ uint8_t s_cnt[16 * 4];        // keypoints per (pass of 256 pixels, wave)
     const int slice = blockIdx.y;
     // locate (level, cell)
     int cid = blockIdx.x, level = 0;
@@ -173,16 +173,19 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restri
     // keypoint test at threshold th: corner (S > th) and score S-1 strictly greater than the 8 neighbours'
     // scores, a non-corner or out-of-domain neighbour scoring 0 (cv::FAST buffers are zero initialised).
     int th = G->iniTh;
+    const int npix = dw * dh, npass = (npix + 255) / 256;          // <= 15 passes of 256 pixels (cells of at most 60 x 60)
+    const int w = tid >> 6, lane = tid & 63;
     for (int attempt = 0; attempt < 2; attempt++) {
-        int emitted_base = 0;
-        // raster order emission in passes of 256 pixels
-        for (int i0 = 0; i0 < dw * dh; i0 += 256) {
-            const int i = i0 + tid;
-            bool kp = false; int S = 0, x = 0, y = 0;
-            if (i < dw * dh) {
-                y = i / dw; x = i - y * dw;
+        // raster order emission: every thread tests its pixel of every pass first (its flags stay in a register), the wave counts go
+        // to LDS, and after ONE barrier every thread knows how many keypoints precede its pixel
+        uint32_t flags = 0u;
+        for (int p = 0; p < npass; p++) {
+            const int i = p * 256 + tid;
+            bool kp = false;
+            if (i < npix) {
+                const int y = i / dw, x = i - y * dw;
                 const uint8_t* c = &smap[(y + 1) * sp + x + 1];
-                S = c[0];
+                const int S = c[0];
                 if (S > th) {
                     const int sc = S - 1;
                     kp = true;
@@ -198,24 +201,30 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restri
                 }
             }
             const uint64_t bal = __ballot(kp);
-            const int w = tid >> 6, lane = tid & 63;
-            if (lane == 0) s_wbase[w] = __popcll(bal);
-            __syncthreads();
-            int base = emitted_base;
-            for (int k = 0; k < w; k++) base += s_wbase[k];
-            const int tot = s_wbase[0] + s_wbase[1] + s_wbase[2] + s_wbase[3];
+            if (kp) flags |= 1u << p;
+            if (lane == 0) s_cnt[p * 4 + w] = (uint8_t)__popcll(bal);
+        }
+        __syncthreads();
+        int run = 0;
+        for (int p = 0; p < npass; p++) {
+            const int c0 = s_cnt[p * 4 + 0], c1 = s_cnt[p * 4 + 1], c2 = s_cnt[p * 4 + 2], c3 = s_cnt[p * 4 + 3];
+            const bool kp = (flags >> p) & 1u;
+            const uint64_t bal = __ballot(kp);
             if (kp) {
+                const int base = run + (w > 0 ? c0 : 0) + (w > 1 ? c1 : 0) + (w > 2 ? c2 : 0);
                 const int pos = base + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                const int i = p * 256 + tid, y = i / dw, x = i - y * dw;
+                const int S = smap[(y + 1) * sp + x + 1];
                 // keypoint coordinates relative to minBorder (:871-872): (x+3 + j*wCell, y+3 + i*hCell)
                 const uint32_t kx = (uint32_t)(x + 3 + cj * L.wCell), ky = (uint32_t)(y + 3 + ci * L.hCell);
                 if (pos < G->cell_cap) out[pos] = kx | (ky << 12) | ((uint32_t)(S - 1) << 24);
             }
-            emitted_base += tot;
-            __syncthreads();
+            run += c0 + c1 + c2 + c3;
         }
-        if (emitted_base > 0 || th == G->minTh) { if (tid == 0) *out_cnt = min(emitted_base, G->cell_cap); break; }
+        if (run > 0 || th == G->minTh) { if (tid == 0) *out_cnt = min(run, G->cell_cap); break; }
         th = G->minTh;        // vKeysCell.empty() -> retry with minThFAST (:849-852)
         if (attempt == 1 && tid == 0) *out_cnt = 0;
+        __syncthreads();      // s_cnt is rewritten by the second attempt
     }
 }
 
