@@ -331,12 +331,27 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     int n = 0;
     {
         const int nc = L.nCols * L.nRows;
-        for (int cidx = 0; cidx < nc; cidx++) {
-            const int ccnt = cell_cnt[(size_t)slice * G->ncells + L.cell_off + cidx];
-            const uint32_t* src = cell_cand + ((size_t)slice * G->ncells + L.cell_off + cidx) * G->cell_cap;
-            for (int i = tid; i < ccnt; i += kOctThreads)
-                if (n + i < ncap) { pts[n + i] = src[i]; keys[0][n + i] = (uint16_t)(n + i); }
-            n += ccnt;
+        const int32_t* ccnt_g = cell_cnt + (size_t)slice * G->ncells + L.cell_off;
+        if (nc <= pc) {
+            // all cell counts at once (one load per thread, not one dependent load per cell), their offsets by a block scan, then a
+            // wave per cell copies its candidates
+            for (int i = tid; i < nc; i += kOctThreads) aux[i] = ccnt_g[i];
+            __syncthreads();
+            n = oct_block_scan(aux, nc, s_ws);
+            for (int cidx = wave; cidx < nc; cidx += nwaves) {
+                const int o = aux[cidx], ccnt = (cidx + 1 < nc ? aux[cidx + 1] : n) - o;
+                const uint32_t* src = cell_cand + ((size_t)slice * G->ncells + L.cell_off + cidx) * G->cell_cap;
+                for (int i = lane; i < ccnt; i += 64)
+                    if (o + i < ncap) { pts[o + i] = src[i]; keys[0][o + i] = (uint16_t)(o + i); }
+            }
+        } else {
+            for (int cidx = 0; cidx < nc; cidx++) {
+                const int ccnt = ccnt_g[cidx];
+                const uint32_t* src = cell_cand + ((size_t)slice * G->ncells + L.cell_off + cidx) * G->cell_cap;
+                for (int i = tid; i < ccnt; i += kOctThreads)
+                    if (n + i < ncap) { pts[n + i] = src[i]; keys[0][n + i] = (uint16_t)(n + i); }
+                n += ccnt;
+            }
         }
         if (n > ncap) { raise(1); n = ncap; }
     }
