@@ -244,6 +244,8 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restri
 struct ONode { uint16_t x0, x1, y0, y1, start, cnt, seq; uint8_t flags, pad; };     // flags: bit0 bNoMore, bit1 key buffer
 static_assert(sizeof(ONode) == 16, "ONode is 16 bytes");
 constexpr int kOctThreads = 512;
+constexpr int kOctBigNode = 1024;   // keys from which a node is partitioned by the whole workgroup
+constexpr int kOctBigMax = 64;      // (ncap < 65 535 keys: at most 63 such nodes at a time)
 
 __device__ __forceinline__ int oct_wave_incl_scan(int x)
 {   // row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 / 31
@@ -306,7 +308,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
 {
     extern __shared__ unsigned char smem[];
     __shared__ int s_ws[kOctThreads / 64 + 2];
-    __shared__ int s_m, s_flag;
+    __shared__ int s_m, s_flag, s_nbig;
+    __shared__ uint16_t s_big[kOctBigMax];
+    __shared__ int s_wc[kOctThreads / 64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kOctThreads / 64;
     const int slice = blockIdx.x / G->nlevels, level = blockIdx.x % G->nlevels;
     const LevelGeom& L = G->lv[level];
@@ -410,9 +414,94 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     auto round = [&](int nP, bool cut, int& nToExpand) {
         const ONode* src = nodes[cur];
         ONode* dst = nodes[cur ^ 1];
-        // 2. one wavefront per node: child counts, stable partition into the other key buffer (DivideNode :531-545)
+        // 2a. nodes with many keys (the first passes: one or two roots hold every candidate): the whole workgroup partitions one
+        //     node, wave w its w-th contiguous share of the keys; the shares' class counts meet in LDS
+        if (tid == 0) s_nbig = 0;
+        __syncthreads();
+        for (int j = tid; j < nP; j += kOctThreads)
+            if (src[P[j]].cnt >= kOctBigNode) { const int k = atomicAdd(&s_nbig, 1); if (k < kOctBigMax) s_big[k] = (uint16_t)j; }
+        __syncthreads();
+        const int nbig = min(s_nbig, kOctBigMax);                   // (at most ncap / kOctBigNode <= 64 such nodes exist)
+        for (int b = 0; b < nbig; b++) {
+            const int j = s_big[b];
+            const ONode nd = src[P[j]];
+            const int sb = (nd.flags >> 1) & 1;
+            const uint16_t* ks = keys[sb]; uint16_t* kd = keys[sb ^ 1];
+            const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+            const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
+            const int start = nd.start, cnt = nd.cnt;
+            const int share = (((cnt + nwaves - 1) / nwaves) + 63) & ~63;          // keys per wave, a multiple of 64
+            const int k_lo = min(wave * share, cnt), k_hi = min(k_lo + share, cnt);
+            int c[4] = {0, 0, 0, 0};
+            for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+                const int i = k0 + lane;
+                int cls = -1;
+                if (i < k_hi) {
+                    const uint32_t p = pts[ks[start + i]];
+                    const int px = p & 0xfff, py = (p >> 12) & 0xfff;
+                    cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) c[q] += __popcll(__ballot(cls == q));
+            }
+            if (lane == 0) { s_wc[wave][0] = c[0]; s_wc[wave][1] = c[1]; s_wc[wave][2] = c[2]; s_wc[wave][3] = c[3]; }
+            __syncthreads();
+            int tot[4] = {0, 0, 0, 0}, before[4] = {0, 0, 0, 0};
+            for (int w = 0; w < nwaves; w++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int v = s_wc[w][q]; tot[q] += v; if (w < wave) before[q] += v; }
+            int sbase[4]; sbase[0] = start; sbase[1] = sbase[0] + tot[0]; sbase[2] = sbase[1] + tot[1]; sbase[3] = sbase[2] + tot[2];
+            int run[4] = {before[0], before[1], before[2], before[3]};
+            for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
+                const int i = k0 + lane;
+                int cls = -1; uint16_t key = 0;
+                if (i < k_hi) {
+                    key = ks[start + i];
+                    const uint32_t p = pts[key];
+                    const int px = p & 0xfff, py = (p >> 12) & 0xfff;
+                    cls = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint64_t bal = __ballot(cls == q);
+                    if (cls == q) kd[sbase[q] + run[q] + __popcll(bal & lt_mask)] = key;
+                    run[q] += __popcll(bal);
+                }
+            }
+            if (tid == 0) {
+                cc[j] = (uint64_t)tot[0] | ((uint64_t)tot[1] << 16) | ((uint64_t)tot[2] << 32) | ((uint64_t)tot[3] << 48);
+                aux[j] = ((tot[0] > 0) + (tot[1] > 0) + (tot[2] > 0) + (tot[3] > 0)) | (((tot[0] > 1) + (tot[1] > 1) + (tot[2] > 1) + (tot[3] > 1)) << 16);
+            }
+            __syncthreads();                                        // s_wc is rewritten by the next node
+        }
+        // 2b. one wavefront per remaining node: child counts, stable partition into the other key buffer (DivideNode :531-545)
         for (int j = wave; j < nP; j += nwaves) {
             const ONode nd = src[P[j]];
+            if (nd.cnt >= kOctBigNode && s_nbig <= kOctBigMax) continue;
+            if (nd.cnt <= 64) {
+                // (most nodes: one sub-batch -- the four ballots give the counts and the ranks at once)
+                const int sb = (nd.flags >> 1) & 1;
+                const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+                const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
+                int cls = -1; uint16_t key = 0;
+                if (lane < nd.cnt) {
+                    key = keys[sb][nd.start + lane];
+                    const uint32_t p = pts[key];
+                    cls = ((int)(p & 0xfff) < midx ? 0 : 1) + ((int)((p >> 12) & 0xfff) < midy ? 0 : 2);
+                }
+                const uint64_t b0 = __ballot(cls == 0), b1 = __ballot(cls == 1), b2 = __ballot(cls == 2), b3 = __ballot(cls == 3);
+                const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2), c3 = __popcll(b3);
+                if (cls >= 0) {
+                    const uint64_t mb = cls == 0 ? b0 : (cls == 1 ? b1 : (cls == 2 ? b2 : b3));
+                    const int base = nd.start + (cls > 0 ? c0 : 0) + (cls > 1 ? c1 : 0) + (cls > 2 ? c2 : 0);
+                    keys[sb ^ 1][base + __popcll(mb & lt_mask)] = key;
+                }
+                if (lane == 0) {
+                    cc[j] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
+                    aux[j] = ((c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0)) | (((c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1)) << 16);
+                }
+                continue;
+            }
             const int sb = (nd.flags >> 1) & 1;
             const uint16_t* ks = keys[sb]; uint16_t* kd = keys[sb ^ 1];
             const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
