@@ -280,12 +280,79 @@ __device__ int oct_block_scan(int* a, int n, int* ws)
     return carry;
 }
 
-// bitonic sort (ascending) of n u64 items by the whole workgroup; padded with ~0 up to the next power of two
+// bitonic sort (ascending) of n u64 items by the whole workgroup; padded with ~0 up to the next power of two.  Thread t keeps
+// items t, t + 512, ... in registers: partners less than 64 apart are exchanged by lane shuffles, partners a multiple of 512 apart
+// are the thread's own registers, and only the distances 64, 128, 256 go through the array and two barriers (6 of the 45 steps of a
+// 512-item sort).
+__device__ __forceinline__ uint64_t oct_shfl_xor_u64(uint64_t v, int j)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int M>
+__device__ void oct_block_sort_regs(uint64_t* a, int np2)
+{
+    const int tid = threadIdx.x;
+    uint64_t v[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) { const int i = tid + kOctThreads * m; v[m] = i < np2 ? a[i] : ~0ull; }
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= kOctThreads) {
+#pragma unroll
+                for (int dm = 1; dm < M; dm <<= 1) {                 // (static register indices)
+                    if (j != dm * kOctThreads) continue;
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        if ((m & dm) == 0 && (m | dm) < M) {
+                            const int i = tid + kOctThreads * m;
+                            const bool up = (i & k) == 0;
+                            const uint64_t x = v[m], y = v[m | dm];
+                            const bool sw = (x > y) == up;
+                            v[m] = sw ? y : x; v[m | dm] = sw ? x : y;
+                        }
+                    }
+                }
+            } else if (j >= 64) {
+#pragma unroll
+                for (int m = 0; m < M; m++) { const int i = tid + kOctThreads * m; if (i < np2) a[i] = v[m]; }
+                __syncthreads();
+                uint64_t o[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) { const int i = tid + kOctThreads * m; o[m] = i < np2 ? a[i ^ j] : ~0ull; }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const int i = tid + kOctThreads * m;
+                    const bool up = (i & k) == 0, low = (i & j) == 0;
+                    const uint64_t mn = v[m] < o[m] ? v[m] : o[m], mx = v[m] < o[m] ? o[m] : v[m];
+                    v[m] = (low == up) ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const int i = tid + kOctThreads * m;
+                    const uint64_t o = oct_shfl_xor_u64(v[m], j);
+                    const bool up = (i & k) == 0, low = (i & j) == 0;
+                    const uint64_t mn = v[m] < o ? v[m] : o, mx = v[m] < o ? o : v[m];
+                    v[m] = (low == up) ? mn : mx;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) { const int i = tid + kOctThreads * m; if (i < np2) a[i] = v[m]; }
+    __syncthreads();
+}
 __device__ void oct_block_sort_u64(uint64_t* a, int n)
 {
     int np2 = 1; while (np2 < n) np2 <<= 1;
     for (int i = n + threadIdx.x; i < np2; i += blockDim.x) a[i] = ~0ull;
     __syncthreads();
+    if (np2 <= kOctThreads) { oct_block_sort_regs<1>(a, np2); return; }
+    if (np2 <= 2 * kOctThreads) { oct_block_sort_regs<2>(a, np2); return; }
+    if (np2 <= 4 * kOctThreads) { oct_block_sort_regs<4>(a, np2); return; }
+    if (np2 <= 8 * kOctThreads) { oct_block_sort_regs<8>(a, np2); return; }
     for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < np2; i += blockDim.x) {
