@@ -1043,6 +1043,48 @@ def test_frontend_batch_raw_equals_float_path(oracle, fe):
     assert np.array_equal(ou, b[0][2]) and a[1].min() > 20
 
 
+def test_large_batch_takes_the_many_workgroup_forms(oracle, fe):
+    """96 slices x 4 levels = 384 octree workgroups (> 256 CUs: the second LDS placement, two workgroups per CU) and 96 x 690 = 66 240
+    nearly empty tiles (the wave-per-tile gather with 8 tiles per wave): every slice must come out as it does in a batch of three
+    (first placement, one tile per wave), and slice 0 is checked against the oracle."""
+    W, H, n, B = 240, 180, 3000, 96
+    mx, my = _maps(W, H)
+    base = [synth.shapes_events(n, W, H, seed=300 + b, motion=0.4, undistort=True, return_raw=True) for b in range(6)]
+
+    def run(idx):
+        nb = len(idx)
+        fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=nb, max_events=n)
+        c, cap = fb.ctx, fb.cap
+        fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
+        blob = np.concatenate([base[i][1] for i in idx])
+        d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
+        d_img = c.dev_alloc(nb * W * H); d_kp = c.dev_alloc(nb * cap * 28); d_desc = c.dev_alloc(nb * cap * 32)
+        d_n = c.dev_alloc(nb * 4); d_m = c.dev_alloc(nb * cap * 4); d_nm = c.dev_alloc(nb * 4)
+        fb.run_dev(d_ev, np.arange(nb + 1, dtype=np.int64) * n, d_img, d_kp, d_desc, d_n, d_m, d_nm, raw=True)
+        c.sync()
+        imgs = np.zeros((nb, H, W), np.uint8); c.download(imgs, d_img)
+        nk = np.zeros(nb, np.int32); c.download(nk, d_n)
+        kps = np.zeros((nb, cap), synth.KP_DTYPE); c.download(kps, d_kp)
+        desc = np.zeros((nb, cap, 32), np.uint8); c.download(desc, d_desc)
+        for p in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
+            c.dev_free(p)
+        c.close()
+        return imgs, nk, kps, desc
+
+    big = run([b % 6 for b in range(B)])
+    small = [run([i, (i + 1) % 6, (i + 2) % 6]) for i in (0, 3)]
+    ref = {}
+    for s, i0 in zip(small, (0, 3)):
+        for k in range(3):
+            ref[(i0 + k) % 6] = (s[0][k], int(s[1][k]), s[2][k], s[3][k])
+    for b in range(B):
+        img, nk, kps, desc = ref[b % 6]
+        assert np.array_equal(big[0][b], img) and int(big[1][b]) == nk, b
+        assert np.array_equal(big[2][b][:nk].view(np.uint8), kps[:nk].view(np.uint8)) and np.array_equal(big[3][b][:nk], desc[:nk]), b
+    _, ou, _ = oracle.ev2im_gauss(base[0][0], W, H, 1.0, False, True)
+    assert np.array_equal(ou, big[0][0]) and big[1].min() > 5
+
+
 def test_full_size_batch_properties(oracle, fe):
     """BASELINE.json configs[1] sizes (1 000 000 events per slice): the raw and the float inputs give the same images / keypoints,
     a slice's result does not depend on its position or company in the batch, and slices 0 and 1 are checked against the oracle:
