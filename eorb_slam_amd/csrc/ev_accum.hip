@@ -811,12 +811,10 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
     // pixel, same logical group) spread over all banks; a value wave's store (lane = slot, one pixel) stays 64 consecutive words.
     __shared__ __attribute__((aligned(16))) float vals[2][64 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // One tile per workgroup when the tiles carry real work (the hardware then balances the heaviest-first order dynamically).  When
-    // they are nearly empty (2 000-event slices leave most of their 690 tiles with a handful of entries) the launch rate of the
-    // workgroups is the cost: the host then starts fewer workgroups and each walks the order with stride gridDim.x.
-    for (int item = blockIdx.x; item < P.total; item += gridDim.x) {
+    // One tile per workgroup: the hardware balances the heaviest-first order dynamically.  (Launches of nearly empty tiles take K2s;
+    // a loop over several tiles around this body cost 14 VGPRs and with them the fifth workgroup per CU.)
     bool any_ok = false;                             // (wave 1) some entry of the tile touches an in-image pixel
-    const int logical = order[item];
+    const int logical = order[blockIdx.x];
     const int slice = logical / P.NT;
     const int tile = logical - slice * P.NT;
     const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
@@ -830,7 +828,7 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
             const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
             if (px < P.W && py < P.H) img[(size_t)slice * P.W * P.H + (size_t)py * P.W + px] = 0.0f;
         }
-        continue;
+        return;
     }
     const uint2* list = entries + (size_t)slice_ebase[slice] + tile_base[logical];
     constexpr int kRowFloats = 8 * 64;
@@ -1027,8 +1025,6 @@ __global__ __launch_bounds__(64 * (1 + 8 / NC)) void ev_gather_raw_kernel(const 
         atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
         atomicMax(&minmax_enc[slice * 2 + 1], enc_f32(vmax));
     }
-    }
-    if (gridDim.x < (unsigned)P.total) __syncthreads();      // (several tiles per workgroup: the list buffer is free for the next one)
     }
 }
 
@@ -1807,8 +1803,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             const int NC = nc_env == 2 || nc_env == 4 ? nc_env : (nb >= 32768 ? 4 : 2);
             const int rthreads = 64 * (1 + 8 / NC);
             const uint2* en2 = (const uint2*)c->entries.p;
-            // nearly empty tiles (fewer than one 64-entry batch per tile on average): ~20 workgroups per CU walk the order
-            const int ngrid = (nev * dup < (int64_t)nb * 64) ? std::min(nb, 20 * 256) : nb;
+            const int ngrid = nb;
 #define LAUNCH_R(PP, CC) ev_gather_raw_kernel<PP, CC><<<ngrid, rthreads, 0, c->stream>>>(d_slice_eb, d_order, G, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc)
             if (pol) { if (NC == 4) LAUNCH_R(true, 4); else LAUNCH_R(true, 2); }
             else { if (NC == 4) LAUNCH_R(false, 4); else LAUNCH_R(false, 2); }
