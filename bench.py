@@ -428,8 +428,22 @@ def run_batch(env):
                 t2 = time.perf_counter()
                 if i >= 20:
                     lat["ev2im_gauss"].append(t1 - t0); lat["orb_detect"].append(t2 - t1); lat["total"].append(t2 - t0)
+            # the same slice as the sensor delivers it: eorb_ev2im_gauss_raw resolves the raw events through the maps on the GPU
+            # (what the reference's loader + ev2im_gauss do together)
+            frontend.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
+            lat["ev2im_gauss_raw"] = []; lat["total_raw"] = []
+            for i in range(a.latency_calls + 20):
+                rw = lat_pairs[i % len(lat_pairs)][1]
+                t0 = time.perf_counter()
+                u8 = frontend.EvImConverter.ev2im_gauss_raw(rw, W, H, 1.0, False, True, ctx=c)
+                t1 = time.perf_counter()
+                ge(u8, (0, 1000), False)
+                t2 = time.perf_counter()
+                if i >= 20:
+                    lat["ev2im_gauss_raw"].append(t1 - t0); lat["total_raw"].append(t2 - t0)
             out["latency"] = {"what": "one %d-event slice per call, host buffers in and out (PCIe and binding overhead included): "
-                                      "eorb_ev2im_gauss -> eorb_orb_extract(detect-only)" % NEV, "calls": a.latency_calls,
+                                      "eorb_ev2im_gauss (undistorted float events, the reference's seam) or eorb_ev2im_gauss_raw (sensor "
+                                      "events, loader fused) -> eorb_orb_extract(detect-only)" % NEV, "calls": a.latency_calls,
                               **{k: _pcts(v) for k, v in lat.items()}}
             c.close()
         # ---- CPU baseline: the oracle (port), bounded sample of the same workload ----

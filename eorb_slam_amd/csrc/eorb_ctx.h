@@ -121,7 +121,7 @@ struct eorb_ctx {
     eorb::DevBuf status;
     // test hooks (eorb_debug_option): shrink the octree node pool to force an overflow; force the octree's global-memory layout
     int dbg_pool_shrink = 0, dbg_force_global = 0;
-    int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s
+    int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
 };
 

@@ -1098,6 +1098,108 @@ __global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(con
     }
 }
 
+// K2d: one or a few SMALL slices per call (the live path: eorb_ev2im_gauss_raw on a 2 000-event slice).  Binning costs four launches
+// and a descriptor upload there; instead every tile's wave reads ALL events of its slice (690 waves x 2 000 events: nothing),
+// keeps those whose stamp reaches the tile -- in event order, ballot-compacted into a small LDS list -- and adds them as K2s does.
+// Same entries in the same order as the binned lists, hence the same image.
+struct DirectSlices { int64_t off[5]; };            // event offsets of up to 4 slices
+constexpr int kDirectList = 1024;                   // entries of the LDS list (flushed when full)
+template <bool POL>
+__global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_event* __restrict__ ev, DirectSlices S, BinParams B, GatherParams P,
+                                                              float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
+{
+    __shared__ uint2 lst[kDirectList];
+    const int lane = threadIdx.x;
+    const int slice = blockIdx.x / P.NT, tile = blockIdx.x - slice * P.NT;
+    const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
+    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+    const bool inimg = px < P.W && py < P.H;
+    const int SW = 2 * P.h + 1, SWP = P.stamp_colstride;
+    const eorb_raw_event* e = ev + S.off[slice];
+    const int n = (int)(S.off[slice + 1] - S.off[slice]);
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
+    bool touched = false, any = false;
+    int nl = 0;
+    // the adds of the listed entries (K2s' loop over a list in LDS)
+    auto flush = [&]() {
+        for (int e0 = 0; e0 < nl; e0 += 64) {
+            const int cnt = min(64, nl - e0);
+            const uint2 mine = lst[e0 + min(lane, cnt - 1)];
+            constexpr int U = 8;
+            for (int k0 = 0; k0 < cnt; k0 += U) {
+                float v[U]; bool in[U]; uint32_t sgn[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = min(k0 + u, cnt - 1);
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, k), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, k);
+                    const int xi = (int)(int16_t)(w1 & 0xffff), yi = (int)(int16_t)(w1 >> 16);
+                    const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
+                    in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
+                    sgn[u] = w0 & 0x80000000u;
+                    const uint32_t off = (w0 & 0x7fffffffu) * (uint32_t)P.stamp_stride + i * (uint32_t)SWP + j;
+                    v[u] = in[u] ? P.stamps[off] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (in[u]) {
+                        acc = acc + (POL ? __uint_as_float(__float_as_uint(v[u]) ^ sgn[u]) : v[u]);
+                        if (POL) { vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); }
+                        touched = true;
+                    }
+            }
+        }
+        nl = 0;
+    };
+    constexpr int G = 8;                                     // sub-batches of 64 events whose loads are in flight together
+    for (int k0 = 0; k0 < n; k0 += 64 * G) {
+        uint32_t xy[G], pp[G], info[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int k = k0 + g * 64 + lane;
+            const uint2 q = k < n ? *(const uint2*)&e[k] : make_uint2(0xffffffffu, 0u);        // { x | y << 16, p }
+            xy[g] = q.x; pp[g] = q.y;
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int x = (int)(xy[g] & 0xffff), y = (int)(xy[g] >> 16);
+            info[g] = (x < B.LW && y < B.LH) ? B.src_info[(uint32_t)y * (uint32_t)B.LW + x] : 0x80008000u;    // (-32768, -32768): dropped
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (k0 + g * 64 >= n) break;
+            const int xi = (int)(int16_t)(info[g] & 0xffff), yi = (int)(int16_t)(info[g] >> 16);
+            // the event has an entry in this tile's list iff the tile lies in its tile range (ev_tile_range_raw)
+            const bool hit = info[g] != 0x80008000u && xi - P.h <= tx0 + kTile - 1 && xi + P.h >= tx0 && yi - P.h <= ty0 + kTile - 1 && yi + P.h >= ty0;
+            const uint64_t m = __ballot(hit);
+            if (m) {
+                if (hit) {
+                    const uint32_t src = (xy[g] >> 16) * (uint32_t)B.LW + (xy[g] & 0xffff);
+                    lst[nl + __popcll(m & lt_mask)] = make_uint2(src | (pp[g] ? 0u : 0x80000000u), info[g]);
+                }
+                nl += __popcll(m); any = true;
+                if (nl > kDirectList - 64) flush();
+            }
+        }
+    }
+    flush();
+    float* const dst = img + (size_t)slice * P.W * P.H + (size_t)py * P.W + px;
+    if (!any) { if (inimg) *dst = 0.0f; return; }          // an empty list: no offer to the running extremes (as K2s / K2r)
+    const bool tile_ok = __any(touched);
+    if (!POL && tile_ok) vmax = fmaxf(vmax, acc);
+    if (inimg) *dst = acc;
+    else { vmax = -1000000.0f; vmin = 0.0f; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
+        vmin = fminf(vmin, __shfl_xor(vmin, d, 64));
+    }
+    if (lane == 0) {
+        atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
+        atomicMax(&minmax_enc[slice * 2 + 1], enc_f32(vmax));
+    }
+}
+
 // exhaustive self-check helper: IEEE quotient vs the reciprocal/fma sequence used above
 __global__ void ev_divcheck_kernel(uint32_t lo_bits, uint32_t hi_bits, float norm, float rcp, unsigned long long* bad)
 {
@@ -1639,6 +1741,57 @@ int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* 
     return EORB_OK;
 }
 
+// arithmetic constants of the Gaussian stamp (shared by all gather kernels)
+static GatherParams ev_gather_params(int W, int H, int h, int TX, int TY, int NT, int mode_count, int nb, float sigma)
+{
+    const float sig2 = sigma * sigma;
+    GatherParams G{W, H, h, TX, TY, NT, mode_count, nb, 2.0f * sig2,
+                   2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0, nullptr, 0, 0};
+    {
+        int ex2 = 0;
+        const float mant = frexpf(G.two_sig2, &ex2);
+        G.div_is_pow2 = (mant == 0.5f) && ex2 > -100 && ex2 < 100;
+        G.inv_two_sig2 = G.div_is_pow2 ? 1.0f / G.two_sig2 : 0.f;
+        G.rcp_norm = (float)(1.0 / (double)G.norm);
+        // the residual ev*2^-24 must stay a normal float: exp(-dd_max) > 1e-27, dd_max = (h+1)^2 / sig2
+        const double ddmax = (double)(h + 1) * (h + 1) / (double)sig2;
+        G.fast_norm = (ddmax < 60.0) && (G.norm < 1e3f) && (G.norm > 1e-3f);
+    }
+    return G;
+}
+
+// raw events: the tables derived from the maps (integer position of every sensor pixel, its stamp); rebuilt only when (image size,
+// sigma, mode) change
+static int ev_raw_tables(eorb_ctx* c, int W, int H, int h, float sigma, int mode_count, GatherParams& G)
+{
+    int rc;
+    const bool raw = true;
+    if (raw) {
+        // tables derived from the maps; rebuilt only when (image size, sigma, mode) change
+        const int nsrc = c->lut_w * c->lut_h;
+        const int SW = 2 * h + 1, SWP = (SW + 3) & ~3;
+        G.stamp_stride = SW * SWP; G.stamp_colstride = SWP;
+        if (c->lut_key_W != W || c->lut_key_H != H || c->lut_key_sigma != sigma || c->lut_key_mode != mode_count) {
+            ProfScope ps(c, "ev_stamp_tables");
+            if ((rc = ensure(c, c->src_info, sizeof(uint32_t) * (size_t)nsrc))) return rc;
+            ev_src_info_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, nsrc, W, H, c->lut_check, mode_count,
+                                                                            (uint32_t*)c->src_info.p);
+            if (!mode_count) {
+                if ((size_t)nsrc * SW * SWP * 4 + 256 >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
+                if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 2 * kStampPad)))) return rc;
+                EORB_HIP(c, hipMemsetAsync(c->stamps.p, 0, sizeof(float) * kStampPad, c->stream));
+                EORB_HIP(c, hipMemsetAsync((float*)c->stamps.p + kStampPad + (size_t)nsrc * SW * SWP, 0, sizeof(float) * kStampPad, c->stream));
+                ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
+                                                             (float*)c->stamps.p + kStampPad);
+            }
+            EORB_LAUNCH_CHECK(c, "ev_stamp_tables kernels");
+            c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
+        }
+        G.stamps = (const float*)c->stamps.p + kStampPad;     // K2r reads up to 7 floats before / behind a column
+    }
+    return EORB_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
@@ -1656,6 +1809,39 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     const int TX = (W + kTile - 1) / kTile, TY = (H + kTile - 1) / kTile, NT = TX * TY;
     int nbits = 1; while ((1 << nbits) < NT) nbits++;
     const int dup = R * R;
+    {
+        // one or a few small slices of raw events (the live per-slice call): no binning at all, K2d
+        const int64_t nev0 = h_offsets[B] - h_offsets[0];
+        if (raw && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
+            DirectSlices S;
+            for (int b = 0; b <= B; b++) {
+                if (b && h_offsets[b] < h_offsets[b - 1]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
+                S.off[b] = h_offsets[b];
+            }
+            if (nev0 * dup >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)nev0);
+            int rc;
+            GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, mode_count, B * NT, sigma);
+            if ((rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
+            BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
+            {
+                ProfScope ps(c, "ev_minmax_init");
+                ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
+            }
+            {
+                ProfScope ps(c, "ev_gather");
+                if (pol) ev_gather_direct_kernel<true><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc);
+                else ev_gather_direct_kernel<false><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc);
+                EORB_LAUNCH_CHECK(c, "ev_gather_direct_kernel");
+            }
+            if (normalized && d_u8) {
+                ProfScope ps(c, "ev_normalize");
+                dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
+                ev_normalize_kernel<<<grid, 256, 0, c->stream>>>(d_f32, d_minmax_enc, d_u8, W * H, mode_count);
+                EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
+            }
+            return EORB_OK;
+        }
+    }
     // chunk list (host) -> device.  A chunk is binned by ONE wavefront, 64 events at a time: large inputs take kChunk events per
     // chunk (fewer segment tables), small ones shorter chunks so that a single 2 000-event slice is not one 32-iteration serial
     // loop (72 us on MI355X) but eight waves side by side
@@ -1710,42 +1896,8 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     uint32_t* d_tile_base = d_tile_cnt + nb;
     int32_t* d_order = (int32_t*)(d_tile_cnt + 2 * (size_t)nb);
 
-    const float sig2 = sigma * sigma;
-    GatherParams G{W, H, h, TX, TY, NT, mode_count, nb, 2.0f * sig2,
-                   2.0f * (float)3.1415926535897932384626433832795 * sig2, 0.f, 0.f, 0, 0, nullptr, 0, 0};
-    {
-        int ex2 = 0;
-        const float mant = frexpf(G.two_sig2, &ex2);
-        G.div_is_pow2 = (mant == 0.5f) && ex2 > -100 && ex2 < 100;
-        G.inv_two_sig2 = G.div_is_pow2 ? 1.0f / G.two_sig2 : 0.f;
-        G.rcp_norm = (float)(1.0 / (double)G.norm);
-        // the residual ev*2^-24 must stay a normal float: exp(-dd_max) > 1e-27, dd_max = (h+1)^2 / sig2
-        const double ddmax = (double)(h + 1) * (h + 1) / (double)sig2;
-        G.fast_norm = (ddmax < 60.0) && (G.norm < 1e3f) && (G.norm > 1e-3f);
-    }
-    if (raw) {
-        // tables derived from the maps; rebuilt only when (image size, sigma, mode) change
-        const int nsrc = c->lut_w * c->lut_h;
-        const int SW = 2 * h + 1, SWP = (SW + 3) & ~3;
-        G.stamp_stride = SW * SWP; G.stamp_colstride = SWP;
-        if (c->lut_key_W != W || c->lut_key_H != H || c->lut_key_sigma != sigma || c->lut_key_mode != mode_count) {
-            ProfScope ps(c, "ev_stamp_tables");
-            if ((rc = ensure(c, c->src_info, sizeof(uint32_t) * (size_t)nsrc))) return rc;
-            ev_src_info_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, nsrc, W, H, c->lut_check, mode_count,
-                                                                            (uint32_t*)c->src_info.p);
-            if (!mode_count) {
-                if ((size_t)nsrc * SW * SWP * 4 + 256 >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
-                if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 2 * kStampPad)))) return rc;
-                EORB_HIP(c, hipMemsetAsync(c->stamps.p, 0, sizeof(float) * kStampPad, c->stream));
-                EORB_HIP(c, hipMemsetAsync((float*)c->stamps.p + kStampPad + (size_t)nsrc * SW * SWP, 0, sizeof(float) * kStampPad, c->stream));
-                ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
-                                                             (float*)c->stamps.p + kStampPad);
-            }
-            EORB_LAUNCH_CHECK(c, "ev_stamp_tables kernels");
-            c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
-        }
-        G.stamps = (const float*)c->stamps.p + kStampPad;     // K2r reads up to 7 floats before / behind a column
-    }
+    GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, mode_count, nb, sigma);
+    if (raw && (rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
     {
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);

@@ -35,7 +35,7 @@ for case in range(ncase):
         raw["x"][:k] = rng.integers(0, LW, k); raw["y"][:k] = rng.integers(0, LH, k)
         rng.shuffle(raw)
     raw["p"] = rng.integers(0, 2, n); raw["t"] = np.arange(n) * 1e-6
-    form = int(rng.integers(0, 3))                                                # gather kernel: by shape / workgroup per tile / wave per tile
+    form = int(rng.integers(0, 4))                                                # gather kernel: by shape / workgroup per tile / wave per tile / no binning
     c.debug_option("gather_form", form)
     fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=c)
     ev = orc.undistort_events(raw, mx, my, W, H, check, 1.0)

@@ -930,12 +930,13 @@ def test_polarity_extremes_of_one_sided_images(oracle, fe, ctx):
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), mm.view(np.uint32))
 
 
-@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("form", [0, 1, 2, 3])
 def test_raw_accumulation_random_sweep(oracle, fe, form):
     """A seeded sweep over image sizes that are not multiples of the tile, stamps of 3x3 ... 17x17 taps, polarity, maps that throw
     pixels out of the image with and without checkInImage, event counts on the 64-entry batch boundaries and hot pixels
-    (tests/fuzz/fuzz_raw.py runs the long version).  form: the gather kernel -- chosen by the batch's shape (0), the pipelined
-    workgroup per tile whatever the shape (1), the wave per tile whatever the shape (2)."""
+    (tests/fuzz/fuzz_raw.py runs the long version).  form: the gather kernel -- chosen by the batch's shape (0: up to 16 384 events
+    per call take the binning-free kernel), the pipelined workgroup per tile whatever the shape (1), the wave per tile whatever the
+    shape (2), no binning whatever the size (3)."""
     ctx = fe.Context()
     ctx.debug_option("gather_form", form)
     rng = np.random.default_rng(2024)
