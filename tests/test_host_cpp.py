@@ -88,3 +88,13 @@ def test_host_mirror_runs(tmp_path):
     exe = _build(str(tmp_path))
     out = subprocess.run([exe, "run"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_latency_tool_compiles(tmp_path):
+    """tools/latency.cpp (per-slice latency through the bare C ABI) must keep compiling and linking."""
+    from eorb_slam_amd import _lib
+    libdir = os.path.dirname(_lib.build())
+    exe = os.path.join(str(tmp_path), "latency")
+    p = subprocess.run(["g++", "-O2", "-std=c++14", "-Wall", "-I", ROOT, os.path.join(ROOT, "tools", "latency.cpp"), "-o", exe, "-L", libdir,
+                        "-leorb_fe", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
