@@ -156,7 +156,8 @@ int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int
                   uint8_t* d_status, float* d_err);
 // orb_extract.hip
 int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
-                    int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono);
+                    int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono,
+                    int32_t* d_flag_out = nullptr);      // d_flag_out: receives the overflow flag of this extraction (host entry point)
 // match.hip
 int search_init_dev(eorb_ctx* c, int npairs,
                     const eorb_keypoint* kps1, const int32_t* n1, size_t kp1_stride, const uint8_t* desc1, int dstride1, size_t desc1_slice,

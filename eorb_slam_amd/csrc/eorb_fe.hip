@@ -355,17 +355,21 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
     if ((rc = A.upload())) return rc;
     int64_t offs[2] = {0, (int64_t)n};
     uint32_t* mm = A.dev<uint32_t>(o_mm);
-    float* mmf = (float*)((char*)mm + 16);
     uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
     float* d_f32 = A.dev<float>(o_f32);
-    if (out_u8) EORB_HIP(c, hipMemsetAsync(d_u8, 0, npix, c->stream));     // count images stay empty when max == min
+    if (out_u8 && mode_count) EORB_HIP(c, hipMemsetAsync(d_u8, 0, npix, c->stream));     // count images stay empty when max == min
     rc = ev_accumulate_dev(c, A.dev<void>(o_ev), raw, offs, 1, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, mm);
     if (rc) return rc;
-    if ((rc = ev_decode_minmax(c, mm, mmf, 1))) return rc;
     const size_t end = out_f32 ? o_f32 + sizeof(float) * npix : (out_u8 ? o_u8 + npix : o_mm + 64);
     const char* h;
     if ((rc = A.download(o_mm, end - o_mm, &h))) return rc;
-    const float* hmm = (const float*)(h + o_mm + 16);
+    // the running extremes come back in their order-preserving integer encoding (enc_f32 of the gather kernels): decoded here
+    float hmm[2];
+    for (int k = 0; k < 2; k++) {
+        uint32_t e; memcpy(&e, h + o_mm + 4 * k, 4);
+        const uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+        memcpy(&hmm[k], &u, 4);
+    }
     if (out_f32) memcpy(out_f32, h + o_f32, sizeof(float) * npix);
     if (out_u8) memcpy(out_u8, h + o_u8, npix);
     if (minmax) { minmax[0] = hmm[0]; minmax[1] = hmm[1]; }
@@ -666,9 +670,8 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     if ((rc = A.upload())) return rc;
     int32_t* dn = A.dev<int32_t>(o_n);
     rc = orb_extract_dev(c, A.dev<uint8_t>(o_img), W, (size_t)W * H, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp),
-                         A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob), dn, dn + 1);
+                         A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob), dn, dn + 1, dn + 2);
     if (rc) return rc;
-    if ((rc = orb_err_flag_to(c, 1, dn + 2))) return rc;
     // one copy back: counters always, the rest up to the caller's capacity
     const size_t ncopy = std::min<size_t>(mo, (size_t)std::max(cap, 0));
     const size_t end = !ncopy ? o_n + 16 : (oob ? o_oob + ncopy : ((want_desc && desc) ? o_desc + 32 * ncopy : (kps ? o_kp + sizeof(eorb_keypoint) * ncopy : o_n + 16)));

@@ -48,8 +48,10 @@ __device__ __constant__ signed char c_pattern[1024];
 // ---------------------------------------------------------------------------------------------------
 // pyramid
 __global__ void pyr_level0_kernel(const uint8_t* __restrict__ img, int stride, size_t slice_bytes,
-                                  const DevGeom* __restrict__ G, uint8_t* __restrict__ pyr)
+                                  const DevGeom* __restrict__ G, uint8_t* __restrict__ pyr, int32_t* __restrict__ err_flag)
 {
+    // (the first kernel of an extraction also clears its overflow flag: one launch less than a memset)
+    if (err_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *err_flag = 0;
     const LevelGeom& L = G->lv[0];
     const int slice = blockIdx.y;
     const int n = L.bw * L.bh;
@@ -921,10 +923,12 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevGeom* __restrict
                                                        int lap0, int lap1, int want_desc, int out_cap,
                                                        eorb_keypoint* __restrict__ out_kp, uint8_t* __restrict__ out_desc,
                                                        uint8_t* __restrict__ out_oob, int32_t* __restrict__ out_n,
-                                                       int32_t* __restrict__ out_mono)
+                                                       int32_t* __restrict__ out_mono, const int32_t* __restrict__ err_flag,
+                                                       int32_t* __restrict__ out_flag)
 {
     __shared__ int s_w[4];
     const int slice = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (out_flag && slice == 0 && tid == 0) *out_flag = *err_flag;         // (host entry point: the flag travels with the counters)
     int nk = 0;
     for (int l = 0; l < G->nlevels; l++) nk += lvl_cnt[slice * G->nlevels + l];
     if (tid == 0) out_n[slice] = nk;
@@ -1156,7 +1160,8 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
 }
 
 int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
-                    int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono)
+                    int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono,
+                    int32_t* d_flag_out)
 {
     OrbState& o = c->orb;
     if (!o.configured) return set_err(c, EORB_E_NOTCONF, "orb_extract: eorb_orb_configure not called");
@@ -1179,9 +1184,8 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     int32_t* err_flag = (int32_t*)((char*)c->lvl_cnt.p + nb * o.nlevels * sizeof(int32_t));
     {
         ProfScope ps(c, "orb_pyr");
-        EORB_HIP(c, hipMemsetAsync(err_flag, 0, sizeof(int32_t), c->stream));
         const int n0 = o.lv[0].bw * o.lv[0].bh;
-        pyr_level0_kernel<<<dim3((n0 / 4 + 256) / 256, B), 256, 0, c->stream>>>(d_img, img_stride, img_slice_bytes, G, pyr);
+        pyr_level0_kernel<<<dim3((n0 / 4 + 256) / 256, B), 256, 0, c->stream>>>(d_img, img_stride, img_slice_bytes, G, pyr, err_flag);
         for (int l = 1; l < o.nlevels; l++) {
             const int n = o.lv[l].bw * o.lv[l].bh;
             pyr_resize_kernel<<<dim3((n + 255) / 256, B), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
@@ -1227,7 +1231,7 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
         assemble_kernel<<<B, 256, 0, c->stream>>>(G, (const uint32_t*)c->lvl_kp.p, (const int32_t*)c->lvl_cnt.p,
                                                   (const float*)c->kp_angle.p, (const uint8_t*)c->out_desc.p,
                                                   (const uint8_t*)c->out_oob.p, lap0, lap1, want_desc, o.max_out, d_kps, d_desc,
-                                                  d_oob, d_n, d_mono);
+                                                  d_oob, d_n, d_mono, err_flag, d_flag_out);
         EORB_LAUNCH_CHECK(c, "assemble_kernel");
     }
     return EORB_OK;
@@ -1245,7 +1249,7 @@ int orb_pyramid_blur_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride)
     uint8_t* pyr = (uint8_t*)c->pyr.p;
     ProfScope ps(c, "orb_pyr_blur");
     const int n0 = o.lv[0].bw * o.lv[0].bh;
-    pyr_level0_kernel<<<dim3((n0 + 255) / 256, 1), 256, 0, c->stream>>>(d_img, img_stride, 0, G, pyr);
+    pyr_level0_kernel<<<dim3((n0 + 255) / 256, 1), 256, 0, c->stream>>>(d_img, img_stride, 0, G, pyr, nullptr);
     for (int l = 1; l < o.nlevels; l++) {
         const int n = o.lv[l].bw * o.lv[l].bh;
         pyr_resize_kernel<<<dim3((n + 255) / 256, 1), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
