@@ -543,8 +543,44 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
             }
             __syncthreads();                                        // s_wc is rewritten by the next node
         }
-        // 2b. one wavefront per remaining node: child counts, stable partition into the other key buffer (DivideNode :531-545)
-        for (int j = wave; j < nP; j += nwaves) {
+        // 2b. the remaining nodes: child counts, stable partition into the other key buffer (DivideNode :531-545).  A wave takes four
+        //     nodes at a time, one per 16-lane group, when they have at most 16 keys (after the first passes nearly all do: a wave per
+        //     node would run a quarter full and walk the nodes one latency chain at a time); larger ones get the whole wave below.
+        for (int j0 = wave * 4; j0 < nP; j0 += nwaves * 4) {
+            const int grp = lane >> 4, gl = lane & 15;
+            const int jg = j0 + grp;
+            ONode nd; nd.cnt = 0; nd.flags = 0; nd.start = 0; nd.x0 = nd.x1 = nd.y0 = nd.y1 = 0;
+            if (jg < nP) nd = src[P[jg]];
+            const bool small = jg < nP && nd.cnt <= 16;
+            {
+                const int sb = (nd.flags >> 1) & 1;
+                const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+                const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
+                int cls = -1; uint16_t key = 0;
+                if (small && gl < nd.cnt) {
+                    key = keys[sb][nd.start + gl];
+                    const uint32_t p = pts[key];
+                    cls = ((int)(p & 0xfff) < midx ? 0 : 1) + ((int)((p >> 12) & 0xfff) < midy ? 0 : 2);
+                }
+                const int sh = grp * 16;
+                const uint32_t b0 = (uint32_t)(__ballot(cls == 0) >> sh) & 0xffffu, b1 = (uint32_t)(__ballot(cls == 1) >> sh) & 0xffffu,
+                               b2 = (uint32_t)(__ballot(cls == 2) >> sh) & 0xffffu, b3 = (uint32_t)(__ballot(cls == 3) >> sh) & 0xffffu;
+                const int c0 = __popc(b0), c1 = __popc(b1), c2 = __popc(b2), c3 = __popc(b3);
+                if (cls >= 0) {
+                    const uint32_t mb = cls == 0 ? b0 : (cls == 1 ? b1 : (cls == 2 ? b2 : b3));
+                    const int base = nd.start + (cls > 0 ? c0 : 0) + (cls > 1 ? c1 : 0) + (cls > 2 ? c2 : 0);
+                    keys[sb ^ 1][base + __popc(mb & ((1u << gl) - 1u))] = key;
+                }
+                if (small && gl == 0) {
+                    cc[jg] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
+                    aux[jg] = ((c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0)) | (((c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1)) << 16);
+                }
+            }
+            // the nodes of this quartet with more than 16 keys, one after the other with the whole wave
+            const uint64_t bigm = __ballot(jg < nP && !small && gl == 0);
+          for (int g = 0; g < 4; g++) {
+            if (!((bigm >> (16 * g)) & 1ull)) continue;
+            const int j = j0 + g;
             const ONode nd = src[P[j]];
             if (nd.cnt >= kOctBigNode && s_nbig <= kOctBigMax) continue;
             if (nd.cnt <= 64) {
@@ -610,6 +646,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 cc[j] = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);
                 aux[j] = ((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) | (((c[0] > 1) + (c[1] > 1) + (c[2] > 1) + (c[3] > 1)) << 16);
             }
+          }
         }
         if (tid == 0) s_m = nP;
         __syncthreads();
