@@ -160,7 +160,7 @@ def cpu_baseline(spec, n1, pool, unit_name, data=None):
         nproc = min(pool, os.cpu_count() or 1)
         big = spec["kind"] == "batch" and spec["events"] >= 100000
         sp = dict(spec); sp["nunits"] = 4 if big else min(spec["nunits"], 16)
-        reps = 8 if big else max(8, min(200, n1 // 4))
+        reps = int(max(8, min(4000, round(2.5 / max(tcpu / n1, 1e-6)))))        # about 2.5 s of wall time per process
         ctx = mp.get_context("spawn")                    # never fork a process that holds a HIP context
         with ctx.Manager() as mgr:
             bar = mgr.Barrier(nproc)
