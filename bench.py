@@ -545,6 +545,32 @@ def run_frames(env):
                          "pass over the same steps")
             out["roofline"] = r
             out["kernels_ms_per_step"] = per_step
+        if world == 1:
+            # throughput mode of the same extraction (+ SearchForInitialization of frame b against b-1, ORB rows only): the frames
+            # resident in HBM, one call per batch of 32 (eorb_fe_run_batch_images_dev)
+            fbi = fe.FrontEndBatch(W, H, 1.0, False, max_batch=nfr, max_events=1, match=True, want_desc=True, windowSize=100, nnratio=0.9,
+                                   checkOri=True, **orb)
+            d_fr = torch.from_numpy(np.concatenate([f.ravel() for f in frames])).to(env["dev"])
+            capb = fbi.cap
+            t_kp = torch.empty(nfr * capb * 28, dtype=torch.uint8, device=env["dev"]); t_d = torch.empty(nfr * capb * 32, dtype=torch.uint8, device=env["dev"])
+            t_n = torch.zeros(nfr, dtype=torch.int32, device=env["dev"]); t_m = torch.empty(nfr * capb, dtype=torch.int32, device=env["dev"])
+            t_nm = torch.zeros(nfr, dtype=torch.int32, device=env["dev"])
+            def bstep():
+                fbi.run_images_dev(d_fr.data_ptr(), nfr, t_kp.data_ptr(), t_d.data_ptr(), t_n.data_ptr(), t_m.data_ptr(), t_nm.data_ptr())
+            for _ in range(3):
+                bstep()
+            fbi.ctx.sync()
+            t0 = time.perf_counter()
+            nrep = 20
+            for _ in range(nrep):
+                bstep()
+            fbi.ctx.sync()
+            tb = time.perf_counter() - t0
+            out["batched"] = {"value": nfr * nrep / tb, "unit": "frames/s", "frames_per_call": nfr, "ms_per_call": tb / nrep * 1e3,
+                              "mean_keypoints": float(t_n.cpu().numpy().mean()),
+                              "what": "the same frames resident in HBM, %d per call: extraction + SearchForInitialization vs the previous frame "
+                                      "(eorb_fe_run_batch_images_dev)" % nfr}
+            fbi.ctx.close()
         if ncpu > 0 and world == 1:
             spec = dict(kind=a.workload, orb=orb, seed0=(3 if a.workload == "w3" else 4), nunits=nfr, events=0)
             out["cpu_baseline"] = cpu_baseline(spec, ncpu, a.cpu_pool, "frames")

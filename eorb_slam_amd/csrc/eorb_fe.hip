@@ -1339,7 +1339,9 @@ static int fe_run_batch_common(eorb_ctx* c, const void* d_events, int raw, const
     if (!c) return EORB_E_ARG;
     if (!c->fe_configured) return set_err(c, EORB_E_NOTCONF, "fe_run_batch: eorb_fe_configure not called");
     const eorb_fe_config& f = c->fe;
-    if (B < 1 || B > f.max_batch || !h_offsets) return set_err(c, EORB_E_ARG, "fe_run_batch: bad batch size %d", B);
+    const bool from_images = raw < 0;                    // (eorb_fe_run_batch_images_dev: the frames are given, nothing to accumulate)
+    if (B < 1 || B > f.max_batch || (!h_offsets && !from_images)) return set_err(c, EORB_E_ARG, "fe_run_batch: bad batch size %d", B);
+    if (from_images && !d_images) return set_err(c, EORB_E_ARG, "fe_run_batch_images: no images");
     hipSetDevice(c->device);
     const size_t npix = (size_t)f.W * f.H, cap = c->orb.max_out;
     uint8_t* img = d_images ? d_images : (uint8_t*)c->img_u8.p;
@@ -1347,8 +1349,8 @@ static int fe_run_batch_common(eorb_ctx* c, const void* d_events, int raw, const
     eorb_keypoint* wk = (eorb_keypoint*)c->fe_prev_kp.p;
     uint8_t* wd = (uint8_t*)c->fe_prev_desc.p;
     int32_t* wn = (int32_t*)c->fe_prev_n.p;             // [0] prev, [1..B] this batch, then mono index
-    int rc = ev_accumulate_dev(c, d_events, raw, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 1,
-                               (uint32_t*)c->minmax.p);
+    int rc = from_images ? EORB_OK : ev_accumulate_dev(c, d_events, raw, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 1,
+                                                       (uint32_t*)c->minmax.p);
     if (rc) return rc;
     rc = orb_extract_dev(c, img, f.W, npix, B, f.lap0, f.lap1, f.want_desc, wk + cap, wd + 32 * cap, nullptr, wn + 1,
                          wn + 1 + f.max_batch + 1);
@@ -1395,6 +1397,12 @@ int eorb_fe_run_batch_raw_dev(eorb_ctx* c, const eorb_raw_event* d_events, const
 {
     if (c && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "fe_run_batch_raw: eorb_set_undistort_maps not called");
     return fe_run_batch_common(c, d_events, 1, h_offsets, B, d_images, d_kps, d_desc, d_nkps, d_matches12, d_nmatches);
+}
+
+int eorb_fe_run_batch_images_dev(eorb_ctx* c, const uint8_t* d_images, int B, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                                 int32_t* d_matches12, int32_t* d_nmatches)
+{
+    return fe_run_batch_common(c, nullptr, -1, nullptr, B, const_cast<uint8_t*>(d_images), d_kps, d_desc, d_nkps, d_matches12, d_nmatches);
 }
 
 }  // extern "C"

@@ -634,3 +634,9 @@ class FrontEndBatch:
         fn = self.ctx.L.eorb_fe_run_batch_raw_dev if raw else self.ctx.L.eorb_fe_run_batch_dev
         self.ctx.check(fn(self.ctx.h, vp(d_events), _p(offsets), B, vp(d_images), vp(d_kps),
                           vp(d_desc), vp(d_nkps), vp(d_m12), vp(d_nm)))
+
+    def run_images_dev(self, d_images, B, d_kps=None, d_desc=None, d_nkps=None, d_m12=None, d_nm=None):
+        """B camera frames (u8, W x H each, back to back in HBM): extraction + SearchForInitialization of frame b against frame b-1."""
+        vp = lambda x: C.c_void_p(x) if x else None
+        self.ctx.check(self.ctx.L.eorb_fe_run_batch_images_dev(self.ctx.h, vp(d_images), int(B), vp(d_kps), vp(d_desc), vp(d_nkps),
+                                                               vp(d_m12), vp(d_nm)))

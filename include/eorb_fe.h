@@ -385,6 +385,12 @@ int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int
                           uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                           int32_t* d_matches12, int32_t* d_nmatches);
 
+/* the same pass for B camera frames resident in HBM (u8, W x H each, back to back; the image side of the front end,
+ * Frame::ExtractORB src/Frame.cc:467-482 + SearchForInitialization of frame b against frame b-1): no accumulation, the frames
+ * are only read.  eorb_fe_configure as above (sigma / pol / max_events unused). */
+int eorb_fe_run_batch_images_dev(eorb_ctx* ctx, const uint8_t* d_images, int B, eorb_keypoint* d_kps, uint8_t* d_desc,
+                                 int32_t* d_nkps, int32_t* d_matches12, int32_t* d_nmatches);
+
 /* self-check used by tests: number of floats v in [lo, hi] (0 < lo <= hi) for which the reciprocal+fma quotient the
  * accumulation kernel uses for v / (2*pi*sigma^2) differs from the IEEE-754 quotient (must be 0). */
 int eorb_selfcheck_division(eorb_ctx* ctx, float lo, float hi, float sigma, uint64_t* mismatches);

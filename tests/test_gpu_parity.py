@@ -1086,6 +1086,48 @@ def test_large_batch_takes_the_many_workgroup_forms(oracle, fe):
     assert np.array_equal(ou, big[0][0]) and big[1].min() > 5
 
 
+def test_frontend_batch_of_camera_frames(oracle, fe):
+    """eorb_fe_run_batch_images_dev: B texture frames in HBM -> keypoints / descriptors of every frame and SearchForInitialization
+    of frame b against frame b-1, equal to the oracle's per-frame extraction and matching (two calls: the last frame of a call is
+    carried into the next one)."""
+    W, H, B = 240, 180, 5
+    base = synth.texture_image(W, H, seed=77)
+    frames = [np.ascontiguousarray(np.roll(base, (i % 4, -(2 * i % 7)), axis=(0, 1))) for i in range(B)]
+    oe = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19)
+    ref = [oe.extract(f) for f in frames]
+    fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=3, max_events=1)
+    c, cap = fb.ctx, fb.cap
+    got = []
+    for lo, hi in ((0, 3), (3, 5)):
+        nb = hi - lo
+        blob = np.concatenate([f.ravel() for f in frames[lo:hi]])
+        d_img = c.dev_alloc(blob.nbytes); c.upload(d_img, blob)
+        d_kp = c.dev_alloc(nb * cap * 28); d_desc = c.dev_alloc(nb * cap * 32); d_n = c.dev_alloc(nb * 4)
+        d_m = c.dev_alloc(nb * cap * 4); d_nm = c.dev_alloc(nb * 4)
+        fb.run_images_dev(d_img, nb, d_kp, d_desc, d_n, d_m, d_nm)
+        c.sync()
+        nk = np.zeros(nb, np.int32); c.download(nk, d_n)
+        kps = np.zeros((nb, cap), synth.KP_DTYPE); c.download(kps, d_kp)
+        desc = np.zeros((nb, cap, 32), np.uint8); c.download(desc, d_desc)
+        m12 = np.zeros((nb, cap), np.int32); c.download(m12, d_m)
+        nm = np.zeros(nb, np.int32); c.download(nm, d_nm)
+        for j in range(nb):
+            got.append((kps[j, :nk[j]].copy(), desc[j, :nk[j]].copy(), m12[j].copy(), int(nm[j])))
+        for p in (d_img, d_kp, d_desc, d_n, d_m, d_nm):
+            c.dev_free(p)
+    c.close()
+    for b in range(B):
+        _, ok, od, _ = ref[b]
+        assert len(ok) > 200
+        assert np.array_equal(ok.view(np.uint8), got[b][0].view(np.uint8)) and np.array_equal(od, got[b][1]), b
+        if b:
+            _, pk, pd, _ = ref[b - 1]
+            pm = np.stack([pk["x"], pk["y"]], axis=1)
+            on, om, _ = oracle.search_for_initialization(oracle.Frame(pk, pd, W, H), oracle.Frame(ok, od, W, H), pm, 100, 0.9, True)
+            assert on == got[b][3] and np.array_equal(om, got[b][2][:len(pk)]), b
+            assert on > 20
+
+
 def test_full_size_batch_properties(oracle, fe):
     """BASELINE.json configs[1] sizes (1 000 000 events per slice): the raw and the float inputs give the same images / keypoints,
     a slice's result does not depend on its position or company in the batch, and slices 0 and 1 are checked against the oracle:
