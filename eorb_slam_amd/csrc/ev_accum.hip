@@ -1104,12 +1104,18 @@ __global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(con
 // Same entries in the same order as the binned lists, hence the same image.
 struct DirectSlices { int64_t off[5]; };            // event offsets of up to 4 slices
 constexpr int kDirectList = 1024;                   // entries of the LDS list (flushed when full)
-template <bool POL>
+// FLT: float events (eorb_event16: the reference's own seam, ev2im_gauss(vector<EventData>)) -- the value of a tap is evaluated as K2
+// evaluates it (exp_XY2f :59-65: the general division form; K2's reciprocal form is proven equal by tests/test_gpu_math.py) instead
+// of being read from the stamp table of a sensor pixel.
+template <bool POL, bool FLT>
 __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_event* __restrict__ ev, DirectSlices S, BinParams B, GatherParams P,
                                                               float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
 {
     __shared__ uint2 lst[kDirectList];
+    __shared__ uint8_t lneg[FLT ? kDirectList : 4];          // FLT: negative polarity of the listed event (raw entries carry it in word 0)
+    __shared__ uint64_t tab[32];
     const int lane = threadIdx.x;
+    if (FLT) { if (lane < 32) tab[lane] = kExp2Tab[lane]; __syncthreads(); }
     const int slice = blockIdx.x / P.NT, tile = blockIdx.x - slice * P.NT;
     const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
@@ -1126,6 +1132,7 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_eve
         for (int e0 = 0; e0 < nl; e0 += 64) {
             const int cnt = min(64, nl - e0);
             const uint2 mine = lst[e0 + min(lane, cnt - 1)];
+            const uint32_t mneg = FLT ? (uint32_t)lneg[e0 + min(lane, cnt - 1)] : 0u;
             constexpr int U = 8;
             for (int k0 = 0; k0 < cnt; k0 += U) {
                 float v[U]; bool in[U]; uint32_t sgn[U];
@@ -1133,12 +1140,26 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_eve
                 for (int u = 0; u < U; u++) {
                     const int k = min(k0 + u, cnt - 1);
                     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, k), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, k);
-                    const int xi = (int)(int16_t)(w1 & 0xffff), yi = (int)(int16_t)(w1 >> 16);
-                    const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
-                    in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
-                    sgn[u] = w0 & 0x80000000u;
-                    const uint32_t off = (w0 & 0x7fffffffu) * (uint32_t)P.stamp_stride + i * (uint32_t)SWP + j;
-                    v[u] = in[u] ? P.stamps[off] : 0.0f;
+                    if (FLT) {
+                        const float ex = __uint_as_float(w0), ey = __uint_as_float(w1);
+                        const int xi = (int)floorf(ex), yi = (int)floorf(ey);               // breakFloatCoords :51-57
+                        const float xr = ex - (float)xi, yr = ey - (float)yi;
+                        const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
+                        in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
+                        sgn[u] = (uint32_t)__builtin_amdgcn_readlane((int)mneg, k) << 31;
+                        const float fx = (float)(px - xi) - xr, fy = (float)(py - yi) - yr;
+                        const float xx = fx * fx, yy = fy * fy;
+                        float dd = xx + yy;
+                        dd = dd / P.two_sig2;
+                        v[u] = in[u] ? dev_expf_nonpos<true>(-dd, tab) / P.norm : 0.0f;
+                    } else {
+                        const int xi = (int)(int16_t)(w1 & 0xffff), yi = (int)(int16_t)(w1 >> 16);
+                        const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
+                        in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
+                        sgn[u] = w0 & 0x80000000u;
+                        const uint32_t off = (w0 & 0x7fffffffu) * (uint32_t)P.stamp_stride + i * (uint32_t)SWP + j;
+                        v[u] = in[u] ? P.stamps[off] : 0.0f;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++)
@@ -1157,25 +1178,45 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_eve
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int k = k0 + g * 64 + lane;
-            const uint2 q = k < n ? *(const uint2*)&e[k] : make_uint2(0xffffffffu, 0u);        // { x | y << 16, p }
-            xy[g] = q.x; pp[g] = q.y;
+            if (FLT) {
+                // { x, y } as float bits in xy / info, negative polarity (sign bit of t) in pp
+                const uint4 q = k < n ? *(const uint4*)&e[k] : make_uint4(0x7fc00000u, 0x7fc00000u, 0u, 0u);
+                xy[g] = q.x; info[g] = q.y; pp[g] = q.w >> 31;
+            } else {
+                const uint2 q = k < n ? *(const uint2*)&e[k] : make_uint2(0xffffffffu, 0u);    // { x | y << 16, p }
+                xy[g] = q.x; pp[g] = q.y;
+            }
         }
+        if (!FLT) {
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int x = (int)(xy[g] & 0xffff), y = (int)(xy[g] >> 16);
-            info[g] = (x < B.LW && y < B.LH) ? B.src_info[(uint32_t)y * (uint32_t)B.LW + x] : 0x80008000u;    // (-32768, -32768): dropped
+            for (int g = 0; g < G; g++) {
+                const int x = (int)(xy[g] & 0xffff), y = (int)(xy[g] >> 16);
+                info[g] = (x < B.LW && y < B.LH) ? B.src_info[(uint32_t)y * (uint32_t)B.LW + x] : 0x80008000u;    // (-32768, -32768): dropped
+            }
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (k0 + g * 64 >= n) break;
-            const int xi = (int)(int16_t)(info[g] & 0xffff), yi = (int)(int16_t)(info[g] >> 16);
-            // the event has an entry in this tile's list iff the tile lies in its tile range (ev_tile_range_raw)
-            const bool hit = info[g] != 0x80008000u && xi - P.h <= tx0 + kTile - 1 && xi + P.h >= tx0 && yi - P.h <= ty0 + kTile - 1 && yi + P.h >= ty0;
+            int xi, yi; bool live;
+            if (FLT) {
+                const float ex = __uint_as_float(xy[g]), ey = __uint_as_float(info[g]);
+                live = ex == ex && ey == ey;                                        // NaN coordinates are never in the image (ev_tile_range)
+                xi = (int)fminf(fmaxf(floorf(ex), -1048576.f), 1048576.f); yi = (int)fminf(fmaxf(floorf(ey), -1048576.f), 1048576.f);
+            } else {
+                live = info[g] != 0x80008000u;
+                xi = (int)(int16_t)(info[g] & 0xffff); yi = (int)(int16_t)(info[g] >> 16);
+            }
+            // the event has an entry in this tile's list iff the tile lies in its tile range (ev_tile_range / ev_tile_range_raw)
+            const bool hit = live && xi - P.h <= tx0 + kTile - 1 && xi + P.h >= tx0 && yi - P.h <= ty0 + kTile - 1 && yi + P.h >= ty0;
             const uint64_t m = __ballot(hit);
             if (m) {
                 if (hit) {
-                    const uint32_t src = (xy[g] >> 16) * (uint32_t)B.LW + (xy[g] & 0xffff);
-                    lst[nl + __popcll(m & lt_mask)] = make_uint2(src | (pp[g] ? 0u : 0x80000000u), info[g]);
+                    const int pos = nl + __popcll(m & lt_mask);
+                    if (FLT) { lst[pos] = make_uint2(xy[g], info[g]); lneg[pos] = (uint8_t)pp[g]; }
+                    else {
+                        const uint32_t src = (xy[g] >> 16) * (uint32_t)B.LW + (xy[g] & 0xffff);
+                        lst[pos] = make_uint2(src | (pp[g] ? 0u : 0x80000000u), info[g]);
+                    }
                 }
                 nl += __popcll(m); any = true;
                 if (nl > kDirectList - 64) flush();
@@ -1812,7 +1853,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     {
         // one or a few small slices of raw events (the live per-slice call): no binning at all, K2d
         const int64_t nev0 = h_offsets[B] - h_offsets[0];
-        if (raw && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
+        if (!mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
             DirectSlices S;
             for (int b = 0; b <= B; b++) {
                 if (b && h_offsets[b] < h_offsets[b - 1]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
@@ -1821,7 +1862,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             if (nev0 * dup >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)nev0);
             int rc;
             GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, mode_count, B * NT, sigma);
-            if ((rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
+            if (raw && (rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
             BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
             {
                 ProfScope ps(c, "ev_minmax_init");
@@ -1829,8 +1870,10 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             }
             {
                 ProfScope ps(c, "ev_gather");
-                if (pol) ev_gather_direct_kernel<true><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc);
-                else ev_gather_direct_kernel<false><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc);
+#define LAUNCH_D(PP, FF) ev_gather_direct_kernel<PP, FF><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc)
+                if (raw) { if (pol) LAUNCH_D(true, false); else LAUNCH_D(false, false); }
+                else { if (pol) LAUNCH_D(true, true); else LAUNCH_D(false, true); }
+#undef LAUNCH_D
                 EORB_LAUNCH_CHECK(c, "ev_gather_direct_kernel");
             }
             if (normalized && d_u8) {

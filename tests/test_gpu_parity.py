@@ -38,15 +38,22 @@ def _same_bits(a, b):
     dict(n=20000, sigma=1.0, pol=False, frac=True, W=346, H=260),   # MVSEC shape, partial last tile
 ])
 def test_ev2im_gauss_bit_exact(oracle, fe, ctx, case):
+    """form: the accumulation kernels -- chosen by the call's size (0: up to 16 384 events take the binning-free kernel), the
+    binned list pipeline whatever the size (1), the binning-free kernel whatever the size (3)."""
     W, H = case.get("W", 240), case.get("H", 180)
     ev = synth.random_events(case["n"], W, H, seed=11 + case["n"], frac=case["frac"])
-    for normalized in (True, False):
-        of, ou, omm = oracle.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized)
-        gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized, ctx=ctx, return_all=True)
-        assert _same_bits(of, gf), "f32 image differs: %d px" % int((of.view(np.uint32) != gf.view(np.uint32)).sum())
-        assert _same_bits(omm, gmm)
-        if normalized:
-            assert np.array_equal(ou, gu)
+    try:
+        for form in (0, 1, 3):
+            ctx.debug_option("gather_form", form)
+            for normalized in (True, False):
+                of, ou, omm = oracle.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized)
+                gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized, ctx=ctx, return_all=True)
+                assert _same_bits(of, gf), "form %d: f32 image differs: %d px" % (form, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
+                assert _same_bits(omm, gmm), form
+                if normalized:
+                    assert np.array_equal(ou, gu), form
+    finally:
+        ctx.debug_option("gather_form", 0)
 
 
 def test_ev2im_gauss_shapes_lut(oracle, fe, ctx):
@@ -64,10 +71,15 @@ def test_ev2im_gauss_hot_pixel_order(oracle, fe, ctx):
     n = 30000
     ev = synth.random_events(n, seed=5)
     ev["x"] = (100 + rng.uniform(0, 3, n)).astype(np.float32); ev["y"] = (60 + rng.uniform(0, 3, n)).astype(np.float32)
-    for pol in (False, True):
-        of, ou, omm = oracle.ev2im_gauss(ev, 240, 180, 1.0, pol, True)
-        gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, 240, 180, 1.0, pol, True, ctx=ctx, return_all=True)
-        assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm)
+    try:
+        for form in (0, 3):                          # 30 000 events: the binned pipeline, then the binning-free kernel (its list is flushed)
+            ctx.debug_option("gather_form", form)
+            for pol in (False, True):
+                of, ou, omm = oracle.ev2im_gauss(ev, 240, 180, 1.0, pol, True)
+                gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, 240, 180, 1.0, pol, True, ctx=ctx, return_all=True)
+                assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm), form
+    finally:
+        ctx.debug_option("gather_form", 0)
 
 
 @pytest.mark.parametrize("pol", [False, True])
