@@ -34,7 +34,7 @@ METRIC = "front-end frames/s (event-accumulate + extract + match) per GPU; HBM G
 # HBM bytes one ev_gather launch moves per million events (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE; bench.py cannot
 # collect PMC counters itself): see TRAFFIC_SOURCE
 GATHER_TRAFFIC_PER_MEV = {"raw": 31.8e6, "float": 30.9e6}
-TRAFFIC_SOURCE = "profiles/r02_v5_pmc_traffic.txt"
+TRAFFIC_SOURCE = "profiles/r02_v6_pmc_traffic.txt"
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
 CPU_POOL = 16              # worker processes of the all-cores CPU baseline (a one-GPU box's CPU share)
 
