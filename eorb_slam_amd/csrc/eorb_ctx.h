@@ -89,6 +89,9 @@ struct eorb_ctx {
     eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order, order_hist;
     // raw sensor events: undistortion maps (float2 per sensor pixel) and the tables derived from them
     eorb::DevBuf lut, src_info, stamps;
+    // float events in bulk: the distinct positions of a call become the rows of a per-call stamp table (ev_accumulate_dev)
+    eorb::DevBuf dd_tab, dd_src_info, dd_stamps, dd_ev, dd_cnt;
+    int64_t dbg_dd_min = (int64_t)1 << 20;       // events from which the positions are deduplicated (test hook: "dedupe_min_events")
     int lut_w = 0, lut_h = 0, lut_check = 1;
     int lut_key_W = -1, lut_key_H = -1, lut_key_mode = -1; float lut_key_sigma = -1.f;
     // extractor workspaces

@@ -47,7 +47,11 @@ struct BinParams {
     // raw sensor events (eorb_raw_event) resolved through the undistortion maps: per sensor pixel xi | yi << 16 (int16 each)
     int raw, LW, LH;
     const uint32_t* src_info;
+    // hashed != 0: the events are 4-byte records { row of the event's position in src_info / the stamp table | negative polarity << 31 }
+    // (0x7fffffff in the low bits: dropped) -- float events in bulk, see dd_insert_kernel
+    int hashed;
 };
+constexpr uint32_t kHashDropped = 0x7fffffffu;
 
 __device__ __forceinline__ bool ev_tile_range(const eorb_event16& e, const BinParams& P, int& tx0, int& tx1, int& ty0, int& ty1)
 {
@@ -91,6 +95,16 @@ __global__ __launch_bounds__(256) void ev_count_kernel(const eorb_event16* __res
         constexpr int U = 8;
         for (int k0 = threadIdx.x; k0 < cd.n; k0 += blockDim.x * U) {
             uint32_t xy[U]; uint32_t info[U];
+            if (P.hashed) {
+                const uint32_t* e4 = (const uint32_t*)ev + cd.start;
+                uint32_t id[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? e4[k] : kHashDropped; }
+#pragma unroll
+                for (int u = 0; u < U; u++) id[u] = (xy[u] & kHashDropped) != kHashDropped ? (xy[u] & kHashDropped) : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < U; u++) info[u] = id[u] != 0xffffffffu ? P.src_info[id[u]] : 0x80008000u;
+            } else {
 #pragma unroll
             for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)&((const eorb_raw_event*)e)[k] : 0xffffffffu; }
 #pragma unroll
@@ -98,6 +112,7 @@ __global__ __launch_bounds__(256) void ev_count_kernel(const eorb_event16* __res
                 const int x = (int)(xy[u] & 0xffff), y = (int)(xy[u] >> 16);
                 const bool ok = x < P.LW && y < P.LH;
                 info[u] = ok ? P.src_info[(uint32_t)y * (uint32_t)P.LW + x] : 0x80008000u;      // (-32768, -32768): touches no tile
+            }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -277,19 +292,30 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
     uint32_t* cw32 = (uint32_t*)(cntw + wave * NTp);
     // (raw events: the event loads of all sub-batches first, then the map lookups, then the LDS work -- the chain event -> map
     // entry -> range is latency, so the loads of the share are in flight together)
-    uint2 rq[SMAX]; uint32_t rinfo[SMAX];
+    uint32_t rsrc[SMAX], rneg[SMAX], rinfo[SMAX];                   // table row of the event (0xffffffff: none), negative polarity, map entry
     if (P.raw) {
+        if (P.hashed) {
+            const uint32_t* e4 = (const uint32_t*)ev + cd.start;
 #pragma unroll
-        for (int s = 0; s < SMAX; s++) {
-            const int k = wave * Q + s * 64 + lane;
-            rq[s] = (s < S && k < cd.n) ? *(const uint2*)&((const eorb_raw_event*)e)[k] : make_uint2(0xffffffffu, 0u);
+            for (int s = 0; s < SMAX; s++) {
+                const int k = wave * Q + s * 64 + lane;
+                const uint32_t rec = (s < S && k < cd.n) ? e4[k] : kHashDropped;
+                rneg[s] = rec >> 31; rsrc[s] = rec & kHashDropped;
+            }
+#pragma unroll
+            for (int s = 0; s < SMAX; s++) rsrc[s] = rsrc[s] != kHashDropped ? rsrc[s] : 0xffffffffu;
+        } else {
+#pragma unroll
+            for (int s = 0; s < SMAX; s++) {
+                const int k = wave * Q + s * 64 + lane;
+                const uint2 q = (s < S && k < cd.n) ? *(const uint2*)&((const eorb_raw_event*)e)[k] : make_uint2(0xffffffffu, 0u);
+                const int x = (int)(q.x & 0xffff), y = (int)(q.x >> 16);
+                rsrc[s] = (x < P.LW && y < P.LH) ? (uint32_t)y * (uint32_t)P.LW + x : 0xffffffffu;
+                rneg[s] = q.y ? 0u : 1u;
+            }
         }
 #pragma unroll
-        for (int s = 0; s < SMAX; s++) {
-            const int x = (int)(rq[s].x & 0xffff), y = (int)(rq[s].x >> 16);
-            const bool in = x < P.LW && y < P.LH;
-            rinfo[s] = in ? P.src_info[(uint32_t)y * (uint32_t)P.LW + x] : 0u;
-        }
+        for (int s = 0; s < SMAX; s++) rinfo[s] = rsrc[s] != 0xffffffffu ? P.src_info[rsrc[s]] : 0u;
     }
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
@@ -301,15 +327,14 @@ __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb
             uint2 pl;
             if (P.raw) {
                 // entry = { sensor pixel | negative polarity << 31, xi | yi << 16 }
-                const int x = (int)(rq[s].x & 0xffff), y = (int)(rq[s].x >> 16);
-                ok = x < P.LW && y < P.LH;
-                const uint32_t src = ok ? (uint32_t)y * (uint32_t)P.LW + x : 0u, info = rinfo[s];
+                ok = rsrc[s] != 0xffffffffu;
+                const uint32_t src = ok ? rsrc[s] : 0u, info = rinfo[s];
                 if (ok) {
                     const int xi = (int)(int16_t)(info & 0xffff), yi = (int)(int16_t)(info >> 16);
                     tx0 = max((xi - P.h) >> 3, 0); tx1 = min((xi + P.h) >> 3, P.TX - 1);
                     ty0 = max((yi - P.h) >> 3, 0); ty1 = min((yi + P.h) >> 3, P.TY - 1);
                 }
-                pl = make_uint2(src | (rq[s].y ? 0u : 0x80000000u), info);
+                pl = make_uint2(src | (rneg[s] ? 0x80000000u : 0u), info);
             } else {
                 const eorb_event16 q = e[k];
                 ok = ev_tile_range(q, P, tx0, tx1, ty0, ty1);
@@ -1782,6 +1807,61 @@ int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* 
     return EORB_OK;
 }
 
+// ---- float events in bulk -------------------------------------------------------------------------------------------------
+// The reference hands ev2im_gauss float coordinates, but a loader produces them from its undistortion maps: a batch of millions of
+// events takes only as many distinct (x, y) as the sensor has pixels.  Per call the distinct positions are collected in a hash table
+// (key = the two floats' bit patterns = a float2: the table IS the "undistortion map" of the call, slot = "sensor pixel", empty
+// slots = (NaN, NaN) = dropped), whose slots become the rows of a stamp table exactly as the maps of the raw path do
+// (ev_src_info_kernel / ev_stamp_kernel evaluate the same arithmetic K2's value waves do); the events become 4-byte records naming
+// their slot, and the raw path (K2r: table reads instead of 49 f64 expf per event) does the rest.  Falls back to K2 when the
+// positions do not repeat (motion-compensated events).
+constexpr int kDdLog = 20;                                         // table slots = 2^20; at most half may fill
+constexpr uint64_t kDdEmpty = ~0ull;                               // (NaN, NaN): never a position that is looked up (NaN events are dropped)
+__device__ __forceinline__ uint32_t dd_hash(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+// every event: the slot of its position (inserted if new) | negative polarity << 31 -> rec[k]
+__global__ __launch_bounds__(256) void dd_insert_kernel(const eorb_event16* __restrict__ ev, int64_t n, unsigned long long* __restrict__ tab, int* __restrict__ cnt,
+                                                        uint32_t* __restrict__ rec)
+{
+    const uint32_t mask = (1u << kDdLog) - 1u;
+    constexpr int U = 4;                                              // events per thread and round: loads and first probes in flight together
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k0 < n; k0 += stride * U) {
+        uint4 q[U]; unsigned long long first[U]; uint32_t h0[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int64_t k = k0 + u * stride; q[u] = k < n ? *(const uint4*)&ev[k] : make_uint4(0x7fc00000u, 0x7fc00000u, 0u, 0u); }
+#pragma unroll
+        for (int u = 0; u < U; u++) { h0[u] = dd_hash((uint64_t)q[u].x | ((uint64_t)q[u].y << 32)) & mask; first[u] = tab[h0[u]]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t k = k0 + u * stride;
+            if (k >= n) continue;
+            const float x = __uint_as_float(q[u].x), y = __uint_as_float(q[u].y);
+            const uint32_t neg = q[u].w & 0x80000000u;                 // sign bit of t
+            if (!(x == x && y == y)) { rec[k] = kHashDropped | neg; continue; }        // never in the image: no position needed
+            const unsigned long long key = (unsigned long long)q[u].x | ((unsigned long long)q[u].y << 32);
+            uint32_t h = h0[u];
+            unsigned long long cur = first[u];                         // (a stale EMPTY only costs the compare-and-swap below)
+            int probes = 0;
+            for (;;) {
+                if (cur == key) break;
+                if (cur == kDdEmpty) {
+                    cur = atomicCAS(&tab[h], kDdEmpty, key);
+                    if (cur == kDdEmpty) { atomicAdd(&cnt[0], 1); break; }
+                    if (cur == key) break;
+                }
+                h = (h + 1) & mask;
+                if (++probes > 256) { atomicOr(&cnt[1], 1); break; }   // table crowded: the caller falls back
+                cur = tab[h];
+            }
+            rec[k] = h | neg;
+        }
+    }
+}
+
 // arithmetic constants of the Gaussian stamp (shared by all gather kernels)
 static GatherParams ev_gather_params(int W, int H, int h, int TX, int TY, int NT, int mode_count, int nb, float sigma)
 {
@@ -1850,10 +1930,53 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     const int TX = (W + kTile - 1) / kTile, TY = (H + kTile - 1) / kTile, NT = TX * TY;
     int nbits = 1; while ((1 << nbits) < NT) nbits++;
     const int dup = R * R;
+    const bool hashed = raw == 2;                        // (recursion of the block below: d_events are 4-byte hashed records)
+    if (!raw && !mode_count && c->dbg_gather_form != 1 && h_offsets[B] - h_offsets[0] >= c->dbg_dd_min && c->dbg_dd_min > 0) {
+        // float events in bulk: tabulate their distinct positions, continue on the raw path (see dd_insert_kernel)
+        const int64_t n0 = h_offsets[B] - h_offsets[0];
+        const int64_t ps0 = n0 / B;
+        const int chunk0 = ps0 >= (int64_t)1 << 17 ? 2048 : (ps0 >= (int64_t)1 << 14 ? 1024 : 256);
+        const int NTp0 = (NT + 1) & ~1;
+        static const int scat_env = [] { const char* e = getenv("EORB_SCATTER"); return e ? atoi(e) : 2; }();
+        // the hashed records are only read by the count kernel and the second form of the scatter
+        const bool fits = scat_env != 1 && TX < 256 && TY < 256 &&
+            (((size_t)chunk0 * 8 + (size_t)chunk0 * 2 + (size_t)chunk0 * R * R * 2 + (size_t)kScatWaves * NTp0 * 2 + (size_t)(NTp0 + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15) <= 64 * 1024;
+        const size_t cap = (size_t)1 << kDdLog;
+        const int max_ids = (int)(cap / 2);
+        int rc;
+        if (fits) {
+            if ((rc = ensure(c, c->dd_tab, 8 * cap)) || (rc = ensure(c, c->dd_cnt, 64)) || (rc = ensure(c, c->dd_ev, 4 * (size_t)n0))) return rc;
+            const eorb_event16* src = (const eorb_event16*)d_events + h_offsets[0];
+            int hc[2] = {0, 0};
+            {
+                ProfScope ps(c, "ev_dedupe");
+                EORB_HIP(c, hipMemsetAsync(c->dd_tab.p, 0xff, 8 * cap, c->stream));
+                EORB_HIP(c, hipMemsetAsync(c->dd_cnt.p, 0, 64, c->stream));
+                dd_insert_kernel<<<4096, 256, 0, c->stream>>>(src, n0, (unsigned long long*)c->dd_tab.p, (int*)c->dd_cnt.p, (uint32_t*)c->dd_ev.p);
+                EORB_LAUNCH_CHECK(c, "dd_insert_kernel");
+                EORB_HIP(c, hipMemcpyAsync(hc, c->dd_cnt.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+                EORB_HIP(c, hipStreamSynchronize(c->stream));
+            }
+            if (!hc[1] && hc[0] <= max_ids) {
+                // the raw path on the per-call tables: the context's map state is swapped for the duration of the call
+                std::swap(c->lut, c->dd_tab); std::swap(c->src_info, c->dd_src_info); std::swap(c->stamps, c->dd_stamps);
+                const int sw = c->lut_w, sh = c->lut_h, sc = c->lut_check, kW = c->lut_key_W, kH = c->lut_key_H, kM = c->lut_key_mode;
+                const float kS = c->lut_key_sigma;
+                c->lut_w = 65536; c->lut_h = (int)(cap / 65536); c->lut_check = 0;       // the hash table as the call's maps: slot = sensor pixel
+                c->lut_key_W = c->lut_key_H = c->lut_key_mode = -1; c->lut_key_sigma = -1.f;
+                std::vector<int64_t> off(B + 1);
+                for (int b = 0; b <= B; b++) off[b] = h_offsets[b] - h_offsets[0];
+                rc = ev_accumulate_dev(c, c->dd_ev.p, 2, off.data(), B, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, d_minmax_enc);
+                std::swap(c->lut, c->dd_tab); std::swap(c->src_info, c->dd_src_info); std::swap(c->stamps, c->dd_stamps);
+                c->lut_w = sw; c->lut_h = sh; c->lut_check = sc; c->lut_key_W = kW; c->lut_key_H = kH; c->lut_key_mode = kM; c->lut_key_sigma = kS;
+                return rc;
+            }
+        }
+    }
     {
         // one or a few small slices of raw events (the live per-slice call): no binning at all, K2d
         const int64_t nev0 = h_offsets[B] - h_offsets[0];
-        if (!mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
+        if (!hashed && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
             DirectSlices S;
             for (int b = 0; b <= B; b++) {
                 if (b && h_offsets[b] < h_offsets[b - 1]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
@@ -1948,7 +2071,8 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     // nearly empty tiles (fewer than one 64-entry batch per tile on average) of raw events with a Gaussian stamp: K2s, a wave per tile
     const bool sparse = raw && !mode_count && (c->dbg_gather_form == 2 || (c->dbg_gather_form == 0 && nev * dup < (int64_t)nb * 64));
     {
-        BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
+        BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol, raw ? 1 : 0, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p,
+                    hashed ? 1 : 0};
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
         if (lds > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
         ProfScope ps(c, "ev_bin");
@@ -1960,6 +2084,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             const size_t lds2 = ((size_t)chunk * 8 + (size_t)chunk * 2 + (size_t)chunk * R * R * 2 + (size_t)kScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
             // (float events with polarity carry 16-byte entries: first form)
             const bool form2 = scat_form != 1 && !(pol && !raw) && lds2 <= 64 * 1024 && TX < 256 && TY < 256;
+            if (hashed && !form2) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: hashed records need the second form of the scatter");
 #define LAUNCH_BIN(RR, PP) do { if (form2) ev_scatter2_kernel<RR><<<nchunks, 64 * kScatWaves, lds2, c->stream>>>(d_ev, d_chunks, P, chunk, d_slice_eb, d_segbase, d_tile_base, (uint2*)en); \
                                 else ev_scatter_kernel<RR, PP><<<nchunks, 64, lds, c->stream>>>(d_ev, d_chunks, P, d_slice_eb, d_segbase, d_tile_base, en); } while (0)
             const bool wide = pol && !raw;                       // raw entries keep the polarity in the sensor-pixel word

@@ -100,7 +100,8 @@ int         eorb_sync(eorb_ctx* ctx);
  * next configure, to force the overflow path), "octree_force_global" (1: keep the whole octree working set in global memory), "win_list_cap" / "win_pool_cap" (window matchers:
  * candidate list capacity per query / pool per pair, to force the full-scan path), "gather_form" (raw events with a Gaussian
  * stamp: 0 = choose the gather kernel by the batch's shape, 1 = the pipelined workgroup per tile, 2 = the wave per tile, 3 = no
- * binning, every tile's wave reads all events of its slice (calls with at most 4 slices)) */
+ * binning, every tile's wave reads all events of its slice (calls with at most 4 slices)), "dedupe_min_events" (float events:
+ * number of events per call from which their distinct positions are tabulated, default 2^20) */
 int         eorb_debug_option(eorb_ctx* ctx, const char* name, int value);
 const char* eorb_last_error(eorb_ctx* ctx);
 const char* eorb_version(void);

@@ -37,6 +37,7 @@ for case in range(ncase):
     raw["p"] = rng.integers(0, 2, n); raw["t"] = np.arange(n) * 1e-6
     form = int(rng.integers(0, 4))                                                # gather kernel: by shape / workgroup per tile / wave per tile / no binning
     c.debug_option("gather_form", form)
+    c.debug_option("dedupe_min_events", 1 if rng.integers(0, 3) == 0 else 1 << 20)     # a third of the cases: float events take the bulk (position table) form
     fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=c)
     ev = orc.undistort_events(raw, mx, my, W, H, check, 1.0)
     of, ou, omm = orc.ev2im_gauss(ev, W, H, sigma, pol, True)

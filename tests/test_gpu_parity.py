@@ -43,8 +43,10 @@ def test_ev2im_gauss_bit_exact(oracle, fe, ctx, case):
     W, H = case.get("W", 240), case.get("H", 180)
     ev = synth.random_events(case["n"], W, H, seed=11 + case["n"], frac=case["frac"])
     try:
-        for form in (0, 1, 3):
-            ctx.debug_option("gather_form", form)
+        for form in (0, 1, 3, -1):
+            # -1: the bulk form of the float path at test size (the distinct positions of the call tabulated, then the raw kernels)
+            ctx.debug_option("gather_form", 2 if form < 0 else form)
+            ctx.debug_option("dedupe_min_events", 1 if form < 0 else 1 << 20)
             for normalized in (True, False):
                 of, ou, omm = oracle.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized)
                 gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized, ctx=ctx, return_all=True)
@@ -54,6 +56,7 @@ def test_ev2im_gauss_bit_exact(oracle, fe, ctx, case):
                     assert np.array_equal(ou, gu), form
     finally:
         ctx.debug_option("gather_form", 0)
+        ctx.debug_option("dedupe_min_events", 1 << 20)
 
 
 def test_ev2im_gauss_shapes_lut(oracle, fe, ctx):
