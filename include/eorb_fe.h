@@ -382,6 +382,8 @@ int eorb_fe_run_batch_raw_dev(eorb_ctx* ctx, const eorb_raw_event* d_events, con
                               uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                               int32_t* d_matches12, int32_t* d_nmatches);
 
+/* (float events: a call with 2^20 events or more waits for the stream once, to learn how many distinct positions its events take --
+ * the raw variant above never waits) */
 int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int64_t* h_offsets, int B,
                           uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                           int32_t* d_matches12, int32_t* d_nmatches);
