@@ -1579,8 +1579,10 @@ __global__ void ev_stamp_kernel(const float2* __restrict__ lut, const uint32_t* 
         const int i = r / SWP, j = r - i * SWP;
         const uint32_t w = info[src];
         const int xi = (int)(int16_t)(w & 0xffff), yi = (int)(int16_t)(w >> 16);
+        if (xi == -32768) continue;                   // a dropped pixel has no entries: its rows are never selected (K2r's reads past a
+                                                      // column's ends may touch them, but only under a zero row mask)
         float v = 0.f;
-        if (xi != -32768 && j < SW) {
+        if (j < SW) {
             const float2 q = lut[src];
             const float xr = q.x - (float)xi, yr = q.y - (float)yi;
             const float fx = (float)(i - P.h) - xr, fy = (float)(j - P.h) - yr;
