@@ -59,6 +59,22 @@ def test_ev2im_gauss_bit_exact(oracle, fe, ctx, case):
         ctx.debug_option("dedupe_min_events", 1 << 20)
 
 
+def test_float_bulk_form_and_its_fallback(oracle, fe):
+    """Float events in bulk: (a) positions that repeat (events a loader resolved through its maps) take the per-call position table and
+    the raw kernels; (b) 600 000 distinct positions overflow the table's 2^19 rows and the call falls back to the list pipeline.  Both
+    equal the oracle, also with polarity."""
+    c = fe.Context()
+    c.debug_option("dedupe_min_events", 1)
+    W, H = 240, 180
+    ev_rep = synth.shapes_events(300000, W, H, seed=41, undistort=True)
+    ev_dis = synth.random_events(600000, W, H, seed=42, frac=True)
+    for ev, pol in ((ev_rep, False), (ev_rep, True), (ev_dis, False)):
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, 1.0, pol, True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, W, H, 1.0, pol, True, ctx=c, return_all=True)
+        assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm), (len(ev), pol)
+    c.close()
+
+
 def test_ev2im_gauss_shapes_lut(oracle, fe, ctx):
     """C1 stand-in: LUT-undistorted shapes events, L1 chunk (2000) and L2 window (6000)."""
     for n in (2000, 6000, 50000):
