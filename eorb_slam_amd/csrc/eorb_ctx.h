@@ -91,6 +91,7 @@ struct eorb_ctx {
     eorb::DevBuf lut, src_info, stamps;
     // float events in bulk: the distinct positions of a call become the rows of a per-call stamp table (ev_accumulate_dev)
     eorb::DevBuf dd_tab, dd_src_info, dd_stamps, dd_ev, dd_cnt;
+    eorb::DevBuf focus_sd;                       // measureImageFocus: per-patch deviations
     int64_t dbg_dd_min = (int64_t)1 << 20;       // events from which the positions are deduplicated (test hook: "dedupe_min_events")
     int lut_w = 0, lut_h = 0, lut_check = 1;
     int lut_key_W = -1, lut_key_H = -1, lut_key_mode = -1; float lut_key_sigma = -1.f;
