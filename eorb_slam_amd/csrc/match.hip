@@ -723,10 +723,74 @@ __global__ __launch_bounds__(256) void search_bow_kernel(BowArgs A)
     for (int a = gw; a < A.kf_nn; a += nw) {
         // the frame node with the same id (both lists ascending): binary search = the reference's lower_bound walk
         const uint32_t node = A.kf_nodes[a];
-        int lo = 0, hi = A.f_nn;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (A.f_nodes[mid] < node) lo = mid + 1; else hi = mid; }
-        if (lo >= A.f_nn || A.f_nodes[lo] != node) continue;
+        // (node ids are unique in a FeatureVector: the lanes look at 64 positions at a time -- one memory round trip, not the seven
+        // dependent ones of a binary search)
+        int lo = -1;
+        for (int base = 0; base < A.f_nn && lo < 0; base += 64) {
+            const int pos = base + lane;
+            const uint64_t hit = __ballot(pos < A.f_nn && A.f_nodes[pos] == node);
+            if (hit) lo = base + __ffsll((unsigned long long)hit) - 1;
+        }
+        if (lo < 0) continue;
         const int f0 = A.f_off[lo], f1 = A.f_off[lo + 1];
+        const int k0n = A.kf_off[a], k1n = A.kf_off[a + 1];
+        if (f1 - f0 <= 64 && k1n - k0n <= 64) {
+            // The usual node (about ten features on either side): everything it touches is loaded once -- lane = frame feature for the
+            // candidates, lane = KeyFrame feature for the queries, handed round by shuffles.  A frame feature belongs to this node
+            // only, so "already matched" (vpMapPointMatches[realIdxF] / vbMatched2) is a lane-local flag: no memory round trip between
+            // the KeyFrame features of the node (the walk below took three dependent global loads per feature).
+            const int nF = f1 - f0, nK = k1n - k0n;
+            int idxF = -1; bool availF = false; uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (lane < nF) {
+                idxF = A.f_idx[f0 + lane];
+                availF = A.match_f[idxF] < 0 && !(A.kf_kf && !A.f_has_mp[idxF]);
+                const uint64_t* tp = (const uint64_t*)(A.f_desc + (size_t)idxF * 32);
+                t0 = tp[0]; t1 = tp[1]; t2 = tp[2]; t3 = tp[3];
+            }
+            int idxK = -1; bool hasK = false; uint64_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+            if (lane < nK) {
+                idxK = A.kf_idx[k0n + lane];
+                hasK = A.kf_has_mp[idxK] != 0;
+                const uint64_t* dq = (const uint64_t*)(A.kf_desc + (size_t)idxK * 32);
+                q0 = dq[0]; q1 = dq[1]; q2 = dq[2]; q3 = dq[3];
+            }
+            for (int i = 0; i < nK; i++) {
+                if (!__shfl((int)hasK, i, 64)) continue;
+                const uint64_t b0 = __shfl(q0, i, 64), b1 = __shfl(q1, i, 64), b2 = __shfl(q2, i, 64), b3 = __shfl(q3, i, 64);
+                const int realIdxKF = __shfl(idxK, i, 64);
+                uint64_t k0 = ~0ull, k1 = ~0ull;
+                if (availF) {
+                    const int dist = __popcll(b0 ^ t0) + __popcll(b1 ^ t1) + __popcll(b2 ^ t2) + __popcll(b3 ^ t3);
+                    k0 = ((uint64_t)dist << 32) | (uint32_t)lane;          // candidate order = vector order = lane order
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
+                    const uint64_t l0 = k0 < o0 ? k0 : o0, h0 = k0 < o0 ? o0 : k0, s1 = k1 < o1 ? k1 : o1;
+                    k0 = l0; k1 = h0 < s1 ? h0 : s1;
+                }
+                if (k0 != ~0ull && (int)(k0 >> 32) < 256) {
+                    const int bestDist1 = (int)(k0 >> 32);
+                    const int bestDist2 = (k1 != ~0ull && (int)(k1 >> 32) < 256) ? (int)(k1 >> 32) : 256;
+                    if ((A.kf_kf ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) && (float)bestDist1 < A.nnratio * (float)bestDist2) {
+                        const int win = (int)(k0 & 63u);
+                        const int bestIdxF = __shfl(idxF, win, 64);
+                        if (lane == win) availF = false;
+                        if (lane == 0) {
+                            A.match_f[bestIdxF] = realIdxKF;
+                            atomicAdd(A.nmatches, 1);
+                            if (A.kf_kf) A.match12[realIdxKF] = bestIdxF;
+                            if (A.checkOri) {
+                                const int bin = rot_bin(A.kf_kps[realIdxKF].angle, A.f_kps[bestIdxF].angle);
+                                A.bin_f[A.kf_kf ? realIdxKF : bestIdxF] = (int8_t)bin;
+                                atomicAdd(&A.histo[bin], 1);
+                            }
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for (int iKF = A.kf_off[a]; iKF < A.kf_off[a + 1]; iKF++) {
             const int realIdxKF = A.kf_idx[iKF];
             if (!A.kf_has_mp[realIdxKF]) continue;
