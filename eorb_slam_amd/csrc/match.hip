@@ -1114,9 +1114,79 @@ __global__ __launch_bounds__(256) void bow_descend_kernel(const uint8_t* __restr
     }
 }
 
-// bitonic sort of P (power of two) 64-bit keys in LDS by the whole workgroup
+// bitonic sort of P (power of two) 64-bit keys in LDS by the whole workgroup (1024 threads).  Thread t keeps keys t, t + 1024, ... in
+// registers: partners less than 64 apart are exchanged by lane shuffles, partners a multiple of 1024 apart are the thread's own
+// registers, and only the distances 64 .. 512 go through LDS and two barriers (10 of the 55 steps of a 1024-key sort).
+__device__ __forceinline__ uint64_t blk_shfl_xor_u64(uint64_t v, int j)
+{
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int M>
+__device__ void block_bitonic_sort_regs(uint64_t* keys, int P)
+{
+    constexpr int NT = 1024;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    uint64_t v[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) { const int i = tid + NT * m; v[m] = i < P ? keys[i] : ~0ull; }
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= NT) {
+#pragma unroll
+                for (int dm = 1; dm < M; dm <<= 1) {
+                    if (j != dm * NT) continue;
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        if ((m & dm) == 0 && (m | dm) < M) {
+                            const int i = tid + NT * m;
+                            const bool up = (i & k) == 0;
+                            const uint64_t x = v[m], y = v[m | dm];
+                            const bool sw = (x > y) == up;
+                            v[m] = sw ? y : x; v[m | dm] = sw ? x : y;
+                        }
+                    }
+                }
+            } else if (j >= 64) {
+#pragma unroll
+                for (int m = 0; m < M; m++) { const int i = tid + NT * m; if (i < P) keys[i] = v[m]; }
+                __syncthreads();
+                uint64_t o[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) { const int i = tid + NT * m; o[m] = i < P ? keys[i ^ j] : ~0ull; }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const int i = tid + NT * m;
+                    const bool up = (i & k) == 0, low = (i & j) == 0;
+                    const uint64_t mn = v[m] < o[m] ? v[m] : o[m], mx = v[m] < o[m] ? o[m] : v[m];
+                    v[m] = (low == up) ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const int i = tid + NT * m;
+                    const uint64_t o = blk_shfl_xor_u64(v[m], j);
+                    const bool up = (i & k) == 0, low = (i & j) == 0;
+                    const uint64_t mn = v[m] < o ? v[m] : o, mx = v[m] < o ? o : v[m];
+                    v[m] = (low == up) ? mn : mx;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) { const int i = tid + NT * m; if (i < P) keys[i] = v[m]; }
+    __syncthreads();
+}
 __device__ __forceinline__ void block_bitonic_sort(uint64_t* keys, int P)
 {
+    if (blockDim.x == 1024) {
+        if (P <= 1024) { block_bitonic_sort_regs<1>(keys, P); return; }
+        if (P <= 2048) { block_bitonic_sort_regs<2>(keys, P); return; }
+        if (P <= 4096) { block_bitonic_sort_regs<4>(keys, P); return; }
+        if (P <= 8192) { block_bitonic_sort_regs<8>(keys, P); return; }
+    }
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             __syncthreads();
@@ -1165,7 +1235,8 @@ __global__ __launch_bounds__(1024) void bow_assemble_kernel(const uint32_t* __re
 {
     extern __shared__ unsigned char smem[];
     uint64_t* keys = (uint64_t*)smem;                       // P
-    uint32_t* ridx = (uint32_t*)(keys + P);                 // P
+    double* vals = (double*)(keys + P);                     // P: the words' values (summed for the norm from here, not from global memory)
+    uint32_t* ridx = (uint32_t*)(vals + P);                 // P
     __shared__ int s_m;
     __shared__ double s_norm;
     // ---- BowVector ----
@@ -1187,22 +1258,23 @@ __global__ __launch_bounds__(1024) void bow_assemble_kernel(const uint32_t* __re
             if (weighting == 0 || weighting == 1)
                 for (int j = i + 1; j < m && ridx[j] == ridx[i]; j++) v += w;
             bow_word[ridx[i]] = (uint32_t)(keys[i] >> 32);
-            bow_val[ridx[i]] = v;
+            vals[ridx[i]] = v;
         }
     }
-    __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
         double nrm = 0.0;
-        if (norm == 1) { for (int i = 0; i < nw; i++) nrm += fabs(bow_val[i]); }
-        else if (norm == 2) { for (int i = 0; i < nw; i++) nrm += bow_val[i] * bow_val[i]; nrm = sqrt(nrm); }
+        if (norm == 1) { for (int i = 0; i < nw; i++) nrm += fabs(vals[i]); }
+        else if (norm == 2) { for (int i = 0; i < nw; i++) nrm += vals[i] * vals[i]; nrm = sqrt(nrm); }
         else if (weighting == 0 || weighting == 1) nrm = (double)nw;     // "unnecessary when normalizing" branch :1166-1172
         s_norm = nrm;
         counts[0] = nw;
     }
     __syncthreads();
-    if (s_norm > 0.0 && (norm != 0 || weighting == 0 || weighting == 1))
-        for (int i = threadIdx.x; i < nw; i += blockDim.x) bow_val[i] /= s_norm;
+    {
+        const bool div = s_norm > 0.0 && (norm != 0 || weighting == 0 || weighting == 1);
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) bow_val[i] = div ? vals[i] / s_norm : vals[i];
+    }
     __syncthreads();
     // ---- FeatureVector ----
     for (int i = threadIdx.x; i < P; i += blockDim.x)
@@ -1221,7 +1293,7 @@ int bow_transform_dev(eorb_ctx* c, const uint8_t* d_desc, int n, int stride, con
                       uint32_t* d_fv_node, int32_t* d_fv_off, int32_t* d_fv_idx, int32_t* d_counts)
 {
     int P = 64; while (P < n) P <<= 1;
-    const size_t lds = (size_t)P * 12;
+    const size_t lds = (size_t)P * 20;
     if (lds > 150 * 1024) return set_err(c, EORB_E_CAPACITY, "bow_transform: %d features exceed the LDS sort", n);
     ProfScope ps(c, "bow_transform");
     bow_descend_kernel<<<(n + 3) / 4, 256, 0, c->stream>>>(d_desc, n, stride, V, V.L - levelsup, d_word_of, d_w_of, d_node_of);
