@@ -527,8 +527,11 @@ static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_ca
     int64_t offs[2] = {0, (int64_t)n};
     uint32_t* mm = (uint32_t*)c->minmax.p;
     float* mmf = (float*)((char*)c->minmax.p + 16);
+    // (warped events: no two share a position -- the position table of the bulk float form would only be filled and thrown away)
+    const int64_t dd_saved = c->dbg_dd_min; c->dbg_dd_min = 0;
     rc = ev_accumulate_dev(c, c->ev16.p, 0, offs, 1, W, H, sigma, pol, 0, (float*)c->img_f32.p, (uint8_t*)c->img_u8.p,
                            normalized, mm);
+    c->dbg_dd_min = dd_saved;
     if (rc) return rc;
     if ((rc = ev_decode_minmax(c, mm, mmf, 1))) return rc;
     float hmm[2];
