@@ -11,7 +11,7 @@ EORB_OK, EORB_E_EMPTY, EORB_E_CONFIG, EORB_E_CAPACITY, EORB_E_ARG, EORB_E_HIP, E
 
 # every symbol include/eorb_fe.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "eorb_create", "eorb_destroy", "eorb_sync", "eorb_debug_option", "eorb_last_error", "eorb_version",
+    "eorb_create", "eorb_destroy", "eorb_sync", "eorb_debug_option", "eorb_debug_counter", "eorb_last_error", "eorb_version",
     "eorb_prof_enable", "eorb_prof_reset", "eorb_prof_count", "eorb_prof_get",
     "eorb_ev2im", "eorb_ev2im_gauss", "eorb_set_undistort_maps", "eorb_undistort_events", "eorb_parse_events_text", "eorb_ev2im_gauss_raw", "eorb_ev2im_raw", "eorb_fe_run_batch_raw_dev", "eorb_fe_run_batch_images_dev", "eorb_ev2mci_se3", "eorb_ev2mci_se2", "eorb_ev2mci_se3_cam", "eorb_ev2mci_se2_cam", "eorb_measure_image_focus", "eorb_normalize_minmax_u8",
     "eorb_orb_configure", "eorb_orb_max_keypoints", "eorb_orb_get_tables", "eorb_orb_extract",
@@ -91,6 +91,7 @@ def lib():
     L.eorb_destroy.restype = None; L.eorb_destroy.argtypes = [vp]
     L.eorb_sync.restype = ci; L.eorb_sync.argtypes = [vp]
     L.eorb_debug_option.restype = ci; L.eorb_debug_option.argtypes = [vp, C.c_char_p, ci]
+    L.eorb_debug_counter.restype = C.c_longlong; L.eorb_debug_counter.argtypes = [vp, C.c_char_p]
     L.eorb_last_error.restype = C.c_char_p; L.eorb_last_error.argtypes = [vp]
     L.eorb_version.restype = C.c_char_p; L.eorb_version.argtypes = []
     L.eorb_prof_enable.restype = ci; L.eorb_prof_enable.argtypes = [vp, ci]

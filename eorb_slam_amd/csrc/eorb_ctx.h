@@ -89,6 +89,10 @@ struct eorb_ctx {
     eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order, order_hist;
     // raw sensor events: undistortion maps (float2 per sensor pixel) and the tables derived from them
     eorb::DevBuf lut, src_info, stamps;
+    // slot form of the raw accumulation (ev_slots.hip): per sensor pixel its tiles / slot numbers, per tile its rows; valid when sl_ok
+    eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_plan, sl_trace; long long sl_trace_n = 0;
+    int sl_ok = 0, sl_null = 0;
+    long long sl_calls = 0; size_t sl_info_off = 0;     // test hook counters (eorb_debug_counter)
     // float events in bulk: the distinct positions of a call become the rows of a per-call stamp table (ev_accumulate_dev)
     eorb::DevBuf dd_tab, dd_src_info, dd_stamps, dd_ev, dd_cnt;
     eorb::DevBuf focus_sd;                       // measureImageFocus: per-patch deviations
@@ -125,7 +129,7 @@ struct eorb_ctx {
     eorb::DevBuf status;
     // test hooks (eorb_debug_option): shrink the octree node pool to force an overflow; force the octree's global-memory layout
     int dbg_pool_shrink = 0, dbg_force_global = 0;
-    int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices)
+    int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices), 4 slot lists (K2p)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
 };
 
@@ -154,6 +158,11 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
 int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, int H, double tsFactor, eorb_event* d_out, uint32_t* d_blk);
 int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* d_lineend, eorb_raw_event* d_ev, uint8_t* d_status,
                       eorb_raw_event* d_out, uint32_t* d_blk, size_t max_lines, uint32_t h_res[3]);
+// ev_slots.hip
+int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps, int stamp_stride, int SWP);
+int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
+                        float* d_f32, uint32_t* d_minmax_enc);
+int ev_slots_trace_read(eorb_ctx* c, unsigned long long* out, long long max_records);
 // klt.hip
 int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int W, int H, int stride, const float* d_prev_pts,
                   float* d_next_pts, int n, int win, int maxLevel, int maxCount, double epsilon, int flags, float minEig,

@@ -228,7 +228,7 @@ void eorb_destroy(eorb_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_plan, &c->sl_trace, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
@@ -268,6 +268,20 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "gather_form")) { c->dbg_gather_form = value; return EORB_OK; }
     if (!strcmp(name, "dedupe_min_events")) { c->dbg_dd_min = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
+}
+
+long long eorb_debug_counter(eorb_ctx* c, const char* name)
+{
+    if (!c || !name) return -1;
+    if (!strcmp(name, "slot_calls")) return c->sl_calls;
+    if (!strcmp(name, "slot_flags")) {
+        if (!c->sl_tile.p || !c->sl_info_off) return 0;
+        int flags = 0;
+        if (hipMemcpyAsync(&flags, (char*)c->sl_tile.p + c->sl_info_off + 3 * sizeof(int), sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+        return flags;
+    }
+    return -1;
 }
 
 const char* eorb_last_error(eorb_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -628,6 +642,10 @@ int eorb_selfcheck_math(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bi
 #ifdef EORB_DIAG
 int eorb_diag_read(unsigned long long* out16) { return ev_diag_read(out16); }
 int eorb_trace_read(unsigned long long* out, int n) { return ev_trace_read(out, n); }
+#endif
+
+#ifdef EORB_SLOT_TRACE
+int eorb_slot_trace_read(eorb_ctx* c, unsigned long long* out, long long max_records) { return c ? ev_slots_trace_read(c, out, max_records) : -1; }
 #endif
 
 // ---- ORB extractor, host buffers -----------------------------------------------------------------------

@@ -18,6 +18,7 @@
 // All kernels are batched over time-slices (blockIdx ranges over slices x tiles / chunks).
 #include "eorb_ctx.h"
 #include "dev_math.h"
+#include "ev_common.h"
 #include <math.h>
 #include <algorithm>
 #include <stdlib.h>
@@ -25,17 +26,6 @@
 #include <vector>
 
 namespace eorb {
-
-__device__ __forceinline__ uint32_t enc_f32(float f)
-{   // order-preserving map float -> uint32 (for atomicMax/atomicMin on floats of either sign)
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dec_f32(uint32_t e)
-{
-    uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
-    return __uint_as_float(u);
-}
 
 struct BinParams {
     int W, H, h;          // image size, stamp half window (0 in count mode)
@@ -260,7 +250,6 @@ __global__ __launch_bounds__(64) void ev_scatter_kernel(const eorb_event16* __re
 //   D  slot p of the sorted order -> (event, tile) -> the entry is rebuilt from the event (L2) and stored at the tile's run base +
 //      (p - loff[tile]): consecutive threads write consecutive entries of a run.
 constexpr int kScatWaves = 8;
-__device__ __forceinline__ int wave_incl_scan(int x);
 template <int R>
 __global__ __launch_bounds__(64 * kScatWaves) void ev_scatter2_kernel(const eorb_event16* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
                                                           BinParams P, int chunk_cap, const int64_t* __restrict__ slice_ebase,
@@ -472,18 +461,6 @@ __global__ __launch_bounds__(1024) void ev_tile_order_kernel(const uint32_t* __r
     __syncthreads();
     const int i0 = blockIdx.x * kOrderItems, i1 = min(i0 + kOrderItems, total);
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) order[atomicAdd(&cur[ev_weight_bucket(weight[i])], 1u)] = i;
-}
-
-// wave-wide inclusive prefix sum without LDS round trips: row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 / 31
-__device__ __forceinline__ int wave_incl_scan(int x)
-{
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);     // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);     // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);     // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);     // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
-    return x;
 }
 
 struct GatherParams {
@@ -1901,7 +1878,7 @@ static GatherParams ev_gather_params(int W, int H, int h, int TX, int TY, int NT
 
 // raw events: the tables derived from the maps (integer position of every sensor pixel, its stamp); rebuilt only when (image size,
 // sigma, mode) change
-static int ev_raw_tables(eorb_ctx* c, int W, int H, int h, float sigma, int mode_count, GatherParams& G)
+static int ev_raw_tables(eorb_ctx* c, int W, int H, int h, float sigma, int mode_count, GatherParams& G, bool hashed = false)
 {
     int rc;
     const bool raw = true;
@@ -1924,6 +1901,11 @@ static int ev_raw_tables(eorb_ctx* c, int W, int H, int h, float sigma, int mode
                                                              (float*)c->stamps.p + kStampPad);
             }
             EORB_LAUNCH_CHECK(c, "ev_stamp_tables kernels");
+            c->sl_ok = 0;
+            if (!mode_count && !hashed) {
+                const int TXs = (W + kTile - 1) / kTile, TYs = (H + kTile - 1) / kTile;
+                if ((rc = ev_slots_prepare(c, W, H, h, TXs, TYs, (const float*)c->stamps.p + kStampPad, G.stamp_stride, G.stamp_colstride))) return rc;
+            }
             c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
         }
         G.stamps = (const float*)c->stamps.p + kStampPad;     // K2r reads up to 7 floats before / behind a column
@@ -2026,6 +2008,30 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             return EORB_OK;
         }
     }
+    // dense batches of raw events without polarity: two-byte slot lists, a tile position's rows in LDS (ev_slots.hip)
+    if (raw && !hashed && !mode_count && !pol && (c->dbg_gather_form == 0 || c->dbg_gather_form == 4)) {
+        const int64_t nev0 = h_offsets[B] - h_offsets[0];
+        const bool sparse0 = nev0 * dup < (int64_t)B * NT * 64;          // (fewer than one 64-entry batch per tile on average: K2s)
+        if (c->dbg_gather_form == 4 || !sparse0) {
+            int rc;
+            GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, mode_count, B * NT, sigma);
+            if ((rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
+            if (c->sl_ok) {
+                {
+                    ProfScope ps(c, "ev_minmax_init");
+                    ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
+                }
+                if ((rc = ev_slots_accumulate(c, d_events, h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc))) return rc;
+                if (normalized && d_u8) {
+                    ProfScope ps(c, "ev_normalize");
+                    dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
+                    ev_normalize_kernel<<<grid, 256, 0, c->stream>>>(d_f32, d_minmax_enc, d_u8, W * H, mode_count);
+                    EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
+                }
+                return EORB_OK;
+            }
+        }
+    }
     // chunk list (host) -> device.  A chunk is binned by ONE wavefront, 64 events at a time: large inputs take kChunk events per
     // chunk (fewer segment tables), small ones shorter chunks so that a single 2 000-event slice is not one 32-iteration serial
     // loop (72 us on MI355X) but eight waves side by side
@@ -2081,7 +2087,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     int32_t* d_order = (int32_t*)(d_tile_cnt + 2 * (size_t)nb);
 
     GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, mode_count, nb, sigma);
-    if (raw && (rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
+    if (raw && (rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G, hashed))) return rc;
     {
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);

@@ -1,0 +1,741 @@
+// ev_slots.hip -- raw sensor events -> Gaussian event image through per-tile SLOT lists (the dense-batch form of ev2im_gauss,
+// src/Event/EventConversion.cc:215-269 of the reference; bit-exact w.r.t. its sequential loop).
+//
+// A raw event is a sensor pixel; its undistorted position, hence its whole (2h+1)^2 stamp (exp_XY2f :59-65), is a function of that
+// pixel (MyCalibrator::undistPointMaps, Utils/MyCalibrator.cpp:164-180).  For an 8x8 image tile T only the ~(8+2h)^2 sensor pixels
+// whose stamps reach T ever contribute: they are T's SLOTS.  Once per (maps, sigma):
+//   slot_tab[sensor pixel]  = { first tile, tiles in x / y, the pixel's slot number in each of its <= 4 tiles }
+//   rows[T][slot][64]       = what that sensor pixel adds to each of T's 64 pixels (its stamp value, +0.0f outside the stamp)
+// Per batch:
+//   K1a sl_count_kernel   entries of every (chunk, tile)           | as in ev_accum.hip, ranges from slot_tab
+//   K1b sl_scan_kernel    one contiguous event-ordered list per (slice, tile); per-tile weights
+//   K1c sl_scatter_kernel order-preserving scatter of TWO-BYTE entries (slot << 8): the chunk is tile-sorted in LDS and leaves as runs
+//   K2p sl_gather_kernel  one workgroup per tile POSITION: the tile's rows staged in LDS once (<= 64 KB), then every wavefront owns
+//                         one (slice, tile) list at a time (next slice by an atomic ticket): lane = pixel, per entry ONE
+//                         ds_read_addtid_b32 (address = M0 + 4 * lane: the entry IS the LDS byte offset of its row, no address
+//                         arithmetic) and ONE v_add_f32, in list order = event order (newVal = image + val, :251-254).  x + 0.0f == x
+//                         bit for bit, so lanes the stamp does not reach keep their value.
+// Versus the batch pipeline of ev_accum.hip (64-entry batches through value waves and an add wave, ~6.4 wave-instructions and 8
+// bytes per entry) an entry costs ~4 issue slots and 2 bytes; the kernel is bound by the LDS array (2 cycles per entry and CU).
+#include "eorb_ctx.h"
+#include "ev_common.h"
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace eorb {
+
+constexpr uint32_t kNoSlot = 0xffu;
+constexpr int kSlotScatWaves = 8;
+
+// ---- tables ---------------------------------------------------------------------------------------------------------------------
+// Tile range of a sensor pixel = tiles that hold an IN-IMAGE pixel of its stamp (:250 `if (isInImage)`): every entry of a list
+// then visits at least one pixel, so "the tile was visited" (resolveMinMaxVals :32-39) is "its list is not empty".
+__global__ void sl_assign_kernel(const uint32_t* __restrict__ src_info, int nsrc, int W, int H, int h, int TX,
+                                 uint32_t* __restrict__ tile_nslots, uint2* __restrict__ slot_tab, int* __restrict__ info)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsrc) return;
+    const uint32_t w = src_info[i];
+    const int xi = (int)(int16_t)(w & 0xffff), yi = (int)(int16_t)(w >> 16);
+    uint2 o = make_uint2(0u, 0xffffffffu);
+    if (xi != -32768) {
+        const int x0 = max(xi - h, 0), x1 = min(xi + h, W - 1), y0 = max(yi - h, 0), y1 = min(yi + h, H - 1);
+        if (x1 >= x0 && y1 >= y0) {
+            const int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = y0 >> 3, ty1 = y1 >> 3;
+            const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;           // 1 or 2 (h <= 4)
+            uint32_t slots = 0xffffffffu;
+            for (int dy = 0; dy < ny; dy++)
+                for (int dx = 0; dx < nx; dx++) {
+                    uint32_t s = atomicAdd(&tile_nslots[(ty0 + dy) * TX + tx0 + dx], 1u);
+                    if (s >= kNoSlot) { atomicOr(&info[2], 1); s = 0; }
+                    const int sh = 8 * (dy * 2 + dx);
+                    slots = (slots & ~(0xffu << sh)) | (s << sh);
+                }
+            o.x = (uint32_t)tx0 | ((uint32_t)ty0 << 8) | ((uint32_t)nx << 16) | ((uint32_t)ny << 18);
+            o.y = slots;
+        }
+    }
+    slot_tab[i] = o;
+}
+
+// rowbase[t] = first row of tile t in the row table; info[0] = rows in all, info[1] = most slots of a tile
+__global__ __launch_bounds__(1024) void sl_rowbase_kernel(const uint32_t* __restrict__ nslots, int NT, uint32_t* __restrict__ rowbase,
+                                                          int* __restrict__ info)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wmax[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (NT + 1023) / 1024;
+    const int t0 = tid * per, t1 = min(t0 + per, NT);
+    uint32_t mine = 0, mx = 0;
+    for (int t = t0; t < t1; t++) { const uint32_t v = nslots[t]; mine += v; mx = max(mx, v); }
+    uint32_t incl = (uint32_t)wave_incl_scan((int)mine);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    for (int t = t0; t < t1; t++) { rowbase[t] = before; before += nslots[t]; }
+    if (tid == 1023) {
+        uint32_t m = 0;
+        for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
+        info[0] = (int)before; info[1] = (int)m;
+    }
+}
+
+// one wavefront per sensor pixel: lane = pixel of the tile; rows[(rowbase[tile] + slot) * 64 + lane] = the stamp tap that falls on
+// that pixel (stamps[src][x offset][y offset], ev_stamp_kernel), +0.0f outside the stamp or the image
+__global__ __launch_bounds__(256) void sl_rows_kernel(const uint32_t* __restrict__ src_info, const uint2* __restrict__ slot_tab, int nsrc,
+                                                      int W, int H, int h, int TX, const float* __restrict__ stamps, int stamp_stride,
+                                                      int SWP, const uint32_t* __restrict__ rowbase, float* __restrict__ rows)
+{
+    const int src = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (src >= nsrc) return;
+    const uint2 st = slot_tab[src];
+    const int nx = (st.x >> 16) & 3, ny = (st.x >> 18) & 3;
+    if (!nx || !ny) return;
+    const uint32_t w = src_info[src];
+    const int xi = (int)(int16_t)(w & 0xffff), yi = (int)(int16_t)(w >> 16);
+    const int tx0 = st.x & 0xff, ty0 = (st.x >> 8) & 0xff;
+    for (int dy = 0; dy < ny; dy++)
+        for (int dx = 0; dx < nx; dx++) {
+            const uint32_t slot = (st.y >> (8 * (dy * 2 + dx))) & 0xffu;
+            const int tile = (ty0 + dy) * TX + tx0 + dx;
+            const int px = (tx0 + dx) * 8 + (lane & 7), py = (ty0 + dy) * 8 + (lane >> 3);
+            const int i = px - xi + h, j = py - yi + h;
+            float v = 0.0f;
+            if (i >= 0 && i <= 2 * h && j >= 0 && j <= 2 * h && px < W && py < H) v = stamps[(size_t)src * stamp_stride + i * SWP + j];
+            rows[((size_t)rowbase[tile] + slot) * 64 + lane] = v;
+        }
+}
+
+// ---- K1a: entries of every (chunk, tile) -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                       const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
+                                                       uint16_t* __restrict__ segcnt)
+{
+    extern __shared__ uint32_t cnt[];               // NT
+    const ChunkDesc cd = chunks[blockIdx.x];
+    for (int i = threadIdx.x; i < NT; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const eorb_raw_event* e = ev + cd.start;
+    constexpr int U = 8;
+    for (int k0 = threadIdx.x; k0 < cd.n; k0 += blockDim.x * U) {
+        uint32_t xy[U], rg[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)&e[k] : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int x = (int)(xy[u] & 0xffff), y = (int)(xy[u] >> 16);
+            rg[u] = (x < LW && y < LH) ? slot_tab[(uint32_t)y * (uint32_t)LW + x].x : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int nx = (rg[u] >> 16) & 3, ny = (rg[u] >> 18) & 3;
+            const int t0 = (int)((rg[u] >> 8) & 0xff) * TX + (int)(rg[u] & 0xff);
+            if (nx && ny) {
+                atomicAdd(&cnt[t0], 1u);
+                if (nx > 1) atomicAdd(&cnt[t0 + 1], 1u);
+                if (ny > 1) { atomicAdd(&cnt[t0 + TX], 1u); if (nx > 1) atomicAdd(&cnt[t0 + TX + 1], 1u); }
+            }
+        }
+    }
+    __syncthreads();
+    uint16_t* sc = segcnt + (size_t)blockIdx.x * NT;
+    for (int i = threadIdx.x; i < NT; i += blockDim.x) sc[i] = (uint16_t)cnt[i];
+}
+
+// ---- K1b: one workgroup per slice.  Per tile: exclusive scan of its counts over the slice's chunks (segbase), the total (tile_cnt);
+// exclusive scan over the tiles of the totals rounded up to 16 entries (tile_base: every list starts on a 16-byte boundary) ----
+__global__ __launch_bounds__(1024) void sl_scan_kernel(const int* __restrict__ slice_chunk0, const uint16_t* __restrict__ segcnt, int NT,
+                                                       uint32_t* __restrict__ segbase, uint32_t* __restrict__ tile_cnt,
+                                                       uint32_t* __restrict__ tile_base)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int slice = blockIdx.x;
+    const int c0 = slice_chunk0[slice], c1 = slice_chunk0[slice + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < NT; t0 += blockDim.x) {
+        const int tile = t0 + threadIdx.x;
+        uint32_t run = 0;
+        if (tile < NT) {
+            int c = c0;
+            for (; c + 8 <= c1; c += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = segcnt[(size_t)(c + u) * NT + tile];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { segbase[(size_t)(c + u) * NT + tile] = run; run += v[u]; }
+            }
+            for (; c < c1; c++) { const uint32_t v = segcnt[(size_t)c * NT + tile]; segbase[(size_t)c * NT + tile] = run; run += v; }
+            tile_cnt[(size_t)slice * NT + tile] = run;
+        }
+        const uint32_t padded = (run + 15u) & ~15u;
+        uint32_t incl = (uint32_t)wave_incl_scan((int)padded);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (tile < NT) tile_base[(size_t)slice * NT + tile] = before + incl - padded;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry = before + incl;
+        __syncthreads();
+    }
+}
+
+// ---- K1c: order-preserving scatter of 2-byte entries.  One 8-wave workgroup per chunk (<= 2048 events); wave w owns the w-th
+// share of the chunk's events.
+//   A  slot bytes / first tile of every event into LDS, tile ranges into registers, counts per (wave, tile) by LDS atomics
+//   B  per tile the exclusive prefix over the waves; exclusive scan of the totals over the tiles: loff[t] = start of tile t's run
+//   C  every wave walks its sub-batches of 64 events in order: rank among the lanes of the same tile by ballot matching (tiles
+//      visited in parity classes: a lane has at most one tile per class) + the wave's running counter: sidx[slot of the sorted
+//      order] = event | dx << 11 | dy << 13
+//   D  slot p -> (event, tile) -> entry = the event's slot number in that tile << 8, stored at the run's place in the tile's
+//      global list: consecutive threads write consecutive entries of a run ----
+__global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                                         const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int TY,
+                                                                         int NT, int chunk_cap, const int64_t* __restrict__ slice_ebase,
+                                                                         const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
+                                                                         uint8_t* __restrict__ entries)
+{
+    extern __shared__ unsigned char sm2[];
+    __shared__ uint32_t s_wsum[kSlotScatWaves];
+    constexpr int NTHR = 64 * kSlotScatWaves;
+    constexpr int R = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x;
+    const ChunkDesc cd = chunks[chunk];
+    const int NTp = (NT + 1) & ~1;
+    uint32_t* pay = (uint32_t*)sm2;                                   // chunk_cap: the event's slot bytes
+    uint16_t* prng = (uint16_t*)(pay + chunk_cap);                    // chunk_cap: first tile of the event's range, tx0 | ty0 << 8
+    uint16_t* sidx = prng + chunk_cap;                                // chunk_cap * 4
+    uint16_t* cntw = sidx + (size_t)chunk_cap * R * R;                // kSlotScatWaves * NTp
+    uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
+    uint32_t* gbase = (uint32_t*)(loff + NTp + 2);                    // NT
+    for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
+    const eorb_raw_event* e = ev + cd.start;
+    const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
+    const int S = Q >> 6;
+    constexpr int SMAX = 4;
+    uint32_t rng[SMAX];                                               // slot_tab.x of the event; 0 = no entry
+    __syncthreads();
+    // ---- A ----
+    uint32_t* cw32 = (uint32_t*)(cntw + wave * NTp);
+    uint32_t rsrc[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        const int k = wave * Q + s * 64 + lane;
+        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)&e[k] : 0xffffffffu;
+        const int x = (int)(q & 0xffff), y = (int)(q >> 16);
+        rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
+    }
+    uint2 rst[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) rst[s] = rsrc[s] != 0xffffffffu ? slot_tab[rsrc[s]] : make_uint2(0u, 0xffffffffu);
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        rng[s] = 0u;
+        const int k = wave * Q + s * 64 + lane;
+        if (s < S && k < cd.n) {
+            const uint32_t rg = rst[s].x;
+            const int nx = (rg >> 16) & 3, ny = (rg >> 18) & 3;
+            pay[k] = rst[s].y;
+            prng[k] = (uint16_t)(rg & 0xffff);
+            if (nx && ny) {
+                rng[s] = rg;
+                const int t0 = (int)((rg >> 8) & 0xff) * TX + (int)(rg & 0xff);
+                for (int dy = 0; dy < ny; dy++)
+                    for (int dx = 0; dx < nx; dx++) {
+                        const int t = t0 + dy * TX + dx;
+                        atomicAdd(&cw32[t >> 1], 1u << (16 * (t & 1)));       // 16-bit counters, two per word (a share has <= 256 events)
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B ----
+    {
+        const int per = (NT + NTHR - 1) / NTHR;
+        const int t0 = tid * per, t1 = min(t0 + per, NT);
+        uint32_t mine = 0;
+        for (int t = t0; t < t1; t++) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < kSlotScatWaves; w++) { const uint32_t v = cntw[w * NTp + t]; cntw[w * NTp + t] = (uint16_t)run; run += v; }
+            loff[t] = (uint16_t)run;
+            mine += run;
+            gbase[t] = tile_base[(size_t)cd.slice * NT + t] + segbase[(size_t)chunk * NT + t];
+        }
+        uint32_t incl = (uint32_t)wave_incl_scan((int)mine);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < wave; w++) before += s_wsum[w];
+        for (int t = t0; t < t1; t++) { const uint32_t v = loff[t]; loff[t] = (uint16_t)before; before += v; }
+        if (tid == NTHR - 1) loff[NT] = (uint16_t)before;
+    }
+    __syncthreads();
+    // ---- C ----
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint16_t* cw = cntw + wave * NTp;
+    const int txr = (TX + R - 1) / R;
+    int mbits = 1; while ((1 << mbits) < txr * ((TY + R - 1) / R)) mbits++;
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        if (s >= S) break;
+        const uint32_t rg = rng[s];
+        const int tx0 = rg & 0xff, ty0 = (rg >> 8) & 0xff, tx1 = tx0 + (int)((rg >> 16) & 3) - 1, ty1 = ty0 + (int)((rg >> 18) & 3) - 1;
+        const bool valid = rg != 0u;
+        const uint16_t kloc = (uint16_t)(wave * Q + s * 64 + lane);
+#pragma unroll
+        for (int cy = 0; cy < R; cy++) {
+#pragma unroll
+            for (int cx = 0; cx < R; cx++) {
+                const int tx = tx0 + ((cx - tx0 % R) + R) % R;
+                const int ty = ty0 + ((cy - ty0 % R) + R) % R;
+                const bool has = valid && tx <= tx1 && ty <= ty1;
+                uint64_t m = __ballot(has);
+                if (m == 0ull) continue;
+                const int key = has ? ty * TX + tx : 0;
+                const int mkey = has ? (ty / R) * txr + (tx / R) : 0;
+                for (int b = 0; b < mbits; b++) {
+                    const bool bit = (mkey >> b) & 1;
+                    const uint64_t bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                if (has) {
+                    const int rank = __popcll(m & lt_mask);
+                    const uint32_t base = cw[key];
+                    sidx[(uint32_t)loff[key] + base + rank] = (uint16_t)(kloc | ((tx - tx0) << 11) | ((ty - ty0) << 13));
+                    if (rank == 0) cw[key] = (uint16_t)(base + (uint32_t)__popcll(m));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- D ----
+    uint8_t* out = entries + (size_t)slice_ebase[cd.slice];
+    const int E = loff[NT];
+    for (int p = tid; p < E; p += NTHR) {
+        const uint32_t sv = sidx[p];
+        const int k = sv & 0x7ff;
+        const int dx = (sv >> 11) & 3, dy = (sv >> 13) & 3;
+        const uint32_t r0 = prng[k];
+        const int t = ((int)(r0 >> 8) + dy) * TX + (int)(r0 & 0xff) + dx;
+        const uint32_t slot = (pay[k] >> (8 * (dy * 2 + dx))) & 0xffu;
+        out[(size_t)gbase[t] + (uint32_t)(p - (int)loff[t])] = (uint8_t)slot;
+    }
+}
+
+// ---- the gather's work plan ----
+// (1) per tile position: its (slice, tile) lists sorted longest first (a list is a serial chain of adds: the long ones must start
+//     early), each with its descriptor { slice, entries, list offset } so that a ticket costs the gather ONE load; the position's
+//     total and its longest list
+__global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_base,
+                                                      const int64_t* __restrict__ slice_ebase, int B, int NT, uint4* __restrict__ items,
+                                                      uint32_t* __restrict__ tile_w, uint32_t* __restrict__ tile_m, uint32_t* __restrict__ ctr)
+{
+    extern __shared__ uint32_t pc[];                 // B counts
+    __shared__ uint32_t red[8];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    uint32_t sum = 0, mx = 0;
+    for (int s = tid; s < B; s += blockDim.x) { const uint32_t c = tile_cnt[(size_t)s * NT + t]; pc[s] = c; sum += c; mx = max(mx, c); }
+    __syncthreads();
+    const bool sorted = B <= 2048;
+    for (int s = tid; s < B; s += blockDim.x) {
+        const uint32_t c = pc[s];
+        int rank = s;
+        if (sorted) { rank = 0; for (int j = 0; j < B; j++) { const uint32_t v = pc[j]; rank += (v > c || (v == c && j < s)) ? 1 : 0; } }
+        const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
+        items[(size_t)t * B + rank] = make_uint4((uint32_t)s, c, (uint32_t)off, (uint32_t)(off >> 32));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sum += (uint32_t)__shfl_xor((int)sum, d, 64); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = sum; red[4 + (tid >> 6)] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        tile_w[t] = red[0] + red[1] + red[2] + red[3];
+        tile_m[t] = max(max(red[4], red[5]), max(red[6], red[7]));
+        ctr[t] = 0u;
+    }
+}
+// (2) the workgroup tasks: tile positions ordered by their longest list, position t repeated n_t = 1 + its share of the G - NT spare
+//     tasks by total entries (no more than its slices can occupy); unused tasks carry 0xffffffff
+__global__ __launch_bounds__(1024) void sl_tasks_kernel(const uint32_t* __restrict__ tile_w, const uint32_t* __restrict__ tile_m, int NT, int G,
+                                                        int max_per_tile, uint32_t* __restrict__ scratch /* 2 * NT */, uint32_t* __restrict__ task_tile)
+{
+    __shared__ unsigned long long wred[16];
+    __shared__ uint32_t wsum[16], wsum2[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long tot = 0;
+    for (int t = tid; t < NT; t += 1024) tot += tile_w[t];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += (unsigned long long)__shfl_xor((long long)tot, d, 64);
+    if (lane == 0) wred[wave] = tot;
+    __syncthreads();
+    tot = 0;
+    for (int w = 0; w < 16; w++) tot += wred[w];
+    const unsigned long long spare = (unsigned long long)max(G - NT, 0);
+    uint32_t* nsorted = scratch; uint32_t* tsorted = scratch + NT;
+    for (int t = tid; t < NT; t += 1024) {
+        const uint32_t m = tile_m[t];
+        int rank = 0;
+        for (int u = 0; u < NT; u++) { const uint32_t v = tile_m[u]; rank += (v > m || (v == m && u < t)) ? 1 : 0; }
+        uint32_t n = 1u + (tot ? (uint32_t)((unsigned long long)tile_w[t] * spare / tot) : 0u);
+        n = min(n, (uint32_t)max(max_per_tile, 1));
+        nsorted[rank] = n; tsorted[rank] = (uint32_t)t;
+    }
+    __syncthreads();
+    // first up to two tasks per position in that order (the longest chains of the heavy positions start in the first round on
+    // different CUs), then the remaining ones: two exclusive scans over the ranks (consecutive ranks per thread)
+    const int per = (NT + 1023) / 1024;
+    const int r0 = tid * per, r1 = min(r0 + per, NT);
+    uint32_t mine1 = 0, mine2 = 0;
+    for (int r = r0; r < r1; r++) { const uint32_t n = nsorted[r], a = min(n, 2u); mine1 += a; mine2 += n - a; }
+    const uint32_t incl1 = (uint32_t)wave_incl_scan((int)mine1), incl2 = (uint32_t)wave_incl_scan((int)mine2);
+    if (lane == 63) { wsum[wave] = incl1; wsum2[wave] = incl2; }
+    __syncthreads();
+    uint32_t b1 = incl1 - mine1, b2 = incl2 - mine2, tot1 = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) { b1 += wsum[w]; b2 += wsum2[w]; } tot1 += wsum[w]; }
+    b2 += tot1;
+    for (int r = r0; r < r1; r++) {
+        const uint32_t n = nsorted[r], a = min(n, 2u), t = tsorted[r];
+        for (uint32_t k = 0; k < a; k++) if (b1 + k < (uint32_t)G) task_tile[b1 + k] = t;
+        for (uint32_t k = 0; k < n - a; k++) if (b2 + k < (uint32_t)G) task_tile[b2 + k] = t;
+        b1 += a; b2 += n - a;
+    }
+    const uint32_t before = b2;
+    if (tid == 1023) for (uint32_t k = before; k < (uint32_t)G; k++) task_tile[k] = 0xffffffffu;
+}
+
+// ---- K2p ----
+// One workgroup per task = a tile position (heavy positions get several tasks): the tile's rows -> LDS once; then every wavefront
+// takes items of the position by ticket (longest first, one ticket at a time, requested when the item in hand has at most four
+// blocks to go so that the round trip hides behind its adds).  A list is read 1024 entries at a time (one global_load_dwordx4 per
+// lane, the next block requested before the current one is consumed); entries past the end of the list become the null slot (a row of
+// zeros).  The inner loop walks one lane's 16 entries per iteration: v_readlane -> SGPR, v_perm_b32 builds the row's LDS address
+// { slot, 4 * lane } per entry, ds_read_b32 three groups of four ahead of their adds (counted lgkmcnt), all inside ONE asm
+// statement that drains its reads before it ends (no load is in flight across the statement's boundary).
+// (Sharing a long list out by pixel quadrant was built and dropped: a 7x7 stamp centred inside an 8x8 tile reaches all four quadrants,
+// so on the tiles that matter a quadrant's wave keeps 95 % of the entries.)
+struct SlotGather {
+    const uint32_t* task_tile; const uint4* items; const uint8_t* entries;
+    const uint32_t* nslots; const uint32_t* rowbase; const float* rows; const uint32_t* tile_w; uint32_t* ctr;
+    float* img; uint32_t* minmax_enc; int* info;
+    int B, W, H, TX, NT, null_slot; uint32_t prio_ref;
+    unsigned long long* trace;      // EORB_SLOT_TRACE builds: per wave { tile, start, end, entries, items } (wall clock, 100 MHz)
+};
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void sl_gather_kernel(SlotGather P)
+{
+    // [slot][64] floats; row null_slot = zeros.  The ONLY LDS object: offset 0
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef EORB_SLOT_TRACE
+    const unsigned long long tr_t0 = wall_clock64(); unsigned long long tr_ent = 0, tr_items = 0, tr_kept = 0;
+#endif
+    const uint32_t task = P.task_tile[blockIdx.x];
+    if (task == 0xffffffffu) return;
+    const int tile = (int)task;
+    const uint32_t wt = P.tile_w[tile];
+    const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
+    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+    const bool inimg = px < P.W && py < P.H;
+    if ((uint32_t)(uintptr_t)lds != 0u) { if (tid == 0) atomicOr(&P.info[3], 1); return; }
+    if (wt) {
+        const int ns = (int)P.nslots[tile];
+        const int n4 = ns * 16;
+        const float4* src = (const float4*)(P.rows + (size_t)P.rowbase[tile] * 64);
+        float4* dst = (float4*)lds;
+        for (int i = tid; i < n4; i += blockDim.x) dst[i] = src[i];
+        if (tid < 16) dst[P.null_slot * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const uint32_t nullword = (uint32_t)P.null_slot * 0x01010101u;
+    uint32_t* const ctr = P.ctr + tile;
+    // v_perm_b32 selectors: LDS byte address of entry j's row for this lane = { 0, 0, slot byte j of the entry dword, 4 * lane }
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    uint32_t sel0 = 0x0c0c0400u, sel1 = 0x0c0c0500u, sel2 = 0x0c0c0600u, sel3 = 0x0c0c0700u;
+    asm volatile("" : "+v"(sel0), "+v"(sel1), "+v"(sel2), "+v"(sel3));
+    const int nit = P.B;
+    const uint4* const items = P.items + (size_t)tile * P.B;
+    auto ticket = [&]() { int t = 0; if (lane == 0) t = (int)atomicAdd(ctr, 1u); return t; };         // lane 0 holds the value
+    auto uni = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto item_of = [&](int tkv) { return (int)min((uint32_t)__builtin_amdgcn_readfirstlane(tkv), (uint32_t)nit); };
+    int k = item_of(ticket());
+    uint4 d = k < nit ? items[k] : make_uint4(0u, 0u, 0u, 0u);
+    uint4 En = make_uint4(0u, 0u, 0u, 0u);
+    bool have_first = false;
+    while (k < nit) {
+        const int s = (int)uni(d.x);
+        const uint32_t cnt = uni(d.y);
+        const uint4* const list = (const uint4*)(P.entries + (((uint64_t)uni(d.w) << 32) | uni(d.z)));
+        // a long list is a serial chain of adds: its wave goes first at the issue arbiter
+        if (cnt >= P.prio_ref) __builtin_amdgcn_s_setprio(3);
+        else if (cnt >= P.prio_ref / 4u) __builtin_amdgcn_s_setprio(2);
+        else if (cnt >= P.prio_ref / 16u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        float acc = 0.0f;
+        const int nblk = (int)((cnt + 1023u) >> 10);
+        if (!have_first && nblk) En = list[lane];
+        have_first = false;
+        int tk = 0; int stage_t = 0;                   // 0: no ticket yet, 1: ticket requested, 2: descriptor requested
+        uint4 dn = make_uint4(0u, 0u, 0u, 0u); int kn = nit;
+        for (int b = 0; b < nblk; b++) {
+            uint4 E = En;
+            // the next item: ticket when at most four blocks are left, its descriptor one block later, its first block with the last one
+            if (stage_t == 1) { kn = item_of(tk); dn = kn < nit ? items[kn] : dn; stage_t = 2; }
+            else if (stage_t == 0 && nblk - b <= 4) { tk = ticket(); stage_t = 1; }
+            if (b + 1 < nblk) En = list[(size_t)(b + 1) * 64 + lane];
+            else if (stage_t == 2 && kn < nit && uni(dn.y)) {
+                En = ((const uint4*)(P.entries + (((uint64_t)uni(dn.w) << 32) | uni(dn.z))))[lane];
+                have_first = true;
+            }
+            const int rem = (int)cnt - b * 1024;
+            if (rem < 1024) {
+                // entries past the end of the list -> the null slot
+                uint32_t* ew = (uint32_t*)&E;
+#pragma unroll
+                for (int dd = 0; dd < 4; dd++) {
+                    const int nv = rem - lane * 16 - dd * 4;                  // valid bytes of this dword
+                    const uint32_t keep = nv >= 4 ? 0xffffffffu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+                    ew[dd] = (ew[dd] & keep) | (nullword & ~keep);
+                }
+            }
+            const int lane_end = min(64, (rem + 15) >> 4);               // one lane (16 entries) per iteration
+#ifdef EORB_SLOT_TRACE
+            tr_kept += (unsigned long long)lane_end * 16;
+#endif
+            {
+            float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+            int sl, se;
+            // one dword = four entries: addresses by v_perm_b32, reads into the address registers, adds of the group read three groups ago
+#define SL_GROUP(EV, RA, RB, RC, RD, AA, AB, AC, AD) \
+            "s_waitcnt lgkmcnt(8)\n" \
+            "v_readlane_b32 %[se], %[" EV "], %[sl]\n" \
+            "v_add_f32 %[acc], %[acc], %[" AA "]\n" \
+            "v_perm_b32 %[" RA "], %[se], %[l4], %[q0]\n" \
+            "v_perm_b32 %[" RB "], %[se], %[l4], %[q1]\n" \
+            "ds_read_b32 %[" RA "], %[" RA "]\n" \
+            "v_add_f32 %[acc], %[acc], %[" AB "]\n" \
+            "v_perm_b32 %[" RC "], %[se], %[l4], %[q2]\n" \
+            "ds_read_b32 %[" RB "], %[" RB "]\n" \
+            "v_add_f32 %[acc], %[acc], %[" AC "]\n" \
+            "v_perm_b32 %[" RD "], %[se], %[l4], %[q3]\n" \
+            "ds_read_b32 %[" RC "], %[" RC "]\n" \
+            "v_add_f32 %[acc], %[acc], %[" AD "]\n" \
+            "ds_read_b32 %[" RD "], %[" RD "]\n"
+            asm volatile(
+                "v_mov_b32 %[r4], 0\n v_mov_b32 %[r5], 0\n v_mov_b32 %[r6], 0\n v_mov_b32 %[r7], 0\n"
+                "v_mov_b32 %[r8], 0\n v_mov_b32 %[r9], 0\n v_mov_b32 %[r10], 0\n v_mov_b32 %[r11], 0\n"
+                "v_mov_b32 %[r12], 0\n v_mov_b32 %[r13], 0\n v_mov_b32 %[r14], 0\n v_mov_b32 %[r15], 0\n"
+                "s_mov_b32 %[sl], 0\n"
+                "1:\n"
+                SL_GROUP("e0", "r0", "r1", "r2", "r3", "r4", "r5", "r6", "r7")
+                SL_GROUP("e1", "r4", "r5", "r6", "r7", "r8", "r9", "r10", "r11")
+                SL_GROUP("e2", "r8", "r9", "r10", "r11", "r12", "r13", "r14", "r15")
+                SL_GROUP("e3", "r12", "r13", "r14", "r15", "r0", "r1", "r2", "r3")
+                "s_add_u32 %[sl], %[sl], 1\n"
+                "s_cmp_lt_u32 %[sl], %[lend]\n"
+                "s_cbranch_scc1 1b\n"
+                "s_waitcnt lgkmcnt(0)\n"
+                "v_add_f32 %[acc], %[acc], %[r4]\n v_add_f32 %[acc], %[acc], %[r5]\n v_add_f32 %[acc], %[acc], %[r6]\n v_add_f32 %[acc], %[acc], %[r7]\n"
+                "v_add_f32 %[acc], %[acc], %[r8]\n v_add_f32 %[acc], %[acc], %[r9]\n v_add_f32 %[acc], %[acc], %[r10]\n v_add_f32 %[acc], %[acc], %[r11]\n"
+                "v_add_f32 %[acc], %[acc], %[r12]\n v_add_f32 %[acc], %[acc], %[r13]\n v_add_f32 %[acc], %[acc], %[r14]\n v_add_f32 %[acc], %[acc], %[r15]\n"
+                : [acc] "+v"(acc), [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5),
+                  [r6] "=&v"(r6), [r7] "=&v"(r7), [r8] "=&v"(r8), [r9] "=&v"(r9), [r10] "=&v"(r10), [r11] "=&v"(r11),
+                  [r12] "=&v"(r12), [r13] "=&v"(r13), [r14] "=&v"(r14), [r15] "=&v"(r15),
+                  [sl] "=&s"(sl), [se] "=&s"(se)
+                : [e0] "v"(E.x), [e1] "v"(E.y), [e2] "v"(E.z), [e3] "v"(E.w), [lend] "s"(lane_end), [l4] "v"(lane4),
+                  [q0] "v"(sel0), [q1] "v"(sel1), [q2] "v"(sel2), [q3] "v"(sel3), [ldsp] "v"(lds)
+                : "scc", "memory");
+#undef SL_GROUP
+            }
+        }
+        // the slice's pixels of this tile; an empty list offers nothing to the running extremes (max stays -1e6:
+        // resolveMinMaxVals :32-39)
+        if (inimg) P.img[(size_t)s * P.W * P.H + (size_t)py * P.W + px] = acc;
+        if (cnt) {
+            // every increment is >= 0: the running maximum is the largest final value of a visited tile, the minimum stays 0
+            float vmax = inimg ? acc : -1000000.0f;
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, dd, 64));
+            if (lane == 0) atomicMax(&P.minmax_enc[s * 2 + 1], enc_f32(vmax));
+        }
+#ifdef EORB_SLOT_TRACE
+        tr_ent += cnt; tr_items++;
+#endif
+        // next item
+        if (stage_t == 0) { tk = ticket(); stage_t = 1; }
+        if (stage_t == 1) { kn = item_of(tk); dn = kn < nit ? items[kn] : dn; }
+        k = kn; d = dn;
+    }
+#ifdef EORB_SLOT_TRACE
+    if (lane == 0 && P.trace) {
+        unsigned long long* r = P.trace + ((size_t)blockIdx.x * 16 + (tid >> 6)) * 6;
+        r[0] = (unsigned long long)tile; r[1] = tr_t0; r[2] = wall_clock64(); r[3] = tr_ent; r[4] = tr_items; r[5] = tr_kept;
+    }
+#endif
+}
+
+// ---- host ----
+// tables of the current maps / sigma (called from ev_raw_tables when they change); c->sl_ok = 1 when the slot form can run
+int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps, int stamp_stride, int SWP)
+{
+    c->sl_ok = 0;
+    if (h < 1 || h > 4 || TX >= 256 || TY >= 256) return EORB_OK;
+    const int nsrc = c->lut_w * c->lut_h, NT = TX * TY;
+    int rc;
+    if ((rc = ensure(c, c->sl_tab, sizeof(uint2) * (size_t)nsrc))) return rc;
+    // nslots | rowbase | tile_w | ctr | (spare) (NT each) | info (4 ints)
+    if ((rc = ensure(c, c->sl_tile, sizeof(uint32_t) * (5 * (size_t)NT + 4)))) return rc;
+    uint32_t* d_nslots = (uint32_t*)c->sl_tile.p;
+    uint32_t* d_rowbase = d_nslots + NT;
+    int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
+    c->sl_info_off = sizeof(uint32_t) * 5 * (size_t)NT;
+    EORB_HIP(c, hipMemsetAsync(c->sl_tile.p, 0, sizeof(uint32_t) * (5 * (size_t)NT + 4), c->stream));
+    sl_assign_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, nsrc, W, H, h, TX, d_nslots, (uint2*)c->sl_tab.p, d_info);
+    sl_rowbase_kernel<<<1, 1024, 0, c->stream>>>(d_nslots, NT, d_rowbase, d_info);
+    EORB_LAUNCH_CHECK(c, "slot table kernels");
+    int hinfo[4] = {0, 0, 0, 0};
+    EORB_HIP(c, hipMemcpyAsync(hinfo, d_info, sizeof(hinfo), hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (hinfo[2] || hinfo[1] >= (int)kNoSlot || hinfo[0] <= 0) return EORB_OK;      // a tile with more than 254 slots: the batch pipeline serves these maps
+    if ((rc = ensure(c, c->sl_rows, sizeof(float) * 64 * (size_t)hinfo[0] + 4096))) return rc;
+    sl_rows_kernel<<<(nsrc + 3) / 4, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, (const uint2*)c->sl_tab.p, nsrc, W, H, h, TX, d_stamps,
+                                                            stamp_stride, SWP, d_rowbase, (float*)c->sl_rows.p);
+    EORB_LAUNCH_CHECK(c, "sl_rows_kernel");
+    c->sl_null = hinfo[1];
+    c->sl_ok = 1;
+    return EORB_OK;
+}
+
+// count -> scan -> scatter -> order -> gather for B slices of raw events (no polarity, Gaussian stamp)
+int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
+                        float* d_f32, uint32_t* d_minmax_enc)
+{
+    const int NT = TX * TY;
+    c->sl_calls++;
+    const int64_t nev = h_offsets[B] - h_offsets[0];
+    const int64_t per_slice = nev / B;
+    const int chunk = per_slice >= (int64_t)1 << 17 ? 2048 : (per_slice >= (int64_t)1 << 14 ? 1024 : 256);
+    std::vector<ChunkDesc> cds;
+    std::vector<int> slice_c0(B + 1);
+    std::vector<int64_t> slice_eb(B + 1);
+    int64_t eb = 0;
+    for (int b = 0; b < B; b++) {
+        slice_c0[b] = (int)cds.size();
+        const int64_t s = h_offsets[b], e = h_offsets[b + 1];
+        if (e < s) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
+        if ((e - s) * 4 + (int64_t)NT * 16 >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)(e - s));
+        slice_eb[b] = eb;
+        eb = (eb + (e - s) * 4 + (int64_t)NT * 16 + 15) & ~(int64_t)15;   // <= 4 entries per event, every list rounded up to 16
+        for (int64_t k = s; k < e; k += chunk) {
+            ChunkDesc cd; cd.start = k; cd.n = (int32_t)std::min<int64_t>(chunk, e - k); cd.slice = b;
+            cds.push_back(cd);
+        }
+    }
+    slice_c0[B] = (int)cds.size(); slice_eb[B] = eb;
+    const int nchunks = (int)cds.size();
+    const size_t cd_bytes = sizeof(ChunkDesc) * (size_t)std::max(nchunks, 1);
+    const size_t sc_bytes = (sizeof(int) * (size_t)(B + 1) + 7) & ~(size_t)7;
+    const size_t eb_bytes = sizeof(int64_t) * (size_t)B;
+    const int nb = B * NT;
+    int rc;
+    if ((rc = ensure(c, c->chunks, cd_bytes + sc_bytes + eb_bytes))) return rc;
+    const size_t cnt_bytes = (sizeof(uint16_t) * (size_t)std::max(nchunks, 1) * NT + 15) & ~(size_t)15;
+    if ((rc = ensure(c, c->segoff, cnt_bytes + sizeof(uint32_t) * (size_t)std::max(nchunks, 1) * NT))) return rc;
+    if ((rc = ensure(c, c->entries, (size_t)eb + 8192))) return rc;      // + slack: the gather requests blocks past a list's end
+    if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
+    char* hp = (char*)pinned(c, cd_bytes + sc_bytes + eb_bytes);
+    if (!hp) return set_err(c, EORB_E_HIP, "pinned alloc failed");
+    if (nchunks) memcpy(hp, cds.data(), sizeof(ChunkDesc) * nchunks);
+    memcpy(hp + cd_bytes, slice_c0.data(), sizeof(int) * (size_t)(B + 1));
+    memcpy(hp + cd_bytes + sc_bytes, slice_eb.data(), eb_bytes);
+    EORB_HIP(c, hipMemcpyAsync(c->chunks.p, hp, cd_bytes + sc_bytes + eb_bytes, hipMemcpyHostToDevice, c->stream));
+    pinned_commit(c);
+    const ChunkDesc* d_chunks = (const ChunkDesc*)c->chunks.p;
+    const int* d_slice_c0 = (const int*)((char*)c->chunks.p + cd_bytes);
+    const int64_t* d_slice_eb = (const int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes);
+    uint16_t* d_segcnt = (uint16_t*)c->segoff.p;
+    uint32_t* d_segbase = (uint32_t*)((char*)c->segoff.p + cnt_bytes);
+    uint32_t* d_tile_cnt = (uint32_t*)c->tile_order.p;
+    uint32_t* d_tile_base = d_tile_cnt + nb;
+    uint32_t* d_nslots = (uint32_t*)c->sl_tile.p;
+    uint32_t* d_rowbase = d_nslots + NT;
+    uint32_t* d_tile_w = d_nslots + 2 * (size_t)NT;
+    uint32_t* d_ctr = d_nslots + 3 * (size_t)NT;
+    int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
+    const eorb_raw_event* d_ev = (const eorb_raw_event*)d_events;
+    const uint2* d_tab = (const uint2*)c->sl_tab.p;
+    {
+        ProfScope ps(c, "ev_bin");
+        const size_t lds = sizeof(uint32_t) * (size_t)NT;
+        const int NTp = (NT + 1) & ~1;
+        const size_t lds2 = ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
+        if (lds > 64 * 1024 || lds2 > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
+        if (nchunks) sl_count_kernel<<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+        sl_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
+        if (nchunks) sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, TY, NT, chunk,
+                                                                                          d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
+        EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
+    }
+    {
+        ProfScope ps(c, "ev_gather");
+        const size_t lds = (size_t)(c->sl_null + 1) * 256;
+        const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds));
+        static const int nw_env = [] { const char* e = getenv("EORB_SLOT_WAVES"); return e ? atoi(e) : 0; }();
+        static const int ns_env = [] { const char* e = getenv("EORB_SLOT_ROUNDS"); return e ? atoi(e) : 0; }();
+        // four wavefronts per SIMD saturate the vector ALUs and leave every list about full single-wave speed (measured: 8 per SIMD
+        // process the same entries per second, each list at half the pace)
+        int nw = std::min(16, std::max(1, 16 / wg_per_cu));
+        if (nw_env >= 1 && nw_env <= 16) nw = nw_env;
+        nw = std::min(nw, std::max(1, B));
+        static int ncu = 0;
+        if (!ncu) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+        // one task per tile position plus a few rounds of spare ones shared out by weight; a position never gets more wavefronts than slices
+        const int rounds = ns_env >= 1 ? ns_env : 4;
+        const int G = NT + rounds * ncu * wg_per_cu;
+        const int max_per_tile = (B + nw - 1) / nw;
+        if ((rc = ensure(c, c->sl_plan, sizeof(uint4) * (size_t)nb + sizeof(uint32_t) * ((size_t)G + 3 * (size_t)NT)))) return rc;
+        uint4* d_items = (uint4*)c->sl_plan.p;
+        uint32_t* d_task = (uint32_t*)(d_items + nb);
+        uint32_t* d_tile_m = d_task + G;
+        uint32_t* d_scr = d_tile_m + NT;
+        const uint32_t prio_ref = (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 2000), 0x7fffffff);   // lists this long go first at the issue arbiter
+        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * (size_t)B, c->stream>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, d_items, d_tile_w, d_tile_m, d_ctr);
+        sl_tasks_kernel<<<1, 1024, 0, c->stream>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task);
+        SlotGather P{d_task, d_items, (const uint8_t*)c->entries.p, d_nslots, d_rowbase, (const float*)c->sl_rows.p,
+                     d_tile_w, d_ctr, d_f32, d_minmax_enc, d_info, B, W, H, TX, NT, c->sl_null, prio_ref, nullptr};
+#ifdef EORB_SLOT_TRACE
+        if ((rc = ensure(c, c->sl_trace, sizeof(unsigned long long) * 6 * 16 * (size_t)G + 64))) return rc;
+        EORB_HIP(c, hipMemsetAsync(c->sl_trace.p, 0, sizeof(unsigned long long) * 6 * 16 * (size_t)G + 64, c->stream));
+        P.trace = (unsigned long long*)c->sl_trace.p + 8;
+        c->sl_trace_n = (long long)G * 16;
+#endif
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)sl_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        sl_gather_kernel<<<G, 64 * nw, lds, c->stream>>>(P);
+        EORB_LAUNCH_CHECK(c, "sl_gather_kernel");
+    }
+    return EORB_OK;
+}
+
+// EORB_SLOT_TRACE builds: the per-wave records of the last gather (tools/slot_trace.py)
+int ev_slots_trace_read(eorb_ctx* c, unsigned long long* out, long long max_records)
+{
+    const long long n = std::min<long long>(c->sl_trace_n, max_records);
+    if (n <= 0 || !c->sl_trace.p) return 0;
+    if (hipMemcpy(out, (unsigned long long*)c->sl_trace.p + 8, sizeof(unsigned long long) * 6 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
+}
+
+}  // namespace eorb

@@ -61,6 +61,9 @@ class Context:
     def debug_option(self, name, value):
         self.check(self.L.eorb_debug_option(self.h, name.encode(), int(value)))
 
+    def debug_counter(self, name):
+        return int(self.L.eorb_debug_counter(self.h, name.encode()))
+
     # profiling ------------------------------------------------------------------------------------
     def prof_enable(self, on=True):
         self.check(self.L.eorb_prof_enable(self.h, int(on)))

@@ -961,13 +961,14 @@ def test_polarity_extremes_of_one_sided_images(oracle, fe, ctx):
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), mm.view(np.uint32))
 
 
-@pytest.mark.parametrize("form", [0, 1, 2, 3])
+@pytest.mark.parametrize("form", [0, 1, 2, 3, 4])
 def test_raw_accumulation_random_sweep(oracle, fe, form):
     """A seeded sweep over image sizes that are not multiples of the tile, stamps of 3x3 ... 17x17 taps, polarity, maps that throw
     pixels out of the image with and without checkInImage, event counts on the 64-entry batch boundaries and hot pixels
     (tests/fuzz/fuzz_raw.py runs the long version).  form: the gather kernel -- chosen by the batch's shape (0: up to 16 384 events
     per call take the binning-free kernel), the pipelined workgroup per tile whatever the shape (1), the wave per tile whatever the
-    shape (2), no binning whatever the size (3)."""
+    shape (2), no binning whatever the size (3), the two-byte slot lists wherever they apply (4: no polarity, sigma <= 4/3, at most 254
+    slots per tile; the pipelined workgroup per tile elsewhere)."""
     ctx = fe.Context()
     ctx.debug_option("gather_form", form)
     rng = np.random.default_rng(2024)
@@ -996,6 +997,68 @@ def test_raw_accumulation_random_sweep(oracle, fe, form):
         assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)) and np.array_equal(ou, gu), what
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), what
     ctx.close()
+
+
+def test_slot_lists_form(oracle, fe):
+    """The slot form of the raw accumulation (ev_slots.hip: two-byte entries, a tile position's rows in LDS, one ds_read_addtid per
+    entry): f32 image, running extremes and u8 image against the oracle for one slice of 1 ... 300 000 events (list lengths around
+    the 512-entry block and the 16-entry loop step, hot pixels, empty tiles), the DAVIS and the MVSEC sensor, three stamp sizes (and a fourth that falls back),
+    maps with and without checkInImage; then slices of a batch against the same slices alone.  The test hook counters show that the
+    slot form ran and raised no flag."""
+    ctx = fe.Context()
+    ctx.debug_option("gather_form", 4)
+    rng = np.random.default_rng(7)
+    calls = 0
+    for (W, H), check in (((240, 180), True), ((346, 260), False), ((64, 48), True)):
+        mx, my = _maps(W, H) if (W, H) == (240, 180) else (None, None)
+        if mx is None:
+            yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+            mx = (xx + 2.5 * np.sin(yy / 19.0) - 1.0).astype(np.float32); my = (yy + 2.0 * np.cos(xx / 29.0) + 0.5).astype(np.float32)
+        fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=ctx)
+        for sigma in (1.0, 0.45, 0.7, 1.3):         # 1.3: (8 + 2 * 4)^2 = 256 slots per tile, one too many: served by the batch pipeline
+            for n in (1, 15, 16, 17, 511, 512, 513, 5000, 70000, 300000):
+                if n > 5000 and (sigma != 1.0 and (W, H) != (240, 180)):
+                    continue
+                if n >= 5000 and rng.integers(0, 2):
+                    _, raw = synth.shapes_events(n, W, H, seed=int(rng.integers(1, 1000)), undistort=False, return_raw=True)
+                else:
+                    raw = synth.random_raw_events(n, W, H, seed=n + int(sigma * 10))
+                    if n > 100 and rng.integers(0, 2):           # hot pixels: lists far longer than a block
+                        raw["x"] = np.clip(rng.normal(W * 0.6, 1.5, n), 0, W - 1); raw["y"] = np.clip(rng.normal(H * 0.3, 1.5, n), 0, H - 1)
+                ev = oracle.undistort_events(raw, mx, my, W, H, check, 1.0)
+                of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, False, True, fast=True)
+                gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, sigma, False, True, ctx=ctx, return_all=True)
+                calls += sigma <= 1.0
+                what = (W, H, check, sigma, n)
+                assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), (what, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
+                assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), (what, omm, gmm)
+                assert np.array_equal(ou, gu), what
+    assert ctx.debug_counter("slot_calls") == calls and ctx.debug_counter("slot_flags") == 0
+    ctx.close()
+    # a batch: every slice as it comes out alone
+    W, H, B = 240, 180, 5
+    mx, my = _maps(W, H)
+    sizes = [40000, 0, 120000, 7, 65536]
+    raws = [synth.shapes_events(max(sz, 1), W, H, seed=500 + b, motion=0.4, undistort=True, return_raw=True)[1][:sz] for b, sz in enumerate(sizes)]
+    fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=max(sizes))
+    c, cap = fb.ctx, fb.cap
+    fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
+    blob = np.concatenate(raws)
+    d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
+    d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32)
+    d_n = c.dev_alloc(B * 4); d_m = c.dev_alloc(B * cap * 4); d_nm = c.dev_alloc(B * 4)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    fb.run_dev(d_ev, off, d_img, d_kp, d_desc, d_n, d_m, d_nm, raw=True)
+    c.sync()
+    assert c.debug_counter("slot_calls") == 1 and c.debug_counter("slot_flags") == 0
+    imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
+    for b in range(B):
+        ev = oracle.undistort_events(raws[b], mx, my, W, H, True, 1.0)
+        _, ou, _ = oracle.ev2im_gauss(ev, W, H, 1.0, False, True, fast=True)
+        assert np.array_equal(ou, imgs[b]), b
+    for p_ in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
+        c.dev_free(p_)
+    c.close()
 
 
 def test_raw_gather_four_column_variant(oracle):
