@@ -91,7 +91,7 @@ struct eorb_ctx {
     eorb::DevBuf lut, src_info, stamps;
     // slot form of the raw accumulation (ev_slots.hip): per sensor pixel its tiles / slot numbers, per tile its rows; valid when sl_ok
     eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_plan, sl_trace; long long sl_trace_n = 0;
-    int sl_ok = 0, sl_null = 0;
+    int sl_ok = 0, sl_null = 0, sl_rank_ok = -1;
     long long sl_calls = 0; size_t sl_info_off = 0;     // test hook counters (eorb_debug_counter)
     // float events in bulk: the distinct positions of a call become the rows of a per-call stamp table (ev_accumulate_dev)
     eorb::DevBuf dd_tab, dd_src_info, dd_stamps, dd_ev, dd_cnt;

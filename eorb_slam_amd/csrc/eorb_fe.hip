@@ -274,6 +274,7 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
 {
     if (!c || !name) return -1;
     if (!strcmp(name, "slot_calls")) return c->sl_calls;
+    if (!strcmp(name, "slot_rank_ok")) return c->sl_rank_ok;
     if (!strcmp(name, "slot_flags")) {
         if (!c->sl_tile.p || !c->sl_info_off) return 0;
         int flags = 0;

@@ -334,6 +334,153 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
     }
 }
 
+// ---- K1c, rank form: the stable rank of an entry inside its wavefront's share of a tile comes back from the LDS atomic that counts
+// it.  Lanes of one ds_add_rtn that hit the same word are served in lane order (not an architectural promise: sl_rankcheck_kernel
+// verifies it on the device once per context, and the ballot form above stays as the fallback), instructions of a wave execute
+// in order, and the waves' shares are ordered by the prefix over the waves -- so no ballots, no parity classes, no per-event list
+// of sorted slots: phase A keeps four 8-bit ranks per event, phase C writes the entry byte and its tile straight to their place
+// in the chunk's tile-sorted order, phase D streams that order out run by run.
+__global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                                              const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
+                                                                              int chunk_cap, const int64_t* __restrict__ slice_ebase,
+                                                                              const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
+                                                                              uint8_t* __restrict__ entries)
+{
+    extern __shared__ unsigned char sm2[];
+    __shared__ uint32_t s_wsum[kSlotScatWaves];
+    constexpr int NTHR = 64 * kSlotScatWaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x;
+    const ChunkDesc cd = chunks[chunk];
+    const int NTp = (NT + 1) & ~1;
+    uint32_t* gbase = (uint32_t*)sm2;                                 // NT: first entry of the tile's run in the global lists, minus loff
+    uint16_t* stile = (uint16_t*)(gbase + NT);                        // chunk_cap * 4: tile of every slot of the sorted order
+    uint16_t* cntw = stile + (size_t)chunk_cap * 4;                   // kSlotScatWaves * NTp
+    uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
+    uint8_t* sorted = (uint8_t*)(loff + NTp + 2);                     // chunk_cap * 4: the entry bytes in tile-sorted order
+    for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
+    const eorb_raw_event* e = ev + cd.start;
+    const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
+    const int S = Q >> 6;
+    constexpr int SMAX = 4;
+    __syncthreads();
+    // ---- A: tile ranges and slot bytes into registers; every entry counted, its rank (< 256: a share has <= 256 events) kept ----
+    uint32_t* cw32 = (uint32_t*)(cntw + wave * NTp);
+    uint32_t rsrc[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        const int k = wave * Q + s * 64 + lane;
+        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)&e[k] : 0xffffffffu;
+        const int x = (int)(q & 0xffff), y = (int)(q >> 16);
+        rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
+    }
+    uint2 rst[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) rst[s] = rsrc[s] != 0xffffffffu ? slot_tab[rsrc[s]] : make_uint2(0u, 0xffffffffu);
+    // Tiles are visited in parity classes (tx & 1, ty & 1): a tile belongs to one class, so all lanes of a sub-batch that target it do
+    // so in the SAME atomic instruction (an event's second tile must not be counted after a later event's first one).
+    uint32_t rk[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        const uint32_t rg = rst[s].x;
+        const int nx = (rg >> 16) & 3, ny = (rg >> 18) & 3;
+        const int tx0 = rg & 0xff, ty0 = (rg >> 8) & 0xff;
+        rk[s] = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#ifdef EORB_TEST_RANK_ORDER_BUG        // (test builds only: the naive order, to show that the parity tests catch it)
+            const int dx = j & 1, dy = j >> 1;
+#else
+            const int dx = ((j & 1) - tx0) & 1, dy = ((j >> 1) - ty0) & 1;       // the event's tile of class j, if it has one
+#endif
+            if (nx && ny && dx < nx && dy < ny) {
+                const int t = (ty0 + dy) * TX + tx0 + dx;
+                const uint32_t o = atomicAdd(&cw32[t >> 1], 1u << (16 * (t & 1)));
+                rk[s] |= ((o >> (16 * (t & 1))) & 0xffu) << (8 * j);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B: per tile the exclusive prefix over the waves; exclusive scan of the totals over the tiles ----
+    {
+        const int per = (NT + NTHR - 1) / NTHR;
+        const int t0 = tid * per, t1 = min(t0 + per, NT);
+        uint32_t mine = 0;
+        for (int t = t0; t < t1; t++) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < kSlotScatWaves; w++) { const uint32_t v = cntw[w * NTp + t]; cntw[w * NTp + t] = (uint16_t)run; run += v; }
+            loff[t] = (uint16_t)run;
+            mine += run;
+        }
+        uint32_t incl = (uint32_t)wave_incl_scan((int)mine);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < wave; w++) before += s_wsum[w];
+        for (int t = t0; t < t1; t++) {
+            const uint32_t v = loff[t]; loff[t] = (uint16_t)before;
+            gbase[t] = tile_base[(size_t)cd.slice * NT + t] + segbase[(size_t)chunk * NT + t] - before;
+            before += v;
+        }
+        if (tid == NTHR - 1) loff[NT] = (uint16_t)before;
+    }
+    __syncthreads();
+    // ---- C: every entry to its place in the tile-sorted order ----
+    const uint16_t* cw = cntw + wave * NTp;
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        const uint32_t rg = rst[s].x, sb = rst[s].y;
+        const int nx = (rg >> 16) & 3, ny = (rg >> 18) & 3;
+        const int tx0 = rg & 0xff, ty0 = (rg >> 8) & 0xff;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#ifdef EORB_TEST_RANK_ORDER_BUG
+            const int dx = j & 1, dy = j >> 1;
+#else
+            const int dx = ((j & 1) - tx0) & 1, dy = ((j >> 1) - ty0) & 1;
+#endif
+            if (nx && ny && dx < nx && dy < ny) {
+                const int t = (ty0 + dy) * TX + tx0 + dx;
+                const uint32_t pos = (uint32_t)loff[t] + cw[t] + ((rk[s] >> (8 * j)) & 0xffu);
+                sorted[pos] = (uint8_t)((sb >> (8 * (dy * 2 + dx))) & 0xffu);
+                stile[pos] = (uint16_t)t;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- D: consecutive threads write consecutive entries of a run ----
+    uint8_t* out = entries + (size_t)slice_ebase[cd.slice];
+    const int E = loff[NT];
+    for (int p = tid; p < E; p += NTHR) out[(size_t)(uint32_t)(gbase[stile[p]] + (uint32_t)p)] = sorted[p];     // (gbase holds base - loff mod 2^32)
+}
+
+// Are the results of a wave's LDS atomic add handed out in lane order among the lanes that hit the same counter (32-bit words
+// holding two 16-bit counters, some lanes inactive)?  bad = number of pairs out of order.
+__global__ __launch_bounds__(256) void sl_rankcheck_kernel(unsigned long long* bad)
+{
+    __shared__ uint32_t cnt[512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long nbad = 0;
+    uint32_t h = (uint32_t)(blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    for (int t = 0; t < 64; t++) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) cnt[i] = 0;
+        __syncthreads();
+        h = h * 1664525u + 1013904223u;
+        const int spread = 1 << (1 + (t % 7));                       // 2 ... 128 distinct counters per wave
+        const uint32_t a = ((h >> 9) % spread) + wave * 128;
+        const bool act = ((h >> 3) & 7u) != 0u;
+        uint32_t r = 0xffffffffu;
+        if (act) { const uint32_t o = atomicAdd(&cnt[a >> 1], 1u << (16 * (a & 1))); r = (o >> (16 * (a & 1))) & 0xffffu; }
+        for (int j = 0; j < 64; j++) {
+            const uint32_t aj = __shfl(a, j, 64), rj = __shfl(r, j, 64);
+            if (act && rj != 0xffffffffu && j < lane && aj == a && !(rj < r)) nbad++;
+        }
+        __syncthreads();
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 // ---- the gather's work plan ----
 // (1) per tile position: its (slice, tile) lists sorted longest first (a list is a serial chain of adds: the long ones must start
 //     early), each with its descriptor { slice, entries, list offset } so that a ticket costs the gather ONE load; the position's
@@ -595,19 +742,25 @@ int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const flo
     const int nsrc = c->lut_w * c->lut_h, NT = TX * TY;
     int rc;
     if ((rc = ensure(c, c->sl_tab, sizeof(uint2) * (size_t)nsrc))) return rc;
-    // nslots | rowbase | tile_w | ctr | (spare) (NT each) | info (4 ints)
-    if ((rc = ensure(c, c->sl_tile, sizeof(uint32_t) * (5 * (size_t)NT + 4)))) return rc;
+    // nslots | rowbase | tile_w | ctr | (spare) (NT each) | info (4 ints) | rank check (u64)
+    if ((rc = ensure(c, c->sl_tile, sizeof(uint32_t) * (5 * (size_t)NT + 8)))) return rc;
     uint32_t* d_nslots = (uint32_t*)c->sl_tile.p;
     uint32_t* d_rowbase = d_nslots + NT;
     int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
     c->sl_info_off = sizeof(uint32_t) * 5 * (size_t)NT;
-    EORB_HIP(c, hipMemsetAsync(c->sl_tile.p, 0, sizeof(uint32_t) * (5 * (size_t)NT + 4), c->stream));
+    EORB_HIP(c, hipMemsetAsync(c->sl_tile.p, 0, sizeof(uint32_t) * (5 * (size_t)NT + 8), c->stream));
     sl_assign_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, nsrc, W, H, h, TX, d_nslots, (uint2*)c->sl_tab.p, d_info);
     sl_rowbase_kernel<<<1, 1024, 0, c->stream>>>(d_nslots, NT, d_rowbase, d_info);
     EORB_LAUNCH_CHECK(c, "slot table kernels");
-    int hinfo[4] = {0, 0, 0, 0};
+    if (c->sl_rank_ok < 0) {
+        // once per context: may the scatter take its stable ranks from LDS atomics? (see sl_scatter_rank_kernel)
+        unsigned long long* d_bad = (unsigned long long*)(d_info + 4);
+        sl_rankcheck_kernel<<<256, 256, 0, c->stream>>>(d_bad);
+    }
+    int hinfo[6] = {0, 0, 0, 0, 0, 0};
     EORB_HIP(c, hipMemcpyAsync(hinfo, d_info, sizeof(hinfo), hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->sl_rank_ok < 0) c->sl_rank_ok = (hinfo[4] == 0 && hinfo[5] == 0) ? 1 : 0;
     if (hinfo[2] || hinfo[1] >= (int)kNoSlot || hinfo[0] <= 0) return EORB_OK;      // a tile with more than 254 slots: the batch pipeline serves these maps
     if ((rc = ensure(c, c->sl_rows, sizeof(float) * 64 * (size_t)hinfo[0] + 4096))) return rc;
     sl_rows_kernel<<<(nsrc + 3) / 4, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, (const uint2*)c->sl_tab.p, nsrc, W, H, h, TX, d_stamps,
@@ -684,8 +837,14 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offs
         if (lds > 64 * 1024 || lds2 > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
         if (nchunks) sl_count_kernel<<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
         sl_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
-        if (nchunks) sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, TY, NT, chunk,
-                                                                                          d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
+        static const int rank_env = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
+        const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
+        if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= 64 * 1024)
+            sl_scatter_rank_kernel<<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk,
+                                                                                      d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
+        else if (nchunks)
+            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, TY, NT, chunk,
+                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
         EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
     }
     {

@@ -1033,7 +1033,22 @@ def test_slot_lists_form(oracle, fe):
                 assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), (what, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
                 assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)), (what, omm, gmm)
                 assert np.array_equal(ou, gu), what
-    assert ctx.debug_counter("slot_calls") == calls and ctx.debug_counter("slot_flags") == 0
+        # neighbours in the event stream whose stamps share a tile but start in different ones (one reaches it as its second tile, the
+        # next as its first): the order inside the shared tile's list must still be the event order
+        n = 60000
+        raw = np.zeros(n, synth.RAW_DTYPE)
+        bx, by = (W // 16) * 8, (H // 16) * 8                            # a tile corner near the middle of the image
+        pat = rng.integers(0, 4, n)
+        raw["x"] = np.clip(bx + np.where(pat & 1, 5, -3) + rng.integers(-1, 2, n), 0, W - 1)
+        raw["y"] = np.clip(by + np.where(pat & 2, 5, -3) + rng.integers(-1, 2, n), 0, H - 1)
+        raw["p"] = 1; raw["t"] = np.arange(n) * 1e-6
+        ev = oracle.undistort_events(raw, mx, my, W, H, check, 1.0)
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, 1.0, False, True, fast=True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, 1.0, False, True, ctx=ctx, return_all=True)
+        calls += 1
+        assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), ("tile corner", W, H, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
+        assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)) and np.array_equal(ou, gu)
+    assert ctx.debug_counter("slot_calls") == calls and ctx.debug_counter("slot_flags") == 0 and ctx.debug_counter("slot_rank_ok") == 1
     ctx.close()
     # a batch: every slice as it comes out alone
     W, H, B = 240, 180, 5
