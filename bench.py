@@ -31,10 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "front-end frames/s (event-accumulate + extract + match) per GPU; HBM GB/s vs roofline"
-# HBM bytes one ev_gather launch moves per million events (rocprofv3 --pmc FETCH_SIZE x2 (gfx950) + WRITE_SIZE; bench.py cannot
-# collect PMC counters itself): see TRAFFIC_SOURCE
-GATHER_TRAFFIC_PER_MEV = {"raw": 31.8e6, "float": 30.9e6}
-TRAFFIC_SOURCE = "profiles/r02_v6_pmc_traffic.txt"
+# HBM bytes and issue-pipe utilisation of the accumulation kernels come from rocprofv3 --pmc passes (bench.py cannot collect PMC counters
+# itself): tools/profile_round.sh writes them, with the hash of the library sources they were measured on, to PROFILE_INPUTS; they are
+# reported only while that hash equals the hash of the sources this run uses (otherwise null + "stale")
+PROFILE_INPUTS = "profiles/roofline_inputs.json"
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
 CPU_POOL = 16              # worker processes of the all-cores CPU baseline (a one-GPU box's CPU share)
 
@@ -219,8 +219,33 @@ def _w4_desc():
 
 
 # --------------------------------------------------------------------------------------------------------------------------
-def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, traffic_of=None):
-    """`roofline` of the dominant kernel: algorithmic bytes per launch / its live HIP-event launch time."""
+def source_hash():
+    """Hash of the library sources (the same function as tools/roofline_inputs.py)."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "eorb_slam_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "eorb_slam_amd", "csrc", "*.h")) +
+                   [os.path.join(ROOT, "include", "eorb_fe.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_inputs(key):
+    """The rocprofv3-derived entry of this workload (tools/profile_round.sh), or (None, reason)."""
+    path = os.path.join(ROOT, PROFILE_INPUTS)
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        return None, "no %s" % PROFILE_INPUTS
+    if doc.get("src_hash") != source_hash():
+        return None, "stale: %s was measured on sources %s, this run uses %s" % (PROFILE_INPUTS, doc.get("src_hash"), source_hash())
+    e = doc.get("entries", {}).get(key)
+    return (e, "%s (sources %s)" % (PROFILE_INPUTS, doc["src_hash"])) if e else (None, "%s has no entry %s" % (PROFILE_INPUTS, key))
+
+
+def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, inputs_key=None):
+    """`roofline` of the dominant kernel: algorithmic bytes per launch / its live HIP-event launch time; HBM traffic and the
+    issue-pipe utilisation of that kernel from the rocprofv3 passes of the same sources (see PROFILE_INPUTS)."""
     tot = {k: v[0] for k, v in prof.items()}
     dom = max(tot, key=tot.get)
     ms, launches = prof[dom]
@@ -228,7 +253,23 @@ def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, traffic_of=
     ub = unit_bytes_by_kernel(dom)
     achieved = ub * units_per_launch / (avg_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": traffic_of(dom) if traffic_of else None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": ub * units_per_launch}
+         "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": ub * units_per_launch}
+    if inputs_key:
+        e, src = profile_inputs(inputs_key)
+        r["traffic_source"] = src
+        sc = e["scopes"].get(dom) if e else None
+        if sc:
+            r["traffic"] = sc["traffic_bytes"]
+            r["rocprof_avg_launch_ms"] = sc["rocprof_ms"]
+            if "issue" in sc:
+                i = sc["issue"]
+                r["issue"] = {"valu_frac": i["valu_frac"], "lds_frac": i["lds_frac"], "wait_frac": i["wait_frac"],
+                              "issue_stall_frac": i["issue_stall_frac"], "kernel": i["kernel"],
+                              "source": "rocprofv3 --pmc, cycles = GRBM_GUI_ACTIVE / 8 XCDs: SQ_INSTS_VALU x 4 / (cycles x 1024 SIMDs), SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs), "
+                                        "SQ_WAIT_ANY / SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; " + src}
+            stage = sum(v["traffic_bytes"] for k, v in e["scopes"].items() if k.startswith("ev_"))
+            r["stage"] = {"what": "all accumulation kernels (ev_*) of a step", "traffic": stage,
+                          "algorithmic": unit_bytes_by_kernel("ev_") * units_per_launch, "ratio": stage / (unit_bytes_by_kernel("ev_") * units_per_launch)}
     return r, {k: v[0] / steps for k, v in sorted(prof.items())}
 
 
@@ -408,10 +449,10 @@ def run_batch(env):
             P = level_pixels(W, H, orb["scaleFactor"], orb["nlevels"])
             ext_bytes = 7.0 * P + 1321.0 * float(nk.mean())  # 7*P + 1321*K per frame
             r, per_step = roofline_of(prof, a.steps, lambda k: acc_bytes if k.startswith("ev_") else ext_bytes, B,
-                                      lambda k: GATHER_TRAFFIC_PER_MEV[a.input] * (NEV / 1e6) * B if (k == "ev_gather" and a.workload == "w2") else None)
-            r["traffic_source"] = TRAFFIC_SOURCE if r["traffic"] is not None else None
-            r["note"] = ("the accumulation is issue/latency-bound by construction: every pixel adds its taps in event order (49 taps per "
-                         "16 B event, DESIGN.md section 4); the HBM fraction is reported as the contract asks")
+                                      "%s:%s:%d:%d" % (a.workload, a.input, B, NEV))
+            r["note"] = ("the accumulation is bound by instruction issue (vector ALU / LDS), not by HBM: every pixel adds its taps in event "
+                         "order (49 taps per 16 B event, DESIGN.md section 4); `issue` carries the utilisation of the binding pipes, the HBM "
+                         "fraction is reported as the contract asks")
             out["roofline"] = r
             out["kernels_ms_per_step"] = per_step
         # ---- single-slice latency of the seams as the reference calls them (host buffers, one slice per call): W1 only ----

@@ -531,10 +531,13 @@ __global__ __launch_bounds__(1024) void sl_tasks_kernel(const uint32_t* __restri
     for (int w = 0; w < 16; w++) tot += wred[w];
     const unsigned long long spare = (unsigned long long)max(G - NT, 0);
     uint32_t* nsorted = scratch; uint32_t* tsorted = scratch + NT;
+    extern __shared__ uint32_t tm[];                 // NT: the longest lists (LDS copy for the rank loop)
+    for (int t = tid; t < NT; t += 1024) tm[t] = tile_m[t];
+    __syncthreads();
     for (int t = tid; t < NT; t += 1024) {
-        const uint32_t m = tile_m[t];
+        const uint32_t m = tm[t];
         int rank = 0;
-        for (int u = 0; u < NT; u++) { const uint32_t v = tile_m[u]; rank += (v > m || (v == m && u < t)) ? 1 : 0; }
+        for (int u = 0; u < NT; u++) { const uint32_t v = tm[u]; rank += (v > m || (v == m && u < t)) ? 1 : 0; }
         uint32_t n = 1u + (tot ? (uint32_t)((unsigned long long)tile_w[t] * spare / tot) : 0u);
         n = min(n, (uint32_t)max(max_per_tile, 1));
         nsorted[rank] = n; tsorted[rank] = (uint32_t)t;
@@ -829,6 +832,7 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offs
     int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
     const eorb_raw_event* d_ev = (const eorb_raw_event*)d_events;
     const uint2* d_tab = (const uint2*)c->sl_tab.p;
+    size_t lds_g = 0; int nw = 1, G = 0; uint4* d_items = nullptr; uint32_t* d_task = nullptr; uint32_t prio_ref = 0;
     {
         ProfScope ps(c, "ev_bin");
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
@@ -845,33 +849,33 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offs
         else if (nchunks)
             sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, TY, NT, chunk,
                                                                                  d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
-        EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
-    }
-    {
-        ProfScope ps(c, "ev_gather");
-        const size_t lds = (size_t)(c->sl_null + 1) * 256;
-        const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds));
+        lds_g = (size_t)(c->sl_null + 1) * 256;
+        const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds_g));
         static const int nw_env = [] { const char* e = getenv("EORB_SLOT_WAVES"); return e ? atoi(e) : 0; }();
         static const int ns_env = [] { const char* e = getenv("EORB_SLOT_ROUNDS"); return e ? atoi(e) : 0; }();
         // four wavefronts per SIMD saturate the vector ALUs and leave every list about full single-wave speed (measured: 8 per SIMD
         // process the same entries per second, each list at half the pace)
-        int nw = std::min(16, std::max(1, 16 / wg_per_cu));
+        nw = std::min(16, std::max(1, 16 / wg_per_cu));
         if (nw_env >= 1 && nw_env <= 16) nw = nw_env;
         nw = std::min(nw, std::max(1, B));
         static int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
         // one task per tile position plus a few rounds of spare ones shared out by weight; a position never gets more wavefronts than slices
         const int rounds = ns_env >= 1 ? ns_env : 4;
-        const int G = NT + rounds * ncu * wg_per_cu;
+        G = NT + rounds * ncu * wg_per_cu;
         const int max_per_tile = (B + nw - 1) / nw;
         if ((rc = ensure(c, c->sl_plan, sizeof(uint4) * (size_t)nb + sizeof(uint32_t) * ((size_t)G + 3 * (size_t)NT)))) return rc;
-        uint4* d_items = (uint4*)c->sl_plan.p;
-        uint32_t* d_task = (uint32_t*)(d_items + nb);
+        d_items = (uint4*)c->sl_plan.p;
+        d_task = (uint32_t*)(d_items + nb);
         uint32_t* d_tile_m = d_task + G;
         uint32_t* d_scr = d_tile_m + NT;
-        const uint32_t prio_ref = (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 2000), 0x7fffffff);   // lists this long go first at the issue arbiter
+        prio_ref = (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 2000), 0x7fffffff);   // lists this long go first at the issue arbiter
         sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * (size_t)B, c->stream>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, d_items, d_tile_w, d_tile_m, d_ctr);
-        sl_tasks_kernel<<<1, 1024, 0, c->stream>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task);
+        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->stream>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task);
+        EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
+    }
+    {
+        ProfScope ps(c, "ev_gather");
         SlotGather P{d_task, d_items, (const uint8_t*)c->entries.p, d_nslots, d_rowbase, (const float*)c->sl_rows.p,
                      d_tile_w, d_ctr, d_f32, d_minmax_enc, d_info, B, W, H, TX, NT, c->sl_null, prio_ref, nullptr};
 #ifdef EORB_SLOT_TRACE
@@ -882,7 +886,7 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offs
 #endif
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)sl_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-        sl_gather_kernel<<<G, 64 * nw, lds, c->stream>>>(P);
+        sl_gather_kernel<<<G, 64 * nw, lds_g, c->stream>>>(P);
         EORB_LAUNCH_CHECK(c, "sl_gather_kernel");
     }
     return EORB_OK;
