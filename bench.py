@@ -303,9 +303,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=600))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     env = dict(a=a, world=world, rank=rank, local_rank=local_rank, dev=dev, torch=torch, dist=dist, frontend=frontend, shard=shard,
                synth=synth)
     out = {"w1": run_batch, "w2": run_batch, "w3": run_frames, "w4": run_frames}[a.workload](env)

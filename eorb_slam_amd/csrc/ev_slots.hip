@@ -621,7 +621,8 @@ void sl_gather_kernel(SlotGather P)
     auto uni = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     auto item_of = [&](int tkv) { return (int)min((uint32_t)__builtin_amdgcn_readfirstlane(tkv), (uint32_t)nit); };
     int k = item_of(ticket());
-    uint4 d = k < nit ? items[k] : make_uint4(0u, 0u, 0u, 0u);
+    uint4 d = make_uint4(0u, 0u, 0u, 0u);
+    if (k < nit) d = items[k];
     uint4 En = make_uint4(0u, 0u, 0u, 0u);
     bool have_first = false;
     while (k < nit) {
@@ -642,7 +643,7 @@ void sl_gather_kernel(SlotGather P)
         for (int b = 0; b < nblk; b++) {
             uint4 E = En;
             // the next item: ticket when at most four blocks are left, its descriptor one block later, its first block with the last one
-            if (stage_t == 1) { kn = item_of(tk); dn = kn < nit ? items[kn] : dn; stage_t = 2; }
+            if (stage_t == 1) { kn = item_of(tk); if (kn < nit) dn = items[kn]; stage_t = 2; }
             else if (stage_t == 0 && nblk - b <= 4) { tk = ticket(); stage_t = 1; }
             if (b + 1 < nblk) En = list[(size_t)(b + 1) * 64 + lane];
             else if (stage_t == 2 && kn < nit && uni(dn.y)) {
@@ -652,13 +653,12 @@ void sl_gather_kernel(SlotGather P)
             const int rem = (int)cnt - b * 1024;
             if (rem < 1024) {
                 // entries past the end of the list -> the null slot
-                uint32_t* ew = (uint32_t*)&E;
-#pragma unroll
-                for (int dd = 0; dd < 4; dd++) {
+                auto fix = [&](uint32_t w, int dd) {
                     const int nv = rem - lane * 16 - dd * 4;                  // valid bytes of this dword
                     const uint32_t keep = nv >= 4 ? 0xffffffffu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
-                    ew[dd] = (ew[dd] & keep) | (nullword & ~keep);
-                }
+                    return (w & keep) | (nullword & ~keep);
+                };
+                E.x = fix(E.x, 0); E.y = fix(E.y, 1); E.z = fix(E.z, 2); E.w = fix(E.w, 3);
             }
             const int lane_end = min(64, (rem + 15) >> 4);               // one lane (16 entries) per iteration
 #ifdef EORB_SLOT_TRACE
@@ -725,7 +725,7 @@ void sl_gather_kernel(SlotGather P)
 #endif
         // next item
         if (stage_t == 0) { tk = ticket(); stage_t = 1; }
-        if (stage_t == 1) { kn = item_of(tk); dn = kn < nit ? items[kn] : dn; }
+        if (stage_t == 1) { kn = item_of(tk); if (kn < nit) dn = items[kn]; }
         k = kn; d = dn;
     }
 #ifdef EORB_SLOT_TRACE

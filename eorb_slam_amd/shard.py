@@ -94,10 +94,17 @@ def free_port():
     return p
 
 
-def spawn_ranks(script, argv, n, extra_env=None):
-    """Start `n` ranks of `script` as CHILD processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), wait for
-    them and return the largest exit code.  The caller must not have touched the GPU: nothing is exec'ed over a process that
-    initialised HIP, the children are ordinary subprocesses and each initialises its own device."""
+def spawn_ranks(script, argv, n, extra_env=None, timeout_s=None):
+    """Start `n` ranks of `script` as CHILD processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and return
+    the first non-zero exit code (0 when all succeed).  All children are polled: when one dies (no GPU, out of memory, a failed
+    RCCL init) its siblings -- which would otherwise wait for it in a barrier or a gather for ever -- are terminated, then killed;
+    the same happens after `timeout_s` seconds (default: EORB_SPAWN_TIMEOUT or 1800).  The caller must not have touched the GPU:
+    nothing is exec'ed over a process that initialised HIP, the children are ordinary subprocesses and each initialises its own
+    device.  (The rendezvous port is picked by binding port 0 and released just before the children start; a child that finds it
+    taken fails its init and brings the launch down with a non-zero code instead of hanging.)"""
+    import time
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("EORB_SPAWN_TIMEOUT", "1800"))
     port = free_port()
     procs = []
     for r in range(n):
@@ -107,8 +114,30 @@ def spawn_ranks(script, argv, n, extra_env=None):
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
-    rc = 0
-    for p in procs:
-        p.wait()
-        rc = max(rc, abs(p.returncode))
+    t0, rc = time.time(), 0
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = abs(code) or 1
+                break
+        if rc == 0 and live:
+            if time.time() - t0 > timeout_s:
+                print("spawn_ranks: %d rank(s) still running after %.0f s, stopping them" % (len(live), timeout_s), file=sys.stderr)
+                rc = 124
+                break
+            time.sleep(0.05)
+    if rc != 0:
+        for p in live:
+            p.terminate()
+        t1 = time.time()
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, 10 - (time.time() - t1)))
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
     return rc

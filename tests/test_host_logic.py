@@ -93,6 +93,20 @@ def test_spawned_ranks_gather_packed_records(tmp_path):
     assert out.read_text() == "ok 2"
 
 
+def test_spawned_rank_failure_stops_the_launch():
+    """A rank that dies must not leave `bench.py --gpus N` hanging on its siblings: the launcher polls all children, returns the
+    failing rank's code and stops the others; a launch that exceeds its time limit is stopped the same way."""
+    import time
+    from eorb_slam_amd import shard
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_fail_worker.py")
+    t0 = time.time()
+    assert shard.spawn_ranks(script, [], 2) == 3
+    assert time.time() - t0 < 30
+    t0 = time.time()
+    assert shard.spawn_ranks(script, [], 1, timeout_s=1.0) == 124          # (rank 0 alone sleeps: the time limit ends it)
+    assert time.time() - t0 < 30
+
+
 def test_bench_refuses_mismatched_world(monkeypatch):
     """`--gpus N` must agree with WORLD_SIZE when a launcher set it (the driver's torch.distributed.run form)."""
     import subprocess, sys
