@@ -247,7 +247,7 @@ struct ONode { uint16_t x0, x1, y0, y1, start, cnt, seq; uint8_t flags, pad; }; 
 static_assert(sizeof(ONode) == 16, "ONode is 16 bytes");
 constexpr int kOctThreads = 512;
 constexpr int kOctBigNode = 1024;   // keys from which a node is partitioned by the whole workgroup
-constexpr int kOctBigMax = 64;      // (ncap < 65 535 keys: at most 63 such nodes at a time)
+constexpr int kOctBigMax = 64;      // (ncap <= 65 534 keys: at most 63 such nodes at a time)
 
 __device__ __forceinline__ int oct_wave_incl_scan(int x)
 {   // row_shr 1/2/4/8 inside the 16-lane rows, then row_bcast 15 / 31
@@ -1142,7 +1142,11 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
         L.cand_off = cand_total; cand_total += L.cand_cap;
         ncap_max = std::max(ncap_max, L.cand_cap);
     }
-    if (ncap_max >= 65535) return set_err(c, EORB_E_CAPACITY, "image too large for the 16-bit octree keys");
+    // The octree addresses a level's candidates with 16-bit keys.  cand_cap is the worst case (every other pixel in x and in y a
+    // corner: 90 000 on level 0 of the reference's default 752x480 frames, include/ORBextractor.h:31, Examples/Event/EuRoC.yaml:86);
+    // real frames stay far below it, so the working arrays hold at most 65 534 candidates per level and a level that does exceed
+    // them is truncated AND reported (status bit 1 of the call / eorb_sync), not refused up front.
+    ncap_max = std::min(ncap_max, 65534);
     if (node_cap_max > 16000) return set_err(c, EORB_E_CAPACITY, "more than 16 000 features on one pyramid level");   // 16-bit packed child counters
     o.pyr_bytes = pyr; o.roi_bytes = roi; o.ncells = cells; o.cell_cap = cell_cap;
     o.cand_total = cand_total; o.kp_total = kp_total; o.max_out = kp_total;

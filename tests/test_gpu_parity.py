@@ -163,6 +163,19 @@ def test_orb_extract_mvsec_shape(oracle, fe):
     _check_extract(oracle, fe, img, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=10, minThFAST=1, edgeTh=15)
 
 
+def test_orb_extract_euroc_frame_size(oracle, fe):
+    """The reference's default extractor width (DEF_IMAGE_WIDTH 752, include/ORBextractor.h:31) and EuRoC frames (752x480,
+    Examples/Event/EuRoC.yaml:86): 8 levels, FAST 20 / 7, 1 000 features, and the monocular initialiser's 5 x nFeatures
+    (src/Tracking.cc:119-122); the default edge threshold (edgeTh < 0: 19 * (imWidth / 752), ORBextractor.cc:481-488)."""
+    img = synth.texture_image(752, 480, seed=12)
+    kp, _ = _check_extract(oracle, fe, img, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, edgeTh=-1)
+    assert len(kp) > 800
+    _check_extract(oracle, fe, img, nfeatures=5000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, edgeTh=19)
+    ev = synth.shapes_events(400000, 752, 480, seed=5)                 # an event image of that size: low thresholds, many candidates
+    img2 = oracle.ev2im_gauss(ev, 752, 480, 1.0, False, True, fast=True)[1]
+    _check_extract(oracle, fe, img2, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=10, minThFAST=0, edgeTh=19)
+
+
 def test_orb_extract_stereo_lapping_and_flat(oracle, fe):
     img = synth.texture_image(240, 180, seed=8)
     _check_extract(oracle, fe, img, lap=(0, 0), nfeatures=500, scaleFactor=1.2, nlevels=3, iniThFAST=20, minThFAST=7, edgeTh=19)
