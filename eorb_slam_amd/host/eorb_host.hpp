@@ -9,6 +9,7 @@
 // what a C++ host without OpenCV uses, and what tests/test_host_cpp.py compiles.  Everything runs on the GPU
 // through libeorb_fe.so; there is no CPU path here.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -62,36 +63,49 @@ public:
             std::lock_guard<std::mutex> g(m_);
             all_.push_back(std::move(n));
         }
-        sync_state(*c);
+        try { sync_state(*c); }
+        catch (...) { release(c); throw; }           // (a failed upload must not strand the context outside the free list)
         return c;
     }
     void release(Context* c) { std::lock_guard<std::mutex> g(m_); free_.push_back(c); }
     size_t created() const { std::lock_guard<std::mutex> g(m_); return all_.size(); }
-    // process-wide state
-    void set_maps(const std::vector<float>& mapX, const std::vector<float>& mapY, int LW, int LH, bool check) {
-        std::lock_guard<std::mutex> g(m_);
-        mapX_ = mapX; mapY_ = mapY; LW_ = LW; LH_ = LH; check_ = check; maps_epoch_++;
-    }
+    // process-wide state: immutable snapshots, replaced as a whole
+    struct Maps { std::vector<float> mapX, mapY; int LW = 0, LH = 0; bool check = true; };
     struct Voc { int L = 0; std::vector<int32_t> childOff, childIds, wordId; std::vector<uint8_t> nodeDesc; std::vector<double> weight; };
-    void set_vocabulary(Voc v) { std::lock_guard<std::mutex> g(m_); voc_ = std::move(v); voc_epoch_++; }
-    void sync_state(Context& c) {
+    void set_maps(const std::vector<float>& mapX, const std::vector<float>& mapY, int LW, int LH, bool check) {
+        auto m = std::make_shared<Maps>(); m->mapX = mapX; m->mapY = mapY; m->LW = LW; m->LH = LH; m->check = check;
         std::lock_guard<std::mutex> g(m_);
-        if (c.maps_epoch != maps_epoch_) {
-            c.check(eorb_set_undistort_maps(c.get(), mapX_.data(), mapY_.data(), LW_, LH_, check_));
-            c.maps_epoch = maps_epoch_;
+        maps_ = std::move(m); maps_epoch_.store(maps_epoch_.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+    }
+    void set_vocabulary(Voc v) {
+        auto p = std::make_shared<Voc>(std::move(v));
+        std::lock_guard<std::mutex> g(m_);
+        voc_ = std::move(p); voc_epoch_.store(voc_epoch_.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+    }
+    // Loads the maps / the vocabulary into a context that has not seen their current version.  Called on every API call of a
+    // thread: the common case is two atomic loads; the process-wide mutex is only held to take a reference to the snapshot, never
+    // across the GPU upload (other threads' calls do not wait for it).  `c` belongs to the calling thread.
+    void sync_state(Context& c) {
+        if (c.maps_epoch != maps_epoch_.load(std::memory_order_acquire)) {
+            std::shared_ptr<const Maps> m; unsigned e;
+            { std::lock_guard<std::mutex> g(m_); m = maps_; e = maps_epoch_.load(std::memory_order_relaxed); }
+            if (m) c.check(eorb_set_undistort_maps(c.get(), m->mapX.data(), m->mapY.data(), m->LW, m->LH, m->check));
+            c.maps_epoch = e;
         }
-        if (c.voc_epoch != voc_epoch_) {
-            c.check(eorb_bow_set_vocabulary(c.get(), (int)voc_.childOff.size() - 1, voc_.L, voc_.childOff.data(), voc_.childIds.data(),
-                                            voc_.nodeDesc.data(), voc_.wordId.data(), voc_.weight.data()));
-            c.voc_epoch = voc_epoch_;
+        if (c.voc_epoch != voc_epoch_.load(std::memory_order_acquire)) {
+            std::shared_ptr<const Voc> v; unsigned e;
+            { std::lock_guard<std::mutex> g(m_); v = voc_; e = voc_epoch_.load(std::memory_order_relaxed); }
+            if (v) c.check(eorb_bow_set_vocabulary(c.get(), (int)v->childOff.size() - 1, v->L, v->childOff.data(), v->childIds.data(),
+                                                   v->nodeDesc.data(), v->wordId.data(), v->weight.data()));
+            c.voc_epoch = e;
         }
     }
 private:
     mutable std::mutex m_;
     std::vector<std::unique_ptr<Context>> all_;
     std::vector<Context*> free_;
-    std::vector<float> mapX_, mapY_; int LW_ = 0, LH_ = 0; bool check_ = true; unsigned maps_epoch_ = 0;
-    Voc voc_; unsigned voc_epoch_ = 0;
+    std::shared_ptr<const Maps> maps_; std::atomic<unsigned> maps_epoch_{0};
+    std::shared_ptr<const Voc> voc_; std::atomic<unsigned> voc_epoch_{0};
 };
 
 // the calling thread's context: borrowed from the pool for the lifetime of the thread

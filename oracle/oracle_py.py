@@ -49,11 +49,39 @@ class GridBounds(C.Structure):
                 ("invW", C.c_float), ("invH", C.c_float)]
 
 
+def _host_signature():
+    """What -march=native means on this machine (CPU model + ISA flags)."""
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+        keep = [l for l in txt.splitlines() if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        keep = []
+    import platform
+    return hashlib.sha1(("|".join(keep) + platform.machine()).encode()).hexdigest()
+
+
 def build(force=False):
-    """Compile the oracle (both the parity and the timing build)."""
+    """Compile the oracle: the parity build and the timing build (make is incremental).  The timing build is -march=native: when the
+    library on disk was built on another machine (the .so travels with the tree to the GPU box) it is rebuilt here, so that
+    bench.py's cpu_baseline is native to the host it is timed on."""
     out = os.path.join(_HERE, "_build", "liboracle.so")
-    if force or not os.path.exists(out) or not os.path.exists(os.path.join(_HERE, "_build", "liboracle_fast.so")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    fast = os.path.join(_HERE, "_build", "liboracle_fast.so")
+    stamp = os.path.join(_HERE, "_build", "fast.host")
+    sig = _host_signature()
+    try:
+        native_here = open(stamp).read().strip() == sig
+    except OSError:
+        native_here = False
+    if force or not native_here:
+        try:
+            os.remove(fast)
+        except OSError:
+            pass
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    if force or not native_here:
+        with open(stamp, "w") as f:
+            f.write(sig)
     return out
 
 
@@ -66,6 +94,9 @@ def lib(fast=False):
         return _libs[key]
     build()
     path = os.path.join(_HERE, "_build", "liboracle_fast.so" if fast else "liboracle.so")
+    if os.environ.get("EORB_ORACLE_VARIANT") == "asan":       # tests/test_oracle_hygiene.py: both roles served by the sanitizer build
+        subprocess.check_call(["make", "-C", _HERE, "-s", "asan"])
+        path = os.path.join(_HERE, "_build", "liboracle_asan.so")
     L = C.CDLL(path)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.orc_expf.restype = cf; L.orc_expf.argtypes = [cf]
