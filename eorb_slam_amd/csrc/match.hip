@@ -385,7 +385,7 @@ __device__ __forceinline__ void wave_top2(uint64_t& k0, uint64_t& k1)
 constexpr int kWinLdsEntries = 6144;      // entries of a pair staged in LDS by phase 2 (the rest is read from global memory)
 
 template <int KIND>
-__global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
+__global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
 {
     extern __shared__ unsigned char smem[];
     const int pair = blockIdx.x;
@@ -428,9 +428,52 @@ __global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
     if (KIND == 0 && M12) for (int i = tid; i < NQ; i += blockDim.x) M12[i] = -1;
     if (tid < 32) histo[tid] = 0;
     if (tid == 0) sh_nm[0] = 0;
-    __syncthreads();
+    int over_any = 0;
+    if (KIND == 1) for (int i = tid; i < NQ; i += blockDim.x) over_any |= (A.cnt[(size_t)pair * cq + i] == kWinOver) ? 1 : 0;
+    const bool fixpoint = KIND == 1 && !__syncthreads_or(over_any);        // (also the barrier behind the LDS set-up)
+    if (KIND != 1) __syncthreads();
 
-    if (wave == 0) {
+    if (fixpoint) {
+        // SearchByProjection(cur, last / KeyFrame): a query takes the FIRST entry of its sorted list whose candidate is free (no
+        // observed map point in the slot: :2045-2047 / :2231) if that entry is within the distance threshold, and its map point
+        // then blocks the candidate for later queries when it is observed.  So query q's outcome is a function of the outcomes of
+        // the queries before it, and the whole walk is the fixed point of "every query takes its first entry that no EARLIER query
+        // with an observed map point has taken", iterated from "nobody has taken anything": query 0 is final after one sweep, and
+        // each sweep finalises at least the first query that still changed -- in practice three to five sweeps settle a window of
+        // 1 024 queries (dependency chains are short), where the walk below spends a round per conflict.
+        int nm = 0;
+        for (int base = 0; base < NQ; base += (int)blockDim.x) {
+            const int q = base + tid;
+            const uint32_t c = q < NQ ? cnts[q] : 0u;
+            const uint32_t o = q < NQ ? offs[q] : 0u;
+            const bool blocks = q < NQ && qobs[q] != 0;
+            int pick = -1;
+            for (;;) {
+                int np = -1;
+                for (uint32_t j = 0; j < c; j++) {
+                    const uint32_t e = o + j;
+                    const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
+                    const int idx = (int)((key >> 8) & 0xffffffu), dist = (int)(key >> 44);
+                    if (obs[idx] == 0 && dist < 256 && !(claim[idx] < (unsigned int)tid)) { if (dist <= A.dist_th) np = idx; break; }
+                }
+                const int changed = np != pick;
+                __syncthreads();                                        // every thread has read the claims of this sweep
+                if (changed && pick >= 0 && blocks) claim[pick] = 0xFFFFFFFFu;
+                __syncthreads();
+                // (a claim cleared above may belong to a candidate other threads still hold: they put it back)
+                pick = np;
+                if (pick >= 0 && blocks) atomicMin(&claim[pick], (unsigned int)tid);
+                if (!__syncthreads_or(changed)) break;
+            }
+            // the window's commits: the LAST query that took a candidate owns its slot; an observed map point closes it
+            if (pick >= 0) { match_at[q] = pick; st_a[pick] = -1; nm++; }      // (the slot's old content -- empty or an unobserved map point -- goes)
+            __syncthreads();
+            if (pick >= 0) atomicMax(&st_a[pick], q);
+            if (pick >= 0 && blocks) { obs[pick] = 1; claim[pick] = 0xFFFFFFFFu; }
+            __syncthreads();
+        }
+        if (nm) atomicAdd(&sh_nm[0], nm);
+    } else if (wave == 0) {
         // The queries are walked in order, 64 at a time (lane = query).  Every lane evaluates its query against the committed
         // state; a query commits in this round only if no EARLIER query of the round changes a candidate it depends on.  The state
         // only ever removes candidates (vMatchedDistance decreases, a slot turns "observed"), and a query's outcome depends on its
@@ -516,7 +559,16 @@ __global__ __launch_bounds__(256) void win_resolve_kernel(WinArgs A)
                 // the list is sorted: the first passing entries are the best and the second best
                 constexpr int need = (KIND == 1) ? 1 : 2;
                 int found = 0;
-                for (uint32_t j = 0; j < c && found < need; j++) {
+                // the first four entries and their states in flight together (a round is a chain of LDS round trips: the two best
+                // passing entries are almost always among them), the rest of the list one by one
+                uint64_t e4[4]; bool p4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint32_t e = o + (uint32_t)u; e4[u] = (uint32_t)u < c ? (e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e]) : ~0ull; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) p4[u] = e4[u] != ~0ull && passes(e4[u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (p4[u] && found < need) { if (found == 0) k0 = e4[u]; else k1 = e4[u]; found++; }
+                for (uint32_t j = 4; j < c && found < need; j++) {
                     const uint32_t e = o + j;
                     const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
                     if (passes(key)) { if (found == 0) k0 = key; else k1 = key; found++; }
@@ -622,7 +674,7 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     A.wcap = c->dbg_win_wcap > 0 ? c->dbg_win_wcap : 512;
     A.ecap = c->dbg_win_ecap > 0 ? c->dbg_win_ecap : std::max(4096, 16 * A.capq);
     const size_t lds1 = win_cand_lds(A.cap2, A.wcap), lds2 = win_resolve_lds(A.cap2, A.capq);
-    if (lds1 > 160 * 1024 || lds2 > 160 * 1024)
+    if (lds1 > 159 * 1024 || lds2 > 159 * 1024)        // (the kernels own a few words of static LDS besides)
         return set_err(c, EORB_E_CAPACITY, "%s: %zu / %zu B of LDS needed (searched frame %d, queries %d)", name, lds1, lds2, A.cap2, A.capq);
     int rc;
     // phase-1 products: entries | off | cnt | total
@@ -634,12 +686,13 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     A.total = A.cnt + (size_t)npairs * A.capq;
     EORB_HIP(c, hipMemsetAsync(A.total, 0, sizeof(uint32_t) * (size_t)npairs, c->stream));
     // per device, not per process: a second context on another GPU needs the opt-in too (the call is cheap)
-    hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    EORB_HIP(c, hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    EORB_HIP(c, hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     ProfScope ps(c, name);
     const int qpb = npairs >= 8 ? 32 : 8;  // queries per phase-1 workgroup (a lone pair is spread over more workgroups)
     win_cand_kernel<KIND><<<dim3((nq_max + qpb - 1) / qpb, npairs), 256, lds1, c->stream>>>(A, qpb);
-    win_resolve_kernel<KIND><<<npairs, 256, lds2, c->stream>>>(A);
+    // (SearchByProjection(cur, last): its fixed-point sweeps settle a window of blockDim queries at a time: the widest block)
+    win_resolve_kernel<KIND><<<npairs, KIND == 1 ? 1024 : 256, lds2, c->stream>>>(A);
     EORB_LAUNCH_CHECK(c, name);
     return EORB_OK;
 }
