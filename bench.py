@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--input", choices=["raw", "float"], default="raw",
                     help="raw: sensor-pixel events (x,y,t,p) + the calibrator's undistortion maps resolved on the GPU; "
                          "float: events already undistorted by the loader (EventData)")
+    ap.add_argument("--stream", action="store_true",
+                    help="w2: also time the batch with its events arriving from pinned host memory: double-buffered H2D on a copy stream "
+                         "overlapped with the previous batch on the compute stream, for the 16-byte and the 4-byte wire record")
     ap.add_argument("--latency-calls", type=int, default=300, help="w1: single-slice calls timed for the latency figures (0 = skip)")
     return ap.parse_args()
 
@@ -351,6 +354,61 @@ def base_line(env, value, dt, workload, config):
             "data": "synthetic", "config": dict(workload=workload, **config)}
 
 
+def stream_ingest(env, seq, comp_s, ev16, offsets, B, NEV, resident_s):
+    """The w2 step with its input streamed: two device buffers, batch i + 1 copied from pinned host memory on a copy stream while
+    batch i runs on the compute stream (events order copy -> compute -> reuse of the buffer).  Steady-state slices/s including the
+    link, for the 16-byte eorb_raw_event and for the 4-byte eorb_raw_event4 (the images never read the time stamp)."""
+    a, torch, dev, frontend = env["a"], env["torch"], env["dev"], env["frontend"]
+    ctx_i, fb_i, bf = seq
+    res = {"what": "pinned host buffer -> HBM per batch on a copy stream, overlapped with the previous batch's kernels (double buffer); "
+                   "value includes the link", "resident_ms_per_step": resident_s * 1e3}
+    for name, rec_bytes, fmt in (("raw16", 16, True), ("raw4", 4, 4)):
+        host_np = ev16 if fmt is True else frontend.pack_raw_events4(ev16)
+        host = torch.from_numpy(host_np.view(np.uint8)).pin_memory()
+        dbuf = [torch.empty(host.numel(), dtype=torch.uint8, device=dev) for _ in range(2)]
+        copy_s = torch.cuda.Stream(device=dev)
+        copied = [torch.cuda.Event() for _ in range(2)]; freed = [torch.cuda.Event() for _ in range(2)]
+
+        def issue_copy(i):
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(freed[i % 2])
+                dbuf[i % 2].copy_(host, non_blocking=True)
+                copied[i % 2].record(copy_s)
+
+        def issue_compute(i):
+            with torch.cuda.stream(comp_s):
+                comp_s.wait_event(copied[i % 2])
+                fb_i.run_dev(dbuf[i % 2].data_ptr(), offsets, bf["img"].data_ptr(), bf["kp"].data_ptr(), bf["desc"].data_ptr(), bf["n"].data_ptr(),
+                             bf["m"].data_ptr(), bf["nm"].data_ptr(), raw=fmt)
+                freed[i % 2].record(comp_s)
+        for e in freed:
+            e.record(comp_s)
+        nsteps = max(4, min(a.steps, 12))
+        issue_copy(0)
+        for i in range(2):                         # warm-up
+            issue_copy(i + 1); issue_compute(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        issue_copy(0)
+        for i in range(nsteps):
+            if i + 1 < nsteps:
+                issue_copy(i + 1)
+            issue_compute(i)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / nsteps
+        # the link alone
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for i in range(4):
+            with torch.cuda.stream(copy_s):
+                dbuf[i % 2].copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        tl = (time.perf_counter() - t1) / 4
+        res[name] = {"value": B / t, "unit": "frames/s", "ms_per_step": t * 1e3, "record_bytes": rec_bytes, "bytes_per_step": int(host.numel()),
+                     "h2d_GBps": host.numel() / tl / 1e9, "h2d_ms_per_step": tl * 1e3}
+        del dbuf, host
+    return res
+
+
 # --------------------------------------------------------------------------------------------------------------------------
 def run_batch(env):
     """w2 (BASELINE.json configs[1]) and w1 (configs[0] stand-in): the batched HBM-resident pipeline."""
@@ -457,6 +515,9 @@ def run_batch(env):
                          "fraction is reported as the contract asks")
             out["roofline"] = r
             out["kernels_ms_per_step"] = per_step
+        # ---- streaming ingest: the events arrive from the host (src/Event/EventLoader.cpp:535-577 hands chunks to the tracker) ----
+        if a.stream and a.workload == "w2" and world == 1 and use_raw:
+            out["streaming"] = stream_ingest(env, seqs[0], streams[0], ev16, offsets, B, NEV, dt / a.steps)
         # ---- single-slice latency of the seams as the reference calls them (host buffers, one slice per call): W1 only ----
         if a.workload == "w1" and a.latency_calls > 0 and world == 1:
             c = frontend.Context(device=env["local_rank"])

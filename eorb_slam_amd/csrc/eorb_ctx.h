@@ -160,7 +160,7 @@ int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* 
                       eorb_raw_event* d_out, uint32_t* d_blk, size_t max_lines, uint32_t h_res[3]);
 // ev_slots.hip
 int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps, int stamp_stride, int SWP);
-int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
+int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
                         float* d_f32, uint32_t* d_minmax_enc);
 int ev_slots_trace_read(eorb_ctx* c, unsigned long long* out, long long max_records);
 // klt.hip

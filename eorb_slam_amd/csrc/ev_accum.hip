@@ -1913,6 +1913,17 @@ static int ev_raw_tables(eorb_ctx* c, int W, int H, int h, float sigma, int mode
     return EORB_OK;
 }
 
+// eorb_raw_event4 (x | p << 15 | y << 16: the 4-byte wire record of a sensor event for the images, which never read the time
+// stamp) -> eorb_raw_event, for the accumulation forms that read 16-byte records
+__global__ void ev_unpack4_kernel(const uint32_t* __restrict__ in, int64_t n, eorb_raw_event* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t q = in[i];
+        eorb_raw_event e; e.x = (uint16_t)(q & 0x7fffu); e.y = (uint16_t)(q >> 16); e.p = (q >> 15) & 1u; e.t = 0.0;
+        out[i] = e;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
@@ -1931,6 +1942,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     int nbits = 1; while ((1 << nbits) < NT) nbits++;
     const int dup = R * R;
     const bool hashed = raw == 2;                        // (recursion of the block below: d_events are 4-byte hashed records)
+    const bool packed4 = raw == 3;                       // 4-byte sensor records (eorb_raw_event4)
     if (!raw && !mode_count && c->dbg_gather_form != 1 && h_offsets[B] - h_offsets[0] >= c->dbg_dd_min && c->dbg_dd_min > 0) {
         // float events in bulk: tabulate their distinct positions, continue on the raw path (see dd_insert_kernel)
         const int64_t n0 = h_offsets[B] - h_offsets[0];
@@ -1976,7 +1988,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     {
         // one or a few small slices of raw events (the live per-slice call): no binning at all, K2d
         const int64_t nev0 = h_offsets[B] - h_offsets[0];
-        if (!hashed && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
+        if (!hashed && !packed4 && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
             DirectSlices S;
             for (int b = 0; b <= B; b++) {
                 if (b && h_offsets[b] < h_offsets[b - 1]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
@@ -2021,7 +2033,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                     ProfScope ps(c, "ev_minmax_init");
                     ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
                 }
-                if ((rc = ev_slots_accumulate(c, d_events, h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc))) return rc;
+                if ((rc = ev_slots_accumulate(c, d_events, packed4 ? 4 : 16, h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc))) return rc;
                 if (normalized && d_u8) {
                     ProfScope ps(c, "ev_normalize");
                     dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
@@ -2031,6 +2043,17 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                 return EORB_OK;
             }
         }
+    }
+    if (packed4) {
+        // the other forms read 16-byte records: widen the batch's events once and go on with those
+        const int64_t n0 = h_offsets[B] - h_offsets[0];
+        int rc;
+        if ((rc = ensure(c, c->ev16, sizeof(eorb_raw_event) * (size_t)std::max<int64_t>(n0, 1)))) return rc;
+        if (n0 > 0) ev_unpack4_kernel<<<(int)std::min<int64_t>((n0 + 255) / 256, 65536), 256, 0, c->stream>>>((const uint32_t*)d_events + h_offsets[0], n0, (eorb_raw_event*)c->ev16.p);
+        EORB_LAUNCH_CHECK(c, "ev_unpack4_kernel");
+        std::vector<int64_t> off(B + 1);
+        for (int b = 0; b <= B; b++) off[b] = h_offsets[b] - h_offsets[0];
+        return ev_accumulate_dev(c, c->ev16.p, 1, off.data(), B, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, d_minmax_enc);
     }
     // chunk list (host) -> device.  A chunk is binned by ONE wavefront, 64 events at a time: large inputs take kChunk events per
     // chunk (fewer segment tables), small ones shorter chunks so that a single 2 000-event slice is not one 32-iteration serial

@@ -115,22 +115,23 @@ __global__ __launch_bounds__(256) void sl_rows_kernel(const uint32_t* __restrict
 
 // ---- K1a: entries of every (chunk, tile) -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
-                                                       const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
+                                                       const uint2* __restrict__ slot_tab, int stride, int LW, int LH, int TX, int NT,
                                                        uint16_t* __restrict__ segcnt)
 {
     extern __shared__ uint32_t cnt[];               // NT
     const ChunkDesc cd = chunks[blockIdx.x];
     for (int i = threadIdx.x; i < NT; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const eorb_raw_event* e = ev + cd.start;
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)stride;      // 16-byte eorb_raw_event or 4-byte eorb_raw_event4
+    const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
     constexpr int U = 8;
     for (int k0 = threadIdx.x; k0 < cd.n; k0 += blockDim.x * U) {
         uint32_t xy[U], rg[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)&e[k] : 0xffffffffu; }
+        for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)(e + (size_t)k * (size_t)stride) : 0xffffffffu; }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int x = (int)(xy[u] & 0xffff), y = (int)(xy[u] >> 16);
+            const int x = (int)(xy[u] & xmask), y = (int)(xy[u] >> 16);
             rg[u] = (x < LW && y < LH) ? slot_tab[(uint32_t)y * (uint32_t)LW + x].x : 0u;
         }
 #pragma unroll
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(1024) void sl_scan_kernel(const int* __restrict__ s
 //   D  slot p -> (event, tile) -> entry = the event's slot number in that tile << 8, stored at the run's place in the tile's
 //      global list: consecutive threads write consecutive entries of a run ----
 __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
-                                                                         const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int TY,
+                                                                         const uint2* __restrict__ slot_tab, int stride, int LW, int LH, int TX, int TY,
                                                                          int NT, int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                                          const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
                                                                          uint8_t* __restrict__ entries)
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
     uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
     uint32_t* gbase = (uint32_t*)(loff + NTp + 2);                    // NT
     for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
-    const eorb_raw_event* e = ev + cd.start;
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)stride;      // 16-byte eorb_raw_event or 4-byte eorb_raw_event4
+    const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
     const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
     const int S = Q >> 6;
     constexpr int SMAX = 4;
@@ -232,8 +234,8 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         const int k = wave * Q + s * 64 + lane;
-        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)&e[k] : 0xffffffffu;
-        const int x = (int)(q & 0xffff), y = (int)(q >> 16);
+        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)stride) : 0xffffffffu;
+        const int x = q == 0xffffffffu ? 0xffff : (int)(q & xmask), y = (int)(q >> 16);
         rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
     }
     uint2 rst[SMAX];
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
 // of sorted slots: phase A keeps four 8-bit ranks per event, phase C writes the entry byte and its tile straight to their place
 // in the chunk's tile-sorted order, phase D streams that order out run by run.
 __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
-                                                                              const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
+                                                                              const uint2* __restrict__ slot_tab, int stride, int LW, int LH, int TX, int NT,
                                                                               int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                                               const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
                                                                               uint8_t* __restrict__ entries)
@@ -359,7 +361,8 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(co
     uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
     uint8_t* sorted = (uint8_t*)(loff + NTp + 2);                     // chunk_cap * 4: the entry bytes in tile-sorted order
     for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
-    const eorb_raw_event* e = ev + cd.start;
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)stride;      // 16-byte eorb_raw_event or 4-byte eorb_raw_event4
+    const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
     const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
     const int S = Q >> 6;
     constexpr int SMAX = 4;
@@ -370,8 +373,8 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(co
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         const int k = wave * Q + s * 64 + lane;
-        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)&e[k] : 0xffffffffu;
-        const int x = (int)(q & 0xffff), y = (int)(q >> 16);
+        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)stride) : 0xffffffffu;
+        const int x = q == 0xffffffffu ? 0xffff : (int)(q & xmask), y = (int)(q >> 16);
         rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
     }
     uint2 rst[SMAX];
@@ -775,7 +778,7 @@ int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const flo
 }
 
 // count -> scan -> scatter -> order -> gather for B slices of raw events (no polarity, Gaussian stamp)
-int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
+int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
                         float* d_f32, uint32_t* d_minmax_enc)
 {
     const int NT = TX * TY;
@@ -839,15 +842,15 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, const int64_t* h_offs
         const int NTp = (NT + 1) & ~1;
         const size_t lds2 = ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
         if (lds > 64 * 1024 || lds2 > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
-        if (nchunks) sl_count_kernel<<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+        if (nchunks) sl_count_kernel<<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, NT, d_segcnt);
         sl_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
         static const int rank_env = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
         const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
         if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= 64 * 1024)
-            sl_scatter_rank_kernel<<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk,
+            sl_scatter_rank_kernel<<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, NT, chunk,
                                                                                       d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
         else if (nchunks)
-            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, TY, NT, chunk,
+            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
                                                                                  d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
         lds_g = (size_t)(c->sl_null + 1) * 256;
         const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds_g));

@@ -61,6 +61,11 @@ typedef struct {
     double   t;
 } eorb_raw_event;
 
+/* the same event as a 4-byte wire record for the event IMAGES (they never read the time stamp: ev2im / ev2im_gauss use x, y and the
+ * polarity, src/Event/EventConversion.cc:173-269): x | p << 15 | y << 16, sensor sizes up to 32767 x 65535.  A quarter of the bytes
+ * on the host -> HBM link (bench.py --stream). */
+typedef uint32_t eorb_raw_event4;
+
 /* cv::KeyPoint (28 B): what ORBextractor::operator() fills (_keypoints) */
 typedef struct {
     float   x, y;
@@ -386,6 +391,11 @@ int eorb_fe_configure(eorb_ctx* ctx, const eorb_fe_config* cfg);
 int eorb_fe_run_batch_raw_dev(eorb_ctx* ctx, const eorb_raw_event* d_events, const int64_t* h_offsets, int B,
                               uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                               int32_t* d_matches12, int32_t* d_nmatches);
+
+/* as eorb_fe_run_batch_raw_dev, for 4-byte sensor records (eorb_raw_event4) resident in HBM */
+int eorb_fe_run_batch_raw4_dev(eorb_ctx* ctx, const eorb_raw_event4* d_events, const int64_t* h_offsets, int B,
+                               uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                               int32_t* d_matches12, int32_t* d_nmatches);
 
 /* (float events: a call with 2^20 events or more waits for the stream once, to learn how many distinct positions its events take --
  * the raw variant above never waits) */
