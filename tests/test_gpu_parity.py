@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
 Run on the GPU box with `pytest -m gpu`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1553,3 +1555,14 @@ def test_ev2mci_se2_and_focus_contest(oracle, fe, ctx):
     flat = np.zeros((180, 240), np.float32)
     assert np.array_equal(oracle.cv_normalize_minmax_u8(flat), fe.cv_normalize_minmax_u8(flat, ctx=ctx))
     assert oracle.measure_image_focus(flat) == fe.EvImConverter.measureImageFocus(flat, ctx=ctx) == 0.0
+
+
+def test_two_ranks_on_one_gpu_gather_their_records(tmp_path):
+    """The multi-GPU path of bench.py --gpus N with everything but the RCCL transport: shard.spawn_ranks starts two ranks that share
+    this GPU, each runs its own sequence's batch through the HIP front end, the packed keypoint records are gathered to rank 0
+    (gloo) and must equal, byte for byte, what each rank's sequence gives in a single process."""
+    from eorb_slam_amd import shard
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_rank_gpu_worker.py")
+    out = tmp_path / "ranks.txt"
+    rc = shard.spawn_ranks(script, [str(out)], 2, timeout_s=400)
+    assert rc == 0 and out.read_text() == "ok 2"
