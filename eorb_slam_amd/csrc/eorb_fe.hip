@@ -17,7 +17,7 @@ int ev_trace_read(unsigned long long* out, int n);
 int ev_warp_se3_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const eorb_camera* cam, double angle,
                     const double axis[3], const double tt[3], float medDepth, const float* d_depth);
 int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, int n, const eorb_camera* cam, const float* params, int nparams);
-int ev_focus_dev(eorb_ctx* c, const float* d_img, int W, int H, float* d_out);
+int ev_focus_dev(eorb_ctx* c, const float* d_img, int nimg, int W, int H, float* d_out);
 int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm, uint8_t* d_out);
 int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out);
 int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H);
@@ -590,19 +590,20 @@ int eorb_ev2mci_se2(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_pinh
     return eorb_ev2mci_se2_cam(c, ev, n, cam ? &cc : nullptr, params2D, nparams, W, H, sigma, pol, normalized, out_f32, out_u8, minmax);
 }
 
-int eorb_measure_image_focus(eorb_ctx* c, const float* img, int W, int H, float* focus)
+int eorb_measure_image_focus_n(eorb_ctx* c, const float* imgs, int n, int W, int H, float* focus)
 {
     if (!c) return EORB_E_ARG;
-    if (!img || !focus || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "measure_image_focus: bad arguments");
+    if (!imgs || !focus || W <= 0 || H <= 0 || n < 1 || n > 64) return set_err(c, EORB_E_ARG, "measure_image_focus: bad arguments");
     hipSetDevice(c->device);
     int rc;
-    if ((rc = up(c, c->img_f32, img, sizeof(float) * (size_t)W * H))) return rc;
-    if ((rc = ensure(c, c->minmax, 64))) return rc;
-    if ((rc = ev_focus_dev(c, (const float*)c->img_f32.p, W, H, (float*)c->minmax.p))) return rc;
-    EORB_HIP(c, hipMemcpyAsync(focus, c->minmax.p, 4, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = up(c, c->img_f32, imgs, sizeof(float) * (size_t)W * H * n))) return rc;
+    if ((rc = ensure(c, c->minmax, 256))) return rc;
+    if ((rc = ev_focus_dev(c, (const float*)c->img_f32.p, n, W, H, (float*)c->minmax.p))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(focus, c->minmax.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     return EORB_OK;
 }
+int eorb_measure_image_focus(eorb_ctx* c, const float* img, int W, int H, float* focus) { return eorb_measure_image_focus_n(c, img, 1, W, H, focus); }
 
 int eorb_normalize_minmax_u8(eorb_ctx* c, const float* img, int W, int H, uint8_t* out)
 {

@@ -1458,52 +1458,62 @@ int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, 
 // accumulation (the order of those 900 additions is part of the result), then the patch deviations summed in patch order.  One
 // wavefront per patch stages the patch in LDS (coalesced rows), one lane walks it in raster order; a second small launch adds the
 // patches up (one thread per patch reading 900 floats from global memory one after the other took 93 us; this takes ~10).
-__global__ __launch_bounds__(64) void ev_focus_patch_kernel(const float* __restrict__ img, int W, int H, float* __restrict__ sd)
+__global__ __launch_bounds__(64) void ev_focus_patch_kernel(const float* __restrict__ imgs, int W, int H, int np, float* __restrict__ sd)
 {
+    // one wavefront per (image, patch): the patch staged in LDS, then cv::meanStdDev's two raster-order f64 sums (sum and sum of
+    // squares are independent chains: lane 0 walks one, lane 1 the other)
     __shared__ __attribute__((aligned(16))) float px[30 * 30 + 12];
+    __shared__ double s_sum[2];
     const int patch = 30;
     const int pc = (W + patch - 1) / patch;
-    const int p = blockIdx.x;
+    const int im = blockIdx.x / np, p = blockIdx.x % np;
+    const float* img = imgs + (size_t)im * W * H;
     const int i = (p / pc) * patch, j = (p % pc) * patch;
     const int maxRow = min(i + patch, H), maxCol = min(j + patch, W);
     const int pw = maxCol - j, ph = maxRow - i, n = pw * ph;
     for (int k = threadIdx.x; k < n; k += 64) { const int y = k / pw, x = k - y * pw; px[k] = img[(size_t)(i + y) * W + j + x]; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0, sq = 0;
+    if (threadIdx.x < 2) {
+        const bool sq = threadIdx.x == 1;
+        double s = 0;
         int k = 0;
         for (; k + 8 <= n; k += 8) {                 // (two 16-byte LDS reads in flight per round; the additions stay in raster order)
             const float4 a = *(const float4*)&px[k], b = *(const float4*)&px[k + 4];
             const float v8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const double v = (double)v8[u]; s += v; sq += v * v; }
+            for (int u = 0; u < 8; u++) { const double v = (double)v8[u]; s += sq ? v * v : v; }
         }
-        for (; k < n; k++) { const double v = (double)px[k]; s += v; sq += v * v; }
+        for (; k < n; k++) { const double v = (double)px[k]; s += sq ? v * v : v; }
+        s_sum[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const double N = (double)ph * (double)pw;
         const double scale = 1.0 / N;
-        const double mean = s * scale;
-        double var = sq * scale - mean * mean;
+        const double mean = s_sum[0] * scale;
+        double var = s_sum[1] * scale - mean * mean;
         if (var < 0) var = 0;
-        sd[p] = (float)sqrt(var);
+        sd[blockIdx.x] = (float)sqrt(var);
     }
 }
 __global__ void ev_focus_sum_kernel(const float* __restrict__ sd, int np, float* __restrict__ out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (threadIdx.x == 0) {                          // one block per image
         float localStd = 0.f;
-        for (int p = 0; p < np; p++) localStd += sd[p];
-        out[0] = localStd / (float)np;
+        for (int p = 0; p < np; p++) localStd += sd[(size_t)blockIdx.x * np + p];
+        out[blockIdx.x] = localStd / (float)np;
     }
 }
 
-int ev_focus_dev(eorb_ctx* c, const float* d_img, int W, int H, float* d_out)
+// nimg images of W x H back to back (the motion-compensation contest scores its reconstructions together, EvImBuilder.cpp:1165-1203)
+int ev_focus_dev(eorb_ctx* c, const float* d_img, int nimg, int W, int H, float* d_out)
 {
     const int np = ((W + 29) / 30) * ((H + 29) / 30);
     int rc;
-    if ((rc = ensure(c, c->focus_sd, sizeof(float) * (size_t)np))) return rc;
+    if ((rc = ensure(c, c->focus_sd, sizeof(float) * (size_t)np * nimg))) return rc;
     ProfScope ps(c, "ev_focus");
-    ev_focus_patch_kernel<<<np, 64, 0, c->stream>>>(d_img, W, H, (float*)c->focus_sd.p);
-    ev_focus_sum_kernel<<<1, 64, 0, c->stream>>>((const float*)c->focus_sd.p, np, d_out);
+    ev_focus_patch_kernel<<<np * nimg, 64, 0, c->stream>>>(d_img, W, H, np, (float*)c->focus_sd.p);
+    ev_focus_sum_kernel<<<nimg, 64, 0, c->stream>>>((const float*)c->focus_sd.p, np, d_out);
     EORB_LAUNCH_CHECK(c, "ev_focus kernels");
     return EORB_OK;
 }

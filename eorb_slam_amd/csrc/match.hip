@@ -25,15 +25,17 @@ namespace eorb {
 constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;      // ORBmatcher.cc:36-38
 
 // ---------------------------------------------------------------------------------------------------
-// brute force 2-NN
+// brute force 2-NN.  LPQ lanes share a query (16, 32 or 64: 16 / 8 / 4 queries per workgroup); the launcher picks the widest
+// sharing that still gives every CU a workgroup (2 000 queries: 125 workgroups at 16 lanes per query, 500 at 64)
+template <int LPQ>
 __global__ __launch_bounds__(256) void bf_knn2_kernel(const uint8_t* __restrict__ q, int nq,
                                                       const uint8_t* __restrict__ t, int nt,
                                                       int32_t* __restrict__ idx2, int32_t* __restrict__ dist2)
 {
     __shared__ uint64_t tile[256 * 4];
     const int tid = threadIdx.x;
-    const int part = tid & 15;
-    const int qi = blockIdx.x * 16 + (tid >> 4);
+    const int part = tid & (LPQ - 1);
+    const int qi = blockIdx.x * (256 / LPQ) + tid / LPQ;
     uint64_t qa[4] = {0, 0, 0, 0};
     if (qi < nq) {
         const uint64_t* qp = (const uint64_t*)(q + (size_t)qi * 32);
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void bf_knn2_kernel(const uint8_t* __restrict_
             tile[tid * 4 + 0] = tp[0]; tile[tid * 4 + 1] = tp[1]; tile[tid * 4 + 2] = tp[2]; tile[tid * 4 + 3] = tp[3];
         }
         __syncthreads();
-        for (int j = part; j < nload; j += 16) {
+        for (int j = part; j < nload; j += LPQ) {
             const uint64_t* tp = &tile[j * 4];
             const int d = __popcll(qa[0] ^ tp[0]) + __popcll(qa[1] ^ tp[1]) + __popcll(qa[2] ^ tp[2]) + __popcll(qa[3] ^ tp[3]);
             const uint64_t key = ((uint64_t)d << 32) | (uint32_t)(t0 + j);
@@ -57,9 +59,9 @@ __global__ __launch_bounds__(256) void bf_knn2_kernel(const uint8_t* __restrict_
             else if (key < k1) k1 = key;
         }
     }
-    // merge the 16 partial top-2 lists of a query
+    // merge the LPQ partial top-2 lists of a query
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) {
+    for (int d = LPQ / 2; d >= 1; d >>= 1) {
         const uint64_t o0 = __shfl_xor(k0, d, 64), o1 = __shfl_xor(k1, d, 64);
         // top-2 of {k0,k1,o0,o1}
         const uint64_t lo = k0 < o0 ? k0 : o0;
@@ -1486,7 +1488,9 @@ int bf_knn2_dev(eorb_ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int
 {
     if (nq <= 0) return EORB_OK;
     ProfScope ps(c, "bf_knn2");
-    bf_knn2_kernel<<<(nq + 15) / 16, 256, 0, c->stream>>>(d_q, nq, d_t, nt, d_idx2, d_dist2);
+    if (nq >= 16 * 1024) bf_knn2_kernel<16><<<(nq + 15) / 16, 256, 0, c->stream>>>(d_q, nq, d_t, nt, d_idx2, d_dist2);
+    else if (nq >= 8 * 512) bf_knn2_kernel<32><<<(nq + 7) / 8, 256, 0, c->stream>>>(d_q, nq, d_t, nt, d_idx2, d_dist2);
+    else bf_knn2_kernel<64><<<(nq + 3) / 4, 256, 0, c->stream>>>(d_q, nq, d_t, nt, d_idx2, d_dist2);
     EORB_LAUNCH_CHECK(c, "bf_knn2_kernel");
     return EORB_OK;
 }

@@ -235,6 +235,16 @@ class EvImConverter:
         ctx.check(ctx.L.eorb_measure_image_focus(ctx.h, _p(img), W, H, C.byref(f)))
         return f.value
 
+    @staticmethod
+    def measureImageFocusN(images, ctx=None):
+        """the focus scores of n images (n, H, W) in one call: the four reconstructions of the motion-compensation contest
+        (src/Event/EvImBuilder.cpp:1165-1203)"""
+        ctx = ctx or default_context()
+        imgs = np.ascontiguousarray(images, np.float32); n, H, W = imgs.shape
+        f = np.zeros(n, np.float32)
+        ctx.check(ctx.L.eorb_measure_image_focus_n(ctx.h, _p(imgs), n, W, H, _p(f)))
+        return f
+
 
 def cv_normalize_minmax_u8(image, ctx=None):
     """cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) as called at src/Event/EvImBuilder.cpp:1076"""

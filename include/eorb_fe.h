@@ -188,6 +188,9 @@ int eorb_ev2mci_se2_cam(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eor
                         int W, int H, float sigma, int pol, int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
 /* replaces EvImConverter::measureImageFocus (src/Event/EventConversion.cc:74-111) */
 int eorb_measure_image_focus(eorb_ctx* ctx, const float* img, int W, int H, float* focus);
+/* n images of W x H back to back in one call (the motion-compensation contest scores its reconstructions together,
+ * src/Event/EvImBuilder.cpp:1165-1203): focus[n] */
+int eorb_measure_image_focus_n(eorb_ctx* ctx, const float* imgs, int n, int W, int H, float* focus);
 /* replaces cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) at src/Event/EvImBuilder.cpp:976,1055,1076,1140 */
 int eorb_normalize_minmax_u8(eorb_ctx* ctx, const float* img, int W, int H, uint8_t* out);
 

@@ -50,6 +50,9 @@ def main():
     img = orc.ev2mci_se3(ev, CAM, 0.031, axis, t, 1.7, W, H)[0]
     g = gpu(ctx, lambda: E.measureImageFocus(img, ctx=ctx)); c = timed(lambda: orc.measure_image_focus(img))
     rows["f1 measureImageFocus 240x180"] = {"gpu_kernels_ms": sum(g.values()), "cpu_oracle_ms": c}
+    img4 = np.stack([img, img * 0.5, img + 0.25, img * 1.5])
+    g = gpu(ctx, lambda: E.measureImageFocusN(img4, ctx=ctx))
+    rows["f1 measureImageFocus x 4 in one call (the MCI contest)"] = {"gpu_kernels_ms": sum(g.values()), "cpu_oracle_ms": 4 * c}
     # ---- f4: loader ----
     raw = synth.random_raw_events(1000000, W, H, seed=5)
     mx, my = synth.undistort_lut(W, H)

@@ -1552,6 +1552,10 @@ def test_ev2mci_se2_and_focus_contest(oracle, fe, ctx):
         assert np.array_equal(oracle.cv_normalize_minmax_u8(of), fe.cv_normalize_minmax_u8(gf, ctx=ctx)), k
         scores[k] = fo
     assert len(set(scores.values())) == len(scores)
+    # the contest's reconstructions scored in one call
+    keys = list(cands)
+    fn = fe.EvImConverter.measureImageFocusN(np.stack([cands[k][1] for k in keys]), ctx=ctx)
+    assert [np.float32(scores[k]).tobytes() for k in keys] == [np.float32(v).tobytes() for v in fn]
     flat = np.zeros((180, 240), np.float32)
     assert np.array_equal(oracle.cv_normalize_minmax_u8(flat), fe.cv_normalize_minmax_u8(flat, ctx=ctx))
     assert oracle.measure_image_focus(flat) == fe.EvImConverter.measureImageFocus(flat, ctx=ctx) == 0.0
