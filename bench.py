@@ -462,14 +462,19 @@ def run_batch(env):
     recv = [torch.empty(seqs[0][2]["rec"].shape, dtype=torch.uint8, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     step_no = [0]
 
+    dbg = os.environ.get("EORB_BENCH_DEBUG")
+
     def step():
         si = step_no[0] % S; step_no[0] += 1
         _, fb_i, bf = seqs[si]
+        t_dbg = time.perf_counter()
         with torch.cuda.stream(streams[si]):
             fb_i.run_dev(d_ev.data_ptr(), offsets, bf["img"].data_ptr(), bf["kp"].data_ptr(), bf["desc"].data_ptr(), bf["n"].data_ptr(),
                          bf["m"].data_ptr(), bf["nm"].data_ptr(), raw=use_raw)
             if world > 1:       # final keypoint gather (RCCL over xGMI), fixed-capacity records, on the producing stream
                 shard.gather_packed(bf["rec"], 0, recv, a.backend)
+        if dbg:
+            print("step %d: %.2f ms inside the call" % (step_no[0], (time.perf_counter() - t_dbg) * 1e3), file=sys.stderr)
 
     def arm_prof():
         if not a.no_prof:

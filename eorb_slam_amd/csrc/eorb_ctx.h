@@ -92,9 +92,13 @@ struct eorb_ctx {
     // slot form of the raw accumulation (ev_slots.hip): per sensor pixel its tiles / slot numbers, per tile its rows; valid when sl_ok
     eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_plan, sl_trace; long long sl_trace_n = 0;
     int sl_ok = 0, sl_null = 0, sl_rank_ok = -1;
+    int* rb_pinned = nullptr;                   // 64 ints of pinned host memory: the landing place of small read-backs (position count, slot info)
+    int sl_launched = 0; int sl_hinfo[6] = {0, 0, 0, 0, 0, 0};      // assignment kernels launched, their read-back (ev_slots_prepare_launch / _finish)
+    int dd_src_info_done = 0;                   // float bulk path: src_info of the per-call table already launched
     long long sl_calls = 0; size_t sl_info_off = 0;     // test hook counters (eorb_debug_counter)
     // float events in bulk: the distinct positions of a call become the rows of a per-call stamp table (ev_accumulate_dev)
-    eorb::DevBuf dd_tab, dd_src_info, dd_stamps, dd_ev, dd_cnt;
+    eorb::DevBuf dd_tab, dd_src_info, dd_stamps, dd_ev, dd_cnt, dd_sl_tab, dd_sl_tile, dd_sl_rows;
+    int dd_sl_ok = 0, dd_sl_null = 0; size_t dd_sl_info_off = 0;
     eorb::DevBuf focus_sd;                       // measureImageFocus: per-patch deviations
     int64_t dbg_dd_min = (int64_t)1 << 20;       // events from which the positions are deduplicated (test hook: "dedupe_min_events")
     int lut_w = 0, lut_h = 0, lut_check = 1;
@@ -140,6 +144,7 @@ int  ensure(eorb_ctx* c, DevBuf& b, size_t bytes);
 void* pinned(eorb_ctx* c, size_t bytes);        // next free slot of the pinned ring (waits for the slot's previous copy)
 void pinned_commit(eorb_ctx* c);                // call right after the hipMemcpyAsync that reads the slot
 int  hip_check(eorb_ctx* c, hipError_t e, const char* what);
+int* readback_buf(eorb_ctx* c);                 // c->rb_pinned, allocated on first use (nullptr: allocation failed)
 
 // scoped per-kernel timing (HIP events on the ctx stream) when profiling is enabled
 struct ProfScope {
@@ -159,7 +164,9 @@ int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, 
 int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* d_lineend, eorb_raw_event* d_ev, uint8_t* d_status,
                       eorb_raw_event* d_out, uint32_t* d_blk, size_t max_lines, uint32_t h_res[3]);
 // ev_slots.hip
-int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps, int stamp_stride, int SWP);
+int ev_slots_prepare_launch(eorb_ctx* c, int W, int H, int h, int TX, int TY);
+int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps /* nullptr: taps from c->lut */, int stamp_stride, int SWP,
+                      float two_sig2, float norm);
 int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
                         float* d_f32, uint32_t* d_minmax_enc);
 int ev_slots_trace_read(eorb_ctx* c, unsigned long long* out, long long max_records);

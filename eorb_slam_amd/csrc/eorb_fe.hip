@@ -130,6 +130,12 @@ void prof_collect(eorb_ctx* c)
     }
 }
 
+int* readback_buf(eorb_ctx* c)
+{
+    if (!c->rb_pinned && hipHostMalloc((void**)&c->rb_pinned, 64 * sizeof(int), hipHostMallocDefault) != hipSuccess) c->rb_pinned = nullptr;
+    return c->rb_pinned;
+}
+
 static void free_buf(DevBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
 
 // Host-buffer entry points are called once per frame (src/Frame.cc:467-482, src/Tracking.cc:1420, EvImBuilder.cpp:1345): their
@@ -228,7 +234,7 @@ void eorb_destroy(eorb_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_plan, &c->sl_trace, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_plan, &c->sl_trace, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_sl_tab, &c->dd_sl_tile, &c->dd_sl_rows, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
@@ -237,6 +243,7 @@ void eorb_destroy(eorb_ctx* c)
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->dl_pinned) hipHostFree(c->dl_pinned);
+    if (c->rb_pinned) hipHostFree(c->rb_pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

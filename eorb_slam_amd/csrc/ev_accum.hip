@@ -1888,38 +1888,46 @@ static GatherParams ev_gather_params(int W, int H, int h, int TX, int TY, int NT
 
 // raw events: the tables derived from the maps (integer position of every sensor pixel, its stamp); rebuilt only when (image size,
 // sigma, mode) change
-static int ev_raw_tables(eorb_ctx* c, int W, int H, int h, float sigma, int mode_count, GatherParams& G, bool hashed = false)
+static int ev_raw_tables(eorb_ctx* c, int W, int H, int h, float sigma, int mode_count, GatherParams& G, bool hashed = false, bool want_slots = false)
 {
     int rc;
-    const bool raw = true;
-    if (raw) {
-        // tables derived from the maps; rebuilt only when (image size, sigma, mode) change
-        const int nsrc = c->lut_w * c->lut_h;
-        const int SW = 2 * h + 1, SWP = (SW + 3) & ~3;
-        G.stamp_stride = SW * SWP; G.stamp_colstride = SWP;
-        if (c->lut_key_W != W || c->lut_key_H != H || c->lut_key_sigma != sigma || c->lut_key_mode != mode_count) {
-            ProfScope ps(c, "ev_stamp_tables");
+    // tables derived from the maps; rebuilt only when (image size, sigma, mode) change
+    const int nsrc = c->lut_w * c->lut_h;
+    const int SW = 2 * h + 1, SWP = (SW + 3) & ~3;
+    G.stamp_stride = SW * SWP; G.stamp_colstride = SWP;
+    if (c->lut_key_W != W || c->lut_key_H != H || c->lut_key_sigma != sigma || c->lut_key_mode != mode_count) {
+        ProfScope ps(c, "ev_stamp_tables");
+        const int TXs = (W + kTile - 1) / kTile, TYs = (H + kTile - 1) / kTile;
+        if (!(hashed && c->dd_src_info_done)) {
             if ((rc = ensure(c, c->src_info, sizeof(uint32_t) * (size_t)nsrc))) return rc;
             ev_src_info_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, nsrc, W, H, c->lut_check, mode_count,
                                                                             (uint32_t*)c->src_info.p);
-            if (!mode_count) {
-                if ((size_t)nsrc * SW * SWP * 4 + 256 >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
-                if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 2 * kStampPad)))) return rc;
-                EORB_HIP(c, hipMemsetAsync(c->stamps.p, 0, sizeof(float) * kStampPad, c->stream));
-                EORB_HIP(c, hipMemsetAsync((float*)c->stamps.p + kStampPad + (size_t)nsrc * SW * SWP, 0, sizeof(float) * kStampPad, c->stream));
-                ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
-                                                             (float*)c->stamps.p + kStampPad);
-            }
-            EORB_LAUNCH_CHECK(c, "ev_stamp_tables kernels");
-            c->sl_ok = 0;
-            if (!mode_count && !hashed) {
-                const int TXs = (W + kTile - 1) / kTile, TYs = (H + kTile - 1) / kTile;
-                if ((rc = ev_slots_prepare(c, W, H, h, TXs, TYs, (const float*)c->stamps.p + kStampPad, G.stamp_stride, G.stamp_colstride))) return rc;
-            }
-            c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
+            EORB_LAUNCH_CHECK(c, "ev_src_info_kernel");
+            c->sl_launched = 0;
         }
-        G.stamps = (const float*)c->stamps.p + kStampPad;     // K2r reads up to 7 floats before / behind a column
+        c->dd_src_info_done = 0;
+        if (!(hashed && want_slots)) c->sl_launched = 0;      // (an assignment launched ahead by the float bulk path serves that call only)
+        c->sl_ok = 0;
+        bool need_stamps = !mode_count;
+        if (!mode_count && hashed && want_slots) {
+            // the per-call positions of float events (2^20 table rows, most of them empty): the slot form computes its rows from the
+            // positions, so the 235 MB stamp table is only built when that form cannot serve the call
+            if ((rc = ev_slots_prepare(c, W, H, h, TXs, TYs, nullptr, G.stamp_stride, G.stamp_colstride, G.two_sig2, G.norm))) return rc;
+            if (c->sl_ok) need_stamps = false;
+        }
+        if (need_stamps) {
+            if ((size_t)nsrc * SW * SWP * 4 + 256 >= ((size_t)1 << 32)) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: stamp table of %d sensor pixels x %d taps is too large", nsrc, SW * SWP);
+            if ((rc = ensure(c, c->stamps, sizeof(float) * ((size_t)nsrc * SW * SWP + 2 * kStampPad)))) return rc;
+            EORB_HIP(c, hipMemsetAsync(c->stamps.p, 0, sizeof(float) * kStampPad, c->stream));
+            EORB_HIP(c, hipMemsetAsync((float*)c->stamps.p + kStampPad + (size_t)nsrc * SW * SWP, 0, sizeof(float) * kStampPad, c->stream));
+            ev_stamp_kernel<<<2048, 256, 0, c->stream>>>((const float2*)c->lut.p, (const uint32_t*)c->src_info.p, nsrc, G,
+                                                         (float*)c->stamps.p + kStampPad);
+            EORB_LAUNCH_CHECK(c, "ev_stamp_kernel");
+            if (!hashed && (rc = ev_slots_prepare(c, W, H, h, TXs, TYs, (const float*)c->stamps.p + kStampPad, G.stamp_stride, G.stamp_colstride, G.two_sig2, G.norm))) return rc;
+        }
+        c->lut_key_W = W; c->lut_key_H = H; c->lut_key_sigma = sigma; c->lut_key_mode = mode_count;
     }
+    G.stamps = (const float*)c->stamps.p + kStampPad;     // K2r reads up to 7 floats before / behind a column
     return EORB_OK;
 }
 
@@ -1976,12 +1984,40 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                 EORB_HIP(c, hipMemsetAsync(c->dd_cnt.p, 0, 64, c->stream));
                 dd_insert_kernel<<<4096, 256, 0, c->stream>>>(src, n0, (unsigned long long*)c->dd_tab.p, (int*)c->dd_cnt.p, (uint32_t*)c->dd_ev.p);
                 EORB_LAUNCH_CHECK(c, "dd_insert_kernel");
-                EORB_HIP(c, hipMemcpyAsync(hc, c->dd_cnt.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+                int* rb = readback_buf(c);
+                if (!rb) return set_err(c, EORB_E_HIP, "pinned alloc failed");
+                EORB_HIP(c, hipMemcpyAsync(rb, c->dd_cnt.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+                // in front of the wait: the integer positions of the table rows and the slot assignment (what the slot form's host
+                // side needs read back), so that the call waits for the stream once
+                if (!pol && !mode_count && (c->dbg_gather_form == 0 || c->dbg_gather_form == 2 || c->dbg_gather_form == 4) && h >= 1 && h <= 4) {
+                    std::swap(c->lut, c->dd_tab); std::swap(c->src_info, c->dd_src_info);
+                    std::swap(c->sl_tab, c->dd_sl_tab); std::swap(c->sl_tile, c->dd_sl_tile); std::swap(c->sl_info_off, c->dd_sl_info_off);
+                    const int sw0 = c->lut_w, sh0 = c->lut_h, sok0 = c->sl_ok;
+                    c->lut_w = 65536; c->lut_h = (int)(cap / 65536);
+                    int rc2 = ensure(c, c->src_info, sizeof(uint32_t) * cap);
+                    if (!rc2) {
+                        ev_src_info_kernel<<<(int)((cap + 255) / 256), 256, 0, c->stream>>>((const float2*)c->lut.p, (int)cap, W, H, 0, mode_count, (uint32_t*)c->src_info.p);
+                        rc2 = ev_slots_prepare_launch(c, W, H, h, TX, TY);
+                    }
+                    c->sl_ok = sok0;
+                    c->lut_w = sw0; c->lut_h = sh0;
+                    std::swap(c->lut, c->dd_tab); std::swap(c->src_info, c->dd_src_info);
+                    std::swap(c->sl_tab, c->dd_sl_tab); std::swap(c->sl_tile, c->dd_sl_tile); std::swap(c->sl_info_off, c->dd_sl_info_off);
+                    if (rc2) return rc2;
+                    c->dd_src_info_done = 1;
+                }
                 EORB_HIP(c, hipStreamSynchronize(c->stream));
+                hc[0] = rb[0]; hc[1] = rb[1];
             }
+            if (!(!hc[1] && hc[0] <= max_ids)) { c->dd_src_info_done = 0; c->sl_launched = 0; }
             if (!hc[1] && hc[0] <= max_ids) {
                 // the raw path on the per-call tables: the context's map state is swapped for the duration of the call
-                std::swap(c->lut, c->dd_tab); std::swap(c->src_info, c->dd_src_info); std::swap(c->stamps, c->dd_stamps);
+                auto swap_tables = [&]() {
+                    std::swap(c->lut, c->dd_tab); std::swap(c->src_info, c->dd_src_info); std::swap(c->stamps, c->dd_stamps);
+                    std::swap(c->sl_tab, c->dd_sl_tab); std::swap(c->sl_tile, c->dd_sl_tile); std::swap(c->sl_rows, c->dd_sl_rows);
+                    std::swap(c->sl_ok, c->dd_sl_ok); std::swap(c->sl_null, c->dd_sl_null); std::swap(c->sl_info_off, c->dd_sl_info_off);
+                };
+                swap_tables();
                 const int sw = c->lut_w, sh = c->lut_h, sc = c->lut_check, kW = c->lut_key_W, kH = c->lut_key_H, kM = c->lut_key_mode;
                 const float kS = c->lut_key_sigma;
                 c->lut_w = 65536; c->lut_h = (int)(cap / 65536); c->lut_check = 0;       // the hash table as the call's maps: slot = sensor pixel
@@ -1989,7 +2025,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                 std::vector<int64_t> off(B + 1);
                 for (int b = 0; b <= B; b++) off[b] = h_offsets[b] - h_offsets[0];
                 rc = ev_accumulate_dev(c, c->dd_ev.p, 2, off.data(), B, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, d_minmax_enc);
-                std::swap(c->lut, c->dd_tab); std::swap(c->src_info, c->dd_src_info); std::swap(c->stamps, c->dd_stamps);
+                swap_tables();
                 c->lut_w = sw; c->lut_h = sh; c->lut_check = sc; c->lut_key_W = kW; c->lut_key_H = kH; c->lut_key_mode = kM; c->lut_key_sigma = kS;
                 return rc;
             }
@@ -2031,19 +2067,19 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         }
     }
     // dense batches of raw events without polarity: two-byte slot lists, a tile position's rows in LDS (ev_slots.hip)
-    if (raw && !hashed && !mode_count && !pol && (c->dbg_gather_form == 0 || c->dbg_gather_form == 4)) {
+    if (raw && !mode_count && !pol && (c->dbg_gather_form == 0 || c->dbg_gather_form == 4 || (hashed && c->dbg_gather_form == 2))) {
         const int64_t nev0 = h_offsets[B] - h_offsets[0];
         const bool sparse0 = nev0 * dup < (int64_t)B * NT * 64;          // (fewer than one 64-entry batch per tile on average: K2s)
         if (c->dbg_gather_form == 4 || !sparse0) {
             int rc;
             GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, mode_count, B * NT, sigma);
-            if ((rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
+            if ((rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G, hashed, true))) return rc;
             if (c->sl_ok) {
                 {
                     ProfScope ps(c, "ev_minmax_init");
                     ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
                 }
-                if ((rc = ev_slots_accumulate(c, d_events, packed4 ? 4 : 16, h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc))) return rc;
+                if ((rc = ev_slots_accumulate(c, d_events, hashed ? -4 : (packed4 ? 4 : 16), h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc))) return rc;
                 if (normalized && d_u8) {
                     ProfScope ps(c, "ev_normalize");
                     dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);

@@ -19,6 +19,7 @@
 // bytes per entry) an entry costs ~4 issue slots and 2 bytes; the kernel is bound by the LDS array (2 cycles per entry and CU).
 #include "eorb_ctx.h"
 #include "ev_common.h"
+#include "dev_math.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <string.h>
@@ -91,8 +92,11 @@ __global__ __launch_bounds__(1024) void sl_rowbase_kernel(const uint32_t* __rest
 // that pixel (stamps[src][x offset][y offset], ev_stamp_kernel), +0.0f outside the stamp or the image
 __global__ __launch_bounds__(256) void sl_rows_kernel(const uint32_t* __restrict__ src_info, const uint2* __restrict__ slot_tab, int nsrc,
                                                       int W, int H, int h, int TX, const float* __restrict__ stamps, int stamp_stride,
-                                                      int SWP, const uint32_t* __restrict__ rowbase, float* __restrict__ rows)
+                                                      int SWP, const float2* __restrict__ lut, float two_sig2, float norm, const uint32_t* __restrict__ rowbase, float* __restrict__ rows)
 {
+    __shared__ uint64_t tab[32];
+    if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    __syncthreads();
     const int src = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (src >= nsrc) return;
     const uint2 st = slot_tab[src];
@@ -108,7 +112,19 @@ __global__ __launch_bounds__(256) void sl_rows_kernel(const uint32_t* __restrict
             const int px = (tx0 + dx) * 8 + (lane & 7), py = (ty0 + dy) * 8 + (lane >> 3);
             const int i = px - xi + h, j = py - yi + h;
             float v = 0.0f;
-            if (i >= 0 && i <= 2 * h && j >= 0 && j <= 2 * h && px < W && py < H) v = stamps[(size_t)src * stamp_stride + i * SWP + j];
+            if (i >= 0 && i <= 2 * h && j >= 0 && j <= 2 * h && px < W && py < H) {
+                if (stamps) v = stamps[(size_t)src * stamp_stride + i * SWP + j];
+                else {
+                    // no stamp table (the per-call positions of float events): the tap as ev_stamp_kernel evaluates it, exp_XY2f :59-65
+                    const float2 q = lut[src];
+                    const float xr = q.x - (float)xi, yr = q.y - (float)yi;
+                    const float fx = (float)(i - h) - xr, fy = (float)(j - h) - yr;
+                    const float xx = fx * fx, yy = fy * fy;
+                    float dd = xx + yy;
+                    dd = dd / two_sig2;
+                    v = dev_expf_nonpos<true>(-dd, tab) / norm;
+                }
+            }
             rows[((size_t)rowbase[tile] + slot) * 64 + lane] = v;
         }
 }
@@ -122,17 +138,20 @@ __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __r
     const ChunkDesc cd = chunks[blockIdx.x];
     for (int i = threadIdx.x; i < NT; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)stride;      // 16-byte eorb_raw_event or 4-byte eorb_raw_event4
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed
     const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
+    const bool hashed = stride < 0;          // stride -4: 4-byte records { row of the position's table entry | polarity << 31 } (float events in bulk)
     constexpr int U = 8;
     for (int k0 = threadIdx.x; k0 < cd.n; k0 += blockDim.x * U) {
         uint32_t xy[U], rg[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)(e + (size_t)k * (size_t)stride) : 0xffffffffu; }
+        for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride)) : 0xffffffffu; }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int x = (int)(xy[u] & xmask), y = (int)(xy[u] >> 16);
-            rg[u] = (x < LW && y < LH) ? slot_tab[(uint32_t)y * (uint32_t)LW + x].x : 0u;
+            const uint32_t row = xy[u] & 0x7fffffffu;                    // hashed records: the row of the event's position
+            if (hashed) rg[u] = (row != 0x7fffffffu && row < (uint32_t)LW * (uint32_t)LH) ? slot_tab[row].x : 0u;
+            else rg[u] = (x < LW && y < LH) ? slot_tab[(uint32_t)y * (uint32_t)LW + x].x : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -221,8 +240,9 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
     uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
     uint32_t* gbase = (uint32_t*)(loff + NTp + 2);                    // NT
     for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
-    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)stride;      // 16-byte eorb_raw_event or 4-byte eorb_raw_event4
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed
     const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
+    const bool hashed = stride < 0;          // stride -4: 4-byte records { row of the position's table entry | polarity << 31 } (float events in bulk)
     const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
     const int S = Q >> 6;
     constexpr int SMAX = 4;
@@ -234,9 +254,10 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         const int k = wave * Q + s * 64 + lane;
-        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)stride) : 0xffffffffu;
+        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride)) : 0xffffffffu;
         const int x = q == 0xffffffffu ? 0xffff : (int)(q & xmask), y = (int)(q >> 16);
-        rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
+        if (hashed) { const uint32_t row = q & 0x7fffffffu; rsrc[s] = (row != 0x7fffffffu && row < (uint32_t)LW * (uint32_t)LH) ? row : 0xffffffffu; }
+        else rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
     }
     uint2 rst[SMAX];
 #pragma unroll
@@ -361,8 +382,9 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(co
     uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
     uint8_t* sorted = (uint8_t*)(loff + NTp + 2);                     // chunk_cap * 4: the entry bytes in tile-sorted order
     for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
-    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)stride;      // 16-byte eorb_raw_event or 4-byte eorb_raw_event4
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed
     const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
+    const bool hashed = stride < 0;          // stride -4: 4-byte records { row of the position's table entry | polarity << 31 } (float events in bulk)
     const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
     const int S = Q >> 6;
     constexpr int SMAX = 4;
@@ -373,9 +395,10 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(co
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         const int k = wave * Q + s * 64 + lane;
-        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)stride) : 0xffffffffu;
+        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride)) : 0xffffffffu;
         const int x = q == 0xffffffffu ? 0xffff : (int)(q & xmask), y = (int)(q >> 16);
-        rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
+        if (hashed) { const uint32_t row = q & 0x7fffffffu; rsrc[s] = (row != 0x7fffffffu && row < (uint32_t)LW * (uint32_t)LH) ? row : 0xffffffffu; }
+        else rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
     }
     uint2 rst[SMAX];
 #pragma unroll
@@ -740,10 +763,12 @@ void sl_gather_kernel(SlotGather P)
 }
 
 // ---- host ----
-// tables of the current maps / sigma (called from ev_raw_tables when they change); c->sl_ok = 1 when the slot form can run
-int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps, int stamp_stride, int SWP)
+// Two halves, so that a caller that synchronises anyway (the float bulk path waits for its position count) can put the slot
+// assignment in front of ITS wait: launch = assignment + row bases (+ the once-per-context rank check), info read back into
+// c->sl_hinfo by an asynchronous copy; finish = after the stream was waited for: the rows, sl_ok.
+int ev_slots_prepare_launch(eorb_ctx* c, int W, int H, int h, int TX, int TY)
 {
-    c->sl_ok = 0;
+    c->sl_ok = 0; c->sl_launched = 0;
     if (h < 1 || h > 4 || TX >= 256 || TY >= 256) return EORB_OK;
     const int nsrc = c->lut_w * c->lut_h, NT = TX * TY;
     int rc;
@@ -763,18 +788,43 @@ int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const flo
         unsigned long long* d_bad = (unsigned long long*)(d_info + 4);
         sl_rankcheck_kernel<<<256, 256, 0, c->stream>>>(d_bad);
     }
-    int hinfo[6] = {0, 0, 0, 0, 0, 0};
-    EORB_HIP(c, hipMemcpyAsync(hinfo, d_info, sizeof(hinfo), hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    int* rb = readback_buf(c);
+    if (!rb) return set_err(c, EORB_E_HIP, "pinned alloc failed");
+    EORB_HIP(c, hipMemcpyAsync(rb + 8, d_info, sizeof(c->sl_hinfo), hipMemcpyDeviceToHost, c->stream));
+    c->sl_launched = 1;
+    return EORB_OK;
+}
+
+int ev_slots_prepare_finish(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps, int stamp_stride, int SWP, float two_sig2, float norm)
+{
+    if (!c->sl_launched) return EORB_OK;
+    c->sl_launched = 0;
+    const int nsrc = c->lut_w * c->lut_h, NT = TX * TY;
+    memcpy(c->sl_hinfo, readback_buf(c) + 8, sizeof(c->sl_hinfo));
+    const int* hinfo = c->sl_hinfo;
+    int rc;
     if (c->sl_rank_ok < 0) c->sl_rank_ok = (hinfo[4] == 0 && hinfo[5] == 0) ? 1 : 0;
     if (hinfo[2] || hinfo[1] >= (int)kNoSlot || hinfo[0] <= 0) return EORB_OK;      // a tile with more than 254 slots: the batch pipeline serves these maps
     if ((rc = ensure(c, c->sl_rows, sizeof(float) * 64 * (size_t)hinfo[0] + 4096))) return rc;
+    const uint32_t* d_rowbase = (const uint32_t*)c->sl_tile.p + NT;
     sl_rows_kernel<<<(nsrc + 3) / 4, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, (const uint2*)c->sl_tab.p, nsrc, W, H, h, TX, d_stamps,
-                                                            stamp_stride, SWP, d_rowbase, (float*)c->sl_rows.p);
+                                                            stamp_stride, SWP, (const float2*)c->lut.p, two_sig2, norm, d_rowbase, (float*)c->sl_rows.p);
     EORB_LAUNCH_CHECK(c, "sl_rows_kernel");
     c->sl_null = hinfo[1];
     c->sl_ok = 1;
     return EORB_OK;
+}
+
+// tables of the current maps / sigma (called from ev_raw_tables when they change); c->sl_ok = 1 when the slot form can run
+int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps, int stamp_stride, int SWP, float two_sig2, float norm)
+{
+    int rc;
+    if (!c->sl_launched) {
+        if ((rc = ev_slots_prepare_launch(c, W, H, h, TX, TY))) return rc;
+        if (!c->sl_launched) return EORB_OK;
+        EORB_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return ev_slots_prepare_finish(c, W, H, h, TX, TY, d_stamps, stamp_stride, SWP, two_sig2, norm);
 }
 
 // count -> scan -> scatter -> order -> gather for B slices of raw events (no polarity, Gaussian stamp)

@@ -45,9 +45,10 @@ def test_ev2im_gauss_bit_exact(oracle, fe, ctx, case):
     W, H = case.get("W", 240), case.get("H", 180)
     ev = synth.random_events(case["n"], W, H, seed=11 + case["n"], frac=case["frac"])
     try:
-        for form in (0, 1, 3, -1):
-            # -1: the bulk form of the float path at test size (the distinct positions of the call tabulated, then the raw kernels)
-            ctx.debug_option("gather_form", 2 if form < 0 else form)
+        for form in (0, 1, 3, -1, -4):
+            # -1: the bulk form of the float path at test size (the distinct positions of the call tabulated, then the raw kernels);
+            # -4: the same with the slot lists (rows computed from the call's positions)
+            ctx.debug_option("gather_form", (2 if form == -1 else 4) if form < 0 else form)
             ctx.debug_option("dedupe_min_events", 1 if form < 0 else 1 << 20)
             for normalized in (True, False):
                 of, ou, omm = oracle.ev2im_gauss(ev, W, H, case["sigma"], case["pol"], normalized)
