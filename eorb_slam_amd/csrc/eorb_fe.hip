@@ -234,7 +234,7 @@ void eorb_destroy(eorb_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_plan, &c->sl_trace, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_sl_tab, &c->dd_sl_tile, &c->dd_sl_rows, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_plan, &c->sl_trace, &c->sl_hot, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_sl_tab, &c->dd_sl_tile, &c->dd_sl_rows, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
@@ -244,6 +244,9 @@ void eorb_destroy(eorb_ctx* c)
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->dl_pinned) hipHostFree(c->dl_pinned);
     if (c->rb_pinned) hipHostFree(c->rb_pinned);
+    if (c->sl_ev_fork) hipEventDestroy(c->sl_ev_fork);
+    if (c->sl_ev_join) hipEventDestroy(c->sl_ev_join);
+    if (c->sl_side) hipStreamDestroy(c->sl_side);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -282,6 +285,14 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
     if (!c || !name) return -1;
     if (!strcmp(name, "slot_calls")) return c->sl_calls;
     if (!strcmp(name, "slot_rank_ok")) return c->sl_rank_ok;
+    if (!strcmp(name, "slot_hot_items")) {              // lists the last slot-form call handed to the register-row kernel (synchronises)
+        if (!c->sl_hot.p) return 0;
+        uint32_t h[16];
+        if (hipMemcpyAsync(h, c->sl_hot.p, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+        long long n = 0;
+        for (int i = 0; i < 16; i++) n += h[i];
+        return n;
+    }
     if (!strcmp(name, "slot_flags")) {
         if (!c->sl_tile.p || !c->sl_info_off) return 0;
         int flags = 0;

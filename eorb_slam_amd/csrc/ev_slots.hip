@@ -20,6 +20,7 @@
 #include "eorb_ctx.h"
 #include "ev_common.h"
 #include "dev_math.h"
+#include "sl_hot_asm.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <string.h>
@@ -130,8 +131,10 @@ __global__ __launch_bounds__(256) void sl_rows_kernel(const uint32_t* __restrict
 }
 
 // ---- K1a: entries of every (chunk, tile) -----------------------------------------------------------------------------------------
+// (stride: 16 = eorb_raw_event, 4 = eorb_raw_event4, -4 = hashed records; a template parameter in the two hot kernels)
+template <int stride>
 __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
-                                                       const uint2* __restrict__ slot_tab, int stride, int LW, int LH, int TX, int NT,
+                                                       const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
                                                        uint16_t* __restrict__ segcnt)
 {
     extern __shared__ uint32_t cnt[];               // NT
@@ -363,8 +366,9 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
 // in order, and the waves' shares are ordered by the prefix over the waves -- so no ballots, no parity classes, no per-event list
 // of sorted slots: phase A keeps four 8-bit ranks per event, phase C writes the entry byte and its tile straight to their place
 // in the chunk's tile-sorted order, phase D streams that order out run by run.
+template <int stride>
 __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
-                                                                              const uint2* __restrict__ slot_tab, int stride, int LW, int LH, int TX, int NT,
+                                                                              const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
                                                                               int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                                               const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
                                                                               uint8_t* __restrict__ entries)
@@ -511,15 +515,56 @@ __global__ __launch_bounds__(256) void sl_rankcheck_kernel(unsigned long long* b
 // (1) per tile position: its (slice, tile) lists sorted longest first (a list is a serial chain of adds: the long ones must start
 //     early), each with its descriptor { slice, entries, list offset } so that a ticket costs the gather ONE load; the position's
 //     total and its longest list
+// A list of hot_min entries or more goes to sl_hot_kernel instead (rows in registers, a third of the time per entry): its descriptor
+// { slice, tile, entries, list offset (2), tile x0, tile y0, byte offset of the tile's rows } lands in one of 16 buckets by length
+// (bucket 0 = longest: the hot kernel takes them in that order), and the position's own list carries it with the top bit of the slice
+// set, for the gather to skip.
+constexpr int kHotBuckets = 16, kHotCap = 8192;
+struct HotDesc { uint32_t slice, tile, cnt, off_lo, off_hi, tx0, ty0, rows_off; };
 __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_base,
-                                                      const int64_t* __restrict__ slice_ebase, int B, int NT, uint4* __restrict__ items,
-                                                      uint32_t* __restrict__ tile_w, uint32_t* __restrict__ tile_m, uint32_t* __restrict__ ctr)
+                                                      const int64_t* __restrict__ slice_ebase, int B, int NT, int TX, uint32_t hot_min,
+                                                      const uint32_t* __restrict__ nslots, const uint32_t* __restrict__ rowbase,
+                                                      uint4* __restrict__ items, uint32_t* __restrict__ tile_w, uint32_t* __restrict__ tile_m,
+                                                      uint32_t* __restrict__ ctr, uint32_t* __restrict__ hot_cnt, HotDesc* __restrict__ hot_items)
 {
-    extern __shared__ uint32_t pc[];                 // B counts
+    extern __shared__ uint32_t pc[];                 // B counts | B (bucket << 16 | index in the block's share of the bucket)
     __shared__ uint32_t red[8];
+    __shared__ uint32_t hb[kHotBuckets], hbase[kHotBuckets];
+    uint32_t* hloc = pc + B;
     const int t = blockIdx.x, tid = threadIdx.x;
+    const bool hot_ok = hot_min != 0u && nslots[t] <= (uint32_t)SL_HOT_NROWS;
+    if (tid < kHotBuckets) hb[tid] = 0u;
+    __syncthreads();
+    for (int s = tid; s < B; s += blockDim.x) {
+        const uint32_t c = tile_cnt[(size_t)s * NT + t];
+        uint32_t v = c;
+        if (hot_ok && c >= hot_min) {
+            // quarter octaves above hot_min, longest first; the block's lists of a bucket are counted here, placed below
+            const int lg = 31 - __clz(c), lg0 = 31 - __clz(hot_min);
+            const int q = (lg - lg0) * 4 + (int)((c >> max(lg - 2, 0)) & 3u) - (int)((hot_min >> max(lg0 - 2, 0)) & 3u);
+            const int b = kHotBuckets - 1 - min(max(q, 0), kHotBuckets - 1);
+            hloc[s] = ((uint32_t)b << 16) | atomicAdd(&hb[b], 1u);
+            v = c | 0x80000000u;
+        }
+        pc[s] = v;
+    }
+    __syncthreads();
+    if (tid < kHotBuckets) hbase[tid] = hb[tid] ? atomicAdd(&hot_cnt[tid], hb[tid]) : 0u;      // (one atomic per bucket and position: sl_tasks_kernel caps the totals)
+    __syncthreads();
     uint32_t sum = 0, mx = 0;
-    for (int s = tid; s < B; s += blockDim.x) { const uint32_t c = tile_cnt[(size_t)s * NT + t]; pc[s] = c; sum += c; mx = max(mx, c); }
+    for (int s = tid; s < B; s += blockDim.x) {
+        uint32_t v = pc[s];
+        if (v & 0x80000000u) {
+            const uint32_t c = v & 0x7fffffffu, b = hloc[s] >> 16, k = hbase[b] + (hloc[s] & 0xffffu);
+            if (k < (uint32_t)kHotCap) {
+                const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
+                HotDesc d; d.slice = (uint32_t)s; d.tile = (uint32_t)t; d.cnt = c; d.off_lo = (uint32_t)off; d.off_hi = (uint32_t)(off >> 32);
+                d.tx0 = (uint32_t)(t % TX) * 8u; d.ty0 = (uint32_t)(t / TX) * 8u; d.rows_off = rowbase[t] * 256u;
+                hot_items[(size_t)b * kHotCap + k] = d;
+            } else { v = c; pc[s] = v; }            // the bucket is full: the gather keeps the list
+        }
+        if (!(v & 0x80000000u)) { sum += v; mx = max(mx, v); }
+    }
     __syncthreads();
     const bool sorted = B <= 2048;
     for (int s = tid; s < B; s += blockDim.x) {
@@ -527,7 +572,7 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
         int rank = s;
         if (sorted) { rank = 0; for (int j = 0; j < B; j++) { const uint32_t v = pc[j]; rank += (v > c || (v == c && j < s)) ? 1 : 0; } }
         const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
-        items[(size_t)t * B + rank] = make_uint4((uint32_t)s, c, (uint32_t)off, (uint32_t)(off >> 32));
+        items[(size_t)t * B + rank] = make_uint4((uint32_t)s | (c & 0x80000000u), c & 0x7fffffffu, (uint32_t)off, (uint32_t)(off >> 32));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { sum += (uint32_t)__shfl_xor((int)sum, d, 64); mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64)); }
@@ -542,8 +587,9 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
 // (2) the workgroup tasks: tile positions ordered by their longest list, position t repeated n_t = 1 + its share of the G - NT spare
 //     tasks by total entries (no more than its slices can occupy); unused tasks carry 0xffffffff
 __global__ __launch_bounds__(1024) void sl_tasks_kernel(const uint32_t* __restrict__ tile_w, const uint32_t* __restrict__ tile_m, int NT, int G,
-                                                        int max_per_tile, uint32_t* __restrict__ scratch /* 2 * NT */, uint32_t* __restrict__ task_tile)
+                                                        int max_per_tile, uint32_t* __restrict__ scratch /* 2 * NT */, uint32_t* __restrict__ task_tile, uint32_t* __restrict__ hot_cnt)
 {
+    if (threadIdx.x < kHotBuckets) hot_cnt[threadIdx.x] = min(hot_cnt[threadIdx.x], (uint32_t)kHotCap);
     __shared__ unsigned long long wred[16];
     __shared__ uint32_t wsum[16], wsum2[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -652,8 +698,9 @@ void sl_gather_kernel(SlotGather P)
     uint4 En = make_uint4(0u, 0u, 0u, 0u);
     bool have_first = false;
     while (k < nit) {
-        const int s = (int)uni(d.x);
-        const uint32_t cnt = uni(d.y);
+        const bool hot = (uni(d.x) >> 31) != 0u;                           // taken by sl_hot_kernel: nothing to do here
+        const int s = (int)(uni(d.x) & 0x7fffffffu);
+        const uint32_t cnt = hot ? 0u : uni(d.y);
         const uint4* const list = (const uint4*)(P.entries + (((uint64_t)uni(d.w) << 32) | uni(d.z)));
         // a long list is a serial chain of adds: its wave goes first at the issue arbiter
         if (cnt >= P.prio_ref) __builtin_amdgcn_s_setprio(3);
@@ -738,7 +785,7 @@ void sl_gather_kernel(SlotGather P)
         }
         // the slice's pixels of this tile; an empty list offers nothing to the running extremes (max stays -1e6:
         // resolveMinMaxVals :32-39)
-        if (inimg) P.img[(size_t)s * P.W * P.H + (size_t)py * P.W + px] = acc;
+        if (inimg && !hot) P.img[(size_t)s * P.W * P.H + (size_t)py * P.W + px] = acc;
         if (cnt) {
             // every increment is >= 0: the running maximum is the largest final value of a visited tile, the minimum stays 0
             float vmax = inimg ? acc : -1000000.0f;
@@ -760,6 +807,25 @@ void sl_gather_kernel(SlotGather P)
         r[0] = (unsigned long long)tile; r[1] = tr_t0; r[2] = wall_clock64(); r[3] = tr_ent; r[4] = tr_items; r[5] = tr_kept;
     }
 #endif
+}
+
+// ---- K2h: the long lists.  One wavefront per item at a time (tickets over the 16 length buckets, longest first): the tile
+// position's rows are loaded into VGPRs v0..v239 (lane = pixel, exactly one register per row), and every entry is one
+// s_set_gpr_idx_idx (M0[7:0] <- entry byte: the VGPR index mode of this ISA) + one v_add_f32 acc, v[M0], acc: 13 cycles per entry
+// against 29 for the LDS form (tools/mb/gpr_idx.hip), which is what bounds a launch whose longest list holds 200 000 entries.
+// 256 VGPRs: one such wavefront per SIMD, beside four of the gather's (56 VGPRs each).  The body is generated (tools/gen_sl_hot.py).
+__global__ __launch_bounds__(64) void sl_hot_kernel(const uint32_t* __restrict__ hcnt, uint32_t* __restrict__ ticket, const HotDesc* __restrict__ items,
+                                                    int hcap, const float* __restrict__ rows, const uint8_t* __restrict__ entries,
+                                                    float* __restrict__ img, uint32_t* __restrict__ mm, int W, int H)
+{
+    const uint32_t rows_lo = (uint32_t)(uintptr_t)rows, rows_hi = (uint32_t)((uintptr_t)rows >> 32);
+    const uint32_t ent_lo = (uint32_t)(uintptr_t)entries, ent_hi = (uint32_t)((uintptr_t)entries >> 32);
+    const uint32_t img_lo = (uint32_t)(uintptr_t)img, img_hi = (uint32_t)((uintptr_t)img >> 32);
+    asm volatile(SL_HOT_ASM
+                 :
+                 : [hcnt] "s"(hcnt), [ticket] "s"(ticket), [items] "s"(items), [hcap] "s"(hcap), [rows_lo] "s"(rows_lo), [rows_hi] "s"(rows_hi),
+                   [ent_lo] "s"(ent_lo), [ent_hi] "s"(ent_hi), [img_lo] "s"(img_lo), [img_hi] "s"(img_hi), [mm] "s"(mm), [W] "s"(W), [H] "s"(H)
+                 : SL_HOT_CLOBBERS);
 }
 
 // ---- host ----
@@ -805,7 +871,7 @@ int ev_slots_prepare_finish(eorb_ctx* c, int W, int H, int h, int TX, int TY, co
     int rc;
     if (c->sl_rank_ok < 0) c->sl_rank_ok = (hinfo[4] == 0 && hinfo[5] == 0) ? 1 : 0;
     if (hinfo[2] || hinfo[1] >= (int)kNoSlot || hinfo[0] <= 0) return EORB_OK;      // a tile with more than 254 slots: the batch pipeline serves these maps
-    if ((rc = ensure(c, c->sl_rows, sizeof(float) * 64 * (size_t)hinfo[0] + 4096))) return rc;
+    if ((rc = ensure(c, c->sl_rows, sizeof(float) * 64 * (size_t)hinfo[0] + 4096 + 256 * 256))) return rc;      // + slack: sl_hot_kernel loads 240 rows whatever the tile holds
     const uint32_t* d_rowbase = (const uint32_t*)c->sl_tile.p + NT;
     sl_rows_kernel<<<(nsrc + 3) / 4, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, (const uint2*)c->sl_tab.p, nsrc, W, H, h, TX, d_stamps,
                                                             stamp_stride, SWP, (const float2*)c->lut.p, two_sig2, norm, d_rowbase, (float*)c->sl_rows.p);
@@ -885,6 +951,7 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
     const eorb_raw_event* d_ev = (const eorb_raw_event*)d_events;
     const uint2* d_tab = (const uint2*)c->sl_tab.p;
+    int ncu_g = 256; uint32_t hot_min = 0; uint32_t* d_hot_cnt = nullptr; HotDesc* d_hot_items = nullptr;
     size_t lds_g = 0; int nw = 1, G = 0; uint4* d_items = nullptr; uint32_t* d_task = nullptr; uint32_t prio_ref = 0;
     {
         ProfScope ps(c, "ev_bin");
@@ -892,13 +959,21 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         const int NTp = (NT + 1) & ~1;
         const size_t lds2 = ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
         if (lds > 64 * 1024 || lds2 > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
-        if (nchunks) sl_count_kernel<<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+        if (nchunks) {
+            if (stride == 16) sl_count_kernel<16><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+            else if (stride == 4) sl_count_kernel<4><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+            else sl_count_kernel<-4><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+        }
         sl_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
         static const int rank_env = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
         const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
         if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= 64 * 1024)
-            sl_scatter_rank_kernel<<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, NT, chunk,
-                                                                                      d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
+        {
+#define SL_SCAT(ST) sl_scatter_rank_kernel<ST><<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
+                                                                                               d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p)
+            if (stride == 16) SL_SCAT(16); else if (stride == 4) SL_SCAT(4); else SL_SCAT(-4);
+#undef SL_SCAT
+        }
         else if (nchunks)
             sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
                                                                                  d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
@@ -913,6 +988,7 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         nw = std::min(nw, std::max(1, B));
         static int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+        ncu_g = ncu;
         // one task per tile position plus a few rounds of spare ones shared out by weight; a position never gets more wavefronts than slices
         const int rounds = ns_env >= 1 ? ns_env : 4;
         G = NT + rounds * ncu * wg_per_cu;
@@ -923,8 +999,19 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         uint32_t* d_tile_m = d_task + G;
         uint32_t* d_scr = d_tile_m + NT;
         prio_ref = (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 2000), 0x7fffffff);   // lists this long go first at the issue arbiter
-        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * (size_t)B, c->stream>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, d_items, d_tile_w, d_tile_m, d_ctr);
-        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->stream>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task);
+        // lists of a few thousand entries or more go to the register-row kernel (when every tile's rows fit its 240 registers): 13
+        // cycles per entry instead of 29, which shortens the launch's longest chains AND moves more entries per second; shorter lists
+        // would not repay the 240 row loads per list (measured at 128 x 1 Mev: threshold 4 096 ... 8 192 1.40-1.45 ms, 16 384 1.53, none 2.44)
+        static const long long hot_env = [] { const char* e = getenv("EORB_SLOT_HOT_MIN"); return e ? atoll(e) : -1ll; }();
+        hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 16000), 0x7fffffff) : 0u;
+        if (hot_env >= 0) hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<long long>(hot_env, 0x7fffffff) : 0u;
+        if ((rc = ensure(c, c->sl_hot, sizeof(HotDesc) * (size_t)kHotBuckets * kHotCap + 256))) return rc;
+        d_hot_cnt = (uint32_t*)c->sl_hot.p;                                  // 16 bucket counts | ticket (at word 32) | descriptors (from byte 256)
+        d_hot_items = (HotDesc*)((char*)c->sl_hot.p + 256);
+        EORB_HIP(c, hipMemsetAsync(c->sl_hot.p, 0, 256, c->stream));
+        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, c->stream>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, TX, hot_min, d_nslots, d_rowbase,
+                                                                             d_items, d_tile_w, d_tile_m, d_ctr, d_hot_cnt, d_hot_items);
+        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->stream>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task, d_hot_cnt);
         EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
     }
     {
@@ -939,7 +1026,25 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
 #endif
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)sl_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        if (hot_min) {
+            // the long lists on a second (high-priority) stream beside the gather: fork after the plan, join before the images are read
+            if (!c->sl_side) {
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                if (hipStreamCreateWithPriority(&c->sl_side, hipStreamNonBlocking, hi) != hipSuccess) return set_err(c, EORB_E_HIP, "side stream");
+                if (hipEventCreateWithFlags(&c->sl_ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->sl_ev_join, hipEventDisableTiming) != hipSuccess)
+                    return set_err(c, EORB_E_HIP, "side stream events");
+            }
+            static const int hw_env = [] { const char* e = getenv("EORB_SLOT_HOT_WAVES"); return e ? atoi(e) : 0; }();
+            const int hw = hw_env > 0 ? hw_env : 8 * ncu_g;               // two per SIMD: all of its registers
+            EORB_HIP(c, hipEventRecord(c->sl_ev_fork, c->stream));
+            EORB_HIP(c, hipStreamWaitEvent(c->sl_side, c->sl_ev_fork, 0));
+            sl_hot_kernel<<<hw, 64, 0, c->sl_side>>>(d_hot_cnt, d_hot_cnt + 32, d_hot_items, kHotCap, (const float*)c->sl_rows.p, (const uint8_t*)c->entries.p,
+                                                     d_f32, d_minmax_enc, W, H);
+            EORB_HIP(c, hipEventRecord(c->sl_ev_join, c->sl_side));
+        }
         sl_gather_kernel<<<G, 64 * nw, lds_g, c->stream>>>(P);
+        if (hot_min) EORB_HIP(c, hipStreamWaitEvent(c->stream, c->sl_ev_join, 0));
         EORB_LAUNCH_CHECK(c, "sl_gather_kernel");
     }
     return EORB_OK;

@@ -110,7 +110,8 @@ int         eorb_sync(eorb_ctx* ctx);
  * number of events per call from which their distinct positions are tabulated, default 2^20) */
 int         eorb_debug_option(eorb_ctx* ctx, const char* name, int value);
 /* test hook: counters a test can read to see which path served its calls.  "slot_calls": accumulation calls that took the slot
- * lists (gather_form 0 on dense batches, or 4); "slot_flags": sticky device flags of that path (0 = fine; synchronises).
+ * lists (gather_form 0 on dense batches, or 4); "slot_flags": sticky device flags of that path (0 = fine; synchronises); "slot_hot_items": lists the last such call handed to
+ * the register-row kernel (synchronises); "slot_rank_ok": 1 when the scatter takes its ranks from LDS atomics.
  * Returns the value, or -1 for an unknown name. */
 long long   eorb_debug_counter(eorb_ctx* ctx, const char* name);
 const char* eorb_last_error(eorb_ctx* ctx);

@@ -71,6 +71,32 @@ def test_slot_gather_has_no_static_lds_and_no_scratch():
     assert vg <= 64, "sl_gather_kernel needs %d VGPRs: fewer than 8 waves per SIMD" % vg
 
 
+def test_hot_kernel_jump_arithmetic(tmp_path):
+    """sl_hot_kernel enters its 64-entry sequence in the middle for the tail of a list: s_getpc + 20 bytes + 44 bytes per entry dword
+    (tools/gen_sl_hot.py).  Both constants are encoding sizes: checked here against the assembled code object."""
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists("/opt/rocm/bin/hipcc") and os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/clang-offload-bundler")):
+        pytest.skip("no ROCm LLVM tools")
+    src = os.path.join(ROOT, "eorb_slam_amd", "csrc", "ev_slots.hip")
+    obj, co = str(tmp_path / "slots.o"), str(tmp_path / "slots.co")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-w", "-c", src, "-o", obj])
+    subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + obj, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout.split("\n")
+    ins = [(int(m.group(2), 16), m.group(1).strip()) for m in (re.match(r"\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", l) for l in dis) if m]
+    gp = [i for i, (a, t) in enumerate(ins) if t.startswith("s_getpc_b64 s[34:35]")]
+    assert len(gp) == 1
+    i = gp[0]
+    sp = next(j for j in range(i, i + 12) if ins[j][1].startswith("s_setpc_b64"))
+    first = ins[sp + 1]
+    assert first[1].startswith("s_set_gpr_idx_idx s64") and first[0] - ins[i + 1][0] == 20, (ins[i + 1], first)
+    starts = [a for a, t in ins[sp + 1:sp + 1 + 16 * 11] if re.fullmatch(r"s_set_gpr_idx_idx s(6[4-9]|7[0-9])", t)]
+    assert len(starts) == 16 and all(b - a == 44 for a, b in zip(starts, starts[1:])), starts
+    # the kernel owns the whole architectural VGPR file of a wave: 256 registers, no scratch
+    text = _device_asm("ev_slots.hip")
+    body = re.findall(r"\.amdhsa_kernel (\S*sl_hot_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)[0][1]
+    assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body) and int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) == 256
+
+
 def _device_asm(src_name):
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

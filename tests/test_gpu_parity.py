@@ -1063,6 +1063,7 @@ def test_slot_lists_form(oracle, fe):
         gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, 1.0, False, True, ctx=ctx, return_all=True)
         calls += 1
         assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), ("tile corner", W, H, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
+        assert ctx.debug_counter("slot_hot_items") >= 1              # (60 000 events on four tiles: lists long enough for the register-row kernel)
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)) and np.array_equal(ou, gu)
     assert ctx.debug_counter("slot_calls") == calls and ctx.debug_counter("slot_flags") == 0 and ctx.debug_counter("slot_rank_ok") == 1
     ctx.close()

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Generates eorb_slam_amd/csrc/sl_hot_asm.h: the body of sl_hot_kernel (ev_slots.hip) as one inline-asm string plus its clobber list.
+
+The kernel keeps a tile position's rows IN REGISTERS (row r = VGPR r, lane = pixel; 240 rows + a zero row) and walks a long
+(slice, tile) list with the VGPR index mode of gfx9-class ISAs: per entry one s_set_gpr_idx_idx (M0[7:0] <- the entry byte) and one
+v_add_f32 acc, v[0 + M0], acc -- no LDS read, no address arithmetic.  Entries come through scalar loads, 64 per s_load_dwordx16, three
+buffers in rotation so that the only load outstanding at a wait is one phase old.  python3 tools/gen_sl_hot.py > eorb_slam_amd/csrc/sl_hot_asm.h
+"""
+NROWS = 240            # rows held in v0..v239; v240 = 0.0 (the null row); v241 acc; v242 4*lane; v243 px; v244 py; v245.. temps
+L = []
+def a(s): L.append(s)
+
+def process(buf0, lab=None):
+    """64 entries held in s[buf0 .. buf0+15]; fixed 44 bytes of code per dword (the tail jumps into this sequence)"""
+    for d in range(16):
+        s = "s%d" % (buf0 + d)
+        a("s_set_gpr_idx_idx %s" % s); a("v_add_f32 v241, v0, v241")
+        for sh in (8, 16, 24):
+            a("s_lshr_b32 s33, %s, %d" % (s, sh)); a("s_set_gpr_idx_idx s33"); a("v_add_f32 v241, v0, v241")
+
+# ---- prologue ----
+a("v_mbcnt_lo_u32_b32 v242, -1, 0"); a("v_mbcnt_hi_u32_b32 v242, -1, v242")
+a("v_and_b32 v243, 7, v242"); a("v_lshrrev_b32 v244, 3, v242"); a("v_lshlrev_b32 v242, 2, v242")
+a("v_mov_b32 v246, v243"); a("v_mov_b32 v247, v244")                      # lx, ly
+a("s_load_dwordx16 s[48:63], %[hcnt], 0x0")                                # items per bucket (16 buckets, heaviest first)
+a("s_waitcnt lgkmcnt(0)")
+# next ticket: lane 0 takes one (global_atomic_add with return), broadcast
+a("SLH_ITEM:")
+a("v_mov_b32 v245, 1"); a("v_mov_b32 v248, 0")
+a("s_mov_b64 s[34:35], exec"); a("s_mov_b64 exec, 1")
+a("global_atomic_add v245, v248, v245, %[ticket] sc0")
+a("s_waitcnt vmcnt(0)")
+a("s_mov_b64 exec, s[34:35]")
+a("s_nop 0")
+a("v_readfirstlane_b32 s98, v245")                                         # ticket
+# ticket -> (bucket, index): walk the 16 counts
+a("s_mov_b32 s36, 0")                                                      # bucket
+for b in range(16):
+    a("s_cmp_lt_u32 s98, s%d" % (48 + b)); a("s_cbranch_scc1 SLH_FOUND")
+    a("s_sub_u32 s98, s98, s%d" % (48 + b)); a("s_add_u32 s36, s36, 1")
+a("s_branch SLH_DONE")
+a("SLH_FOUND:")
+a("s_mul_i32 s36, s36, %[hcap]"); a("s_add_u32 s36, s36, s98"); a("s_lshl_b32 s36, s36, 5")       # byte offset of the 32-byte descriptor
+a("s_load_dwordx8 s[36:43], %[items], s36")                                # slice, tile, cnt, off_lo, off_hi, tx0, ty0, rows byte offset
+a("s_waitcnt lgkmcnt(0)")
+a("s_add_u32 s44, %[rows_lo], s43"); a("s_addc_u32 s45, %[rows_hi], 0")
+for blk in range(NROWS // 16):
+    for r in range(16):
+        a("global_load_dword v%d, v242, s[44:45] offset:%d" % (blk * 16 + r, r * 256))
+    a("s_add_u32 s44, s44, 0x1000"); a("s_addc_u32 s45, s45, 0")
+a("v_mov_b32 v240, 0"); a("v_mov_b32 v241, 0")
+a("s_add_u32 s44, %[ent_lo], s39"); a("s_addc_u32 s45, %[ent_hi], s40")   # the list
+a("s_lshr_b32 s46, s38, 6")                                                # full 64-entry phases
+a("s_load_dwordx16 s[64:79], s[44:45], 0x0"); a("s_load_dwordx16 s[80:95], s[44:45], 0x40")
+a("s_add_u32 s34, s44, 0x80"); a("s_addc_u32 s35, s45, 0")                 # next block to request
+a("s_mov_b32 s47, 0")
+a("s_waitcnt vmcnt(0)")
+a("s_set_gpr_idx_on s47, gpr_idx(SRC0)")
+# ---- phases: buffers s[64:79], s[80:95], s[96:101]+...: keep to three buffers at s64, s80 and s48 (the bucket counts are reloaded per item) ----
+bufs = [64, 80, 48]
+a("SLH_LOOP:")
+for k in range(3):
+    a("s_cmp_eq_u32 s46, 0"); a("s_cbranch_scc1 SLH_TAIL")
+    a("s_waitcnt lgkmcnt(0)")
+    nb = bufs[(k + 2) % 3]
+    a("s_load_dwordx16 s[%d:%d], s[34:35], 0x0" % (nb, nb + 15)); a("s_add_u32 s34, s34, 0x40"); a("s_addc_u32 s35, s35, 0")
+    process(bufs[k])
+    a("s_sub_u32 s46, s46, 1")
+a("s_branch SLH_LOOP")
+# ---- tail: the last (cnt mod 64) entries = the last bytes of the 64-byte block that ends at the list's (4-byte rounded) end ----
+a("SLH_TAIL:")
+a("s_waitcnt lgkmcnt(0)")
+a("s_and_b32 s46, s38, 63"); a("s_cmp_eq_u32 s46, 0"); a("s_cbranch_scc1 SLH_STORE")
+a("s_add_u32 s47, s38, 3"); a("s_and_b32 s47, s47, -4")                    # cnt rounded up to a dword
+a("s_add_u32 s34, s44, s47"); a("s_addc_u32 s35, s45, 0"); a("s_sub_u32 s34, s34, 0x40"); a("s_subb_u32 s35, s35, 0")
+a("s_load_dwordx16 s[64:79], s[34:35], 0x0")
+a("s_waitcnt lgkmcnt(0)")
+# bytes of the last dword past the end of the list -> the null row (240 = 0xf0)
+a("s_and_b32 s33, s38, 3"); a("s_cmp_eq_u32 s33, 0"); a("s_cbranch_scc1 SLH_TAILGO")
+a("s_lshl_b32 s33, s33, 3"); a("s_lshl_b32 s98, -1, s33")                  # mask of the invalid bytes
+a("s_andn2_b32 s79, s79, s98"); a("s_and_b32 s98, s98, 0xf0f0f0f0"); a("s_or_b32 s79, s79, s98")
+a("SLH_TAILGO:")
+# jump to dword (16 - ndw) of the sequence below, ndw = dwords that hold tail entries; 44 bytes of code per dword
+a("s_and_b32 s33, s47, 63"); a("s_cmp_eq_u32 s33, 0"); a("s_cselect_b32 s33, 64, s33"); a("s_lshr_b32 s33, s33, 2")   # ndw in 1..16
+a("s_sub_u32 s33, 16, s33"); a("s_mul_i32 s33, s33, 44")
+a("s_getpc_b64 s[34:35]")
+a("s_add_u32 s34, s34, s33"); a("s_addc_u32 s35, s35, 0")
+a("s_add_u32 s34, s34, 20"); a("s_addc_u32 s35, s35, 0")                   # the five 4-byte instructions between s_getpc's return value and the sequence
+a("s_setpc_b64 s[34:35]")
+process(64)
+# ---- the item's pixels ----
+a("SLH_STORE:")
+a("s_set_gpr_idx_off")
+a("v_add_u32 v243, s41, v246"); a("v_add_u32 v244, s42, v247")            # px, py
+a("v_cmp_gt_u32 vcc, %[W], v243"); a("v_cmp_gt_u32 s[34:35], %[H], v244"); a("s_and_b64 s[34:35], s[34:35], vcc")
+a("v_mul_lo_u32 v245, v244, %[W]"); a("v_add_u32 v245, v245, v243"); a("v_lshlrev_b32 v245, 2, v245")
+a("s_mul_i32 s33, %[W], %[H]"); a("s_mul_i32 s33, s33, s36"); a("s_mul_hi_u32 s47, s33, 4"); a("s_lshl_b32 s33, s33, 2")
+a("s_add_u32 s44, %[img_lo], s33"); a("s_addc_u32 s45, %[img_hi], s47")
+a("s_mov_b64 s[46:47], exec"); a("s_and_b64 exec, exec, s[34:35]")
+a("global_store_dword v245, v241, s[44:45]")
+a("s_mov_b64 exec, s[46:47]")
+# running maximum (every increment is >= 0: the largest final value): wave reduction, one atomic
+a("v_mov_b32 v248, v241"); a("s_nop 1")
+for sh in (1, 2, 4, 8):
+    a("v_max_f32_dpp v248, v248, v248 row_shr:%d row_mask:0xf bank_mask:0xf bound_ctrl:0" % sh); a("s_nop 1")
+a("v_max_f32_dpp v248, v248, v248 row_bcast:15 row_mask:0xa bank_mask:0xf"); a("s_nop 1")
+a("v_max_f32_dpp v248, v248, v248 row_bcast:31 row_mask:0xc bank_mask:0xf"); a("s_nop 1")
+a("v_readlane_b32 s33, v248, 63")
+a("s_or_b32 s33, s33, 0x80000000")                                          # enc_f32 of a non-negative float
+a("s_lshl_b32 s34, s36, 3"); a("s_add_u32 s34, s34, 4")
+a("v_mov_b32 v245, s34"); a("v_mov_b32 v248, s33")
+a("s_mov_b64 s[46:47], exec"); a("s_mov_b64 exec, 1")
+a("global_atomic_umax v245, v248, %[mm]")
+a("s_mov_b64 exec, s[46:47]")
+a("s_load_dwordx16 s[48:63], %[hcnt], 0x0")                                # (the third buffer held entries: the bucket counts again)
+a("s_waitcnt vmcnt(0) lgkmcnt(0)")
+a("s_branch SLH_ITEM")
+a("SLH_DONE:")
+
+print("// generated by tools/gen_sl_hot.py -- do not edit")
+print("#define SL_HOT_NROWS %d" % NROWS)
+print("#define SL_HOT_ASM \\")
+for s in L:
+    print('    "%s\\n" \\' % s)
+print('    ""')
+clob = ["v%d" % i for i in range(256)] + ["s%d" % i for i in range(33, 96)] + ["s98"] + ["vcc", "scc", "m0", "memory"]
+print("#define SL_HOT_CLOBBERS " + ", ".join('"%s"' % c for c in clob))
