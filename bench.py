@@ -266,13 +266,18 @@ def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, inputs_key=
             r["rocprof_avg_launch_ms"] = sc["rocprof_ms"]
             if "issue" in sc:
                 i = sc["issue"]
-                r["issue"] = {"valu_frac": i["valu_frac"], "lds_frac": i["lds_frac"], "wait_frac": i["wait_frac"],
+                r["issue"] = {"valu_frac": i["valu_frac"], "lds_frac": i["lds_frac"], "salu_frac": i.get("salu_frac"), "wait_frac": i["wait_frac"],
                               "issue_stall_frac": i["issue_stall_frac"], "kernel": i["kernel"],
-                              "source": "rocprofv3 --pmc, cycles = GRBM_GUI_ACTIVE / 8 XCDs: SQ_INSTS_VALU x 4 / (cycles x 1024 SIMDs), SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs), "
+                              "source": "rocprofv3 --pmc, cycles = GRBM_GUI_ACTIVE / 8 XCDs: SQ_INSTS_VALU x 4 / (cycles x 1024 SIMDs), SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs), SQ_INSTS_SALU / (cycles x 256 CUs), "
                                         "SQ_WAIT_ANY / SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; " + src}
             stage = sum(v["traffic_bytes"] for k, v in e["scopes"].items() if k.startswith("ev_"))
-            r["stage"] = {"what": "all accumulation kernels (ev_*) of a step", "traffic": stage,
-                          "algorithmic": unit_bytes_by_kernel("ev_") * units_per_launch, "ratio": stage / (unit_bytes_by_kernel("ev_") * units_per_launch)}
+            alg = unit_bytes_by_kernel("ev_") * units_per_launch
+            r["stage"] = {"what": "all accumulation kernels (ev_*) of a step", "traffic": stage, "algorithmic": alg, "ratio": stage / alg,
+                          "scopes": {k: {"live_ms": prof[k][0] / max(prof[k][1], 1), "rocprof_ms": v["rocprof_ms"], "traffic": v["traffic_bytes"],
+                                         "algorithmic_GBps": alg / (prof[k][0] / max(prof[k][1], 1) * 1e-3) / 1e9,
+                                         **({"issue_by_kernel": v["issue_by_kernel"]} if "issue_by_kernel" in v else {}),
+                                         **({"issue": {kk: vv for kk, vv in v["issue"].items() if kk != "counters"}} if "issue" in v else {})}
+                                     for k, v in e["scopes"].items() if k.startswith("ev_") and k in prof}}
     return r, {k: v[0] / steps for k, v in sorted(prof.items())}
 
 

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __r
         uint32_t xy[U], rg[U];
 #pragma unroll
         for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride)) : 0xffffffffu; }
+        // (whole 16-byte records per lane, non-temporal, were measured: 0.69 ms instead of 0.62)
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int x = (int)(xy[u] & xmask), y = (int)(xy[u] >> 16);

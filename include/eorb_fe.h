@@ -9,9 +9,10 @@
  *
  * Conventions
  *   - every call returns 0 on success, <0 on error (EORB_E_*); never throws, never aborts.
- *   - an eorb_ctx owns device workspaces and runs on ONE HIP stream; it is single-threaded:
- *     create one per calling thread (the reference calls ev2im_gauss from 4 transient threads,
- *     src/Event/EvImBuilder.cpp:1165-1193: give each its own ctx).
+ *   - an eorb_ctx owns device workspaces and runs on ONE HIP stream; it is single-threaded: one
+ *     thread uses it at a time.  The reference also calls ev2im_gauss from 4 transient threads per
+ *     motion-compensated image (src/Event/EvImBuilder.cpp:1165-1193): let those BORROW warm contexts
+ *     from a pool instead of creating one per thread (eorb_host::ContextPool).
  *   - "host" entry points take host pointers, copy in/out and synchronise before returning.
  *   - "_dev" entry points take DEVICE pointers (HBM resident), enqueue on the ctx stream and do
  *     not synchronise: this is the throughput path (batches of slices).
@@ -134,7 +135,6 @@ int eorb_ev2im(eorb_ctx* ctx, const eorb_event* ev, size_t n, int W, int H, int 
 int eorb_ev2im_gauss(eorb_ctx* ctx, const eorb_event* ev, size_t n, int W, int H, float sigma, int pol,
                      int normalized, float* out_f32, uint8_t* out_u8, float* minmax);
 
-/* ---- motion-compensated accumulation (SURVEY §8(f) f1; host buffers) ------------------------------------------------ */
 /* ---- raw sensor events through the undistortion maps ------------------------------
  * mapX / mapY = MyCalibrator::mUndistMapX / mUndistMapY (Utils/MyCalibrator.cpp:60-101, LH x LW floats each, built by the
  * caller with cv::undistortPoints as the reference does).  checkInImage = the flag the loader passes to
@@ -166,6 +166,7 @@ int eorb_ev2im_gauss_raw(eorb_ctx* ctx, const eorb_raw_event* raw, size_t n, int
 int eorb_ev2im_raw(eorb_ctx* ctx, const eorb_raw_event* raw, size_t n, int W, int H, int pol, int normalized,
                    float* out_f32, uint8_t* out_u8, float* minmax, int* is_u8);
 
+/* ---- motion-compensated accumulation (SURVEY §8(f) f1; host buffers) ------------------------------------------------ */
 typedef struct { float fx, fy, cx, cy; } eorb_pinhole;     /* Pinhole::mvParameters (CameraModels/Pinhole.cpp:30-62) */
 
 /* replaces EvImConverter::ev2mci_gg_f(evs, pCamera, Tcw, medDepth, W, H, sigma, pol, normalized)

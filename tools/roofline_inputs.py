@@ -9,13 +9,14 @@ key = "<workload>:<input>:<batch>:<events>".  Counters (separate --pmc passes, M
   cycles    = GRBM_GUI_ACTIVE / 8                                          (summed over the 8 XCDs)
   valu_frac = SQ_INSTS_VALU x 4 cycles / (cycles x 1024 SIMDs)             (a wave64 VALU instruction holds its SIMD's ALU for 4 cycles)
   lds_frac  = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs)                       (LDS-array cycles)
+  salu_frac = SQ_INSTS_SALU / (cycles x 256 CUs)                           (one scalar ALU per CU, one instruction per cycle)
   wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES                                 (wave-cycles parked at s_waitcnt / barrier)
 """
 import collections, csv, glob, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCOPES = {   # HIP-event scope of bench.py -> kernels it brackets
-    "ev_gather": ["sl_gather_kernel", "ev_gather_"],
+    "ev_gather": ["sl_gather_kernel", "sl_hot_kernel", "ev_gather_"],
     "ev_bin": ["sl_count_kernel", "sl_scan_kernel", "sl_scatter", "sl_plan_kernel", "sl_tasks_kernel", "ev_count_kernel", "ev_scan_kernel",
                "ev_scatter", "ev_tile_hist", "ev_tile_order"],
     "ev_normalize": ["ev_normalize_kernel"], "ev_dedupe": ["dd_insert_kernel"],
@@ -64,15 +65,27 @@ def main():
             fetch = cf.get(k, {}).get("FETCH_SIZE", 0.0) * 1024 * 2; write = cw.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
             e["kernels"][k.split("(")[0]] = {"avg_ms": st[k][0], "calls": st[k][1], "fetch_bytes": fetch, "write_bytes": write}
             e["traffic_bytes"] += fetch + write; e["rocprof_ms"] += st[k][0]
+        def issue_of(k):
+            a, b = c1.get(k, {}), c2.get(k, {})
+            cyc = b.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD      # (the counter is summed over the 8 XCDs: 4.38e7 for a 2.36 ms launch at 2.3 GHz)
+            if not (cyc > 0 and a):
+                return None
+            return {"kernel": k.split("(")[0], "valu_frac": a.get("SQ_INSTS_VALU", 0.0) * 4 / (cyc * N_SIMD),
+                    "salu_frac": a.get("SQ_INSTS_SALU", 0.0) / (cyc * N_CU),
+                    "lds_frac": b.get("SQ_LDS_IDX_ACTIVE", 0.0) / (cyc * N_CU),
+                    "wait_frac": a.get("SQ_WAIT_ANY", 0.0) / max(a.get("SQ_WAVE_CYCLES", 0.0), 1.0),
+                    "issue_stall_frac": a.get("SQ_WAIT_INST_ANY", 0.0) / max(a.get("SQ_WAVE_CYCLES", 0.0), 1.0),
+                    "counters": {**{kk: v for kk, v in a.items()}, **{kk: v for kk, v in b.items()}}}
         dom = max(ks, key=lambda k: st[k][0])
-        a, b = c1.get(dom, {}), c2.get(dom, {})
-        cyc = b.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD      # (the counter is summed over the 8 XCDs: 4.38e7 for a 2.36 ms launch at 2.3 GHz)
-        if cyc > 0 and a:
-            e["issue"] = {"kernel": dom.split("(")[0], "valu_frac": a.get("SQ_INSTS_VALU", 0.0) * 4 / (cyc * N_SIMD),
-                          "lds_frac": b.get("SQ_LDS_IDX_ACTIVE", 0.0) / (cyc * N_CU),
-                          "wait_frac": a.get("SQ_WAIT_ANY", 0.0) / max(a.get("SQ_WAVE_CYCLES", 0.0), 1.0),
-                          "issue_stall_frac": a.get("SQ_WAIT_INST_ANY", 0.0) / max(a.get("SQ_WAVE_CYCLES", 0.0), 1.0),
-                          "counters": {**{k: v for k, v in a.items()}, **{k: v for k, v in b.items()}}}
+        i = issue_of(dom)
+        if i:
+            e["issue"] = i
+        if scope == "ev_gather" and len(ks) > 1:
+            # sl_gather_kernel and sl_hot_kernel run side by side on two streams: the scope lasts as long as the longer one.  (The
+            # counters of a pass are collected with the kernels serialised by the profiler: per-kernel fractions, not a sum.)
+            e["concurrent"] = True
+            e["rocprof_ms"] = max(st[k][0] for k in ks)
+            e["issue_by_kernel"] = {k.split("(")[0]: {kk: vv for kk, vv in (issue_of(k) or {}).items() if kk != "counters"} for k in ks}
         scopes[scope] = e
     doc = {}
     if os.path.exists(out_path):
