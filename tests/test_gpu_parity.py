@@ -1093,6 +1093,31 @@ def test_slot_lists_form(oracle, fe):
     c.close()
 
 
+def test_register_row_kernel_list_tails(oracle, fe):
+    """sl_hot_kernel walks a list 64 entries per scalar load and enters its unrolled sequence in the middle for the last (length mod 64)
+    entries, with the bytes of the last dword past the end replaced by the null row: every residue of the length mod 64 (hence mod 4),
+    on lists just long enough for that kernel (4 096 entries), against the oracle.  All events sit on a 3x3 patch of sensor pixels in the
+    middle of a tile, so the tile's list holds every event."""
+    W, H = 240, 180
+    mx, my = _maps(W, H)
+    ctx = fe.Context()
+    ctx.debug_option("gather_form", 4)
+    fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx)
+    rng = np.random.default_rng(11)
+    hot_seen = 0
+    for n in list(range(4096, 4096 + 66)) + [4096 + 127, 4096 + 128, 4096 + 129, 8191, 8192, 8193, 12345]:
+        raw = np.zeros(n, synth.RAW_DTYPE)
+        raw["x"] = 123 + rng.integers(0, 3, n); raw["y"] = 91 + rng.integers(0, 3, n); raw["p"] = 1; raw["t"] = np.arange(n) * 1e-6
+        ev = oracle.undistort_events(raw, mx, my, W, H, True, 1.0)
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, 1.0, False, True, fast=True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, 1.0, False, True, ctx=ctx, return_all=True)
+        assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), (n, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
+        assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)) and np.array_equal(ou, gu), n
+        hot_seen += ctx.debug_counter("slot_hot_items") >= 1
+    assert hot_seen >= 60
+    ctx.close()
+
+
 def test_packed_wire_records_equal_raw_records(oracle, fe):
     """eorb_raw_event4 (x | p << 15 | y << 16, a quarter of the bytes on the host -> HBM link) through the batch entry point: the
     images, keypoints and descriptors of the 16-byte records, for a dense batch (slot lists read the 4-byte records directly), a
