@@ -35,7 +35,7 @@ for case in range(ncase):
         raw["x"][:k] = rng.integers(0, LW, k); raw["y"][:k] = rng.integers(0, LH, k)
         rng.shuffle(raw)
     raw["p"] = rng.integers(0, 2, n); raw["t"] = np.arange(n) * 1e-6
-    form = int(rng.integers(0, 4))                                                # gather kernel: by shape / workgroup per tile / wave per tile / no binning
+    form = int(rng.integers(0, 5))                                                # gather kernel: by shape / workgroup per tile / wave per tile / no binning / slot lists
     c.debug_option("gather_form", form)
     c.debug_option("dedupe_min_events", 1 if rng.integers(0, 3) == 0 else 1 << 20)     # a third of the cases: float events take the bulk (position table) form
     fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=c)
