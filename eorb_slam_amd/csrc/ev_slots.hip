@@ -30,15 +30,18 @@ namespace eorb {
 
 constexpr uint32_t kNoSlot = 0xffu;
 constexpr int kSlotScatWaves = 8;
+constexpr uint16_t kNoGeo = 0xffffu;           // (tile 127,127 with a second tile: never a valid range, TX and TY <= 127 there)
+constexpr int kCountWaves = 16;
 
 // ---- tables ---------------------------------------------------------------------------------------------------------------------
 // Tile range of a sensor pixel = tiles that hold an IN-IMAGE pixel of its stamp (:250 `if (isInImage)`): every entry of a list
 // then visits at least one pixel, so "the tile was visited" (resolveMinMaxVals :32-39) is "its list is not empty".
 __global__ void sl_assign_kernel(const uint32_t* __restrict__ src_info, int nsrc, int W, int H, int h, int TX,
-                                 uint32_t* __restrict__ tile_nslots, uint2* __restrict__ slot_tab, int* __restrict__ info)
+                                 uint32_t* __restrict__ tile_nslots, uint2* __restrict__ slot_tab, uint16_t* __restrict__ slot_geo,
+                                 int* __restrict__ info)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nsrc) return;
+    if (i >= nsrc) { if (i == nsrc) slot_geo[i] = kNoGeo; return; }      // (pad: the table is copied to LDS as dwords)
     const uint32_t w = src_info[i];
     const int xi = (int)(int16_t)(w & 0xffff), yi = (int)(int16_t)(w >> 16);
     uint2 o = make_uint2(0u, 0xffffffffu);
@@ -60,6 +63,8 @@ __global__ void sl_assign_kernel(const uint32_t* __restrict__ src_info, int nsrc
         }
     }
     slot_tab[i] = o;
+    // the tile range alone in 16 bits, for the count pass (its table lives in LDS): first tile x | y << 7 | two tiles in x << 14 | in y << 15
+    slot_geo[i] = o.x ? (uint16_t)((o.x & 0x7f) | (((o.x >> 8) & 0x7f) << 7) | ((((o.x >> 16) & 3) - 1) << 14) | ((((o.x >> 18) & 3) - 1) << 15)) : kNoGeo;
 }
 
 // rowbase[t] = first row of tile t in the row table; info[0] = rows in all, info[1] = most slots of a tile
@@ -171,6 +176,63 @@ __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __r
     __syncthreads();
     uint16_t* sc = segcnt + (size_t)blockIdx.x * NT;
     for (int i = threadIdx.x; i < NT; i += blockDim.x) sc[i] = (uint16_t)cnt[i];
+}
+
+// K1a with the tile ranges in LDS.  The count pass is a streaming read of the events plus ONE table lookup per event; with the table
+// in global memory every lookup of a random sensor pixel is its own L2 request (345 KB of uint2: no L1 hit rate to speak of) and the
+// pass ran at 3.2 TB/s, with the lookup computed instead it ran at 5.2 (profiles/r03_ko_table_lookup.txt).  So: one 16-wave
+// workgroup per CU copies the 16-bit ranges of all sensor pixels into LDS once (240x180: 86 KB) and every WAVEFRONT counts whole
+// chunks on its own -- own counters (packed 16-bit, a chunk has <= 2048 events), no workgroup barrier after the table is in.
+template <int stride>
+__global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+                                                                       int nchunks, const uint16_t* __restrict__ slot_geo, int LW, int LH,
+                                                                       int TX, int NT, uint16_t* __restrict__ segcnt)
+{
+    extern __shared__ uint32_t smc[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntab = (LW * LH + 2) >> 1, NTp = (NT + 1) & ~1;
+    for (int i = tid; i < ntab; i += 64 * kCountWaves) smc[i] = ((const uint32_t*)slot_geo)[i];
+    const uint16_t* tab = (const uint16_t*)smc;
+    uint32_t* cnt = smc + ntab + wave * (NTp >> 1);
+    __syncthreads();
+    constexpr int astride = stride < 0 ? -stride : stride;
+    const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
+    constexpr int U = 8;
+    for (int ch = blockIdx.x * kCountWaves + wave; ch < nchunks; ch += gridDim.x * kCountWaves) {
+        const ChunkDesc cd = chunks[ch];
+        for (int i = lane; i < (NTp >> 1); i += 64) cnt[i] = 0u;
+        const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)astride;
+        for (int k0 = lane; k0 < cd.n; k0 += 64 * U) {
+            uint32_t xy[U], g[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int k = k0 + u * 64; xy[u] = k < cd.n ? *(const uint32_t*)(e + (size_t)k * (size_t)astride) : 0xffffffffu; }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t x = xy[u] & xmask, y = xy[u] >> 16, row = xy[u] & 0x7fffffffu;      // (hashed records: the row itself)
+                if (stride < 0) g[u] = row < (uint32_t)LW * (uint32_t)LH ? tab[row] : kNoGeo;
+                else g[u] = (x < (uint32_t)LW && y < (uint32_t)LH) ? tab[y * (uint32_t)LW + x] : kNoGeo;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (g[u] != kNoGeo) {
+                    const int t0 = (int)((g[u] >> 7) & 0x7f) * TX + (int)(g[u] & 0x7f);
+                    const bool two_x = (g[u] >> 14) & 1, two_y = (g[u] >> 15) & 1;
+                    atomicAdd(&cnt[t0 >> 1], 1u << (16 * (t0 & 1)));
+                    if (two_x) atomicAdd(&cnt[(t0 + 1) >> 1], 1u << (16 * ((t0 + 1) & 1)));
+                    if (two_y) {
+                        atomicAdd(&cnt[(t0 + TX) >> 1], 1u << (16 * ((t0 + TX) & 1)));
+                        if (two_x) atomicAdd(&cnt[(t0 + TX + 1) >> 1], 1u << (16 * ((t0 + TX + 1) & 1)));
+                    }
+                }
+            }
+        }
+        // (one wavefront: its LDS instructions execute in order, nothing to wait for but the compiler must keep that order)
+        __builtin_amdgcn_wave_barrier();
+        uint16_t* sc = segcnt + (size_t)ch * NT;
+        const uint16_t* c16 = (const uint16_t*)cnt;
+        for (int i = lane; i < NT; i += 64) sc[i] = c16[i];
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---- K1b: one workgroup per slice.  Per tile: exclusive scan of its counts over the slice's chunks (segbase), the total (tile_cnt);
@@ -839,7 +901,8 @@ int ev_slots_prepare_launch(eorb_ctx* c, int W, int H, int h, int TX, int TY)
     if (h < 1 || h > 4 || TX >= 256 || TY >= 256) return EORB_OK;
     const int nsrc = c->lut_w * c->lut_h, NT = TX * TY;
     int rc;
-    if ((rc = ensure(c, c->sl_tab, sizeof(uint2) * (size_t)nsrc))) return rc;
+    const size_t geo_off = sizeof(uint2) * (size_t)nsrc;                // slot_tab | slot_geo (16 bits per sensor pixel, + pad)
+    if ((rc = ensure(c, c->sl_tab, geo_off + sizeof(uint16_t) * ((size_t)nsrc + 2)))) return rc;
     // nslots | rowbase | tile_w | ctr | (spare) (NT each) | info (4 ints) | rank check (u64)
     if ((rc = ensure(c, c->sl_tile, sizeof(uint32_t) * (5 * (size_t)NT + 8)))) return rc;
     uint32_t* d_nslots = (uint32_t*)c->sl_tile.p;
@@ -847,7 +910,8 @@ int ev_slots_prepare_launch(eorb_ctx* c, int W, int H, int h, int TX, int TY)
     int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
     c->sl_info_off = sizeof(uint32_t) * 5 * (size_t)NT;
     EORB_HIP(c, hipMemsetAsync(c->sl_tile.p, 0, sizeof(uint32_t) * (5 * (size_t)NT + 8), c->stream));
-    sl_assign_kernel<<<(nsrc + 255) / 256, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, nsrc, W, H, h, TX, d_nslots, (uint2*)c->sl_tab.p, d_info);
+    sl_assign_kernel<<<(nsrc + 256) / 256, 256, 0, c->stream>>>((const uint32_t*)c->src_info.p, nsrc, W, H, h, TX, d_nslots, (uint2*)c->sl_tab.p,
+                                                                (uint16_t*)((char*)c->sl_tab.p + geo_off), d_info);
     sl_rowbase_kernel<<<1, 1024, 0, c->stream>>>(d_nslots, NT, d_rowbase, d_info);
     EORB_LAUNCH_CHECK(c, "slot table kernels");
     if (c->sl_rank_ok < 0) {
@@ -960,7 +1024,22 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         const int NTp = (NT + 1) & ~1;
         const size_t lds2 = ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
         if (lds > 64 * 1024 || lds2 > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
-        if (nchunks) {
+        // the tile ranges of all sensor pixels + one set of counters per wavefront in the LDS of one workgroup per CU?
+        const size_t nsrc = (size_t)c->lut_w * (size_t)c->lut_h;
+        const size_t lds_c = 4 * ((nsrc + 2) / 2) + (size_t)kCountWaves * NTp * 2;
+        static const int cl_env = [] { const char* e = getenv("EORB_SLOT_COUNT_LDS"); return e ? atoi(e) : 1; }();
+        if (nchunks && cl_env && TX <= 127 && TY <= 127 && lds_c <= 159 * 1024) {
+            static int ncu_c = 0;
+            if (!ncu_c) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ncu_c = pr.multiProcessorCount; if (ncu_c <= 0) ncu_c = 256; }
+            const uint16_t* d_geo = (const uint16_t*)((const char*)c->sl_tab.p + sizeof(uint2) * nsrc);
+            const int g = std::min(ncu_c, (nchunks + kCountWaves - 1) / kCountWaves);
+#define SL_COUNT(ST) do { static bool attr = false; \
+                if (!attr) { EORB_HIP(c, hipFuncSetAttribute((const void*)sl_count_lds_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); attr = true; } \
+                sl_count_lds_kernel<ST><<<g, 64 * kCountWaves, lds_c, c->stream>>>(d_ev, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt); } while (0)
+            if (stride == 16) SL_COUNT(16); else if (stride == 4) SL_COUNT(4); else SL_COUNT(-4);
+#undef SL_COUNT
+        }
+        else if (nchunks) {
             if (stride == 16) sl_count_kernel<16><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
             else if (stride == 4) sl_count_kernel<4><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
             else sl_count_kernel<-4><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
