@@ -19,7 +19,7 @@ Prints ONE JSON line (rank 0): metric/value/unit + `roofline` for the dominant k
 + `cpu_baseline` (the CPU oracle, -O3 -march=native build, on a bounded sample of the same workload: 1 thread with p50/p95, and
 all cores).
 """
-import argparse
+import argparse, gc
 import json
 import os
 import sys
@@ -331,6 +331,10 @@ def timed_steps(env, step, sync_extra=None):
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    # The interpreter's cyclic collector stays on, but the objects that exist by now (torch's import alone leaves millions) move to the
+    # permanent generation: a full collection inside the timed steps otherwise walks all of them -- a 40-60 ms host stall once per run
+    # (gpurun_out/gap_float.txt: the GPU idle between two calls), visible wherever a call waits for its results (float input, w3, w4).
+    gc.collect(); gc.freeze()
     if sync_extra:
         sync_extra()
     if world > 1:
