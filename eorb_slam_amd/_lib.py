@@ -12,7 +12,7 @@ EORB_OK, EORB_E_EMPTY, EORB_E_CONFIG, EORB_E_CAPACITY, EORB_E_ARG, EORB_E_HIP, E
 # every symbol include/eorb_fe.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "eorb_create", "eorb_destroy", "eorb_sync", "eorb_debug_option", "eorb_debug_counter", "eorb_last_error", "eorb_version",
-    "eorb_prof_enable", "eorb_prof_reset", "eorb_prof_count", "eorb_prof_get",
+    "eorb_prof_enable", "eorb_prof_reset", "eorb_prof_only", "eorb_prof_count", "eorb_prof_get",
     "eorb_ev2im", "eorb_ev2im_gauss", "eorb_set_undistort_maps", "eorb_undistort_events", "eorb_parse_events_text", "eorb_ev2im_gauss_raw", "eorb_ev2im_raw", "eorb_fe_run_batch_raw_dev", "eorb_fe_run_batch_raw4_dev", "eorb_fe_run_batch_images_dev", "eorb_ev2mci_se3", "eorb_ev2mci_se2", "eorb_ev2mci_se3_cam", "eorb_ev2mci_se2_cam", "eorb_measure_image_focus", "eorb_measure_image_focus_n", "eorb_normalize_minmax_u8",
     "eorb_orb_configure", "eorb_orb_max_keypoints", "eorb_orb_get_tables", "eorb_orb_extract",
     "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map", "eorb_search_by_projection_kf",
@@ -96,6 +96,7 @@ def lib():
     L.eorb_version.restype = C.c_char_p; L.eorb_version.argtypes = []
     L.eorb_prof_enable.restype = ci; L.eorb_prof_enable.argtypes = [vp, ci]
     L.eorb_prof_reset.restype = ci; L.eorb_prof_reset.argtypes = [vp]
+    L.eorb_prof_only.restype = ci; L.eorb_prof_only.argtypes = [vp, C.c_char_p]
     L.eorb_prof_count.restype = ci; L.eorb_prof_count.argtypes = [vp]
     L.eorb_prof_get.restype = ci
     L.eorb_prof_get.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]

@@ -82,6 +82,7 @@ struct eorb_ctx {
     bool own_stream = false;
     std::string err;
     bool prof = false;
+    std::string prof_only;                       // ",name,name,": only these scopes are timed (empty: all)
     std::vector<eorb::ProfEntry> profs;
     std::vector<hipEvent_t> ev_pool;
 

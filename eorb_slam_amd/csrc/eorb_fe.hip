@@ -102,6 +102,7 @@ void pinned_commit(eorb_ctx* c)
 ProfScope::ProfScope(eorb_ctx* cc, const char* name) : c(cc), idx(-1)
 {
     if (!c->prof) return;
+    if (!c->prof_only.empty() && c->prof_only.find(std::string(",") + name + ",") == std::string::npos) return;
     for (size_t i = 0; i < c->profs.size(); i++) if (c->profs[i].name == name) { idx = (int)i; break; }
     if (idx < 0) { c->profs.emplace_back(); c->profs.back().name = name; idx = (int)c->profs.size() - 1; }
     // events come from a pool (creating a pair costs several microseconds: visible on the one-frame-per-call paths)
@@ -306,6 +307,12 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
 const char* eorb_last_error(eorb_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int eorb_prof_enable(eorb_ctx* c, int on) { if (!c) return EORB_E_ARG; c->prof = on != 0; return EORB_OK; }
+int eorb_prof_only(eorb_ctx* c, const char* names)
+{
+    if (!c) return EORB_E_ARG;
+    c->prof_only = (names && *names) ? std::string(",") + names + "," : std::string();
+    return EORB_OK;
+}
 int eorb_prof_reset(eorb_ctx* c)
 {
     if (!c) return EORB_E_ARG;

@@ -68,6 +68,10 @@ class Context:
     def prof_enable(self, on=True):
         self.check(self.L.eorb_prof_enable(self.h, int(on)))
 
+    def prof_only(self, names=()):
+        """Time only these scopes (empty: all)."""
+        self.check(self.L.eorb_prof_only(self.h, ",".join(names).encode()))
+
     def prof_reset(self):
         self.check(self.L.eorb_prof_reset(self.h))
 

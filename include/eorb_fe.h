@@ -120,6 +120,9 @@ const char* eorb_version(void);
 /* per-kernel HIP-event timing on the ctx stream (off by default; used by bench.py) */
 int         eorb_prof_enable(eorb_ctx* ctx, int on);
 int         eorb_prof_reset(eorb_ctx* ctx);
+/* names: comma-separated scope names to time, NULL or "" = all (two event records per scope and call are a visible share of a
+ * short step: bench.py times only the accumulation scopes inside its timed steps) */
+int         eorb_prof_only(eorb_ctx* ctx, const char* names);
 int         eorb_prof_count(eorb_ctx* ctx);
 int         eorb_prof_get(eorb_ctx* ctx, int i, const char** name, double* total_ms, int64_t* launches);
 

@@ -20,4 +20,13 @@ for a, b in zip(rows, rows[1:]):
     gaps.append((int(b["Start_Timestamp"]) - end, a, b))
 for g, a, b in sorted(gaps, key=lambda x: -x[0])[:8]:
     print("gap %8.3f ms at %9.2f ms  after %-40s before %-40s" % (g / 1e6, (int(a["End_Timestamp"]) - t0) / 1e6, a["Kernel_Name"][:40], b["Kernel_Name"][:40]))
+# one step in the middle of the run, kernel by kernel: start offset, duration, idle time before it
+starts = [i for i, r in enumerate(rows) if "ev_minmax_init" in r["Kernel_Name"]]
+if len(starts) > 6:
+    i0, i1 = starts[len(starts) // 2], starts[len(starts) // 2 + 1]
+    base = int(rows[i0]["Start_Timestamp"]); end = base
+    for r in rows[i0:i1 + 1]:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print("%9.1f us  dur %8.1f  idle before %7.1f  %s" % ((st - base) / 1e3, (en - st) / 1e3, max(0, st - end) / 1e3, r["Kernel_Name"][:60]))
+        end = max(end, en)
 PY
