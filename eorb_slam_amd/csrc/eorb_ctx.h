@@ -135,8 +135,6 @@ struct eorb_ctx {
     eorb::DevBuf status;
     // test hooks (eorb_debug_option): shrink the octree node pool to force an overflow; force the octree's global-memory layout
     int dbg_pool_shrink = 0, dbg_force_global = 0;
-    int dbg_slot_reg = -1;                       // slot lists: -1 by EORB_SLOT_REG (default on), 0 K2p + K2h (8-bit entries), 1 the register-row kernel for every list
-    long long sl_reg_calls = 0;
     int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices), 4 slot lists (K2p)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
 };

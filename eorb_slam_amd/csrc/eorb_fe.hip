@@ -277,7 +277,6 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "win_list_cap")) { c->dbg_win_wcap = value; return EORB_OK; }
     if (!strcmp(name, "win_pool_cap")) { c->dbg_win_ecap = value; return EORB_OK; }
     if (!strcmp(name, "gather_form")) { c->dbg_gather_form = value; return EORB_OK; }
-    if (!strcmp(name, "slot_reg")) { c->dbg_slot_reg = value; return EORB_OK; }
     if (!strcmp(name, "dedupe_min_events")) { c->dbg_dd_min = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
@@ -287,7 +286,6 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
     if (!c || !name) return -1;
     if (!strcmp(name, "slot_calls")) return c->sl_calls;
     if (!strcmp(name, "slot_rank_ok")) return c->sl_rank_ok;
-    if (!strcmp(name, "slot_reg_calls")) return c->sl_reg_calls;
     if (!strcmp(name, "slot_hot_items")) {              // lists the last slot-form call handed to the register-row kernel (synchronises)
         if (!c->sl_hot.p) return 0;
         uint32_t h[16];

@@ -21,7 +21,6 @@
 #include "ev_common.h"
 #include "dev_math.h"
 #include "sl_hot_asm.h"
-#include "sl_reg_asm.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <string.h>
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
                                                                          const uint2* __restrict__ slot_tab, int stride, int LW, int LH, int TX, int TY,
                                                                          int NT, int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                                          const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
-                                                                         uint8_t* __restrict__ entries, int e16 /* 16-bit entries: slot | SL_REG_ENTRY_FLAG */)
+                                                                         uint8_t* __restrict__ entries)
 {
     extern __shared__ unsigned char sm2[];
     __shared__ uint32_t s_wsum[kSlotScatWaves];
@@ -420,9 +419,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
         const uint32_t r0 = prng[k];
         const int t = ((int)(r0 >> 8) + dy) * TX + (int)(r0 & 0xff) + dx;
         const uint32_t slot = (pay[k] >> (8 * (dy * 2 + dx))) & 0xffu;
-        const size_t at = (size_t)gbase[t] + (uint32_t)(p - (int)loff[t]);
-        if (e16) ((uint16_t*)out)[at] = (uint16_t)(slot | SL_REG_ENTRY_FLAG);
-        else out[at] = (uint8_t)slot;
+        out[(size_t)gbase[t] + (uint32_t)(p - (int)loff[t])] = (uint8_t)slot;
     }
 }
 
@@ -432,7 +429,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
 // in order, and the waves' shares are ordered by the prefix over the waves -- so no ballots, no parity classes, no per-event list
 // of sorted slots: phase A keeps four 8-bit ranks per event, phase C writes the entry byte and its tile straight to their place
 // in the chunk's tile-sorted order, phase D streams that order out run by run.
-template <int stride, bool E16>
+template <int stride>
 __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
                                                                               const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
                                                                               int chunk_cap, const int64_t* __restrict__ slice_ebase,
@@ -548,11 +545,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(co
     // ---- D: consecutive threads write consecutive entries of a run ----
     uint8_t* out = entries + (size_t)slice_ebase[cd.slice];
     const int E = loff[NT];
-    for (int p = tid; p < E; p += NTHR) {
-        const size_t at = (size_t)(uint32_t)(gbase[stile[p]] + (uint32_t)p);                                    // (gbase holds base - loff mod 2^32)
-        if (E16) ((uint16_t*)out)[at] = (uint16_t)(sorted[p] | SL_REG_ENTRY_FLAG);                               // (the register-row kernel's entries)
-        else out[at] = sorted[p];
-    }
+    for (int p = tid; p < E; p += NTHR) out[(size_t)(uint32_t)(gbase[stile[p]] + (uint32_t)p)] = sorted[p];     // (gbase holds base - loff mod 2^32)
 }
 
 // Are the results of a wave's LDS atomic add handed out in lane order among the lanes that hit the same counter (32-bit words
@@ -592,8 +585,7 @@ __global__ __launch_bounds__(256) void sl_rankcheck_kernel(unsigned long long* b
 constexpr int kHotBuckets = 16, kHotCap = 8192;
 struct HotDesc { uint32_t slice, tile, cnt, off_lo, off_hi, tx0, ty0, rows_off; };
 __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict__ tile_cnt, const uint32_t* __restrict__ tile_base,
-                                                      const int64_t* __restrict__ slice_ebase, int eshift /* log2 of the bytes per entry */,
-                                                      int B, int NT, int TX, uint32_t hot_min,
+                                                      const int64_t* __restrict__ slice_ebase, int B, int NT, int TX, uint32_t hot_min,
                                                       const uint32_t* __restrict__ nslots, const uint32_t* __restrict__ rowbase,
                                                       uint4* __restrict__ items, uint32_t* __restrict__ tile_w, uint32_t* __restrict__ tile_m,
                                                       uint32_t* __restrict__ ctr, uint32_t* __restrict__ hot_cnt, HotDesc* __restrict__ hot_items)
@@ -628,7 +620,7 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
         if (v & 0x80000000u) {
             const uint32_t c = v & 0x7fffffffu, b = hloc[s] >> 16, k = hbase[b] + (hloc[s] & 0xffffu);
             if (k < (uint32_t)kHotCap) {
-                const uint64_t off = (uint64_t)slice_ebase[s] + ((uint64_t)tile_base[(size_t)s * NT + t] << eshift);
+                const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
                 HotDesc d; d.slice = (uint32_t)s; d.tile = (uint32_t)t; d.cnt = c; d.off_lo = (uint32_t)off; d.off_hi = (uint32_t)(off >> 32);
                 d.tx0 = (uint32_t)(t % TX) * 8u; d.ty0 = (uint32_t)(t / TX) * 8u; d.rows_off = rowbase[t] * 256u;
                 hot_items[(size_t)b * kHotCap + k] = d;
@@ -642,7 +634,7 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
         const uint32_t c = pc[s];
         int rank = s;
         if (sorted) { rank = 0; for (int j = 0; j < B; j++) { const uint32_t v = pc[j]; rank += (v > c || (v == c && j < s)) ? 1 : 0; } }
-        const uint64_t off = (uint64_t)slice_ebase[s] + ((uint64_t)tile_base[(size_t)s * NT + t] << eshift);
+        const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
         items[(size_t)t * B + rank] = make_uint4((uint32_t)s | (c & 0x80000000u), c & 0x7fffffffu, (uint32_t)off, (uint32_t)(off >> 32));
     }
 #pragma unroll
@@ -899,33 +891,6 @@ __global__ __launch_bounds__(64) void sl_hot_kernel(const uint32_t* __restrict__
                  : SL_HOT_CLOBBERS);
 }
 
-// ---- K2g: every list through registers.  One wavefront per task = a tile position (sl_tasks_kernel: heavy positions get several,
-// two resident per SIMD): the position's rows go into v0..v239 ONCE, then the wave takes the position's lists by ticket, longest
-// first (the gather's own plan), and every 16-bit entry (slot | 0x1000 = the M0 image of the VGPR index mode) costs one scalar
-// instruction and one v_add_f32 -- 4.6 ns per entry and wave with two waves per SIMD against 7.5 for sl_hot_kernel's 8-bit entries
-// (tools/mb/gpr_idx.hip), and no second kernel beside it.  Needs every tile's rows to fit 240 registers; otherwise K2p (+ K2h)
-// with 8-bit entries as before.  The body is generated (tools/gen_sl_reg.py).
-__global__ __launch_bounds__(64) void sl_reg_kernel(const uint32_t* __restrict__ task_tile, const uint4* __restrict__ items, uint32_t* __restrict__ ctr,
-                                                    const uint32_t* __restrict__ rowbase, const float* __restrict__ rows, const uint8_t* __restrict__ entries,
-                                                    float* __restrict__ img, uint32_t* __restrict__ mm, int B, int W, int H, int TX)
-{
-    const uint32_t task = task_tile[blockIdx.x];
-    if (task == 0xffffffffu) return;
-    const int tile = (int)task;
-    const uint4* const it = items + (size_t)tile * B;
-    uint32_t* const ct = ctr + tile;
-    const float* const rw = rows + (size_t)rowbase[tile] * 64;
-    const int tx0 = (tile % TX) * kTile, ty0 = (tile / TX) * kTile;
-    const uint32_t rows_lo = (uint32_t)(uintptr_t)rw, rows_hi = (uint32_t)((uintptr_t)rw >> 32);
-    const uint32_t ent_lo = (uint32_t)(uintptr_t)entries, ent_hi = (uint32_t)((uintptr_t)entries >> 32);
-    const uint32_t img_lo = (uint32_t)(uintptr_t)img, img_hi = (uint32_t)((uintptr_t)img >> 32);
-    asm volatile(SL_REG_ASM
-                 :
-                 : [items] "s"(it), [ctr] "s"(ct), [nit] "s"(B), [rows_lo] "s"(rows_lo), [rows_hi] "s"(rows_hi), [ent_lo] "s"(ent_lo), [ent_hi] "s"(ent_hi),
-                   [img_lo] "s"(img_lo), [img_hi] "s"(img_hi), [mm] "s"(mm), [W] "s"(W), [H] "s"(H), [tx0] "s"(tx0), [ty0] "s"(ty0)
-                 : SL_REG_CLOBBERS);
-}
-
 // ---- host ----
 // Two halves, so that a caller that synchronises anyway (the float bulk path waits for its position count) can put the slot
 // assignment in front of ITS wait: launch = assignment + row bases (+ the once-per-context rank check), info read back into
@@ -1005,18 +970,14 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     std::vector<ChunkDesc> cds;
     std::vector<int> slice_c0(B + 1);
     std::vector<int64_t> slice_eb(B + 1);
-    // every list through the register-row kernel (16-bit entries) when all tiles' rows fit its registers
-    static const int reg_env = [] { const char* e = getenv("EORB_SLOT_REG"); return e ? atoi(e) : 1; }();
-    const bool reg = (c->dbg_slot_reg >= 0 ? c->dbg_slot_reg != 0 : reg_env != 0) && c->sl_null <= SL_REG_NROWS;
-    const int esize = reg ? 2 : 1;
-    int64_t eb = reg ? 64 : 0;                  // (sl_reg_kernel reads the 64 bytes that END at a list's end: front padding for a short first list)
+    int64_t eb = 0;
     for (int b = 0; b < B; b++) {
         slice_c0[b] = (int)cds.size();
         const int64_t s = h_offsets[b], e = h_offsets[b + 1];
         if (e < s) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
         if ((e - s) * 4 + (int64_t)NT * 16 >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)(e - s));
         slice_eb[b] = eb;
-        eb = (eb + ((e - s) * 4 + (int64_t)NT * 16) * esize + 15) & ~(int64_t)15;   // <= 4 entries per event, every list rounded up to 16
+        eb = (eb + (e - s) * 4 + (int64_t)NT * 16 + 15) & ~(int64_t)15;   // <= 4 entries per event, every list rounded up to 16
         for (int64_t k = s; k < e; k += chunk) {
             ChunkDesc cd; cd.start = k; cd.n = (int32_t)std::min<int64_t>(chunk, e - k); cd.slice = b;
             cds.push_back(cd);
@@ -1088,15 +1049,14 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
         if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= 64 * 1024)
         {
-#define SL_SCAT(ST, E) sl_scatter_rank_kernel<ST, E><<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
-                                                                                                  d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p)
-            if (reg) { if (stride == 16) SL_SCAT(16, true); else if (stride == 4) SL_SCAT(4, true); else SL_SCAT(-4, true); }
-            else { if (stride == 16) SL_SCAT(16, false); else if (stride == 4) SL_SCAT(4, false); else SL_SCAT(-4, false); }
+#define SL_SCAT(ST) sl_scatter_rank_kernel<ST><<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
+                                                                                               d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p)
+            if (stride == 16) SL_SCAT(16); else if (stride == 4) SL_SCAT(4); else SL_SCAT(-4);
 #undef SL_SCAT
         }
         else if (nchunks)
             sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
-                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p, reg ? 1 : 0);
+                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
         lds_g = (size_t)(c->sl_null + 1) * 256;
         const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds_g));
         static const int nw_env = [] { const char* e = getenv("EORB_SLOT_WAVES"); return e ? atoi(e) : 0; }();
@@ -1111,8 +1071,8 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         ncu_g = ncu;
         // one task per tile position plus a few rounds of spare ones shared out by weight; a position never gets more wavefronts than slices
         const int rounds = ns_env >= 1 ? ns_env : 4;
-        G = NT + rounds * ncu * (reg ? 8 : wg_per_cu);                     // (register-row tasks are single wavefronts, two resident per SIMD)
-        const int max_per_tile = reg ? B : (B + nw - 1) / nw;
+        G = NT + rounds * ncu * wg_per_cu;
+        const int max_per_tile = (B + nw - 1) / nw;
         if ((rc = ensure(c, c->sl_plan, sizeof(uint4) * (size_t)nb + sizeof(uint32_t) * ((size_t)G + 3 * (size_t)NT)))) return rc;
         d_items = (uint4*)c->sl_plan.p;
         d_task = (uint32_t*)(d_items + nb);
@@ -1125,12 +1085,11 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         static const long long hot_env = [] { const char* e = getenv("EORB_SLOT_HOT_MIN"); return e ? atoll(e) : -1ll; }();
         hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 16000), 0x7fffffff) : 0u;
         if (hot_env >= 0) hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<long long>(hot_env, 0x7fffffff) : 0u;
-        if (reg) hot_min = 0u;                                               // (one kernel takes every list)
         if ((rc = ensure(c, c->sl_hot, sizeof(HotDesc) * (size_t)kHotBuckets * kHotCap + 256))) return rc;
         d_hot_cnt = (uint32_t*)c->sl_hot.p;                                  // 16 bucket counts | ticket (at word 32) | descriptors (from byte 256)
         d_hot_items = (HotDesc*)((char*)c->sl_hot.p + 256);
         EORB_HIP(c, hipMemsetAsync(c->sl_hot.p, 0, 256, c->stream));
-        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, c->stream>>>(d_tile_cnt, d_tile_base, d_slice_eb, reg ? 1 : 0, B, NT, TX, hot_min, d_nslots, d_rowbase,
+        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, c->stream>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, TX, hot_min, d_nslots, d_rowbase,
                                                                              d_items, d_tile_w, d_tile_m, d_ctr, d_hot_cnt, d_hot_items);
         sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->stream>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task, d_hot_cnt);
         EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
@@ -1145,13 +1104,6 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         P.trace = (unsigned long long*)c->sl_trace.p + 8;
         c->sl_trace_n = (long long)G * 16;
 #endif
-        if (reg) {
-            sl_reg_kernel<<<G, 64, 0, c->stream>>>(d_task, d_items, d_ctr, d_rowbase, (const float*)c->sl_rows.p, (const uint8_t*)c->entries.p, d_f32, d_minmax_enc,
-                                                   B, W, H, TX);
-            EORB_LAUNCH_CHECK(c, "sl_reg_kernel");
-            c->sl_reg_calls++;
-            return EORB_OK;
-        }
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)sl_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         if (hot_min) {

@@ -107,15 +107,12 @@ int         eorb_sync(eorb_ctx* ctx);
  * candidate list capacity per query / pool per pair, to force the full-scan path), "gather_form" (raw events with a Gaussian
  * stamp: 0 = choose the gather kernel by the batch's shape, 1 = the pipelined workgroup per tile, 2 = the wave per tile, 3 = no
  * binning, every tile's wave reads all events of its slice (calls with at most 4 slices), 4 = two-byte slot lists whatever the
- * batch's shape (falls back to 1 where they do not apply: polarity, sigma > 4/3, a tile with more than 254 slots)), "slot_reg" (slot lists: 1 = every list
- * through the register-row kernel with 16-bit entries (the default where every tile has at most 240 slots), 0 = the LDS-row kernel beside the
- * register-row kernel for long lists, 8-bit entries), "dedupe_min_events" (float events:
+ * batch's shape (falls back to 1 where they do not apply: polarity, sigma > 4/3, a tile with more than 254 slots)), "dedupe_min_events" (float events:
  * number of events per call from which their distinct positions are tabulated, default 2^20) */
 int         eorb_debug_option(eorb_ctx* ctx, const char* name, int value);
 /* test hook: counters a test can read to see which path served its calls.  "slot_calls": accumulation calls that took the slot
  * lists (gather_form 0 on dense batches, or 4); "slot_flags": sticky device flags of that path (0 = fine; synchronises); "slot_hot_items": lists the last such call handed to
- * the long-list kernel of the "slot_reg" 0 form (synchronises); "slot_reg_calls": calls whose lists all went through the register-row kernel;
- * "slot_rank_ok": 1 when the scatter takes its ranks from LDS atomics.
+ * the register-row kernel (synchronises); "slot_rank_ok": 1 when the scatter takes its ranks from LDS atomics.
  * Returns the value, or -1 for an unknown name. */
 long long   eorb_debug_counter(eorb_ctx* ctx, const char* name);
 const char* eorb_last_error(eorb_ctx* ctx);

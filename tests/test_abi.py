@@ -81,8 +81,7 @@ def test_hot_kernel_jump_arithmetic(tmp_path):
     obj, co = str(tmp_path / "slots.o"), str(tmp_path / "slots.co")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-w", "-c", src, "-o", obj])
     subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + obj, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
-    dis = re.search(r"^[0-9a-f]+ <[^>\n]*sl_hot_kernel[^>\n]*>:\n(.*?)s_endpgm", dis, re.S | re.M).group(1).split("\n")
+    dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout.split("\n")
     ins = [(int(m.group(2), 16), m.group(1).strip()) for m in (re.match(r"\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", l) for l in dis) if m]
     gp = [i for i, (a, t) in enumerate(ins) if t.startswith("s_getpc_b64 s[34:35]")]
     assert len(gp) == 1
@@ -96,38 +95,6 @@ def test_hot_kernel_jump_arithmetic(tmp_path):
     text = _device_asm("ev_slots.hip")
     body = re.findall(r"\.amdhsa_kernel (\S*sl_hot_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)[0][1]
     assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", body) and int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1)) == 256
-
-
-def test_reg_kernel_jump_arithmetic(tmp_path):
-    """sl_reg_kernel (16-bit entries) enters its 32-entry sequence in the middle for the tail of a list: s_getpc + 20 bytes + 16 bytes
-    per entry dword (tools/gen_sl_reg.py); one scalar and one vector instruction per entry; 256 VGPRs, no scratch."""
-    llvm = "/opt/rocm/lib/llvm/bin"
-    if not (os.path.exists("/opt/rocm/bin/hipcc") and os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/clang-offload-bundler")):
-        pytest.skip("no ROCm LLVM tools")
-    src = os.path.join(ROOT, "eorb_slam_amd", "csrc", "ev_slots.hip")
-    obj, co = str(tmp_path / "slots.o"), str(tmp_path / "slots.co")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only", "-w", "-c", src, "-o", obj])
-    subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + obj, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
-    body = re.search(r"^[0-9a-f]+ <[^>\n]*sl_reg_kernel[^>\n]*>:\n(.*?)s_endpgm", dis, re.S | re.M).group(1).split("\n")
-    ins = [(int(m.group(2), 16), m.group(1).strip()) for m in (re.match(r"\s*(.*?)\s*//\s*([0-9A-Fa-f]+):", l) for l in body) if m]
-    gp = [i for i, (a, t) in enumerate(ins) if t.startswith("s_getpc_b64 s[34:35]")]
-    assert len(gp) == 1
-    i = gp[0]
-    sp = next(j for j in range(i, i + 12) if ins[j][1].startswith("s_setpc_b64"))
-    seq = ins[sp + 1:sp + 1 + 64]
-    assert seq[0][1] == "s_mov_b32 m0, s64" and seq[0][0] - ins[i + 1][0] == 20, (ins[i + 1], seq[0])
-    for d in range(16):
-        q = seq[4 * d:4 * d + 4]
-        assert [t for _, t in q] == ["s_mov_b32 m0, s%d" % (64 + d), "v_add_f32_e32 v241, v0, v241", "s_lshr_b32 m0, s%d, 16" % (64 + d),
-                                     "v_add_f32_e32 v241, v0, v241"], q
-        assert q[0][0] - seq[0][0] == 16 * d
-    # the loop's three phases: the same two instructions per entry, nothing else between two scalar loads' worth of entries
-    movs = [t for _, t in ins if re.fullmatch(r"s_mov_b32 m0, s\d+", t)]
-    assert len(movs) == 16 * 4                                  # three rotating buffers + the tail sequence
-    text = _device_asm("ev_slots.hip")
-    meta = re.findall(r"\.amdhsa_kernel (\S*sl_reg_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)[0][1]
-    assert re.search(r"\.amdhsa_private_segment_fixed_size 0\b", meta) and int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)) == 256
 
 
 def _device_asm(src_name):

@@ -1015,16 +1015,14 @@ def test_raw_accumulation_random_sweep(oracle, fe, form):
     ctx.close()
 
 
-@pytest.mark.parametrize("reg", [1, 0])
-def test_slot_lists_form(oracle, fe, reg):
-    """The slot forms of the raw accumulation (ev_slots.hip; reg = 1: 16-bit entries, a tile position's rows in registers, every list
-    through sl_reg_kernel; reg = 0: 8-bit entries, the rows in LDS (sl_gather_kernel) and long lists through sl_hot_kernel): f32 image, running extremes and u8 image against the oracle for one slice of 1 ... 300 000 events (list lengths around
+def test_slot_lists_form(oracle, fe):
+    """The slot form of the raw accumulation (ev_slots.hip: two-byte entries, a tile position's rows in LDS, one ds_read_addtid per
+    entry): f32 image, running extremes and u8 image against the oracle for one slice of 1 ... 300 000 events (list lengths around
     the 512-entry block and the 16-entry loop step, hot pixels, empty tiles), the DAVIS and the MVSEC sensor, three stamp sizes (and a fourth that falls back),
     maps with and without checkInImage; then slices of a batch against the same slices alone.  The test hook counters show that the
     slot form ran and raised no flag."""
     ctx = fe.Context()
     ctx.debug_option("gather_form", 4)
-    ctx.debug_option("slot_reg", reg)
     rng = np.random.default_rng(7)
     calls = 0
     for (W, H), check in (((240, 180), True), ((346, 260), False), ((64, 48), True)):
@@ -1065,8 +1063,7 @@ def test_slot_lists_form(oracle, fe, reg):
         gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, 1.0, False, True, ctx=ctx, return_all=True)
         calls += 1
         assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), ("tile corner", W, H, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
-        # (60 000 events on four tiles: the register-row kernel of either form took lists)
-        assert (ctx.debug_counter("slot_reg_calls") >= 1) if reg else (ctx.debug_counter("slot_hot_items") >= 1 and ctx.debug_counter("slot_reg_calls") == 0)
+        assert ctx.debug_counter("slot_hot_items") >= 1              # (60 000 events on four tiles: lists long enough for the register-row kernel)
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)) and np.array_equal(ou, gu)
     assert ctx.debug_counter("slot_calls") == calls and ctx.debug_counter("slot_flags") == 0 and ctx.debug_counter("slot_rank_ok") == 1
     ctx.close()
@@ -1096,25 +1093,19 @@ def test_slot_lists_form(oracle, fe, reg):
     c.close()
 
 
-@pytest.mark.parametrize("reg", [1, 0])
-def test_register_row_kernel_list_tails(oracle, fe, reg):
-    """The register-row kernels walk a list one scalar load (64 bytes) at a time and enter their unrolled sequence in the middle for the
-    last entries, with the part of the last dword past the end replaced by the null row.  reg = 1 (sl_reg_kernel, 16-bit entries, 32 per
-    load, every list): every length from 1 to 70 (lists shorter than a load: the block that ENDS at the list's end starts before it) and
-    every residue mod 64 above 4 096.  reg = 0 (sl_hot_kernel, 8-bit entries, 64 per load, lists of 4 096 entries or more): every residue
-    mod 64 (hence mod 4).  All events sit on a 3x3 patch of sensor pixels in the middle of a tile, so the tile's list holds every event."""
+def test_register_row_kernel_list_tails(oracle, fe):
+    """sl_hot_kernel walks a list 64 entries per scalar load and enters its unrolled sequence in the middle for the last (length mod 64)
+    entries, with the bytes of the last dword past the end replaced by the null row: every residue of the length mod 64 (hence mod 4),
+    on lists just long enough for that kernel (4 096 entries), against the oracle.  All events sit on a 3x3 patch of sensor pixels in the
+    middle of a tile, so the tile's list holds every event."""
     W, H = 240, 180
     mx, my = _maps(W, H)
     ctx = fe.Context()
     ctx.debug_option("gather_form", 4)
-    ctx.debug_option("slot_reg", reg)
     fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=ctx)
     rng = np.random.default_rng(11)
     hot_seen = 0
-    lengths = list(range(4096, 4096 + 66)) + [4096 + 127, 4096 + 128, 4096 + 129, 8191, 8192, 8193, 12345]
-    if reg:
-        lengths = list(range(1, 71)) + [95, 96, 97, 191, 192, 193, 255, 256, 257] + lengths
-    for n in lengths:
+    for n in list(range(4096, 4096 + 66)) + [4096 + 127, 4096 + 128, 4096 + 129, 8191, 8192, 8193, 12345]:
         raw = np.zeros(n, synth.RAW_DTYPE)
         raw["x"] = 123 + rng.integers(0, 3, n); raw["y"] = 91 + rng.integers(0, 3, n); raw["p"] = 1; raw["t"] = np.arange(n) * 1e-6
         ev = oracle.undistort_events(raw, mx, my, W, H, True, 1.0)
@@ -1122,8 +1113,8 @@ def test_register_row_kernel_list_tails(oracle, fe, reg):
         gf, gu, gmm = fe.EvImConverter.ev2im_gauss_raw(raw, W, H, 1.0, False, True, ctx=ctx, return_all=True)
         assert np.array_equal(of.view(np.uint32), gf.view(np.uint32)), (n, int((of.view(np.uint32) != gf.view(np.uint32)).sum()))
         assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), gmm.view(np.uint32)) and np.array_equal(ou, gu), n
-        hot_seen += (ctx.debug_counter("slot_hot_items") >= 1) if not reg else 0
-    assert (ctx.debug_counter("slot_reg_calls") == len(lengths)) if reg else (hot_seen >= 60 and ctx.debug_counter("slot_reg_calls") == 0)
+        hot_seen += ctx.debug_counter("slot_hot_items") >= 1
+    assert hot_seen >= 60
     ctx.close()
 
 
