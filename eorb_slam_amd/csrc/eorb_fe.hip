@@ -727,10 +727,8 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     const char* h;
     if ((rc = A.download(o_n, end - o_n, &h))) return rc;
     const int32_t* hn = (const int32_t*)(h + o_n);
-    if (hn[2]) {
-        hipMemsetAsync(c->status.p, 0, sizeof(int32_t), c->stream);       // reported here, not again by eorb_sync
+    if (hn[2])                                    // (reported here; the sticky word of the *_dev calls is not involved)
         return set_err(c, EORB_E_CAPACITY, "orb_extract: internal capacity exceeded (flag %d)", hn[2]);
-    }
     if (hn[0] > cap) return set_err(c, EORB_E_CAPACITY, "orb_extract: %d keypoints > caller capacity %d", hn[0], cap);
     if (hn[0] > 0) {
         if (kps) memcpy(kps, h + o_kp, sizeof(eorb_keypoint) * (size_t)hn[0]);

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     uint64_t* cc = (uint64_t*)(((uintptr_t)(dv + pc) + 7) & ~(uintptr_t)7);       // pc: child counts of the processed nodes, 4 x 16 bits
     uint32_t* lkp = lvl_kp + (size_t)slice * G->kp_total + L.kp_off;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    auto raise = [&](int bit) { if (tid == 0) { atomicOr(err_flag, bit); atomicOr(sticky, bit); } };
+    auto raise = [&](int bit) { if (tid == 0) { atomicOr(err_flag, bit); if (sticky) atomicOr(sticky, bit); } };
 
     // ---- gather the level's candidates in cell order (vToDistributeKeys) ----
     int n = 0;
@@ -1242,7 +1242,10 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
         ProfScope ps(c, "orb_octree");
         octree_kernel<<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
                                                                     (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p,
-                                                                    (int32_t*)c->lvl_cnt.p, err_flag, (int32_t*)c->status.p, placement);
+                                                                    (int32_t*)c->lvl_cnt.p, err_flag,
+                                                                    // a call that hands its own flag back (the host entry point) stays out of the sticky word
+                                                                    // of the *_dev calls: eorb_sync still reports an earlier batch's overflow
+                                                                    d_flag_out ? nullptr : (int32_t*)c->status.p, placement);
         EORB_LAUNCH_CHECK(c, "octree_kernel");
     }
     {

@@ -1454,6 +1454,15 @@ def test_batched_overflow_is_reported_by_sync(oracle, fe):
         ge(img)
     assert e.value.code == -3
     c.sync()
+    # an overflow of a batch is not lost when a host call on the same context overflows before the sync: the host call reports its own
+    # flag and leaves the sticky word of the batch alone
+    fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * n)
+    with pytest.raises(fe.EorbError):
+        ge(img)
+    with pytest.raises(fe.EorbError) as e:
+        c.sync()
+    assert e.value.code == -3
+    c.sync()
     c.dev_free(d_ev); c.close()
 
 
