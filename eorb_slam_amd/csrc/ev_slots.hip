@@ -135,6 +135,36 @@ __global__ __launch_bounds__(256) void sl_rows_kernel(const uint32_t* __restrict
         }
 }
 
+// ---- K0: the chunk descriptors, the slices' first chunks and entry bases, from the slice offsets (a kernel argument: no staging
+// buffer, no host-to-device copy in front of the count pass).  Same arithmetic as the host loop of ev_slots_accumulate. ----
+constexpr int kOffsetsInArg = 256;
+struct SliceOffsets { int64_t off[kOffsetsInArg + 1]; };
+__global__ __launch_bounds__(256) void sl_chunks_kernel(SliceOffsets S, int B, int chunk_shift /* chunks are 2^shift events */, int NT, int nchunks, ChunkDesc* __restrict__ chunks,
+                                                        int* __restrict__ slice_c0, int64_t* __restrict__ slice_eb)
+{
+    __shared__ int c0[kOffsetsInArg + 1];
+    const int tid = threadIdx.x;
+    const int64_t chunk = (int64_t)1 << chunk_shift;
+    if (tid == 0) {
+        int run = 0; int64_t eb = 0;
+        for (int b = 0; b < B; b++) {
+            const int64_t n = S.off[b + 1] - S.off[b];
+            c0[b] = run; run += (int)((n + chunk - 1) >> chunk_shift);
+            if (blockIdx.x == 0) { slice_eb[b] = eb; eb = (eb + n * 4 + (int64_t)NT * 16 + 15) & ~(int64_t)15; }
+        }
+        c0[B] = run;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) for (int b = tid; b <= B; b += blockDim.x) slice_c0[b] = c0[b];
+    const int g = blockIdx.x * blockDim.x + tid;
+    if (g >= nchunks) return;
+    int lo = 0, hi = B;                      // the slice whose chunks hold g: c0[lo] <= g < c0[lo + 1] (empty slices own no chunk)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c0[mid] <= g) lo = mid; else hi = mid; }
+    const int64_t start = S.off[lo] + ((int64_t)(g - c0[lo]) << chunk_shift);
+    ChunkDesc cd; cd.start = start; cd.n = (int32_t)min(chunk, S.off[lo + 1] - start); cd.slice = lo;
+    chunks[g] = cd;
+}
+
 // ---- K1a: entries of every (chunk, tile) -----------------------------------------------------------------------------------------
 // (stride: 16 = eorb_raw_event, 4 = eorb_raw_event4, -4 = hashed records; a template parameter in the two hot kernels)
 template <int stride>
@@ -967,24 +997,29 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     const int64_t nev = h_offsets[B] - h_offsets[0];
     const int64_t per_slice = nev / B;
     const int chunk = per_slice >= (int64_t)1 << 17 ? 2048 : (per_slice >= (int64_t)1 << 14 ? 1024 : 256);
+    // up to 256 slices: the descriptors are made on the device from the offsets (sl_chunks_kernel); more: on the host, one copy
+    const bool on_dev = B <= kOffsetsInArg;
     std::vector<ChunkDesc> cds;
-    std::vector<int> slice_c0(B + 1);
-    std::vector<int64_t> slice_eb(B + 1);
-    int64_t eb = 0;
+    std::vector<int> slice_c0(on_dev ? 0 : B + 1);
+    std::vector<int64_t> slice_eb(on_dev ? 0 : B + 1);
+    int64_t eb = 0, nch = 0;
     for (int b = 0; b < B; b++) {
-        slice_c0[b] = (int)cds.size();
+        if (!on_dev) slice_c0[b] = (int)nch;
         const int64_t s = h_offsets[b], e = h_offsets[b + 1];
         if (e < s) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
         if ((e - s) * 4 + (int64_t)NT * 16 >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)(e - s));
-        slice_eb[b] = eb;
+        if (!on_dev) slice_eb[b] = eb;
         eb = (eb + (e - s) * 4 + (int64_t)NT * 16 + 15) & ~(int64_t)15;   // <= 4 entries per event, every list rounded up to 16
-        for (int64_t k = s; k < e; k += chunk) {
-            ChunkDesc cd; cd.start = k; cd.n = (int32_t)std::min<int64_t>(chunk, e - k); cd.slice = b;
-            cds.push_back(cd);
-        }
+        nch += (e - s + chunk - 1) / chunk;
+        if (!on_dev)
+            for (int64_t k = s; k < e; k += chunk) {
+                ChunkDesc cd; cd.start = k; cd.n = (int32_t)std::min<int64_t>(chunk, e - k); cd.slice = b;
+                cds.push_back(cd);
+            }
     }
-    slice_c0[B] = (int)cds.size(); slice_eb[B] = eb;
-    const int nchunks = (int)cds.size();
+    if (nch >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: too many chunks");
+    if (!on_dev) { slice_c0[B] = (int)nch; slice_eb[B] = eb; }
+    const int nchunks = (int)nch;
     const size_t cd_bytes = sizeof(ChunkDesc) * (size_t)std::max(nchunks, 1);
     const size_t sc_bytes = (sizeof(int) * (size_t)(B + 1) + 7) & ~(size_t)7;
     const size_t eb_bytes = sizeof(int64_t) * (size_t)B;
@@ -995,13 +1030,21 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     if ((rc = ensure(c, c->segoff, cnt_bytes + sizeof(uint32_t) * (size_t)std::max(nchunks, 1) * NT))) return rc;
     if ((rc = ensure(c, c->entries, (size_t)eb + 8192))) return rc;      // + slack: the gather requests blocks past a list's end
     if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
-    char* hp = (char*)pinned(c, cd_bytes + sc_bytes + eb_bytes);
-    if (!hp) return set_err(c, EORB_E_HIP, "pinned alloc failed");
-    if (nchunks) memcpy(hp, cds.data(), sizeof(ChunkDesc) * nchunks);
-    memcpy(hp + cd_bytes, slice_c0.data(), sizeof(int) * (size_t)(B + 1));
-    memcpy(hp + cd_bytes + sc_bytes, slice_eb.data(), eb_bytes);
-    EORB_HIP(c, hipMemcpyAsync(c->chunks.p, hp, cd_bytes + sc_bytes + eb_bytes, hipMemcpyHostToDevice, c->stream));
-    pinned_commit(c);
+    if (on_dev) {
+        SliceOffsets so;
+        for (int b = 0; b <= B; b++) so.off[b] = h_offsets[b];
+        sl_chunks_kernel<<<std::max(1, (nchunks + 255) / 256), 256, 0, c->stream>>>(so, B, chunk == 2048 ? 11 : (chunk == 1024 ? 10 : 8), NT, nchunks, (ChunkDesc*)c->chunks.p, (int*)((char*)c->chunks.p + cd_bytes),
+                                                                                  (int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes));
+    }
+    else {
+        char* hp = (char*)pinned(c, cd_bytes + sc_bytes + eb_bytes);
+        if (!hp) return set_err(c, EORB_E_HIP, "pinned alloc failed");
+        if (nchunks) memcpy(hp, cds.data(), sizeof(ChunkDesc) * nchunks);
+        memcpy(hp + cd_bytes, slice_c0.data(), sizeof(int) * (size_t)(B + 1));
+        memcpy(hp + cd_bytes + sc_bytes, slice_eb.data(), eb_bytes);
+        EORB_HIP(c, hipMemcpyAsync(c->chunks.p, hp, cd_bytes + sc_bytes + eb_bytes, hipMemcpyHostToDevice, c->stream));
+        pinned_commit(c);
+    }
     const ChunkDesc* d_chunks = (const ChunkDesc*)c->chunks.p;
     const int* d_slice_c0 = (const int*)((char*)c->chunks.p + cd_bytes);
     const int64_t* d_slice_eb = (const int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes);
