@@ -92,7 +92,7 @@ struct eorb_ctx {
     eorb::DevBuf lut, src_info, stamps;
     // slot form of the raw accumulation (ev_slots.hip): per sensor pixel its tiles / slot numbers, per tile its rows; valid when sl_ok
     eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_plan, sl_trace, sl_hot; long long sl_trace_n = 0;
-    hipStream_t sl_side = nullptr; hipEvent_t sl_ev_fork = nullptr, sl_ev_join = nullptr;      // the long lists run beside the gather
+    hipStream_t sl_side = nullptr; hipEvent_t sl_ev_fork = nullptr, sl_ev_join = nullptr, sl_ev_plan = nullptr, sl_ev_scat = nullptr;      // the long lists run beside the gather
     int sl_ok = 0, sl_null = 0, sl_rank_ok = -1;
     int* rb_pinned = nullptr;                   // 64 ints of pinned host memory: the landing place of small read-backs (position count, slot info)
     int sl_launched = 0; int sl_hinfo[6] = {0, 0, 0, 0, 0, 0};      // assignment kernels launched, their read-back (ev_slots_prepare_launch / _finish)

@@ -247,6 +247,8 @@ void eorb_destroy(eorb_ctx* c)
     if (c->rb_pinned) hipHostFree(c->rb_pinned);
     if (c->sl_ev_fork) hipEventDestroy(c->sl_ev_fork);
     if (c->sl_ev_join) hipEventDestroy(c->sl_ev_join);
+    if (c->sl_ev_plan) hipEventDestroy(c->sl_ev_plan);
+    if (c->sl_ev_scat) hipEventDestroy(c->sl_ev_scat);
     if (c->sl_side) hipStreamDestroy(c->sl_side);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;

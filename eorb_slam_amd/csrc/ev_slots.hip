@@ -139,29 +139,38 @@ __global__ __launch_bounds__(256) void sl_rows_kernel(const uint32_t* __restrict
 // buffer, no host-to-device copy in front of the count pass).  Same arithmetic as the host loop of ev_slots_accumulate. ----
 constexpr int kOffsetsInArg = 256;
 struct SliceOffsets { int64_t off[kOffsetsInArg + 1]; };
-__global__ __launch_bounds__(256) void sl_chunks_kernel(SliceOffsets S, int B, int chunk_shift /* chunks are 2^shift events */, int NT, int nchunks, ChunkDesc* __restrict__ chunks,
-                                                        int* __restrict__ slice_c0, int64_t* __restrict__ slice_eb)
+__global__ __launch_bounds__(256) void sl_chunks_kernel(SliceOffsets S, int B, int chunk_shift /* chunks are 2^shift events */, int NT, int nchunks,
+                                                        ChunkDesc* __restrict__ chunks, int* __restrict__ slice_c0, int64_t* __restrict__ slice_eb)
 {
     __shared__ int c0[kOffsetsInArg + 1];
+    __shared__ long long e0[kOffsetsInArg + 1];
     const int tid = threadIdx.x;
     const int64_t chunk = (int64_t)1 << chunk_shift;
-    if (tid == 0) {
-        int run = 0; int64_t eb = 0;
-        for (int b = 0; b < B; b++) {
-            const int64_t n = S.off[b + 1] - S.off[b];
-            c0[b] = run; run += (int)((n + chunk - 1) >> chunk_shift);
-            if (blockIdx.x == 0) { slice_eb[b] = eb; eb = (eb + n * 4 + (int64_t)NT * 16 + 15) & ~(int64_t)15; }
-        }
-        c0[B] = run;
-    }
+    // thread b = slice b: S is the FIRST kernel argument, read per lane straight from the kernarg segment (a loop over S.off[b] is a
+    // chain of 2 B dependent scalar loads: 14 us for 128 slices)
+    const int64_t* off = (const int64_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int64_t n = tid < B ? off[tid + 1] - off[tid] : 0;
+    c0[tid + 1] = tid < B ? (int)((n + chunk - 1) >> chunk_shift) : 0;
+    e0[tid + 1] = tid < B ? ((n * 4 + (int64_t)NT * 16 + 15) & ~(int64_t)15) : 0;     // (bases are multiples of 16: aligning the sum = summing the aligned sizes)
+    if (tid == 0) { c0[0] = 0; e0[0] = 0; }
     __syncthreads();
-    if (blockIdx.x == 0) for (int b = tid; b <= B; b += blockDim.x) slice_c0[b] = c0[b];
+    for (int d = 1; d < kOffsetsInArg; d <<= 1) {                                     // inclusive scans over [1 .. 256]
+        const int a = tid + 1 > d ? c0[tid + 1 - d] : 0;
+        const long long b = tid + 1 > d ? e0[tid + 1 - d] : 0;
+        __syncthreads();
+        c0[tid + 1] += a; e0[tid + 1] += b;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        if (tid < B) slice_eb[tid] = e0[tid];
+        for (int b = tid; b <= B; b += blockDim.x) slice_c0[b] = c0[b];
+    }
     const int g = blockIdx.x * blockDim.x + tid;
     if (g >= nchunks) return;
     int lo = 0, hi = B;                      // the slice whose chunks hold g: c0[lo] <= g < c0[lo + 1] (empty slices own no chunk)
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c0[mid] <= g) lo = mid; else hi = mid; }
-    const int64_t start = S.off[lo] + ((int64_t)(g - c0[lo]) << chunk_shift);
-    ChunkDesc cd; cd.start = start; cd.n = (int32_t)min(chunk, S.off[lo + 1] - start); cd.slice = lo;
+    const int64_t start = off[lo] + ((int64_t)(g - c0[lo]) << chunk_shift);
+    ChunkDesc cd; cd.start = start; cd.n = (int32_t)min(chunk, off[lo + 1] - start); cd.slice = lo;
     chunks[g] = cd;
 }
 
@@ -1088,18 +1097,16 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
             else sl_count_kernel<-4><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
         }
         sl_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
-        static const int rank_env = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
-        const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
-        if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= 64 * 1024)
-        {
-#define SL_SCAT(ST) sl_scatter_rank_kernel<ST><<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
-                                                                                               d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p)
-            if (stride == 16) SL_SCAT(16); else if (stride == 4) SL_SCAT(4); else SL_SCAT(-4);
-#undef SL_SCAT
+        // ---- the gather's plan needs the scan's counts only: it runs on the side stream BESIDE the scatter (50 us of single-block
+        //      kernels off the critical path); the side stream goes on to the long lists once the scatter's entries are there ----
+        if (!c->sl_side) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&c->sl_side, hipStreamNonBlocking, hi) != hipSuccess) return set_err(c, EORB_E_HIP, "side stream");
+            if (hipEventCreateWithFlags(&c->sl_ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->sl_ev_join, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->sl_ev_plan, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->sl_ev_scat, hipEventDisableTiming) != hipSuccess)
+                return set_err(c, EORB_E_HIP, "side stream events");
         }
-        else if (nchunks)
-            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
-                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
         lds_g = (size_t)(c->sl_null + 1) * 256;
         const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds_g));
         static const int nw_env = [] { const char* e = getenv("EORB_SLOT_WAVES"); return e ? atoi(e) : 0; }();
@@ -1131,10 +1138,26 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         if ((rc = ensure(c, c->sl_hot, sizeof(HotDesc) * (size_t)kHotBuckets * kHotCap + 256))) return rc;
         d_hot_cnt = (uint32_t*)c->sl_hot.p;                                  // 16 bucket counts | ticket (at word 32) | descriptors (from byte 256)
         d_hot_items = (HotDesc*)((char*)c->sl_hot.p + 256);
-        EORB_HIP(c, hipMemsetAsync(c->sl_hot.p, 0, 256, c->stream));
-        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, c->stream>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, TX, hot_min, d_nslots, d_rowbase,
-                                                                             d_items, d_tile_w, d_tile_m, d_ctr, d_hot_cnt, d_hot_items);
-        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->stream>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task, d_hot_cnt);
+        EORB_HIP(c, hipEventRecord(c->sl_ev_fork, c->stream));
+        EORB_HIP(c, hipStreamWaitEvent(c->sl_side, c->sl_ev_fork, 0));
+        EORB_HIP(c, hipMemsetAsync(c->sl_hot.p, 0, 256, c->sl_side));
+        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, c->sl_side>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, TX, hot_min, d_nslots, d_rowbase,
+                                                                               d_items, d_tile_w, d_tile_m, d_ctr, d_hot_cnt, d_hot_items);
+        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->sl_side>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task, d_hot_cnt);
+        EORB_HIP(c, hipEventRecord(c->sl_ev_plan, c->sl_side));
+        // ---- the scatter ----
+        static const int rank_env = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
+        const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
+        if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= 64 * 1024)
+        {
+#define SL_SCAT(ST) sl_scatter_rank_kernel<ST><<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
+                                                                                               d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p)
+            if (stride == 16) SL_SCAT(16); else if (stride == 4) SL_SCAT(4); else SL_SCAT(-4);
+#undef SL_SCAT
+        }
+        else if (nchunks)
+            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
+                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
         EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
     }
     {
@@ -1150,24 +1173,18 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)sl_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         if (hot_min) {
-            // the long lists on a second (high-priority) stream beside the gather: fork after the plan, join before the images are read
-            if (!c->sl_side) {
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                if (hipStreamCreateWithPriority(&c->sl_side, hipStreamNonBlocking, hi) != hipSuccess) return set_err(c, EORB_E_HIP, "side stream");
-                if (hipEventCreateWithFlags(&c->sl_ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->sl_ev_join, hipEventDisableTiming) != hipSuccess)
-                    return set_err(c, EORB_E_HIP, "side stream events");
-            }
+            // the long lists on the side (high-priority) stream beside the gather: they need the scatter's entries
             static const int hw_env = [] { const char* e = getenv("EORB_SLOT_HOT_WAVES"); return e ? atoi(e) : 0; }();
             const int hw = hw_env > 0 ? hw_env : 8 * ncu_g;               // two per SIMD: all of its registers
-            EORB_HIP(c, hipEventRecord(c->sl_ev_fork, c->stream));
-            EORB_HIP(c, hipStreamWaitEvent(c->sl_side, c->sl_ev_fork, 0));
+            EORB_HIP(c, hipEventRecord(c->sl_ev_scat, c->stream));
+            EORB_HIP(c, hipStreamWaitEvent(c->sl_side, c->sl_ev_scat, 0));
             sl_hot_kernel<<<hw, 64, 0, c->sl_side>>>(d_hot_cnt, d_hot_cnt + 32, d_hot_items, kHotCap, (const float*)c->sl_rows.p, (const uint8_t*)c->entries.p,
                                                      d_f32, d_minmax_enc, W, H);
-            EORB_HIP(c, hipEventRecord(c->sl_ev_join, c->sl_side));
         }
+        EORB_HIP(c, hipEventRecord(c->sl_ev_join, c->sl_side));
+        EORB_HIP(c, hipStreamWaitEvent(c->stream, c->sl_ev_plan, 0));       // the plan and the task table
         sl_gather_kernel<<<G, 64 * nw, lds_g, c->stream>>>(P);
-        if (hot_min) EORB_HIP(c, hipStreamWaitEvent(c->stream, c->sl_ev_join, 0));
+        EORB_HIP(c, hipStreamWaitEvent(c->stream, c->sl_ev_join, 0));       // (whatever the side stream did is done before the images are read)
         EORB_LAUNCH_CHECK(c, "sl_gather_kernel");
     }
     return EORB_OK;
