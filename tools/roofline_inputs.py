@@ -17,7 +17,7 @@ import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCOPES = {   # HIP-event scope of bench.py -> kernels it brackets
     "ev_gather": ["sl_gather_kernel", "sl_hot_kernel", "ev_gather_"],
-    "ev_bin": ["sl_count_kernel", "sl_scan_kernel", "sl_scatter", "sl_plan_kernel", "sl_tasks_kernel", "ev_count_kernel", "ev_scan_kernel",
+    "ev_bin": ["sl_chunks_kernel", "sl_count_kernel", "sl_count_lds_kernel", "sl_scan_kernel", "sl_scatter", "sl_plan_kernel", "sl_tasks_kernel", "ev_count_kernel", "ev_scan_kernel",
                "ev_scatter", "ev_tile_hist", "ev_tile_order"],
     "ev_normalize": ["ev_normalize_kernel"], "ev_dedupe": ["dd_insert_kernel"],
 }
@@ -86,6 +86,10 @@ def main():
             e["concurrent"] = True
             e["rocprof_ms"] = max(st[k][0] for k in ks)
             e["issue_by_kernel"] = {k.split("(")[0]: {kk: vv for kk, vv in (issue_of(k) or {}).items() if kk != "counters"} for k in ks}
+        if scope == "ev_bin" and any("sl_scatter" in k for k in ks):
+            # sl_plan_kernel and sl_tasks_kernel run on the side stream beside the scatter: their traffic counts, their time does not
+            e["rocprof_ms"] = sum(st[k][0] for k in ks if "sl_plan_kernel" not in k and "sl_tasks_kernel" not in k)
+            e["beside_the_scatter"] = [k.split("(")[0] for k in ks if "sl_plan_kernel" in k or "sl_tasks_kernel" in k]
         scopes[scope] = e
     doc = {}
     if os.path.exists(out_path):
