@@ -1046,20 +1046,40 @@ __global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(con
     const int lane = threadIdx.x & 63;
     const int first = (blockIdx.x * kSparseWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * per_wave;
     const int SW = 2 * P.h + 1, SWP = P.stamp_colstride;
-    for (int logical = first; logical < min(first + per_wave, P.total); logical++) {
-        const int slice = logical / P.NT, tile = logical - slice * P.NT;
-        const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
+    // A work item is a chain of dependent loads (count -> entries -> stamp taps) for a handful of adds.  The wave reads the counts and
+    // list places of ALL its items at once (lane = item, per_wave <= 64) and the first 64 entries of item k + 1 while it works on item k.
+    const int n_here = min(per_wave, P.total - first);
+    uint32_t cnt_v = 0u, off_lo = 0u, off_hi = 0u;
+    if (lane < n_here) {
+        const int li = first + lane;
+        cnt_v = tile_cnt[li];
+        const uint64_t o = (uint64_t)slice_ebase[li / P.NT] + tile_base[li];
+        off_lo = (uint32_t)o; off_hi = (uint32_t)(o >> 32);
+    }
+    auto list_of = [&](int k) {
+        return entries + (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)off_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)off_lo, k));
+    };
+    uint2 ahead = make_uint2(0u, 0u);
+    if (n_here > 0) { const int n0 = __builtin_amdgcn_readlane((int)cnt_v, 0); if (n0) ahead = list_of(0)[min(lane, min(64, n0) - 1)]; }
+    // (slice, tile column, tile row) of the items by increments: three integer divisions per item were a quarter of its instructions
+    int slice = first / P.NT, tx = (first - slice * P.NT) % P.TX, ty = (first - slice * P.NT) / P.TX;
+    tx -= 1;
+    for (int k = 0; k < n_here; k++) {
+        if (++tx == P.TX) { tx = 0; if (++ty == P.NT / P.TX) { ty = 0; slice++; } }
+        const int tx0 = tx * kTile, ty0 = ty * kTile;
         const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
         const bool inimg = px < P.W && py < P.H;
         float* const dst = img + (size_t)slice * P.W * P.H + (size_t)py * P.W + px;
-        const int nent = (int)tile_cnt[logical];
+        const int nent = __builtin_amdgcn_readlane((int)cnt_v, k);
+        const uint2 first64 = ahead;
+        if (k + 1 < n_here) { const int n1 = __builtin_amdgcn_readlane((int)cnt_v, k + 1); if (n1) ahead = list_of(k + 1)[min(lane, min(64, n1) - 1)]; }
         if (nent == 0) { if (inimg) *dst = 0.0f; continue; }      // no offer to the running extremes (resolveMinMaxVals :32-39)
-        const uint2* list = entries + (size_t)slice_ebase[slice] + tile_base[logical];
+        const uint2* list = list_of(k);
         float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
         bool touched = false;                                   // this (in-image) pixel was reached by some stamp
         for (int e0 = 0; e0 < nent; e0 += 64) {
             const int cnt = min(64, nent - e0);
-            const uint2 mine = list[e0 + min(lane, cnt - 1)];
+            const uint2 mine = e0 == 0 ? first64 : list[e0 + min(lane, cnt - 1)];
             constexpr int U = 8;
             for (int k0 = 0; k0 < cnt; k0 += U) {
                 float v[U]; bool in[U]; uint32_t sgn[U];
@@ -1088,13 +1108,11 @@ __global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(con
         if (!POL && tile_ok) vmax = fmaxf(vmax, acc);
         if (inimg) *dst = acc;
         else { vmax = -1000000.0f; vmin = 0.0f; }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            vmax = fmaxf(vmax, __shfl_xor(vmax, d, 64));
-            vmin = fminf(vmin, __shfl_xor(vmin, d, 64));
-        }
-        if (lane == 0) {
-            atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
+        // (DPP reductions, result in lane 63; without polarity the minimum never leaves its initial 0: ev_minmax_init_kernel)
+        vmax = wave_max_to_lane63(vmax);
+        if (POL) vmin = wave_min_to_lane63(vmin);
+        if (lane == 63) {
+            if (POL) atomicMin(&minmax_enc[slice * 2 + 0], enc_f32(vmin));
             atomicMax(&minmax_enc[slice * 2 + 1], enc_f32(vmax));
         }
     }
@@ -2204,7 +2222,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         if (sparse) {
             const uint2* en2 = (const uint2*)c->entries.p;
             // large launches: 8 consecutive work items per wave (a wave per item leaves the launch bound by workgroup dispatch)
-            const int per_wave = nb >= 65536 ? 8 : 1;
+            const int per_wave = nb >= 65536 ? 16 : 1;
             const int grid = (nb + kSparseWaves * per_wave - 1) / (kSparseWaves * per_wave);
             if (pol) ev_gather_sparse_kernel<true><<<grid, 64 * kSparseWaves, 0, c->stream>>>(d_slice_eb, G, per_wave, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);
             else ev_gather_sparse_kernel<false><<<grid, 64 * kSparseWaves, 0, c->stream>>>(d_slice_eb, G, per_wave, d_tile_cnt, d_tile_base, en2, d_f32, d_minmax_enc);

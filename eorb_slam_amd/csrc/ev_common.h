@@ -28,4 +28,22 @@ __device__ __forceinline__ int wave_incl_scan(int x)
     return x;
 }
 
+// wave-wide maximum / minimum of a float by the same DPP steps (a lane without a source keeps its own value): the result is in lane 63
+__device__ __forceinline__ float wave_max_to_lane63(float x)
+{
+#define EORB_DPP_STEP(ctrl, rmask) x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, 0xf, false)))
+    EORB_DPP_STEP(0x111, 0xf); EORB_DPP_STEP(0x112, 0xf); EORB_DPP_STEP(0x114, 0xf); EORB_DPP_STEP(0x118, 0xf);
+    EORB_DPP_STEP(0x142, 0xa); EORB_DPP_STEP(0x143, 0xc);
+#undef EORB_DPP_STEP
+    return x;
+}
+__device__ __forceinline__ float wave_min_to_lane63(float x)
+{
+#define EORB_DPP_STEP(ctrl, rmask) x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), ctrl, rmask, 0xf, false)))
+    EORB_DPP_STEP(0x111, 0xf); EORB_DPP_STEP(0x112, 0xf); EORB_DPP_STEP(0x114, 0xf); EORB_DPP_STEP(0x118, 0xf);
+    EORB_DPP_STEP(0x142, 0xa); EORB_DPP_STEP(0x143, 0xc);
+#undef EORB_DPP_STEP
+    return x;
+}
+
 }  // namespace eorb

@@ -1093,6 +1093,38 @@ def test_slot_lists_form(oracle, fe):
     c.close()
 
 
+def test_slot_lists_many_slices(oracle, fe):
+    """The slot form on batches with more slices than the chunk kernel takes as a kernel argument (> 256: descriptors made on the host),
+    and with 256 and 255 (device side), ragged and empty slices among them, 256-event chunks: every slice's image as it comes out alone
+    from the oracle."""
+    W, H = 240, 180
+    mx, my = _maps(W, H)
+    rng = np.random.default_rng(21)
+    for B in (300, 256, 255):
+        sizes = rng.integers(0, 3000, B); sizes[rng.integers(0, B, 12)] = 0; sizes[0] = 2999
+        raws = [synth.random_raw_events(int(max(sz, 1)), W, H, seed=900 + b)[:int(sz)] for b, sz in enumerate(sizes)]
+        fb = fe.FrontEndBatch(W, H, 1.0, False, 400, 1.2, 1, 10, 0, 9, max_batch=B, max_events=3000, want_desc=False, match=False)
+        c, cap = fb.ctx, fb.cap
+        c.debug_option("gather_form", 4)
+        fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
+        blob = np.concatenate(raws)
+        d_ev = c.dev_alloc(max(blob.nbytes, 16)); c.upload(d_ev, blob)
+        d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32)
+        d_n = c.dev_alloc(B * 4); d_m = c.dev_alloc(B * cap * 4); d_nm = c.dev_alloc(B * 4)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        fb.run_dev(d_ev, off, d_img, d_kp, d_desc, d_n, d_m, d_nm, raw=True)
+        c.sync()
+        assert c.debug_counter("slot_calls") == 1 and c.debug_counter("slot_flags") == 0
+        imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
+        for b in list(range(0, B, 17)) + [B - 1]:
+            ev = oracle.undistort_events(raws[b], mx, my, W, H, True, 1.0)
+            _, ou, _ = oracle.ev2im_gauss(ev, W, H, 1.0, False, True, fast=True)
+            assert np.array_equal(ou, imgs[b]), (B, b, int(sizes[b]))
+        for p_ in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
+            c.dev_free(p_)
+        c.close()
+
+
 def test_register_row_kernel_list_tails(oracle, fe):
     """sl_hot_kernel walks a list 64 entries per scalar load and enters its unrolled sequence in the middle for the last (length mod 64)
     entries, with the bytes of the last dword past the end replaced by the null row: every residue of the length mod 64 (hence mod 4),
