@@ -11,7 +11,7 @@
 //                       raster-ordered emission                                    (:784-878, cv::FAST)
 //   octree_kernel       DistributeOctTree (:558-782): the reference's sequential list algorithm, run by
 //                       one wavefront per (slice, level); only DivideNode's key partition is lane-parallel
-//   orient_kernel       IC_Angle (:77-104) + cv::fastAtan2, 16 lanes per keypoint
+//   orient_kernel       IC_Angle (:77-104) + cv::fastAtan2, 32 lanes per keypoint (lane = column)
 //   blur_kernel         GaussianBlur(5x5, sigma 2, REFLECT_101) 8u Q8 separable     (:1141-1142)
 //   brief_kernel        computeOrbDescriptor (:108-157): 32 lanes per keypoint, 16 taps each
 //   assemble_kernel     output ordering of operator() (:1150-1173): scale, lapping-area back-fill
@@ -760,46 +760,44 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
-// orientation: IC_Angle :77-104.  16 lanes per keypoint; lane j sums rows +j and -j of the disc.
+// orientation: IC_Angle :77-104.  32 lanes per keypoint: lane = column u of the disc (-15 .. 15, one lane idle), walking the row pairs
+// +-v: consecutive lanes read consecutive bytes of a row (with a lane per ROW every load instruction of a wave touched 64 different
+// image lines).  Integer moments: the order of the sums is free.
 __global__ __launch_bounds__(256) void orient_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
                                                      const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_cnt,
                                                      float* __restrict__ kp_angle)
 {
     const int slice = blockIdx.y;
-    const int gid = blockIdx.x * 16 + (threadIdx.x >> 4);      // keypoint slot in the slice's level arrays
-    const int j = threadIdx.x & 15;
+    const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);       // keypoint slot in the slice's level arrays
+    const int u = (int)(threadIdx.x & 31) - 15;                // -15 .. 16 (16: no column)
     if (gid >= G->kp_total) return;
     int level = 0;
     while (level + 1 < G->nlevels && gid >= G->lv[level + 1].kp_off) level++;
     const LevelGeom& L = G->lv[level];
     const int i = gid - L.kp_off;
-    if (i >= lvl_cnt[slice * G->nlevels + level]) return;     // whole 16-lane group exits together
+    if (i >= lvl_cnt[slice * G->nlevels + level]) return;     // whole 32-lane group exits together
     const uint32_t p = lvl_kp[(size_t)slice * G->kp_total + gid];
     // keypoint in level coordinates: candidate coords are relative to minBorder (:889-893)
     const int cx = (int)(p & 0xfff) + L.minBX, cy = (int)((p >> 12) & 0xfff) + L.minBY;
     const uint8_t* center = pyr + (size_t)slice * G->pyr_bytes + L.buf_off + (size_t)(cy + G->edge) * L.bw + (cx + G->edge);
     const int step = L.bw;
+    const int au = u < 0 ? -u : u;
     int m_01 = 0, m_10 = 0;
-    if (j == 0) {
-        for (int u = -15; u <= 15; ++u) m_10 += u * center[u];
-    } else {
-        const int v = j;
-        int v_sum = 0;
-        const int d = G->umax[v];
-        for (int u = -d; u <= d; ++u) {
+    if (au <= 15) m_10 = u * (int)center[u];
+#pragma unroll
+    for (int v = 1; v <= 15; ++v) {
+        if (au <= G->umax[v]) {
             const int val_plus = center[u + v * step], val_minus = center[u - v * step];
-            v_sum += (val_plus - val_minus);
+            m_01 += v * (val_plus - val_minus);
             m_10 += u * (val_plus + val_minus);
         }
-        m_01 += v * v_sum;
     }
-    // v = 15 row pair is handled by lane 15; rows 1..15 -> lanes 1..15 (16 lanes: j = 0..15)
 #pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) {
+    for (int d = 16; d >= 1; d >>= 1) {
         m_01 += __shfl_xor(m_01, d, 64);
         m_10 += __shfl_xor(m_10, d, 64);
     }
-    if (j == 0) kp_angle[(size_t)slice * G->kp_total + gid] = dev_fast_atan2((float)m_01, (float)m_10);
+    if ((threadIdx.x & 31) == 0) kp_angle[(size_t)slice * G->kp_total + gid] = dev_fast_atan2((float)m_01, (float)m_10);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1250,7 +1248,7 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     }
     {
         ProfScope ps(c, "orb_orient");
-        orient_kernel<<<dim3((o.kp_total + 15) / 16, B), 256, 0, c->stream>>>(G, pyr, (const uint32_t*)c->lvl_kp.p,
+        orient_kernel<<<dim3((o.kp_total + 7) / 8, B), 256, 0, c->stream>>>(G, pyr, (const uint32_t*)c->lvl_kp.p,
                                                                               (const int32_t*)c->lvl_cnt.p, (float*)c->kp_angle.p);
         EORB_LAUNCH_CHECK(c, "orient_kernel");
     }
