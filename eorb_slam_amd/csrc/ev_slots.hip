@@ -468,30 +468,30 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
 // in order, and the waves' shares are ordered by the prefix over the waves -- so no ballots, no parity classes, no per-event list
 // of sorted slots: phase A keeps four 8-bit ranks per event, phase C writes the entry byte and its tile straight to their place
 // in the chunk's tile-sorted order, phase D streams that order out run by run.
-template <int stride>
-__global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
+template <int stride, int NW /* wavefronts = 256-event shares of a chunk: 8 (2 048 events) or 16 (4 096) */>
+__global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
                                                                               const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
                                                                               int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                                               const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
                                                                               uint8_t* __restrict__ entries)
 {
     extern __shared__ unsigned char sm2[];
-    __shared__ uint32_t s_wsum[kSlotScatWaves];
-    constexpr int NTHR = 64 * kSlotScatWaves;
+    __shared__ uint32_t s_wsum[NW];
+    constexpr int NTHR = 64 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
     const ChunkDesc cd = chunks[chunk];
     const int NTp = (NT + 1) & ~1;
     uint32_t* gbase = (uint32_t*)sm2;                                 // NT: first entry of the tile's run in the global lists, minus loff
     uint16_t* stile = (uint16_t*)(gbase + NT);                        // chunk_cap * 4: tile of every slot of the sorted order
-    uint16_t* cntw = stile + (size_t)chunk_cap * 4;                   // kSlotScatWaves * NTp
-    uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
+    uint16_t* cntw = stile + (size_t)chunk_cap * 4;                   // NW * NTp
+    uint16_t* loff = cntw + NW * NTp;                     // NT + 1 (+ 1 pad)
     uint8_t* sorted = (uint8_t*)(loff + NTp + 2);                     // chunk_cap * 4: the entry bytes in tile-sorted order
-    for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
+    for (int i = tid; i < NW * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
     const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed
     const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
     const bool hashed = stride < 0;          // stride -4: 4-byte records { row of the position's table entry | polarity << 31 } (float events in bulk)
-    const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
+    const int Q = (((cd.n + NW - 1) / NW) + 63) & ~63;
     const int S = Q >> 6;
     constexpr int SMAX = 4;
     __syncthreads();
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_rank_kernel(co
         for (int t = t0; t < t1; t++) {
             uint32_t run = 0;
 #pragma unroll
-            for (int w = 0; w < kSlotScatWaves; w++) { const uint32_t v = cntw[w * NTp + t]; cntw[w * NTp + t] = (uint16_t)run; run += v; }
+            for (int w = 0; w < NW; w++) { const uint32_t v = cntw[w * NTp + t]; cntw[w * NTp + t] = (uint16_t)run; run += v; }
             loff[t] = (uint16_t)run;
             mine += run;
         }
@@ -1005,7 +1005,13 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     c->sl_calls++;
     const int64_t nev = h_offsets[B] - h_offsets[0];
     const int64_t per_slice = nev / B;
-    const int chunk = per_slice >= (int64_t)1 << 17 ? 2048 : (per_slice >= (int64_t)1 << 14 ? 1024 : 256);
+    // chunks of 4 096 events (16 wavefronts per scatter workgroup) where the rank scatter runs and the slices are long: per-chunk work
+    // (the tiles' list bases, the prefix over the waves, the count rows) is shared by twice the events
+    static const int chunk_env = [] { const char* e = getenv("EORB_SLOT_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 1024 || v == 2048 || v == 4096) ? v : 0; }();
+    static const int rank_env0 = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
+    const bool big_ok = c->sl_rank_ok == 1 && rank_env0 && (size_t)NT * 4 + 4096 * 12 + 16 * (size_t)((NT + 1) & ~1) * 2 + (size_t)(NT + 4) * 2 + 32 <= 79 * 1024;
+    int chunk = chunk_env ? chunk_env : (per_slice >= (int64_t)1 << 18 ? 4096 : (per_slice >= (int64_t)1 << 17 ? 2048 : (per_slice >= (int64_t)1 << 14 ? 1024 : 256)));   // (128 x 1 Mev: binning 1.46-1.51 ms with 2 048, 1.41-1.44 with 4 096)
+    if (chunk == 4096 && !big_ok) chunk = 2048;
     // up to 256 slices: the descriptors are made on the device from the offsets (sl_chunks_kernel); more: on the host, one copy
     const bool on_dev = B <= kOffsetsInArg;
     std::vector<ChunkDesc> cds;
@@ -1042,7 +1048,7 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     if (on_dev) {
         SliceOffsets so;
         for (int b = 0; b <= B; b++) so.off[b] = h_offsets[b];
-        sl_chunks_kernel<<<std::max(1, (nchunks + 255) / 256), 256, 0, c->stream>>>(so, B, chunk == 2048 ? 11 : (chunk == 1024 ? 10 : 8), NT, nchunks, (ChunkDesc*)c->chunks.p, (int*)((char*)c->chunks.p + cd_bytes),
+        sl_chunks_kernel<<<std::max(1, (nchunks + 255) / 256), 256, 0, c->stream>>>(so, B, chunk == 4096 ? 12 : (chunk == 2048 ? 11 : (chunk == 1024 ? 10 : 8)), NT, nchunks, (ChunkDesc*)c->chunks.p, (int*)((char*)c->chunks.p + cd_bytes),
                                                                                   (int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes));
     }
     else {
@@ -1075,7 +1081,8 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
         const int NTp = (NT + 1) & ~1;
         const size_t lds2 = ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
-        if (lds > 64 * 1024 || lds2 > 64 * 1024) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
+        if (lds > 64 * 1024 || (chunk != 4096 && lds2 > 64 * 1024))       // (4 096-event chunks are chosen only where the rank scatter takes them)
+            return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
         // the tile ranges of all sensor pixels + one set of counters per wavefront in the LDS of one workgroup per CU?
         const size_t nsrc = (size_t)c->lut_w * (size_t)c->lut_h;
         const size_t lds_c = 4 * ((nsrc + 2) / 2) + (size_t)kCountWaves * NTp * 2;
@@ -1147,12 +1154,16 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         EORB_HIP(c, hipEventRecord(c->sl_ev_plan, c->sl_side));
         // ---- the scatter ----
         static const int rank_env = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
-        const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
-        if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= 64 * 1024)
+        const int scw = chunk == 4096 ? 16 : kSlotScatWaves;
+        const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)scw * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
+        if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= (size_t)(chunk == 4096 ? 79 : 64) * 1024)
         {
-#define SL_SCAT(ST) sl_scatter_rank_kernel<ST><<<nchunks, 64 * kSlotScatWaves, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
-                                                                                               d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p)
-            if (stride == 16) SL_SCAT(16); else if (stride == 4) SL_SCAT(4); else SL_SCAT(-4);
+#define SL_SCAT(ST, NW) do { static bool attr = false; \
+                if (!attr) { EORB_HIP(c, hipFuncSetAttribute((const void*)sl_scatter_rank_kernel<ST, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr = true; } \
+                sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
+                                                                                   d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p); } while (0)
+            if (scw == 16) { if (stride == 16) SL_SCAT(16, 16); else if (stride == 4) SL_SCAT(4, 16); else SL_SCAT(-4, 16); }
+            else { if (stride == 16) SL_SCAT(16, 8); else if (stride == 4) SL_SCAT(4, 8); else SL_SCAT(-4, 8); }
 #undef SL_SCAT
         }
         else if (nchunks)
