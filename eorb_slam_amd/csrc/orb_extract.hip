@@ -802,27 +802,28 @@ __global__ __launch_bounds__(256) void orient_kernel(const DevGeom* __restrict__
 
 // ---------------------------------------------------------------------------------------------------
 // GaussianBlur 5x5 sigma 2 (Q8 coefficients 39 57 64 57 39), REFLECT_101, on the un-bordered level
+constexpr int kBlurTW = 64, kBlurTH = 16;        // outputs per workgroup (32 x 8 tiles: 74 000 workgroups per 128 frames, the launch bound by their dispatch)
 __global__ __launch_bounds__(256) void blur_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr,
                                                    uint8_t* __restrict__ blur)
 {
-    __shared__ int rows[(8 + 4) * 32];
+    __shared__ int rows[(kBlurTH + 4) * kBlurTW];
     const int slice = blockIdx.z;
     // blockIdx.y encodes (level, tile row); blockIdx.x tile column
     int level = 0, ty = blockIdx.y;
     while (level < G->nlevels) {
-        const int nty = (G->lv[level].h + 7) / 8;
+        const int nty = (G->lv[level].h + kBlurTH - 1) / kBlurTH;
         if (ty < nty) break;
         ty -= nty; level++;
     }
     if (level >= G->nlevels) return;
     const LevelGeom& L = G->lv[level];
-    const int x0 = blockIdx.x * 32, y0 = ty * 8;
+    const int x0 = blockIdx.x * kBlurTW, y0 = ty * kBlurTH;
     if (x0 >= L.w) return;
     const uint8_t* roi = pyr + (size_t)slice * G->pyr_bytes + L.buf_off + (size_t)G->edge * L.bw + G->edge;
     const int k0 = 39, k1 = 57, k2 = 64;
-    // horizontal pass for 12 source rows x 32 columns
-    for (int i = threadIdx.x; i < 12 * 32; i += 256) {
-        const int r = i / 32, cxi = i - r * 32;
+    // horizontal pass for TH + 4 source rows x TW columns
+    for (int i = threadIdx.x; i < (kBlurTH + 4) * kBlurTW; i += 256) {
+        const int r = i / kBlurTW, cxi = i - r * kBlurTW;
         const int sy = reflect101(y0 + r - 2, L.h);
         const int x = x0 + cxi;
         int acc = 0;
@@ -834,14 +835,16 @@ __global__ __launch_bounds__(256) void blur_kernel(const DevGeom* __restrict__ G
         rows[i] = acc;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x < L.w && y < L.h) {
-        const int acc = k0 * rows[(ly + 0) * 32 + lx] + k1 * rows[(ly + 1) * 32 + lx] + k2 * rows[(ly + 2) * 32 + lx] +
-                        k1 * rows[(ly + 3) * 32 + lx] + k0 * rows[(ly + 4) * 32 + lx];
-        int v = (acc + (1 << 15)) >> 16;
-        v = min(max(v, 0), 255);
-        blur[(size_t)slice * G->roi_bytes + L.roi_off + (size_t)y * L.w + x] = (uint8_t)v;
+    for (int i = threadIdx.x; i < kBlurTH * kBlurTW; i += 256) {
+        const int ly = i / kBlurTW, lx = i - ly * kBlurTW;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < L.w && y < L.h) {
+            const int acc = k0 * rows[(ly + 0) * kBlurTW + lx] + k1 * rows[(ly + 1) * kBlurTW + lx] + k2 * rows[(ly + 2) * kBlurTW + lx] +
+                            k1 * rows[(ly + 3) * kBlurTW + lx] + k0 * rows[(ly + 4) * kBlurTW + lx];
+            int v = (acc + (1 << 15)) >> 16;
+            v = min(max(v, 0), 255);
+            blur[(size_t)slice * G->roi_bytes + L.roi_off + (size_t)y * L.w + x] = (uint8_t)v;
+        }
     }
 }
 
@@ -1256,8 +1259,8 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
         {
             ProfScope ps(c, "orb_blur");
             int tyt = 0, wmax = 0;
-            for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + 7) / 8; wmax = std::max(wmax, o.lv[l].w); }
-            blur_kernel<<<dim3((wmax + 31) / 32, tyt, B), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
+            for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + kBlurTH - 1) / kBlurTH; wmax = std::max(wmax, o.lv[l].w); }
+            blur_kernel<<<dim3((wmax + kBlurTW - 1) / kBlurTW, tyt, B), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
             EORB_LAUNCH_CHECK(c, "blur_kernel");
         }
         {
@@ -1297,8 +1300,8 @@ int orb_pyramid_blur_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride)
         pyr_resize_kernel<<<dim3((n + 255) / 256, 1), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
     }
     int tyt = 0, wmax = 0;
-    for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + 7) / 8; wmax = std::max(wmax, o.lv[l].w); }
-    blur_kernel<<<dim3((wmax + 31) / 32, tyt, 1), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
+    for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + kBlurTH - 1) / kBlurTH; wmax = std::max(wmax, o.lv[l].w); }
+    blur_kernel<<<dim3((wmax + kBlurTW - 1) / kBlurTW, tyt, 1), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
     EORB_LAUNCH_CHECK(c, "pyramid/blur kernels");
     return EORB_OK;
 }
