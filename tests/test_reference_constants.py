@@ -57,7 +57,8 @@ def test_extractor_constants_equal_reference():
         assert re.search(r"31\.0f \* |\(float\)PATCH_SIZE \* ", src), "scaledPatchSize"
     assert re.search(r"width / 30\.0f", prod) and re.search(r"height / 30\.0f", prod), "W_denom (product)"
     assert _const(orc, r"#define W_DENOM (\d+)\.0f") == wden and "width / W_DENOM" in orc and "height / W_DENOM" in orc
-    assert "d = G->umax[v]" in prod and "u = -15; u <= 15" in prod            # HALF_PATCH_SIZE in IC_Angle (:77-104)
+    # HALF_PATCH_SIZE in IC_Angle (:77-104): columns -15 .. 15 (one lane each), row pairs 1 .. 15 inside the disc
+    assert "au <= G->umax[v]" in prod and "(int)(threadIdx.x & 31) - 15" in prod and "for (int v = 1; v <= 15; ++v)" in prod and "if (au <= 15)" in prod
 
 
 def test_matcher_constants_equal_reference():
