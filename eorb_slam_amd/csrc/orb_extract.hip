@@ -1230,7 +1230,7 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
         pyr_level0_kernel<<<dim3((n0 / 4 + 256) / 256, B), 256, 0, c->stream>>>(d_img, img_stride, img_slice_bytes, G, pyr, err_flag);
         for (int l = 1; l < o.nlevels; l++) {
             const int n = o.lv[l].bw * o.lv[l].bh;
-            pyr_resize_kernel<<<dim3((n + 255) / 256, B), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
+            pyr_resize_kernel<<<dim3(B >= 16 ? (n + 1023) / 1024 : (n + 255) / 256, B), 256, 0, c->stream>>>(l, G, (const short4*)o.tabs.p, pyr);
         }
         EORB_LAUNCH_CHECK(c, "pyramid kernels");
     }
