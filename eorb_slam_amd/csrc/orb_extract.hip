@@ -157,11 +157,17 @@ __global__ __launch_bounds__(256) void fast_cells_kernel(const DevGeom* __restri
     if (dw <= 0 || dh <= 0) { if (tid == 0) *out_cnt = 0; return; }
     const uint8_t* roi = pyr + (size_t)slice * G->pyr_bytes + L.buf_off + (size_t)G->edge * L.bw + G->edge;
     const int pitch = kCellMax + 8;
+    // A cell window of ONE grey value has no corner at any threshold >= 0 (every arc difference is 0): event images of short slices
+    // are mostly such windows, and the arc scores (80 min / max per pixel) are the kernel's work.
+    const uint8_t first = roi[(size_t)iniY * L.bw + iniX];
+    int differs = 0;
     for (int i = tid; i < cw * ch; i += 256) {
         const int y = i / cw, x = i - y * cw;
-        tile[y * pitch + x] = roi[(size_t)(iniY + y) * L.bw + iniX + x];
+        const uint8_t v = roi[(size_t)(iniY + y) * L.bw + iniX + x];
+        tile[y * pitch + x] = v;
+        differs |= (v != first);
     }
-    __syncthreads();
+    if (!__syncthreads_or(differs) && G->iniTh >= 0 && G->minTh >= 0) { if (tid == 0) *out_cnt = 0; return; }
     // score plane with a zero ring: smap[(y+1)*sp + (x+1)] for domain pixel (x,y)
     const int sp = dw + 2;
     for (int i = tid; i < (dw + 2) * (dh + 2); i += 256) smap[i] = 0;

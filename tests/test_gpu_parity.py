@@ -1093,6 +1093,37 @@ def test_slot_lists_form(oracle, fe):
     c.close()
 
 
+def test_profiling_scopes_can_be_selected(fe):
+    """eorb_prof_enable / eorb_prof_only (what bench.py's roofline times come from): all scopes of a batch call, then only the
+    accumulation's, each once per call, with a positive time."""
+    W, H, B, n = 240, 180, 2, 50000
+    raws = [synth.shapes_events(n, W, H, seed=70 + b, motion=0.3, undistort=True, return_raw=True)[1] for b in range(B)]
+    fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=n)
+    c, cap = fb.ctx, fb.cap
+    mx, my = _maps(W, H)
+    fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
+    blob = np.concatenate(raws)
+    d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
+    d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32)
+    d_n = c.dev_alloc(B * 4); d_m = c.dev_alloc(B * cap * 4); d_nm = c.dev_alloc(B * 4)
+    off = np.arange(B + 1, dtype=np.int64) * n
+    run = lambda: fb.run_dev(d_ev, off, d_img, d_kp, d_desc, d_n, d_m, d_nm, raw=True)
+    run(); c.sync()
+    c.prof_reset(); c.prof_only(()); c.prof_enable(True)
+    run(); run(); c.sync(); c.prof_enable(False)
+    every = c.prof_results()
+    assert {"ev_bin", "ev_gather", "orb_fast_cells", "orb_octree", "search_init"} <= set(every)
+    assert all(cnt == 2 and ms > 0 for ms, cnt in every.values()), every
+    c.prof_reset(); c.prof_only(("ev_bin", "ev_gather")); c.prof_enable(True)
+    run(); c.sync(); c.prof_enable(False)
+    some = {k: v for k, v in c.prof_results().items() if v[1]}
+    assert set(some) == {"ev_bin", "ev_gather"} and all(cnt == 1 and ms > 0 for ms, cnt in some.values()), some
+    c.prof_only(())
+    for p_ in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
+        c.dev_free(p_)
+    c.close()
+
+
 def test_slot_lists_many_slices(oracle, fe):
     """The slot form on batches with more slices than the chunk kernel takes as a kernel argument (> 256: descriptors made on the host),
     and with 256 and 255 (device side), ragged and empty slices among them, 256-event chunks: every slice's image as it comes out alone
