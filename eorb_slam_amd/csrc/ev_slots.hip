@@ -6,17 +6,23 @@
 // whose stamps reach T ever contribute: they are T's SLOTS.  Once per (maps, sigma):
 //   slot_tab[sensor pixel]  = { first tile, tiles in x / y, the pixel's slot number in each of its <= 4 tiles }
 //   rows[T][slot][64]       = what that sensor pixel adds to each of T's 64 pixels (its stamp value, +0.0f outside the stamp)
-// Per batch:
-//   K1a sl_count_kernel   entries of every (chunk, tile)           | as in ev_accum.hip, ranges from slot_tab
-//   K1b sl_scan_kernel    one contiguous event-ordered list per (slice, tile); per-tile weights
-//   K1c sl_scatter_kernel order-preserving scatter of TWO-BYTE entries (slot << 8): the chunk is tile-sorted in LDS and leaves as runs
-//   K2p sl_gather_kernel  one workgroup per tile POSITION: the tile's rows staged in LDS once (<= 64 KB), then every wavefront owns
-//                         one (slice, tile) list at a time (next slice by an atomic ticket): lane = pixel, per entry ONE
-//                         ds_read_addtid_b32 (address = M0 + 4 * lane: the entry IS the LDS byte offset of its row, no address
-//                         arithmetic) and ONE v_add_f32, in list order = event order (newVal = image + val, :251-254).  x + 0.0f == x
-//                         bit for bit, so lanes the stamp does not reach keep their value.
+// Per batch ("Round 3: a different decomposition"):
+//   K0  sl_chunks_kernel       chunk descriptors, the slices' first chunks and entry bases from the slice offsets (a kernel argument)
+//   K1a sl_count_lds_kernel    entries of every (chunk, tile): the sensor pixels' tile ranges as a 16-bit table in LDS, one wavefront per
+//                              chunk (sl_count_kernel where that table does not fit)
+//   K1b sl_scan_kernel         one contiguous event-ordered list per (slice, tile); per-tile weights
+//   K1c sl_scatter_rank_kernel order-preserving scatter of ONE-BYTE entries (the slot number): stable ranks from the return values of the
+//                              counting LDS atomics, the chunk tile-sorted in LDS, runs streamed out (sl_scatter_kernel: the ballot form,
+//                              kept as the fallback when the device check of the atomics' lane order fails)
+//       sl_plan_kernel / sl_tasks_kernel   per tile position its lists sorted longest first, long lists to the buckets of K2h, workgroup
+//                              tasks by weight -- on the side stream, beside the scatter
+//   K2p sl_gather_kernel       one workgroup per task = tile POSITION: the tile's rows staged in LDS once (<= 64 KB), every wavefront takes
+//                              (slice, tile) lists by ticket: lane = pixel, per entry v_readlane (1/4) + v_perm_b32 (row address
+//                              { slot, 4 * lane }) + ds_read_b32 + v_add_f32, in list order = event order (newVal = image + val,
+//                              :251-254).  x + 0.0f == x bit for bit, so lanes the stamp does not reach keep their value.
+//   K2h sl_hot_kernel          long lists, beside K2p on the side stream: the rows in 240 VGPRs, per entry s_set_gpr_idx_idx + v_add_f32
 // Versus the batch pipeline of ev_accum.hip (64-entry batches through value waves and an add wave, ~6.4 wave-instructions and 8
-// bytes per entry) an entry costs ~4 issue slots and 2 bytes; the kernel is bound by the LDS array (2 cycles per entry and CU).
+// bytes per entry) an entry costs ~3 issue slots and 1 byte; K2p sits on the LDS array (2 cycles per entry and CU), K2h on the scalar ALU.
 #include "eorb_ctx.h"
 #include "ev_common.h"
 #include "dev_math.h"
