@@ -184,27 +184,38 @@ def _w3_frames(n, seed0):
     return [np.ascontiguousarray(np.roll(base, (i % 7, -(2 * i % 11)), axis=(0, 1))) for i in range(n)]
 
 
+_W3_CACHE = {}        # the synthetic parts of a frame (random rows, noise) are drawn once per frame index / size, not inside the timed calls
+
+
 def _w3_mix(kps, desc, i):
     """MixedFrame stand-in: the extractor's ORB keypoints + 500 AKAZE-like rows (61 bytes, the first 32 compared)."""
     from eorb_slam_amd import synth
-    rng = np.random.default_rng(1000 + i)
     n, na = len(kps), 500
-    ak = synth.random_keypoints(na, 240, 180, nlevels=3, scale=1.26, seed=2000 + i)
-    ak["class_id"] = 0
+    key = ("mix", i % 64)
+    if key not in _W3_CACHE:
+        rng = np.random.default_rng(1000 + i % 64)
+        ak = synth.random_keypoints(na, 240, 180, nlevels=3, scale=1.26, seed=2000 + i % 64)
+        ak["class_id"] = 0
+        _W3_CACHE[key] = (ak, rng.integers(0, 256, (na, 61)).astype(np.uint8))
+    ak, ad = _W3_CACHE[key]
     k = np.concatenate([kps, ak])
-    d = np.zeros((n + na, 61), np.uint8); d[:n, :32] = desc; d[n:] = rng.integers(0, 256, (na, 61))
+    d = np.zeros((n + na, 61), np.uint8); d[:n, :32] = desc; d[n:] = ad
     o = np.concatenate([np.ones(n, np.uint8), np.zeros(na, np.uint8)])
     return k, d, o
 
 
 def _w3_proj_args(pk, pd, po, ncur):
-    rng = np.random.default_rng(7)
     n = len(pk)
+    key = ("proj", n)
+    if key not in _W3_CACHE:
+        rng = np.random.default_rng(7)
+        _W3_CACHE[key] = ((rng.uniform(size=n) < 0.8).astype(np.uint8), rng.normal(0, 1, n), rng.normal(0, 1, n))
+    valid, nx, ny = _W3_CACHE[key]
     sf = np.float32(1.2) ** np.arange(4, dtype=np.float32)
     asf = np.float32(1.26) ** np.arange(4, dtype=np.float32)
     octv = np.clip(pk["octave"], 0, 3)
-    return dict(valid=(rng.uniform(size=n) < 0.8).astype(np.uint8),
-                uv=np.stack([pk["x"] + rng.normal(0, 1, n), pk["y"] + rng.normal(0, 1, n)], axis=1).astype(np.float32),
+    return dict(valid=valid,
+                uv=np.stack([pk["x"] + nx, pk["y"] + ny], axis=1).astype(np.float32),
                 mp_desc=np.ascontiguousarray(pd[:, :32]), mp_obs=np.ones(n, np.uint8),
                 cur_mp=np.full(ncur, -1, np.int32), ls=np.where(po == 1, sf[octv], asf[octv]).astype(np.float32))
 
