@@ -63,7 +63,15 @@ def parse():
                     help="w2: also time the batch with its events arriving from pinned host memory: double-buffered H2D on a copy stream "
                          "overlapped with the previous batch on the compute stream, for the 16-byte and the 4-byte wire record")
     ap.add_argument("--latency-calls", type=int, default=300, help="w1: single-slice calls timed for the latency figures (0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--no-side", action="store_true",
+                    help="default w2 line only: skip the `side` object (short verified runs of w1, w3, w4, the float input and the streamed "
+                         "input, so that one line carries a number for every BASELINE config)")
+    a = ap.parse_args()
+    # the `side` object rides on the default line: w2, raw input, one GPU, one sequence
+    a.side = (not a.no_side) and a.workload == "w2" and a.input == "raw" and a.gpus == 1 and a.sequences == 1 and not a.no_prof
+    if a.side:
+        a.stream = True
+    return a
 
 
 # --------------------------------------------------------------------------------------------------------------------------
@@ -73,9 +81,15 @@ def _pcts(ts):
     return {"mean_ms": float(a.mean()), "p50_ms": float(np.percentile(a, 50)), "p95_ms": float(np.percentile(a, 95))}
 
 
+class _Unit:
+    """One sample unit of a workload on the CPU oracle: run(i) processes unit i (one slice / one frame) and returns its outputs (what
+    the GPU run is verified against), reset() forgets the frame-to-frame state."""
+    def __init__(self, run, reset):
+        self.run, self.reset = run, reset
+
+
 def _cpu_batch_unit(spec, data=None):
-    """Returns a closure `run(i)` that processes sample unit i of the workload on the CPU oracle (one slice / one frame).
-    data: the (float events, raw events) pairs of a batch workload when the caller already holds them."""
+    """data: the (float events, raw events) pairs of a batch workload when the caller already holds them."""
     from oracle import oracle_py
     from eorb_slam_amd import synth
     kind = spec["kind"]
@@ -91,15 +105,17 @@ def _cpu_batch_unit(spec, data=None):
         def run(i):
             f, r = data[i % len(data)]
             evs = oracle_py.undistort_events(r, lx, ly, W, H, True, 1.0) if use_raw else f
-            _, u8, _ = oracle_py.ev2im_gauss(evs, W, H, spec["sigma"], False, True, fast=True)
+            f32, u8, mm = oracle_py.ev2im_gauss(evs, W, H, spec["sigma"], False, True, fast=True)
             _, kps, desc, _ = oe.extract(u8, (0, 1000), bool(spec["want_desc"]))
+            out = {"f32": f32, "u8": u8, "mm": np.asarray(mm, np.float32), "kps": kps, "desc": desc, "nm": None, "m12": None}
             if spec["match"] and spec["want_desc"]:
                 F = oracle_py.Frame(kps, desc, W, H, fast=True)
                 if state["prev"] is not None:
                     pm = np.stack([state["prev"].kps["x"], state["prev"].kps["y"]], axis=1)
-                    oracle_py.search_for_initialization(state["prev"], F, pm, 100, 0.9, True)
+                    out["nm"], out["m12"], _ = oracle_py.search_for_initialization(state["prev"], F, pm, 100, 0.9, True)
                 state["prev"] = F
-        return run
+            return out
+        return _Unit(run, lambda: state.update(prev=None))
     if kind == "w3":
         frames = _w3_frames(spec["nunits"], spec["seed0"])
         oe = oracle_py.OrbExtractor(fast=True, imWidth=240, **spec["orb"])
@@ -108,25 +124,28 @@ def _cpu_batch_unit(spec, data=None):
         def run(i):
             img = frames[i % len(frames)]
             _, kps, desc, _ = oe.extract(img)
-            k, d, o = _w3_mix(kps, desc, i)
+            k, d, o = _w3_mix(kps, desc, i % len(frames))
             F = oracle_py.Frame(k, d, 240, 180, o, fast=True)
+            out = {"kps": kps, "desc": desc, "n1": None, "m12": None, "n2": None, "cur_mp": None}
             if st["prev"] is not None:
                 P, Pd = st["prev"]
                 pm = np.stack([P.kps["x"], P.kps["y"]], axis=1)
-                oracle_py.search_for_initialization(P, F, pm, 100, 0.9, True)
+                out["n1"], out["m12"], _ = oracle_py.search_for_initialization(P, F, pm, 100, 0.9, True)
                 a = _w3_proj_args(P.kps, Pd, P.is_orb, len(k))
-                oracle_py.search_by_projection_last(F, P, a["valid"], a["uv"], a["mp_desc"], a["mp_obs"], a["cur_mp"], 15.0, a["ls"], 0, True)
+                out["n2"], out["cur_mp"] = oracle_py.search_by_projection_last(F, P, a["valid"], a["uv"], a["mp_desc"], a["mp_obs"], a["cur_mp"], 15.0, a["ls"], 0, True)
             st["prev"] = (F, d)
-        return run
+            return out
+        return _Unit(run, lambda: st.update(prev=None))
     if kind == "w4":
         frames = _w4_frames(spec["nunits"], spec["seed0"])
         oe = oracle_py.OrbExtractor(fast=True, imWidth=346, **spec["orb"])
         q, t = _w4_desc()
 
         def run(i):
-            oe.extract(frames[i % len(frames)])
-            oracle_py.bf_knn2(q, t, fast=True)
-        return run
+            _, kps, desc, _ = oe.extract(frames[i % len(frames)])
+            idx, dist = oracle_py.bf_knn2(q, t, fast=True)
+            return {"kps": kps, "desc": desc, "idx": idx, "dist": dist}
+        return _Unit(run, lambda: None)
     raise ValueError(kind)
 
 
@@ -134,7 +153,7 @@ def _cpu_worker(args):
     """All-cores baseline: one process = one core working through its own units; returns (units, t_start, t_end)."""
     spec, idx, reps, barrier = args
     spec = dict(spec); spec["seed0"] = spec["seed0"] + 100 * (idx + 1)
-    run = _cpu_batch_unit(spec)
+    run = _cpu_batch_unit(spec).run
     run(0)                                               # warm-up (page cache, branch predictors)
     barrier.wait(timeout=600)                            # all workers start their timed loop together
     t0 = time.time()
@@ -143,16 +162,20 @@ def _cpu_worker(args):
     return reps, t0, time.time()
 
 
-def cpu_baseline(spec, n1, pool, unit_name, data=None):
-    """1-thread throughput + p50/p95 per unit, and the all-cores throughput (one unit per core at a time)."""
-    out = {}
+def cpu_baseline(spec, n1, pool, unit_name, data=None, keep=0):
+    """1-thread throughput + p50/p95 per unit, and the all-cores throughput (one unit per core at a time).  Returns (the `cpu_baseline`
+    object, the oracle's outputs of the first `keep` units: what the GPU's results for the same units are verified against)."""
+    out, kept = {}, []
     if n1 > 0:
-        run = _cpu_batch_unit(spec, data)
-        run(0)
+        unit = _cpu_batch_unit(spec, data)
+        unit.run(0)
+        unit.reset()                                     # (the timed pass starts like the GPU run: no previous frame)
         ts = []
         t_all = time.perf_counter()
         for i in range(n1):
-            t0 = time.perf_counter(); run(i); ts.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); r = unit.run(i); ts.append(time.perf_counter() - t0)
+            if i < keep:
+                kept.append(r)
         tcpu = time.perf_counter() - t_all
         out = {"value": n1 / tcpu, "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d %s (same generator / seeds as the GPU run), oracle built -O3 -march=native -ffp-contract=off, %.1f s"
@@ -173,7 +196,66 @@ def cpu_baseline(spec, n1, pool, unit_name, data=None):
         wall = max(r[2] for r in res) - min(r[1] for r in res)
         out["all_cores"] = {"value": units / wall, "unit": "frames/s", "cores": nproc,
                             "sample": "%d processes x %d %s each (one unit per core at a time), wall %.1f s" % (nproc, reps, unit_name, wall)}
+    return out, kept
+
+
+def _bits_equal(a, b):
+    """same bytes (structured records against their byte rows included)"""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.nbytes == b.nbytes and np.array_equal(a.view(np.uint8).ravel(), b.view(np.uint8).ravel())
+
+
+def _verified(checked, mismatches, units, what):
+    return {"units": units, "mismatches": len(mismatches), "compared": checked, "what": what,
+            **({"first_mismatches": mismatches[:8]} if mismatches else {})}
+
+
+def _gen_slice(args):
+    """One synthetic slice (a worker of the generator pool): the 16-byte HBM record of the chosen input."""
+    NEV, W, H, seed, use_raw = args
+    from eorb_slam_amd import synth
+    f, r = synth.shapes_events(NEV, W, H, seed=seed, motion=0.5, undistort=True, return_raw=True)
+    if use_raw:
+        return r
+    from eorb_slam_amd import frontend
+    return frontend.pack_events(f)
+
+
+def unpack_events(ev16):
+    """eorb_event16 records -> the reference's EventData (what the oracle takes): polarity back out of t's sign bit"""
+    from eorb_slam_amd import synth
+    out = np.zeros(len(ev16), synth.EVENT_DTYPE)
+    out["x"] = ev16["x"]; out["y"] = ev16["y"]
+    tb = ev16["t"].view(np.uint64)
+    out["p"] = ((tb >> np.uint64(63)) == 0).astype(np.uint8)
+    out["ts"] = (tb & np.uint64(0x7fffffffffffffff)).view(np.float64)
     return out
+
+
+def raw_to_float16(raw, lx, ly):
+    """eorb_raw_event -> eorb_event16 of the same events: the loader's undistortion (EventLoader.cpp:111-125: the maps at the sensor
+    pixel; the generator only keeps events that stay inside the image) and eorb_pack_events' polarity-in-the-sign-bit"""
+    from eorb_slam_amd import frontend
+    out = np.zeros(len(raw), frontend.EV16_DTYPE)
+    yi = raw["y"].astype(np.intp); xi = raw["x"].astype(np.intp)
+    out["x"] = lx[yi, xi]; out["y"] = ly[yi, xi]
+    tb = raw["t"].astype(np.float64).view(np.uint64).copy()
+    tb[raw["p"] == 0] |= np.uint64(0x8000000000000000)
+    out["t"] = tb.view(np.float64)
+    return out
+
+
+def gen_slices(NEV, W, H, seeds, use_raw, world):
+    """The batch's slices as 16-byte records, one array per seed.  Large batches (the 128 x 1 M events of w2 take minutes on one core)
+    are drawn by a pool of processes -- same seeds, same events as the serial loop -- started before this process touches the GPU
+    any further; N > 1 ranks share the host's cores."""
+    jobs = [(NEV, W, H, int(sd), use_raw) for sd in seeds]
+    if NEV * len(seeds) < 8000000:
+        return [_gen_slice(j) for j in jobs]
+    import multiprocessing as mp
+    nproc = max(2, min(CPU_POOL, (os.cpu_count() or 2) // max(world, 1), len(jobs)))
+    with mp.get_context("spawn").Pool(nproc) as p:
+        return p.map(_gen_slice, jobs, chunksize=1)
 
 
 # --------------------------------------------------------------------------------------------------------------------------
@@ -330,10 +412,60 @@ def main():
     env = dict(a=a, world=world, rank=rank, local_rank=local_rank, dev=dev, torch=torch, dist=dist, frontend=frontend, shard=shard,
                synth=synth)
     out = {"w1": run_batch, "w2": run_batch, "w3": run_frames, "w4": run_frames}[a.workload](env)
+    failed = 0
     if rank == 0:
+        if a.side and world == 1:
+            out["side"] = side_runs(env, out)
+        failed = int(out.get("verified", {}).get("mismatches", 0)) + sum(int((v.get("verified") or {}).get("mismatches", 0)) for v in out.get("side", {}).values() if isinstance(v, dict))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        print("bench.py: %d outputs of the timed path differ from the CPU oracle's (see `verified`)" % failed, file=sys.stderr)
+        sys.exit(3)
+
+
+def _compact(o):
+    """A side run's line, reduced to what a reader needs to place it: value, the workload, the dominant kernel's roofline, the CPU
+    sample and the verification."""
+    if not o:
+        return None
+    r = o.get("roofline") or {}
+    c = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+         "workload": o["config"]["workload"], "config": {k: v for k, v in o["config"].items() if k != "workload"},
+         "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "traffic", "traffic_source") if k in r} or None,
+         "cpu_baseline": {k: o["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample", "p50_ms") if k in o.get("cpu_baseline", {})} or None,
+         "verified": o.get("verified")}
+    for k in ("latency", "batched", "speedup_vs_cpu_1thread", "kernels_ms_per_step"):
+        if k in o:
+            c[k] = o[k]
+    return c
+
+
+def side_runs(env, main_out):
+    """Short runs of the other BASELINE configs and input forms inside the default command, each with its own CPU sample and its own
+    verification against the oracle, so that ONE recorded line carries a number for configs[0]..[3] (w1, w2, w3, w4), for the
+    reference's own float EventData input and for events streamed from the host."""
+    import argparse
+    a = env["a"]
+    side = {"what": "short runs of the other workloads / input forms by the same command (fewer steps, a smaller CPU sample, no all-cores "
+                    "leg); `python bench.py --workload w1|w3|w4` and `--input float` print their full lines"}
+    plan = (("w1", run_batch, dict(workload="w1", input="raw", steps=10, warmup=2, cpu_slices=400, cpu_pool=0, latency_calls=100)),
+            ("w3", run_frames, dict(workload="w3", steps=6, warmup=1, cpu_slices=16, cpu_pool=0)),
+            ("w4", run_frames, dict(workload="w4", steps=6, warmup=1, cpu_slices=8, cpu_pool=0)),
+            ("w2_float_input", run_batch, dict(workload="w2", input="float", steps=6, warmup=2, cpu_slices=4, cpu_pool=0)))
+    for name, fn, over in plan:
+        v = dict(vars(a)); v.update(over); v.update(side=False, stream=False, batch=0, events=0)
+        env2 = dict(env); env2["a"] = argparse.Namespace(**v)
+        t0 = time.perf_counter()
+        try:
+            side[name] = _compact(fn(env2))
+            side[name]["wall_s"] = time.perf_counter() - t0
+        except Exception as e:                                   # a side run must not cost the main line
+            side[name] = {"error": "%s: %s" % (type(e).__name__, e), "verified": {"mismatches": 1, "what": "the side run failed"}}
+    if "streaming" in main_out:
+        side["streaming"] = main_out["streaming"]
+    return side
 
 
 def timed_steps(env, step, sync_extra=None):
@@ -450,13 +582,28 @@ def run_batch(env):
     use_raw = a.input == "raw"
     # ---- synthetic input: B independent slices per rank (seeded), packed to the 16 B HBM record ----
     seed0 = 2 + 1000 * rank
-    pairs = [synth.shapes_events(NEV, W, H, seed=seed0 + b, motion=0.5, undistort=True, return_raw=True) for b in range(B)]
-    ev16 = np.concatenate([p[1] for p in pairs]) if use_raw else np.concatenate([frontend.pack_events(p[0]) for p in pairs])
+    # N = 1: B distinct slices (the line the driver records).  N > 1: every rank of a node draws its events on the same host, so a
+    # rank draws 16 distinct slices and tiles them -- the scaling run measures the GPUs and the gather, not 8 x 128 x 1 M draws
+    ndist = B if (world == 1 or NEV * B < 8000000) else min(B, 16)
+    cache = env.setdefault("_slices", {})
+    key = (a.workload, NEV, B, seed0, ndist)
+    if key not in cache:
+        cache[key] = gen_slices(NEV, W, H, [seed0 + b for b in range(ndist)], True, world)
+    recs = cache[key]                                   # raw sensor records; the float form = the loader's map lookup of the same events
+    if not use_raw:
+        lx, ly = synth.undistort_lut(W, H)
+        recs = [raw_to_float16(r, lx, ly) for r in recs]
+    ev16 = np.concatenate([recs[b % ndist] for b in range(B)])
     offsets = np.arange(B + 1, dtype=np.int64) * NEV
-    lat_pairs = pairs[:min(len(pairs), 64)] if a.workload == "w1" else []
-    # host copies are only needed again by the CPU baseline (rank 0 at N = 1): keep those slices, drop the rest (40 MB per slice at w2)
-    cpu_pairs = pairs[:min(ncpu, 64, B)] if (ncpu > 0 and world == 1) else []
-    del pairs
+    # the CPU baseline / the verification (rank 0 at N = 1) work on the first slices of the batch
+    ncmp = min(ncpu, 64, B) if world == 1 else 0
+    if use_raw:
+        cpu_pairs = [(None, recs[b]) for b in range(ncmp)]
+    else:
+        cpu_pairs = [(unpack_events(recs[b]), None) for b in range(ncmp)]
+    lat_pairs = []
+    if a.workload == "w1" and a.latency_calls > 0 and world == 1:
+        lat_pairs = [synth.shapes_events(NEV, W, H, seed=seed0 + b, motion=0.5, undistort=True, return_raw=True) for b in range(min(B, 64))]
 
     S = max(1, a.sequences)
     d_ev = torch.from_numpy(ev16.view(np.uint8)).to(dev)
@@ -530,6 +677,17 @@ def run_batch(env):
     for c_i, _, _ in seqs:
         c_i.sync()                                   # raises if a batch overflowed an internal capacity (sticky status)
     nk = seqs[0][2]["n"].cpu().numpy(); nm = seqs[0][2]["nm"].cpu().numpy()
+    # ---- what the timed steps computed, for the verification below (rank 0, N = 1): the LAST step's outputs of sequence 0 for the
+    #      first `ncmp` slices -- float images, extremes, u8 images, keypoints, descriptors, matches -- downloaded outside the timed region
+    gpu_out = None
+    if rank == 0 and ncmp > 0:
+        _, fb0, bf0 = seqs[(step_no[0] - 1) % S]
+        cap0 = fb0.cap
+        p32, mm = fb0.last_f32(B)
+        f32 = np.zeros((ncmp, H, W), np.float32); fb0.ctx.download(f32, p32)
+        gpu_out = dict(f32=f32, mm=mm[:ncmp], u8=bf0["img"][:ncmp * W * H].cpu().numpy().reshape(ncmp, H, W), n=bf0["n"][:ncmp].cpu().numpy(),
+                       kp=bf0["kp"][:ncmp * cap0 * 28].cpu().numpy().reshape(ncmp, cap0, 28), desc=bf0["desc"][:ncmp * cap0 * 32].cpu().numpy().reshape(ncmp, cap0, 32),
+                       m=bf0["m"][:ncmp * cap0].cpu().numpy().reshape(ncmp, cap0), nm=bf0["nm"][:ncmp].cpu().numpy(), cap=cap0)
     out = None
     if rank == 0:
         frames = world * B * a.steps
@@ -595,12 +753,39 @@ def run_batch(env):
                                       "events, loader fused) -> eorb_orb_extract(detect-only)" % NEV, "calls": a.latency_calls,
                               **{k: _pcts(v) for k, v in lat.items()}}
             c.close()
-        # ---- CPU baseline: the oracle (port), bounded sample of the same workload ----
+        # ---- CPU baseline: the oracle (port), bounded sample of the same workload; its outputs for the first slices are what the
+        #      GPU's last timed step is verified against, bit for bit ----
         if ncpu > 0 and world == 1:
             spec = dict(kind="batch", W=W, H=H, events=NEV, orb=orb, sigma=1.0, input=a.input, want_desc=want_desc, match=match,
                         seed0=seed0, nunits=min(ncpu, 64))
-            out["cpu_baseline"] = cpu_baseline(spec, ncpu, a.cpu_pool, "slices of %d events" % NEV, cpu_pairs)
+            out["cpu_baseline"], ref = cpu_baseline(spec, ncpu, a.cpu_pool, "slices of %d events" % NEV, cpu_pairs, keep=ncmp)
             out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
+            out["verified"] = verify_batch(gpu_out, ref, want_desc, match)
+    for c_i, _, _ in seqs:
+        c_i.close()
+    return out
+
+
+def verify_batch(g, ref, want_desc, match):
+    """The GPU's outputs of the last timed step against the oracle's for the same slices (the `for k` order of
+    src/Event/EventConversion.cc:231-263 decides every float): float image, running extremes, u8 image, keypoint records,
+    descriptor bytes, SearchForInitialization matches against the previous slice -- all compared as bytes."""
+    bad = []
+    compared = ["f32 image bits", "min/max bits", "u8 image", "keypoint count", "keypoint records (28 B)"] + \
+               (["descriptors (32 B)"] if want_desc else []) + (["matches12 + nmatches vs the previous slice (slices 1..)"] if (want_desc and match) else [])
+    for b, r in enumerate(ref):
+        n = len(r["kps"])
+        if not _bits_equal(r["f32"], g["f32"][b]): bad.append("slice %d: f32 image (%d px)" % (b, int((r["f32"].view(np.uint32) != g["f32"][b].view(np.uint32)).sum())))
+        if not _bits_equal(r["mm"], g["mm"][b]): bad.append("slice %d: extremes %s vs %s" % (b, r["mm"].tolist(), g["mm"][b].tolist()))
+        if not np.array_equal(r["u8"], g["u8"][b]): bad.append("slice %d: u8 image" % b)
+        if n != int(g["n"][b]): bad.append("slice %d: %d keypoints vs %d" % (b, n, int(g["n"][b]))); continue
+        if not _bits_equal(r["kps"], g["kp"][b, :n]): bad.append("slice %d: keypoint records" % b)
+        if want_desc and not np.array_equal(r["desc"], g["desc"][b, :n]): bad.append("slice %d: descriptors" % b)
+        if want_desc and match and b >= 1:
+            npv = len(ref[b - 1]["kps"])
+            if int(r["nm"]) != int(g["nm"][b]) or not np.array_equal(r["m12"], g["m"][b, :npv]): bad.append("slice %d: matches (%s vs %d)" % (b, r["nm"], int(g["nm"][b])))
+    return _verified(compared, bad, len(ref), "the last timed step's outputs for the first %d slices of the batch against the CPU oracle's (the cpu_baseline "
+                     "leg's own results), compared as bytes outside the timed region" % len(ref))
     for c_i, _, _ in seqs:
         c_i.close()
     return out
@@ -621,20 +806,24 @@ def run_frames(env):
         m = fe.ORBmatcher(0.9, True, c)
         st = {"prev": None, "i": 0, "nm": [], "nk": []}
 
-        def one():
+        def one(keep=False):
             i = st["i"]; st["i"] += 1
             _, kps, desc, _ = ge(frames[i % nfr])
             k, d, o = _w3_mix(kps, desc, i % nfr)
             F = fe.FrameView(k, d, W, H, o)
+            res = {"kps": kps, "desc": desc} if keep else None
             if st["prev"] is not None:
                 P, Pd = st["prev"]
                 pm = np.stack([P.kps["x"], P.kps["y"]], axis=1)
-                n1, _, _ = m.SearchForInitialization(P, F, pm, 100)
+                n1, m12, _ = m.SearchForInitialization(P, F, pm, 100)
                 pa = _w3_proj_args(P.kps, Pd, P.is_orb, len(k))
-                n2, _ = m.SearchByProjectionLast(F, P, pa["valid"], pa["uv"], pa["mp_desc"], pa["mp_obs"], pa["cur_mp"], 15.0, pa["ls"], 0)
+                n2, cmp_ = m.SearchByProjectionLast(F, P, pa["valid"], pa["uv"], pa["mp_desc"], pa["mp_obs"], pa["cur_mp"], 15.0, pa["ls"], 0)
                 st["nm"].append((n1, n2))
+                if keep:
+                    res.update(n1=n1, m12=m12, n2=n2, cur_mp=cmp_)
             st["nk"].append(len(kps))
             st["prev"] = (F, d)
+            return res
         wl = ("BASELINE.json configs[2] stand-in (W3): 240x180 texture frames, ORB-1000 (1.2, 4 levels, FAST 10/0, edge 19) + 500 AKAZE-like "
               "61-byte rows per frame, MixedMatcher SearchForInitialization (window 100) + SearchByProjection(cur, last) with the type "
               "gate; one frame per call, host buffers")
@@ -649,11 +838,12 @@ def run_frames(env):
         q, t = _w4_desc()
         st = {"i": 0, "nk": [], "nm": []}
 
-        def one():
+        def one(keep=False):
             i = st["i"]; st["i"] += 1
-            _, kps, _, _ = ge(frames[i % nfr])
-            bf.knnMatch2(q, t)
+            _, kps, desc, _ = ge(frames[i % nfr])
+            idx, dist = bf.knnMatch2(q, t)
             st["nk"].append(len(kps))
+            return {"kps": kps, "desc": desc, "idx": idx, "dist": dist} if keep else None
         wl = ("BASELINE.json configs[3] stand-in (W4): 346x260 texture frames, ORB extraction of 2 000 features on 8 levels @1.2 (edge 15) "
               "+ cv::BFMatcher-style Hamming 2-NN of 2000 x 2000 descriptors (planted matches); one frame per call, host buffers")
         P = level_pixels(W, H, 1.2, 8)
@@ -722,8 +912,26 @@ def run_frames(env):
             fbi.ctx.close()
         if ncpu > 0 and world == 1:
             spec = dict(kind=a.workload, orb=orb, seed0=(3 if a.workload == "w3" else 4), nunits=nfr, events=0)
-            out["cpu_baseline"] = cpu_baseline(spec, ncpu, a.cpu_pool, "frames")
+            nver = min(ncpu, nfr)
+            out["cpu_baseline"], ref = cpu_baseline(spec, ncpu, a.cpu_pool, "frames", keep=nver)
             out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
+            # the same calls the timed steps made, from a fresh start, their results kept: frame i against the oracle's frame i
+            st["i"] = 0
+            if "prev" in st:
+                st["prev"] = None
+            bad = []
+            for i in range(nver):
+                g = one(keep=True); r = ref[i]
+                if len(g["kps"]) != len(r["kps"]) or not _bits_equal(g["kps"], r["kps"]): bad.append("frame %d: keypoints" % i)
+                elif not np.array_equal(g["desc"], r["desc"]): bad.append("frame %d: descriptors" % i)
+                if a.workload == "w3" and i >= 1:
+                    if g["n1"] != r["n1"] or not np.array_equal(g["m12"], r["m12"]): bad.append("frame %d: SearchForInitialization (%s vs %s)" % (i, g["n1"], r["n1"]))
+                    if g["n2"] != r["n2"] or not np.array_equal(g["cur_mp"], r["cur_mp"]): bad.append("frame %d: SearchByProjection (%s vs %s)" % (i, g["n2"], r["n2"]))
+                if a.workload == "w4" and (not np.array_equal(g["idx"], r["idx"]) or not np.array_equal(g["dist"], r["dist"])): bad.append("frame %d: 2-NN" % i)
+            cmp_ = ["keypoint records (28 B)", "descriptors (32 B)"] + (["SearchForInitialization matches12 + count", "SearchByProjection(cur, last) map-point indices + count"]
+                                                                        if a.workload == "w3" else ["brute-force 2-NN indices + distances (2000 x 2000)"])
+            out["verified"] = _verified(cmp_, bad, nver, "the calls of the timed steps repeated from a fresh start for the first %d frames, their results against "
+                                        "the CPU oracle's (the cpu_baseline leg's own results), compared as bytes" % nver)
     c.close()
     return out
 

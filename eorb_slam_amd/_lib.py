@@ -18,7 +18,7 @@ EXPORTS = [
     "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map", "eorb_search_by_projection_kf",
     "eorb_hamming_bf_knn2", "eorb_search_by_bow", "eorb_search_by_bow_kf", "eorb_distinctive_descriptors", "eorb_hamming_window_match", "eorb_calc_optical_flow_pyr_lk", "eorb_bow_set_vocabulary", "eorb_bow_transform", "eorb_search_for_triangulation", "eorb_kf_radius_match", "eorb_sort_by_response", "eorb_resolve_num_mixed",
     "eorb_orb_tracked_descriptors", "eorb_orb_assign_level_by_best_desc",
-    "eorb_fe_configure", "eorb_fe_run_batch_dev",
+    "eorb_fe_configure", "eorb_fe_run_batch_dev", "eorb_fe_last_f32_dev",
     "eorb_selfcheck_division", "eorb_selfcheck_math",
     "eorb_pack_events", "eorb_dev_alloc", "eorb_dev_free", "eorb_dev_upload", "eorb_dev_download",
 ]
@@ -169,6 +169,7 @@ def lib():
     L.eorb_fe_configure.restype = ci; L.eorb_fe_configure.argtypes = [vp, C.POINTER(FeConfig)]
     L.eorb_fe_run_batch_dev.restype = ci
     L.eorb_fe_run_batch_dev.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
+    L.eorb_fe_last_f32_dev.restype = ci; L.eorb_fe_last_f32_dev.argtypes = [vp, C.POINTER(vp), vp, ci]
     L.eorb_selfcheck_division.restype = ci; L.eorb_selfcheck_division.argtypes = [vp, cf, cf, cf, C.POINTER(C.c_uint64)]
     L.eorb_selfcheck_math.restype = ci; L.eorb_selfcheck_math.argtypes = [vp, ci, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.eorb_pack_events.restype = None; L.eorb_pack_events.argtypes = [vp, C.c_size_t, vp]

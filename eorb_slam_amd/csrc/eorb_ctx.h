@@ -94,6 +94,9 @@ struct eorb_ctx {
     eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_plan, sl_trace, sl_hot; long long sl_trace_n = 0;
     hipStream_t sl_side = nullptr; hipEvent_t sl_ev_fork = nullptr, sl_ev_join = nullptr, sl_ev_plan = nullptr, sl_ev_scat = nullptr;      // the long lists run beside the gather
     int sl_ok = 0, sl_null = 0, sl_rank_ok = -1;
+    int ncu = 0;                                 // compute units of c->device (per context: a second context may sit on another GPU)
+    unsigned sl_attr = 0;                        // bit per kernel instantiation whose dynamic-LDS opt-in was made on c->device
+    int sl_last_rank = -1, sl_last_chunk = 0;    // the scatter the last slot-form call ran (1 rank form, 0 ballot form), its chunk size
     int* rb_pinned = nullptr;                   // 64 ints of pinned host memory: the landing place of small read-backs (position count, slot info)
     int sl_launched = 0; int sl_hinfo[6] = {0, 0, 0, 0, 0, 0};      // assignment kernels launched, their read-back (ev_slots_prepare_launch / _finish)
     int dd_src_info_done = 0;                   // float bulk path: src_info of the per-call table already launched
@@ -137,6 +140,9 @@ struct eorb_ctx {
     int dbg_pool_shrink = 0, dbg_force_global = 0;
     int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices), 4 slot lists (K2p)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
+    int dbg_slot_rank = -1;                      // slot form: -1 by the device check / EORB_SLOT_RANK, 0 ballot scatter, 1 rank scatter (if the check passed)
+    long long dbg_slot_hot_min = -1;             // slot form: list length from which the register-row kernel takes a list (-1: default / EORB_SLOT_HOT_MIN)
+    int dbg_slot_hot_cap = 0;                    // slot form: lists per length bucket of the register-row kernel (0: kHotCap), to force the overflow branch
 };
 
 namespace eorb {

@@ -265,6 +265,8 @@ int eorb_sync(eorb_ctx* c)
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     if (bits) {
         EORB_HIP(c, hipMemsetAsync(c->status.p, 0, sizeof(bits), c->stream));
+        if (bits & 256)
+            return set_err(c, EORB_E_HIP, "internal error: the slot gather found its LDS rows at a non-zero base (status %d); the images of that call were not written", bits);
         return set_err(c, EORB_E_CAPACITY, "a batched call exceeded an internal capacity (octree flags %d: 1 = candidates, 2 = node pool / "
                        "size list, 4 = keypoints per level); its keypoints are truncated", bits);
     }
@@ -280,6 +282,9 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "win_pool_cap")) { c->dbg_win_ecap = value; return EORB_OK; }
     if (!strcmp(name, "gather_form")) { c->dbg_gather_form = value; return EORB_OK; }
     if (!strcmp(name, "dedupe_min_events")) { c->dbg_dd_min = value; return EORB_OK; }
+    if (!strcmp(name, "slot_rank")) { c->dbg_slot_rank = value; return EORB_OK; }
+    if (!strcmp(name, "slot_hot_min")) { c->dbg_slot_hot_min = value; return EORB_OK; }
+    if (!strcmp(name, "slot_hot_cap")) { c->dbg_slot_hot_cap = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
 
@@ -288,12 +293,20 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
     if (!c || !name) return -1;
     if (!strcmp(name, "slot_calls")) return c->sl_calls;
     if (!strcmp(name, "slot_rank_ok")) return c->sl_rank_ok;
+    if (!strcmp(name, "slot_scatter_form")) return c->sl_last_rank;       // the scatter of the last slot-form call: 1 rank form, 0 ballot form
+    if (!strcmp(name, "slot_chunk")) return c->sl_last_chunk;
+    if (!strcmp(name, "slot_hot_overflow")) {           // lists the last slot-form call handed back to the LDS gather because their length bucket was full (synchronises)
+        if (!c->sl_hot.p) return 0;
+        uint32_t h = 0;
+        if (hipMemcpyAsync(&h, (uint32_t*)c->sl_hot.p + 33, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+        return h;
+    }
     if (!strcmp(name, "slot_hot_items")) {              // lists the last slot-form call handed to the register-row kernel (synchronises)
         if (!c->sl_hot.p) return 0;
         uint32_t h[16];
         if (hipMemcpyAsync(h, c->sl_hot.p, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
         long long n = 0;
-        for (int i = 0; i < 16; i++) n += h[i];
+        for (int i = 0; i < 16; i++) n += h[i];      // (sl_tasks_kernel capped the counts at the buckets' capacity)
         return n;
     }
     if (!strcmp(name, "slot_flags")) {
@@ -401,11 +414,20 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
     uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
     float* d_f32 = A.dev<float>(o_f32);
     if (out_u8 && mode_count) EORB_HIP(c, hipMemsetAsync(d_u8, 0, npix, c->stream));     // count images stay empty when max == min
+    const long long slot_calls0 = c->sl_calls;
     rc = ev_accumulate_dev(c, A.dev<void>(o_ev), raw, offs, 1, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, mm);
     if (rc) return rc;
+    // the slot form reports an internal fault (its gather found no rows at LDS offset 0 and wrote no image) through the sticky status
+    // word: this call's copy of it travels with the outputs (word 2 of the min/max block)
+    const bool slot_ran = c->sl_calls != slot_calls0;
+    if (slot_ran) EORB_HIP(c, hipMemcpyAsync(mm + 2, c->status.p, 4, hipMemcpyDeviceToDevice, c->stream));
     const size_t end = out_f32 ? o_f32 + sizeof(float) * npix : (out_u8 ? o_u8 + npix : o_mm + 64);
     const char* h;
     if ((rc = A.download(o_mm, end - o_mm, &h))) return rc;
+    if (slot_ran) {
+        int32_t st; memcpy(&st, h + o_mm + 8, 4);
+        if (st & 256) return set_err(c, EORB_E_HIP, "internal error: the slot gather found its LDS rows at a non-zero base; no image was written");
+    }
     // the running extremes come back in their order-preserving integer encoding (enc_f32 of the gather kernels): decoded here
     float hmm[2];
     for (int k = 0; k < 2; k++) {
@@ -1476,6 +1498,25 @@ int eorb_fe_run_batch_raw_dev(eorb_ctx* c, const eorb_raw_event* d_events, const
 {
     if (c && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "fe_run_batch_raw: eorb_set_undistort_maps not called");
     return fe_run_batch_common(c, d_events, 1, h_offsets, B, d_images, d_kps, d_desc, d_nkps, d_matches12, d_nmatches);
+}
+
+int eorb_fe_last_f32_dev(eorb_ctx* c, const float** d_f32, float* h_minmax, int B)
+{
+    if (!c) return EORB_E_ARG;
+    if (!c->fe_configured || !c->img_f32.p) return set_err(c, EORB_E_NOTCONF, "fe_last_f32: eorb_fe_configure not called");
+    if (B < 0 || B > c->fe.max_batch) return set_err(c, EORB_E_ARG, "fe_last_f32: bad batch size %d", B);
+    if (d_f32) *d_f32 = (const float*)c->img_f32.p;
+    if (h_minmax && B) {
+        hipSetDevice(c->device);
+        std::vector<uint32_t> enc(2 * (size_t)B);
+        EORB_HIP(c, hipMemcpyAsync(enc.data(), c->minmax.p, sizeof(uint32_t) * enc.size(), hipMemcpyDeviceToHost, c->stream));
+        EORB_HIP(c, hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < enc.size(); k++) {           // the order-preserving integer encoding of the gather kernels' atomics
+            const uint32_t e = enc[k], u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+            memcpy(&h_minmax[k], &u, 4);
+        }
+    }
+    return EORB_OK;
 }
 
 int eorb_fe_run_batch_images_dev(eorb_ctx* c, const uint8_t* d_images, int B, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,

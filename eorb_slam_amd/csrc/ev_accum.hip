@@ -2097,14 +2097,18 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                     ProfScope ps(c, "ev_minmax_init");
                     ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
                 }
-                if ((rc = ev_slots_accumulate(c, d_events, hashed ? -4 : (packed4 ? 4 : 16), h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc))) return rc;
-                if (normalized && d_u8) {
-                    ProfScope ps(c, "ev_normalize");
-                    dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
-                    ev_normalize_kernel<<<grid, 256, 0, c->stream>>>(d_f32, d_minmax_enc, d_u8, W * H, mode_count);
-                    EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
+                // > 0: the batch's shape does not fit the slot form (tile grids beyond the scatter's LDS, e.g. VGA-class sensors; more than
+                // 2 048 slices) and nothing was launched: the batch pipeline below serves it
+                if ((rc = ev_slots_accumulate(c, d_events, hashed ? -4 : (packed4 ? 4 : 16), h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc)) < 0) return rc;
+                if (rc == 0) {
+                    if (normalized && d_u8) {
+                        ProfScope ps(c, "ev_normalize");
+                        dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
+                        ev_normalize_kernel<<<grid, 256, 0, c->stream>>>(d_f32, d_minmax_enc, d_u8, W * H, mode_count);
+                        EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
+                    }
+                    return EORB_OK;
                 }
-                return EORB_OK;
             }
         }
     }

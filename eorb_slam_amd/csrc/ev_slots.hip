@@ -594,28 +594,43 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
 }
 
 // Are the results of a wave's LDS atomic add handed out in lane order among the lanes that hit the same counter (32-bit words
-// holding two 16-bit counters, some lanes inactive)?  bad = number of pairs out of order.
-__global__ __launch_bounds__(256) void sl_rankcheck_kernel(unsigned long long* bad)
+// holding two 16-bit counters, some lanes inactive)?  bad = number of pairs out of order.  Run once per context with the shapes the
+// scatter itself uses: 8 and 16 wavefronts per workgroup, every wavefront on its own counter row, plain LDS stores of the other
+// wavefronts in flight between the atomics (phase A of the scatter overlaps phase C of nobody, but the count kernels' stores do).
+__global__ __launch_bounds__(1024) void sl_rankcheck_kernel(unsigned long long* bad)
 {
-    __shared__ uint32_t cnt[512];
+    __shared__ uint32_t cnt[16 * 64];                                 // 128 16-bit counters per wavefront
+    __shared__ uint32_t noise[1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long nbad = 0;
-    uint32_t h = (uint32_t)(blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    uint32_t h = (uint32_t)(blockIdx.x * 1024 + threadIdx.x) * 2654435761u + 12345u;
     for (int t = 0; t < 64; t++) {
-        for (int i = threadIdx.x; i < 512; i += blockDim.x) cnt[i] = 0;
+        for (int i = threadIdx.x; i < 16 * 64; i += blockDim.x) cnt[i] = 0;
         __syncthreads();
         h = h * 1664525u + 1013904223u;
         const int spread = 1 << (1 + (t % 7));                       // 2 ... 128 distinct counters per wave
         const uint32_t a = ((h >> 9) % spread) + wave * 128;
         const bool act = ((h >> 3) & 7u) != 0u;
         uint32_t r = 0xffffffffu;
-        if (act) { const uint32_t o = atomicAdd(&cnt[a >> 1], 1u << (16 * (a & 1))); r = (o >> (16 * (a & 1))) & 0xffffu; }
-        for (int j = 0; j < 64; j++) {
-            const uint32_t aj = __shfl(a, j, 64), rj = __shfl(r, j, 64);
-            if (act && rj != 0xffffffffu && j < lane && aj == a && !(rj < r)) nbad++;
+        noise[(threadIdx.x * 33 + t) & 1023] = h;                    // plain stores beside the atomics
+        // four atomics in a row, as the scatter issues them (one per parity class): the order inside each must hold
+        uint32_t rr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            rr[q] = 0xffffffffu;
+            if (act && ((h >> (12 + q)) & 1u)) { const uint32_t o = atomicAdd(&cnt[a >> 1], 1u << (16 * (a & 1))); rr[q] = (o >> (16 * (a & 1))) & 0xffffu; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            r = rr[q];
+            for (int j = 0; j < 64; j++) {
+                const uint32_t aj = __shfl(a, j, 64), rj = __shfl(r, j, 64);
+                if (r != 0xffffffffu && rj != 0xffffffffu && j < lane && aj == a && !(rj < r)) nbad++;
+            }
         }
         __syncthreads();
     }
+    if (noise[threadIdx.x] == 0x12345u) nbad += 0;                    // (keeps the stores)
     if (nbad) atomicAdd(bad, nbad);
 }
 
@@ -633,7 +648,8 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
                                                       const int64_t* __restrict__ slice_ebase, int B, int NT, int TX, uint32_t hot_min,
                                                       const uint32_t* __restrict__ nslots, const uint32_t* __restrict__ rowbase,
                                                       uint4* __restrict__ items, uint32_t* __restrict__ tile_w, uint32_t* __restrict__ tile_m,
-                                                      uint32_t* __restrict__ ctr, uint32_t* __restrict__ hot_cnt, HotDesc* __restrict__ hot_items)
+                                                      uint32_t* __restrict__ ctr, uint32_t* __restrict__ hot_cnt, HotDesc* __restrict__ hot_items,
+                                                      uint32_t hot_cap /* lists per bucket: kHotCap, less under the test hook */)
 {
     extern __shared__ uint32_t pc[];                 // B counts | B (bucket << 16 | index in the block's share of the bucket)
     __shared__ uint32_t red[8];
@@ -664,12 +680,12 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
         uint32_t v = pc[s];
         if (v & 0x80000000u) {
             const uint32_t c = v & 0x7fffffffu, b = hloc[s] >> 16, k = hbase[b] + (hloc[s] & 0xffffu);
-            if (k < (uint32_t)kHotCap) {
+            if (k < hot_cap) {
                 const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
                 HotDesc d; d.slice = (uint32_t)s; d.tile = (uint32_t)t; d.cnt = c; d.off_lo = (uint32_t)off; d.off_hi = (uint32_t)(off >> 32);
                 d.tx0 = (uint32_t)(t % TX) * 8u; d.ty0 = (uint32_t)(t / TX) * 8u; d.rows_off = rowbase[t] * 256u;
                 hot_items[(size_t)b * kHotCap + k] = d;
-            } else { v = c; pc[s] = v; }            // the bucket is full: the gather keeps the list
+            } else { v = c; pc[s] = v; atomicAdd(&hot_cnt[33], 1u); }      // the bucket is full: the gather keeps the list (counted: eorb_debug_counter "slot_hot_overflow")
         }
         if (!(v & 0x80000000u)) { sum += v; mx = max(mx, v); }
     }
@@ -695,9 +711,10 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
 // (2) the workgroup tasks: tile positions ordered by their longest list, position t repeated n_t = 1 + its share of the G - NT spare
 //     tasks by total entries (no more than its slices can occupy); unused tasks carry 0xffffffff
 __global__ __launch_bounds__(1024) void sl_tasks_kernel(const uint32_t* __restrict__ tile_w, const uint32_t* __restrict__ tile_m, int NT, int G,
-                                                        int max_per_tile, uint32_t* __restrict__ scratch /* 2 * NT */, uint32_t* __restrict__ task_tile, uint32_t* __restrict__ hot_cnt)
+                                                        int max_per_tile, uint32_t* __restrict__ scratch /* 2 * NT */, uint32_t* __restrict__ task_tile, uint32_t* __restrict__ hot_cnt,
+                                                        uint32_t hot_cap)
 {
-    if (threadIdx.x < kHotBuckets) hot_cnt[threadIdx.x] = min(hot_cnt[threadIdx.x], (uint32_t)kHotCap);
+    if (threadIdx.x < kHotBuckets) hot_cnt[threadIdx.x] = min(hot_cnt[threadIdx.x], hot_cap);
     __shared__ unsigned long long wred[16];
     __shared__ uint32_t wsum[16], wsum2[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -758,7 +775,7 @@ __global__ __launch_bounds__(1024) void sl_tasks_kernel(const uint32_t* __restri
 struct SlotGather {
     const uint32_t* task_tile; const uint4* items; const uint8_t* entries;
     const uint32_t* nslots; const uint32_t* rowbase; const float* rows; const uint32_t* tile_w; uint32_t* ctr;
-    float* img; uint32_t* minmax_enc; int* info;
+    float* img; uint32_t* minmax_enc; int* info; int* status;
     int B, W, H, TX, NT, null_slot; uint32_t prio_ref;
     unsigned long long* trace;      // EORB_SLOT_TRACE builds: per wave { tile, start, end, entries, items } (wall clock, 100 MHz)
 };
@@ -779,7 +796,7 @@ void sl_gather_kernel(SlotGather P)
     const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
     const bool inimg = px < P.W && py < P.H;
-    if ((uint32_t)(uintptr_t)lds != 0u) { if (tid == 0) atomicOr(&P.info[3], 1); return; }
+    if ((uint32_t)(uintptr_t)lds != 0u) { if (tid == 0) { atomicOr(&P.info[3], 1); atomicOr(P.status, 256); } return; }      // (reported by eorb_sync / the host entry point)
     if (wt) {
         const int ns = (int)P.nslots[tile];
         const int n4 = ns * 16;
@@ -962,7 +979,8 @@ int ev_slots_prepare_launch(eorb_ctx* c, int W, int H, int h, int TX, int TY)
     if (c->sl_rank_ok < 0) {
         // once per context: may the scatter take its stable ranks from LDS atomics? (see sl_scatter_rank_kernel)
         unsigned long long* d_bad = (unsigned long long*)(d_info + 4);
-        sl_rankcheck_kernel<<<256, 256, 0, c->stream>>>(d_bad);
+        sl_rankcheck_kernel<<<128, 512, 0, c->stream>>>(d_bad);            // 8 wavefronts: the 2 048-event chunks
+        sl_rankcheck_kernel<<<128, 1024, 0, c->stream>>>(d_bad);           // 16 wavefronts: the 4 096-event chunks
     }
     int* rb = readback_buf(c);
     if (!rb) return set_err(c, EORB_E_HIP, "pinned alloc failed");
@@ -1003,21 +1021,72 @@ int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const flo
     return ev_slots_prepare_finish(c, W, H, h, TX, TY, d_stamps, stamp_stride, SWP, two_sig2, norm);
 }
 
-// count -> scan -> scatter -> order -> gather for B slices of raw events (no polarity, Gaussian stamp)
+// dynamic-LDS opt-in of one kernel instantiation, once per CONTEXT (= per device: a second context may sit on another GPU)
+static int sl_optin(eorb_ctx* c, int bit, const void* fn, int bytes)
+{
+    if (c->sl_attr & (1u << bit)) return EORB_OK;
+    EORB_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    c->sl_attr |= 1u << bit;
+    return EORB_OK;
+}
+static int sl_ncu(eorb_ctx* c)
+{
+    if (!c->ncu) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) c->ncu = pr.multiProcessorCount; if (c->ncu <= 0) c->ncu = 256; }
+    return c->ncu;
+}
+
+constexpr int kSlotDeclined = 1;       // ev_slots_accumulate: the batch's shape does not fit this form, nothing was launched
+
+// The scatter a batch will run -- decided before anything is launched: the preferred chunk size first, then shorter chunks; for each
+// the rank form (its own LDS footprint, <= 160 KB with the opt-in) where the device check allows it, else the ballot form (64 KB).
+// false: no form fits (e.g. VGA-class sensors: 4 800 tiles x 8 per-wave counter rows alone are 77 KB) and the caller falls back to
+// the batch pipeline, whose first scatter form needs 4 bytes of LDS per tile only.
+struct SlotScatterChoice { int chunk, waves; bool rank; size_t lds; };
+static size_t sl_lds_rank(int NT, int chunk, int waves) { const int NTp = (NT + 1) & ~1; return ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)waves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15; }
+static size_t sl_lds_ballot(int NT, int chunk) { const int NTp = (NT + 1) & ~1; return ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15; }
+static bool sl_choose_scatter(const eorb_ctx* c, int NT, int64_t per_slice, bool rank_allowed, SlotScatterChoice* out)
+{
+    static const int chunk_env = [] { const char* e = getenv("EORB_SLOT_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 1024 || v == 2048 || v == 4096) ? v : 0; }();
+    // chunks of 4 096 events (16 wavefronts per scatter workgroup) where the rank scatter runs and the slices are long: per-chunk work
+    // (the tiles' list bases, the prefix over the waves, the count rows) is shared by twice the events
+    // (128 x 1 Mev: binning 1.46-1.51 ms with 2 048, 1.41-1.44 with 4 096)
+    const int pref = chunk_env ? chunk_env : (per_slice >= (int64_t)1 << 18 ? 4096 : (per_slice >= (int64_t)1 << 17 ? 2048 : (per_slice >= (int64_t)1 << 14 ? 1024 : 256)));
+    static const int sizes[4] = {4096, 2048, 1024, 256};
+    for (int i = 0; i < 4; i++) {
+        const int chunk = sizes[i];
+        if (chunk > pref) continue;
+        if (rank_allowed) {
+            const int waves = chunk == 4096 ? 16 : kSlotScatWaves;
+            const size_t l = sl_lds_rank(NT, chunk, waves);
+            // (two or more workgroups per CU: the phases of different chunks overlap; one 130 KB workgroup per CU still beats falling back)
+            if (l <= (size_t)(chunk == 4096 ? 79 : 158) * 1024) { *out = {chunk, waves, true, l}; return true; }
+        }
+        if (chunk <= 2048) {
+            const size_t l = sl_lds_ballot(NT, chunk);
+            if (l <= 64 * 1024) { *out = {chunk, kSlotScatWaves, false, l}; return true; }
+        }
+    }
+    (void)c;
+    return false;
+}
+
+// count -> scan -> scatter -> order -> gather for B slices of raw events (no polarity, Gaussian stamp).
+// Returns kSlotDeclined (> 0, nothing launched) when the batch's shape does not fit: the caller goes on with the batch pipeline.
 int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
                         float* d_f32, uint32_t* d_minmax_enc)
 {
     const int NT = TX * TY;
-    c->sl_calls++;
     const int64_t nev = h_offsets[B] - h_offsets[0];
     const int64_t per_slice = nev / B;
-    // chunks of 4 096 events (16 wavefronts per scatter workgroup) where the rank scatter runs and the slices are long: per-chunk work
-    // (the tiles' list bases, the prefix over the waves, the count rows) is shared by twice the events
-    static const int chunk_env = [] { const char* e = getenv("EORB_SLOT_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 1024 || v == 2048 || v == 4096) ? v : 0; }();
     static const int rank_env0 = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
-    const bool big_ok = c->sl_rank_ok == 1 && rank_env0 && (size_t)NT * 4 + 4096 * 12 + 16 * (size_t)((NT + 1) & ~1) * 2 + (size_t)(NT + 4) * 2 + 32 <= 79 * 1024;
-    int chunk = chunk_env ? chunk_env : (per_slice >= (int64_t)1 << 18 ? 4096 : (per_slice >= (int64_t)1 << 17 ? 2048 : (per_slice >= (int64_t)1 << 14 ? 1024 : 256)));   // (128 x 1 Mev: binning 1.46-1.51 ms with 2 048, 1.41-1.44 with 4 096)
-    if (chunk == 4096 && !big_ok) chunk = 2048;
+    const bool rank_allowed = c->sl_rank_ok == 1 && (c->dbg_slot_rank < 0 ? rank_env0 != 0 : c->dbg_slot_rank != 0);
+    SlotScatterChoice sc;
+    // sl_plan_kernel keeps two words per slice in LDS and ranks a position's lists by an O(B^2) loop, sl_scan_kernel is one workgroup
+    // per slice: batches of more than 2 048 slices take the batch pipeline; so do tile grids whose count rows do not fit the LDS
+    if (B > 2048 || (size_t)NT * 4 > 64 * 1024 || !sl_choose_scatter(c, NT, per_slice, rank_allowed, &sc)) return kSlotDeclined;
+    const int chunk = sc.chunk;
+    c->sl_calls++;
+    c->sl_last_rank = sc.rank ? 1 : 0; c->sl_last_chunk = chunk;
     // up to 256 slices: the descriptors are made on the device from the offsets (sl_chunks_kernel); more: on the host, one copy
     const bool on_dev = B <= kOffsetsInArg;
     std::vector<ChunkDesc> cds;
@@ -1086,22 +1155,17 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         ProfScope ps(c, "ev_bin");
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
         const int NTp = (NT + 1) & ~1;
-        const size_t lds2 = ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15;
-        if (lds > 64 * 1024 || (chunk != 4096 && lds2 > 64 * 1024))       // (4 096-event chunks are chosen only where the rank scatter takes them)
-            return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %d tiles exceed the binning LDS", NT);
         // the tile ranges of all sensor pixels + one set of counters per wavefront in the LDS of one workgroup per CU?
         const size_t nsrc = (size_t)c->lut_w * (size_t)c->lut_h;
         const size_t lds_c = 4 * ((nsrc + 2) / 2) + (size_t)kCountWaves * NTp * 2;
         static const int cl_env = [] { const char* e = getenv("EORB_SLOT_COUNT_LDS"); return e ? atoi(e) : 1; }();
         if (nchunks && cl_env && TX <= 127 && TY <= 127 && lds_c <= 159 * 1024) {
-            static int ncu_c = 0;
-            if (!ncu_c) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ncu_c = pr.multiProcessorCount; if (ncu_c <= 0) ncu_c = 256; }
+            const int ncu_c = sl_ncu(c);
             const uint16_t* d_geo = (const uint16_t*)((const char*)c->sl_tab.p + sizeof(uint2) * nsrc);
             const int g = std::min(ncu_c, (nchunks + kCountWaves - 1) / kCountWaves);
-#define SL_COUNT(ST) do { static bool attr = false; \
-                if (!attr) { EORB_HIP(c, hipFuncSetAttribute((const void*)sl_count_lds_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024)); attr = true; } \
+#define SL_COUNT(ST, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_count_lds_kernel<ST>, 159 * 1024))) return rc; \
                 sl_count_lds_kernel<ST><<<g, 64 * kCountWaves, lds_c, c->stream>>>(d_ev, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt); } while (0)
-            if (stride == 16) SL_COUNT(16); else if (stride == 4) SL_COUNT(4); else SL_COUNT(-4);
+            if (stride == 16) SL_COUNT(16, 0); else if (stride == 4) SL_COUNT(4, 1); else SL_COUNT(-4, 2);
 #undef SL_COUNT
         }
         else if (nchunks) {
@@ -1115,10 +1179,15 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         if (!c->sl_side) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (hipStreamCreateWithPriority(&c->sl_side, hipStreamNonBlocking, hi) != hipSuccess) return set_err(c, EORB_E_HIP, "side stream");
-            if (hipEventCreateWithFlags(&c->sl_ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->sl_ev_join, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->sl_ev_plan, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->sl_ev_scat, hipEventDisableTiming) != hipSuccess)
-                return set_err(c, EORB_E_HIP, "side stream events");
+            hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+            bool ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) == hipSuccess;
+            for (int i = 0; ok && i < 4; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) {                                   // all or nothing: a half-made side stream must not be used by a later call
+                for (int i = 0; i < 4; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+                if (st) (void)hipStreamDestroy(st);
+                return set_err(c, EORB_E_HIP, "side stream / events");
+            }
+            c->sl_side = st; c->sl_ev_fork = ev[0]; c->sl_ev_join = ev[1]; c->sl_ev_plan = ev[2]; c->sl_ev_scat = ev[3];
         }
         lds_g = (size_t)(c->sl_null + 1) * 256;
         const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds_g));
@@ -1129,8 +1198,7 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         nw = std::min(16, std::max(1, 16 / wg_per_cu));
         if (nw_env >= 1 && nw_env <= 16) nw = nw_env;
         nw = std::min(nw, std::max(1, B));
-        static int ncu = 0;
-        if (!ncu) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+        const int ncu = sl_ncu(c);
         ncu_g = ncu;
         // one task per tile position plus a few rounds of spare ones shared out by weight; a position never gets more wavefronts than slices
         const int rounds = ns_env >= 1 ? ns_env : 4;
@@ -1147,7 +1215,10 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         // would not repay the 240 row loads per list (measured at 128 x 1 Mev: threshold 4 096 ... 8 192 1.40-1.45 ms, 16 384 1.53, none 2.44)
         static const long long hot_env = [] { const char* e = getenv("EORB_SLOT_HOT_MIN"); return e ? atoll(e) : -1ll; }();
         hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 16000), 0x7fffffff) : 0u;
-        if (hot_env >= 0) hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<long long>(hot_env, 0x7fffffff) : 0u;
+        const long long hot_over = c->dbg_slot_hot_min >= 0 ? c->dbg_slot_hot_min : hot_env;
+        // (never below 64: the register-row kernel's tail load reads the 64 bytes that END at the list's end; 0 = that kernel off)
+        if (hot_over >= 0) hot_min = (c->sl_null <= SL_HOT_NROWS && hot_over > 0) ? (uint32_t)std::min<long long>(std::max<long long>(hot_over, 64), 0x7fffffff) : 0u;
+        const uint32_t hot_cap = c->dbg_slot_hot_cap > 0 ? (uint32_t)std::min(c->dbg_slot_hot_cap, kHotCap) : (uint32_t)kHotCap;
         if ((rc = ensure(c, c->sl_hot, sizeof(HotDesc) * (size_t)kHotBuckets * kHotCap + 256))) return rc;
         d_hot_cnt = (uint32_t*)c->sl_hot.p;                                  // 16 bucket counts | ticket (at word 32) | descriptors (from byte 256)
         d_hot_items = (HotDesc*)((char*)c->sl_hot.p + 256);
@@ -1155,40 +1226,34 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         EORB_HIP(c, hipStreamWaitEvent(c->sl_side, c->sl_ev_fork, 0));
         EORB_HIP(c, hipMemsetAsync(c->sl_hot.p, 0, 256, c->sl_side));
         sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, c->sl_side>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, TX, hot_min, d_nslots, d_rowbase,
-                                                                               d_items, d_tile_w, d_tile_m, d_ctr, d_hot_cnt, d_hot_items);
-        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->sl_side>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task, d_hot_cnt);
+                                                                               d_items, d_tile_w, d_tile_m, d_ctr, d_hot_cnt, d_hot_items, hot_cap);
+        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->sl_side>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task, d_hot_cnt, hot_cap);
         EORB_HIP(c, hipEventRecord(c->sl_ev_plan, c->sl_side));
-        // ---- the scatter ----
-        static const int rank_env = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
-        const int scw = chunk == 4096 ? 16 : kSlotScatWaves;
-        const size_t lds3 = ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)scw * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15;
-        if (nchunks && c->sl_rank_ok == 1 && rank_env && lds3 <= (size_t)(chunk == 4096 ? 79 : 64) * 1024)
-        {
-#define SL_SCAT(ST, NW) do { static bool attr = false; \
-                if (!attr) { EORB_HIP(c, hipFuncSetAttribute((const void*)sl_scatter_rank_kernel<ST, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr = true; } \
-                sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, lds3, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
+        // ---- the scatter (form and chunk size chosen up front: sl_choose_scatter) ----
+        if (nchunks && sc.rank) {
+#define SL_SCAT(ST, NW, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_scatter_rank_kernel<ST, NW>, 159 * 1024))) return rc; \
+                sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, sc.lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
                                                                                    d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p); } while (0)
-            if (scw == 16) { if (stride == 16) SL_SCAT(16, 16); else if (stride == 4) SL_SCAT(4, 16); else SL_SCAT(-4, 16); }
-            else { if (stride == 16) SL_SCAT(16, 8); else if (stride == 4) SL_SCAT(4, 8); else SL_SCAT(-4, 8); }
+            if (sc.waves == 16) { if (stride == 16) SL_SCAT(16, 16, 3); else if (stride == 4) SL_SCAT(4, 16, 4); else SL_SCAT(-4, 16, 5); }
+            else { if (stride == 16) SL_SCAT(16, 8, 6); else if (stride == 4) SL_SCAT(4, 8, 7); else SL_SCAT(-4, 8, 8); }
 #undef SL_SCAT
         }
         else if (nchunks)
-            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, lds2, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
+            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, sc.lds, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
                                                                                  d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
         EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
     }
     {
         ProfScope ps(c, "ev_gather");
         SlotGather P{d_task, d_items, (const uint8_t*)c->entries.p, d_nslots, d_rowbase, (const float*)c->sl_rows.p,
-                     d_tile_w, d_ctr, d_f32, d_minmax_enc, d_info, B, W, H, TX, NT, c->sl_null, prio_ref, nullptr};
+                     d_tile_w, d_ctr, d_f32, d_minmax_enc, d_info, (int*)c->status.p, B, W, H, TX, NT, c->sl_null, prio_ref, nullptr};
 #ifdef EORB_SLOT_TRACE
         if ((rc = ensure(c, c->sl_trace, sizeof(unsigned long long) * 6 * 16 * (size_t)G + 64))) return rc;
         EORB_HIP(c, hipMemsetAsync(c->sl_trace.p, 0, sizeof(unsigned long long) * 6 * 16 * (size_t)G + 64, c->stream));
         P.trace = (unsigned long long*)c->sl_trace.p + 8;
         c->sl_trace_n = (long long)G * 16;
 #endif
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)sl_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        if ((rc = sl_optin(c, 9, (const void*)sl_gather_kernel, 160 * 1024))) return rc;
         if (hot_min) {
             // the long lists on the side (high-priority) stream beside the gather: they need the scatter's entries
             static const int hw_env = [] { const char* e = getenv("EORB_SLOT_HOT_WAVES"); return e ? atoi(e) : 0; }();

@@ -659,6 +659,13 @@ class FrontEndBatch:
         self.ctx.check(fn(self.ctx.h, vp(d_events), _p(offsets), B, vp(d_images), vp(d_kps),
                           vp(d_desc), vp(d_nkps), vp(d_m12), vp(d_nm)))
 
+    def last_f32(self, B, want_minmax=True):
+        """(device pointer of the last batch's B x H x W float images, (min, max) per slice) -- eorb_fe_last_f32_dev"""
+        p = C.c_void_p()
+        mm = np.zeros((B, 2), np.float32)
+        self.ctx.check(self.ctx.L.eorb_fe_last_f32_dev(self.ctx.h, C.byref(p), _p(mm) if want_minmax else None, int(B)))
+        return p.value, mm
+
     def run_images_dev(self, d_images, B, d_kps=None, d_desc=None, d_nkps=None, d_m12=None, d_nm=None):
         """B camera frames (u8, W x H each, back to back in HBM): extraction + SearchForInitialization of frame b against frame b-1."""
         vp = lambda x: C.c_void_p(x) if x else None

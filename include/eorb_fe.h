@@ -411,6 +411,13 @@ int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int
                           uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                           int32_t* d_matches12, int32_t* d_nmatches);
 
+/* The float images of the context's last eorb_fe_run_batch_*_dev call (what ev2im_gauss(..., normalized = false) returns,
+ * src/Event/EventConversion.cc:264-268: the CV_32FC1 sums before normaliseImage): *d_f32 = device pointer to B x H x W floats, valid
+ * until the next batch call on the context; h_minmax (optional, 2 * B floats: min, max per slice = the running extremes of
+ * resolveMinMaxVals :32-39) is downloaded, which waits for the stream.  For callers that want the un-normalised image of a slice
+ * (EvImBuilder::getEvHist, src/Event/EvImBuilder.cpp:1060-1079) and for bit-level verification of a batch. */
+int eorb_fe_last_f32_dev(eorb_ctx* ctx, const float** d_f32, float* h_minmax, int B);
+
 /* the same pass for B camera frames resident in HBM (u8, W x H each, back to back; the image side of the front end,
  * Frame::ExtractORB src/Frame.cc:467-482 + SearchForInitialization of frame b against frame b-1): no accumulation, the frames
  * are only read.  eorb_fe_configure as above (sigma / pol / max_events unused). */

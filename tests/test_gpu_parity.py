@@ -1181,6 +1181,131 @@ def test_register_row_kernel_list_tails(oracle, fe):
     ctx.close()
 
 
+def _raw_batch(fe, raws, W, H, mx, my, opts=(), check=True, sigma=1.0):
+    """One eorb_fe_run_batch_raw_dev call over the slices `raws` (detect-only extraction, no matching): u8 images, the float images
+    behind them (eorb_fe_last_f32_dev), the running extremes and the slot form's test-hook counters."""
+    B = len(raws)
+    sizes = [len(r) for r in raws]
+    fb = fe.FrontEndBatch(W, H, sigma, False, 400, 1.2, 1, 10, 0, 9, max_batch=B, max_events=max(max(sizes), 1), want_desc=False, match=False)
+    c, cap = fb.ctx, fb.cap
+    for k, v in opts:
+        c.debug_option(k, v)
+    fe.EvImConverter.set_undistort_maps(mx, my, check, ctx=c)
+    blob = np.concatenate(raws)
+    d_ev = c.dev_alloc(max(blob.nbytes, 16)); c.upload(d_ev, blob)
+    d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_n = c.dev_alloc(B * 4)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    fb.run_dev(d_ev, off, d_img, d_kp, None, d_n, None, None, raw=True)
+    c.sync()
+    imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
+    p32, mm = fb.last_f32(B)
+    f32 = np.zeros((B, H, W), np.float32); c.download(f32, p32)
+    cnt = {k: c.debug_counter(k) for k in ("slot_calls", "slot_flags", "slot_hot_items", "slot_hot_overflow", "slot_scatter_form", "slot_chunk", "slot_rank_ok")}
+    for p_ in (d_ev, d_img, d_kp, d_n):
+        c.dev_free(p_)
+    c.close()
+    return imgs, f32, mm, cnt
+
+
+def _check_raw_batch(oracle, raws, W, H, mx, my, got, what, check=True, sigma=1.0):
+    imgs, f32, mm, _ = got
+    for b, raw in enumerate(raws):
+        ev = oracle.undistort_events(raw, mx, my, W, H, check, 1.0)
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, False, True, fast=True)
+        assert np.array_equal(of.view(np.uint32), f32[b].view(np.uint32)), (what, b, len(raw), int((of.view(np.uint32) != f32[b].view(np.uint32)).sum()))
+        assert np.array_equal(np.asarray(omm, np.float32).view(np.uint32), mm[b].view(np.uint32)), (what, b, omm, mm[b])
+        assert np.array_equal(ou, imgs[b]), (what, b)
+
+
+def _hot_slices(B, n, W, H, seed):
+    """Slices whose events pile up on a few tiles (60 % on 3x3-pixel patches around one of three centres), the rest anywhere."""
+    rng = np.random.default_rng(seed)
+    cents = [(123, 91), (60, 40), (200, 150)]
+    raws = []
+    for b in range(B):
+        m = int(n * (0.5 + 0.5 * rng.uniform())) if b % 7 else n
+        raw = synth.random_raw_events(m, W, H, seed=seed * 1000 + b)
+        hot = rng.uniform(size=m) < 0.6
+        cx, cy = cents[b % 3]
+        raw["x"][hot] = np.clip(cx + rng.integers(-1, 2, int(hot.sum())) + 8 * rng.integers(0, 2, int(hot.sum())) * (b % 2), 0, W - 1)
+        raw["y"][hot] = np.clip(cy + rng.integers(-1, 2, int(hot.sum())), 0, H - 1)
+        raws.append(raw)
+    return raws
+
+
+def test_slot_hot_bucket_overflow_many_slices(oracle, fe):
+    """The slot form at the benchmark's batch shape in small: 160 slices whose long lists compete for the register-row kernel's length
+    buckets.  (a) the buckets as shipped; (b) buckets of 8 lists (test hook "slot_hot_cap"): the lists that find their bucket full are
+    handed back to the LDS gather (ev_slots.hip, sl_plan_kernel: `the bucket is full`), counted by "slot_hot_overflow"; (c) the
+    register-row kernel off: 160 lists per tile position through the LDS gather's longest-first tickets.  Every slice of every run:
+    float image, running extremes and u8 image against the oracle, bit for bit (the `for k` loop of src/Event/EventConversion.cc:231-263)."""
+    W, H, B = 240, 180, 160
+    mx, my = _maps(W, H)
+    raws = _hot_slices(B, 6000, W, H, seed=31)
+    ref = None
+    for name, opts, expect in (
+            ("buckets as shipped", (("gather_form", 4), ("slot_hot_min", 256)), dict(hot=True, over=False)),
+            ("buckets of 8", (("gather_form", 4), ("slot_hot_min", 256), ("slot_hot_cap", 8)), dict(hot=True, over=True)),
+            ("register-row kernel off", (("gather_form", 4), ("slot_hot_min", 0)), dict(hot=False, over=False))):
+        got = _raw_batch(fe, raws, W, H, mx, my, opts)
+        cnt = got[3]
+        assert cnt["slot_calls"] == 1 and cnt["slot_flags"] == 0, (name, cnt)
+        assert (cnt["slot_hot_items"] > 0) == expect["hot"] and (cnt["slot_hot_overflow"] > 0) == expect["over"], (name, cnt)
+        if expect["over"]:
+            assert cnt["slot_hot_items"] <= 16 * 8, cnt
+        if ref is None:
+            _check_raw_batch(oracle, raws, W, H, mx, my, got, name)
+            ref = got
+        else:       # (the oracle's answer is the first run's, already compared)
+            assert np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32)) and np.array_equal(ref[0], got[0]), name
+            assert np.array_equal(ref[2].view(np.uint32), got[2].view(np.uint32)), name
+
+
+def test_slot_scatter_ballot_form_equals_rank_form(oracle, fe):
+    """The product's safety net for the rank scatter (whose order rests on the lane order of LDS atomics, checked on the device once per
+    context) is the ballot scatter sl_scatter_kernel: both forms on the same batches (test hook "slot_rank"; the environment's
+    EORB_SLOT_RANK=0 selects the same branch), against the oracle -- two 300 000-event slices (4 096-event chunks for the rank form,
+    2 048 for the ballot form), a ragged batch with empty slices (256- / 1 024-event chunks) and the hot-tile slices."""
+    W, H = 240, 180
+    mx, my = _maps(W, H)
+    rng = np.random.default_rng(77)
+    batches = {
+        "2 x 300k": [synth.shapes_events(300000, W, H, seed=810 + b, motion=0.4, undistort=True, return_raw=True)[1] for b in range(2)],
+        "ragged": [synth.random_raw_events(max(int(sz), 1), W, H, seed=820 + b)[:int(sz)] for b, sz in enumerate([40000, 0, 25000, 7, 65536, 0, 1])],
+        "hot tiles": _hot_slices(12, 20000, W, H, seed=32),
+    }
+    for name, raws in batches.items():
+        for form in (1, 0):
+            got = _raw_batch(fe, raws, W, H, mx, my, (("gather_form", 4), ("slot_rank", form)))
+            cnt = got[3]
+            assert cnt["slot_calls"] == 1 and cnt["slot_flags"] == 0 and cnt["slot_rank_ok"] == 1, (name, form, cnt)
+            assert cnt["slot_scatter_form"] == form, (name, form, cnt)
+            if name == "2 x 300k":
+                assert cnt["slot_chunk"] == (4096 if form else 2048), cnt
+            _check_raw_batch(oracle, raws, W, H, mx, my, got, (name, form))
+
+
+def test_raw_dense_batch_on_vga_class_sensors(oracle, fe):
+    """Dense raw batches on the 640x480 and 752x480 sensors of the reference's Examples/Event/*.yaml (4 800 / 5 640 tiles): the slot
+    form runs with the rank scatter's larger LDS footprint; where that scatter is not available (ballot form: its per-wave count rows
+    alone exceed 64 KB) the call falls back to the batch pipeline instead of failing.  Both against the oracle."""
+    rng = np.random.default_rng(5)
+    for (W, H) in ((640, 480), (752, 480)):
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+        mx = (xx + 3.0 * np.sin(yy / 41.0) - 1.5).astype(np.float32); my = (yy + 2.5 * np.cos(xx / 57.0) + 0.75).astype(np.float32)
+        raws = []
+        for b in range(2):
+            n = 250000 - 70000 * b
+            raw = synth.random_raw_events(n, W, H, seed=840 + b)
+            hot = rng.uniform(size=n) < 0.3                       # a blob: long lists on a few tiles
+            raw["x"][hot] = np.clip(rng.normal(W * 0.7, 6.0, int(hot.sum())), 0, W - 1); raw["y"][hot] = np.clip(rng.normal(H * 0.4, 6.0, int(hot.sum())), 0, H - 1)
+            raws.append(raw)
+        for form, slot_rank, slot_calls in ((0, 1, 1), (4, 1, 1), (0, 0, 0), (4, 0, 0)):
+            got = _raw_batch(fe, raws, W, H, mx, my, (("gather_form", form), ("slot_rank", slot_rank)))
+            assert got[3]["slot_calls"] == slot_calls and got[3]["slot_flags"] == 0, (W, H, form, slot_rank, got[3])
+            _check_raw_batch(oracle, raws, W, H, mx, my, got, (W, H, form, slot_rank))
+
+
 def test_packed_wire_records_equal_raw_records(oracle, fe):
     """eorb_raw_event4 (x | p << 15 | y << 16, a quarter of the bytes on the host -> HBM link) through the batch entry point: the
     images, keypoints and descriptors of the 16-byte records, for a dense batch (slot lists read the 4-byte records directly), a
