@@ -19,6 +19,7 @@ EXPORTS = [
     "eorb_hamming_bf_knn2", "eorb_search_by_bow", "eorb_search_by_bow_kf", "eorb_distinctive_descriptors", "eorb_hamming_window_match", "eorb_calc_optical_flow_pyr_lk", "eorb_bow_set_vocabulary", "eorb_bow_transform", "eorb_search_for_triangulation", "eorb_kf_radius_match", "eorb_sort_by_response", "eorb_resolve_num_mixed",
     "eorb_orb_tracked_descriptors", "eorb_orb_assign_level_by_best_desc",
     "eorb_fe_configure", "eorb_fe_run_batch_dev", "eorb_fe_last_f32_dev",
+    "eorb_ev_slice_extract", "eorb_ev_slice_track", "eorb_ev_slice_image", "eorb_ev_mc_contest",
     "eorb_selfcheck_division", "eorb_selfcheck_math",
     "eorb_pack_events", "eorb_dev_alloc", "eorb_dev_free", "eorb_dev_upload", "eorb_dev_download",
 ]
@@ -48,6 +49,25 @@ def camera(cam):
             c.k[i] = float(cam[4 + i])
         c.precision = float(cam[8]) if len(cam) > 8 else 1e-6
     return c
+
+
+class KltParams(C.Structure):
+    _fields_ = [("win", C.c_int), ("maxLevel", C.c_int), ("maxCount", C.c_int), ("epsilon", C.c_double), ("minEigThreshold", C.c_float)]
+
+
+class Se3Motion(C.Structure):
+    _fields_ = [("angle", C.c_double), ("axis", C.c_double * 3), ("t", C.c_double * 3), ("medDepth", C.c_float)]
+
+
+def se3_motion(m):
+    """dict(angle, axis, t, medDepth) -> eorb_se3_motion (None -> None)"""
+    if m is None:
+        return None
+    o = Se3Motion()
+    o.angle = float(m["angle"]); o.medDepth = float(m["medDepth"])
+    for i in range(3):
+        o.axis[i] = float(m["axis"][i]); o.t[i] = float(m["t"][i])
+    return o
 
 
 class GridBounds(C.Structure):
@@ -170,6 +190,14 @@ def lib():
     L.eorb_fe_run_batch_dev.restype = ci
     L.eorb_fe_run_batch_dev.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp]
     L.eorb_fe_last_f32_dev.restype = ci; L.eorb_fe_last_f32_dev.argtypes = [vp, C.POINTER(vp), vp, ci]
+    L.eorb_ev_slice_extract.restype = ci
+    L.eorb_ev_slice_extract.argtypes = [vp, vp, vp, C.c_size_t, cf, ci, ci, ci, vp, vp, vp, ci, pi, pi, vp]
+    L.eorb_ev_slice_track.restype = ci
+    L.eorb_ev_slice_track.argtypes = [vp, vp, vp, C.c_size_t, cf, C.POINTER(KltParams), vp, vp, vp, ci, vp]
+    L.eorb_ev_slice_image.restype = ci; L.eorb_ev_slice_image.argtypes = [vp, vp]
+    L.eorb_ev_mc_contest.restype = ci
+    L.eorb_ev_mc_contest.argtypes = [vp, vp, C.c_size_t, C.POINTER(Camera), C.POINTER(Se3Motion), C.POINTER(Se3Motion), vp, ci, ci, ci, cf,
+                                     vp, pi, vp, vp, ci, ci, vp, ci, pi]
     L.eorb_selfcheck_division.restype = ci; L.eorb_selfcheck_division.argtypes = [vp, cf, cf, cf, C.POINTER(C.c_uint64)]
     L.eorb_selfcheck_math.restype = ci; L.eorb_selfcheck_math.argtypes = [vp, ci, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.eorb_pack_events.restype = None; L.eorb_pack_events.argtypes = [vp, C.c_size_t, vp]

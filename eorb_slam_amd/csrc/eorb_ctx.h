@@ -117,8 +117,13 @@ struct eorb_ctx {
     eorb::DevBuf win_ws;                 // candidate lists of the two-phase window matchers
     eorb::DevBuf arena;                  // host-buffer entry points: all inputs / outputs of one call, one H2D and one D2H copy
     void* dl_pinned = nullptr; size_t dl_cap = 0;      // pinned landing buffer of the D2H copy (the call synchronises before reading it)
-    // pyramidal LK workspaces
+    // pyramidal LK workspaces; klt_ref_key: the reference frame whose pyramid and derivatives the buffers hold (0 = none)
     eorb::DevBuf klt_pyr, klt_der, klt_scratch;
+    unsigned long long klt_ref_key = 0, klt_ref_geo = 0, klt_ref_serial = 0;
+    // L1 chain (eorb_ev_slice_extract / eorb_ev_slice_track): the tracker's reference image and points stay on the device
+    eorb::DevBuf l1_ref_img, l1_ref_pts;
+    int l1_nref = -1, l1_W = 0, l1_H = 0;
+    size_t l1_img_off = 0; unsigned long long arena_gen = 0, l1_img_gen = 0;      // the last slice's u8 image inside the arena (eorb_ev_slice_image)
     // DBoW2 vocabulary (device copy) for eorb_bow_transform
     eorb::DevBuf voc;
     int voc_nnodes = 0, voc_L = 0; size_t voc_off[5] = {0, 0, 0, 0, 0};
@@ -168,6 +173,8 @@ struct ProfScope {
 int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
                       uint32_t* d_minmax_enc);
+int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* beg, const int64_t* end, int B, int W, int H,
+                         float sigma, int pol, float* d_f32, uint8_t* d_u8, int normalized, uint32_t* d_minmax_enc);
 int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, int H, double tsFactor, eorb_event* d_out, uint32_t* d_blk);
 int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* d_lineend, eorb_raw_event* d_ev, uint8_t* d_status,
                       eorb_raw_event* d_out, uint32_t* d_blk, size_t max_lines, uint32_t h_res[3]);
@@ -181,7 +188,8 @@ int ev_slots_trace_read(eorb_ctx* c, unsigned long long* out, long long max_reco
 // klt.hip
 int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int W, int H, int stride, const float* d_prev_pts,
                   float* d_next_pts, int n, int win, int maxLevel, int maxCount, double epsilon, int flags, float minEig,
-                  uint8_t* d_status, float* d_err);
+                  uint8_t* d_status, float* d_err, unsigned long long ref_key = 0);
+// ref_key != 0: d_prev is the reference frame `ref_key` -- its pyramid and derivatives are built once and reused while the key stays
 // orb_extract.hip
 int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
                     int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono,

@@ -20,6 +20,10 @@ int ev_warp_se2_dev(eorb_ctx* c, const eorb_event16* d_in, eorb_event16* d_out, 
 int ev_focus_dev(eorb_ctx* c, const float* d_img, int nimg, int W, int H, float* d_out);
 int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm, uint8_t* d_out);
 int ev_mathhash(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, unsigned long long* out);
+int ev_cvnormalize_n_dev(eorb_ctx* c, const float* d_imgs, int nimg, int npix, uint32_t* d_mm, uint8_t* d_outs);
+int ev_contest_select_dev(eorb_ctx* c, const float* d_focus_img, const int img_of[4], int half_img, const uint8_t* d_u8s, int npix,
+                          float* d_focus_out, int* d_winner, uint8_t* d_out);
+int ev_kp_points_dev(eorb_ctx* c, const eorb_keypoint* d_kps, const int32_t* d_n, int cap, float* d_pts);
 int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H);
 int orb_err_flag(eorb_ctx* c, int B, int* flag);
 int orb_err_flag_to(eorb_ctx* c, int B, int32_t* d_dst);
@@ -165,6 +169,7 @@ struct Arena {
     {
         int rc = ensure(c, c->arena, total);
         if (rc) return rc;
+        c->arena_gen++;                              // (whatever an earlier call left in the arena is gone)
         if (!in_end) return EORB_OK;
         char* hp = (char*)pinned(c, in_end);
         if (!hp) return set_err(c, EORB_E_HIP, "pinned alloc failed");
@@ -239,7 +244,7 @@ void eorb_destroy(eorb_ctx* c)
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
-                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena};
+                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena, &c->l1_ref_img, &c->l1_ref_pts};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -667,6 +672,237 @@ int eorb_normalize_minmax_u8(eorb_ctx* c, const float* img, int W, int H, uint8_
     if ((rc = ev_cvnormalize_dev(c, (const float*)c->img_f32.p, (int)npix, (uint32_t*)c->minmax.p, (uint8_t*)c->img_u8.p))) return rc;
     EORB_HIP(c, hipMemcpyAsync(out, c->img_u8.p, npix, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+// ---- the L1 image builder's per-chunk path, one call per chunk (src/Event/EvImBuilder.cpp:1300-1515) ----------------------------
+// events of a chunk -> arena; float EventData are packed to the 16-byte record on the host, raw sensor events go as they are
+static int slice_events_in(eorb_ctx* c, Arena& A, const eorb_event* ev, const eorb_raw_event* raw, size_t n, std::vector<eorb_event16>& packed,
+                           size_t* o_ev, int* is_raw, const char* who)
+{
+    if (n && !ev && !raw) return set_err(c, EORB_E_ARG, "%s: no events", who);
+    if (ev && raw) return set_err(c, EORB_E_ARG, "%s: float events OR raw sensor events", who);
+    *is_raw = raw != nullptr;
+    if (raw) {
+        if (!c->lut_w) return set_err(c, EORB_E_NOTCONF, "%s: raw events need eorb_set_undistort_maps first", who);
+        for (size_t i = 0; i < n; i++)
+            if ((int)raw[i].x >= c->lut_w || (int)raw[i].y >= c->lut_h)       // the reference asserts (MyCalibrator.cpp:176)
+                return set_err(c, EORB_E_ARG, "%s: event %zu at (%u,%u) lies outside the %dx%d maps", who, i, raw[i].x, raw[i].y, c->lut_w, c->lut_h);
+        *o_ev = A.in(raw, sizeof(eorb_raw_event) * n);
+    } else {
+        packed.resize(n);
+        if (n) eorb_pack_events(ev, n, packed.data());
+        *o_ev = A.in(packed.data(), sizeof(eorb_event16) * n);
+    }
+    return EORB_OK;
+}
+
+int eorb_ev_slice_extract(eorb_ctx* c, const eorb_event* ev, const eorb_raw_event* raw, size_t n, float sigma, int lap0, int lap1,
+                          int want_desc, eorb_keypoint* kps, uint8_t* desc, uint8_t* oob, int cap, int* n_out, int* mono_index,
+                          uint8_t* out_u8)
+{
+    if (!c) return EORB_E_ARG;
+    if (n_out) *n_out = 0;
+    OrbState& o = c->orb;
+    if (!o.configured) return set_err(c, EORB_E_NOTCONF, "ev_slice_extract: eorb_orb_configure not called");
+    if (!(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev_slice_extract: sigma must be > 0");
+    hipSetDevice(c->device);
+    const int W = o.W, H = o.H;
+    const size_t npix = (size_t)W * H, mo = (size_t)o.max_out;
+    int rc, is_raw = 0;
+    Arena A(c);
+    std::vector<eorb_event16> packed;
+    size_t o_ev = 0;
+    if ((rc = slice_events_in(c, A, ev, raw, n, packed, &o_ev, &is_raw, "ev_slice_extract"))) return rc;
+    // device-only: extremes, float image; outputs, contiguous: u8 image | {n, mono, flag, pad} | keypoints | descriptors | oob
+    const size_t o_mm = A.reserve(64), o_f32 = A.reserve(sizeof(float) * npix);
+    const size_t o_u8 = A.reserve(npix), o_n = A.reserve(16), o_kp = A.reserve(sizeof(eorb_keypoint) * mo), o_desc = A.reserve(32 * mo), o_oob = A.reserve(mo);
+    if ((rc = A.upload())) return rc;
+    int64_t offs[2] = {0, (int64_t)n};
+    uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
+    int32_t* dn = A.dev<int32_t>(o_n);
+    // EvImConverter::ev2im_gauss(l1Evs, W, H, sigma) :1345 (pol = false, normalized = true)
+    if ((rc = ev_accumulate_dev(c, A.dev<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 1, A.dev<uint32_t>(o_mm)))) return rc;
+    // makeFrame :1348 -> EvFrame ctor -> ORBextractor::operator() (EventFrame.cpp:220)
+    if ((rc = orb_extract_dev(c, d_u8, W, npix, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp), A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob),
+                              dn, dn + 1, dn + 2))) return rc;
+    // ELK_Tracker::setRefImage(image, keypoints) (:1363 init -> KLT_Tracker.cpp:22-46): the image and its points stay on the device
+    if ((rc = ensure(c, c->l1_ref_img, npix)) || (rc = ensure(c, c->l1_ref_pts, sizeof(float) * 2 * mo))) return rc;
+    EORB_HIP(c, hipMemcpyAsync(c->l1_ref_img.p, d_u8, npix, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = ev_kp_points_dev(c, A.dev<eorb_keypoint>(o_kp), dn, (int)mo, (float*)c->l1_ref_pts.p))) return rc;
+    c->l1_nref = -1; c->l1_W = W; c->l1_H = H; c->klt_ref_serial++;
+    c->l1_img_off = o_u8; c->l1_img_gen = c->arena_gen;
+    const size_t ncopy = std::min<size_t>(mo, (size_t)std::max(cap, 0));
+    const size_t first = out_u8 ? o_u8 : o_n;
+    const size_t end = !ncopy ? o_n + 16 : (oob ? o_oob + ncopy : ((want_desc && desc) ? o_desc + 32 * ncopy : (kps ? o_kp + sizeof(eorb_keypoint) * ncopy : o_n + 16)));
+    const char* h;
+    if ((rc = A.download(first, end - first, &h))) return rc;
+    const int32_t* hn = (const int32_t*)(h + o_n);
+    if (hn[2]) return set_err(c, EORB_E_CAPACITY, "ev_slice_extract: internal capacity exceeded (flag %d)", hn[2]);
+    c->l1_nref = hn[0];
+    if (out_u8) memcpy(out_u8, h + o_u8, npix);
+    if (hn[0] > cap) return set_err(c, EORB_E_CAPACITY, "ev_slice_extract: %d keypoints > caller capacity %d", hn[0], cap);
+    if (hn[0] > 0) {
+        if (kps) memcpy(kps, h + o_kp, sizeof(eorb_keypoint) * (size_t)hn[0]);
+        if (want_desc && desc) memcpy(desc, h + o_desc, 32 * (size_t)hn[0]);
+        if (oob) memcpy(oob, h + o_oob, (size_t)hn[0]);
+    }
+    if (n_out) *n_out = hn[0];
+    if (mono_index) *mono_index = hn[1];
+    return EORB_OK;
+}
+
+int eorb_ev_slice_track(eorb_ctx* c, const eorb_event* ev, const eorb_raw_event* raw, size_t n, float sigma, const eorb_klt_params* klt,
+                        float* pts, uint8_t* status, float* err, int nref, uint8_t* out_u8)
+{
+    if (!c) return EORB_E_ARG;
+    if (!klt || !(sigma > 0.f) || nref < 0 || (nref && (!pts || !status || !err))) return set_err(c, EORB_E_ARG, "ev_slice_track: bad arguments");
+    if (klt->win < 3 || klt->win > 63 || klt->maxLevel < 0) return set_err(c, EORB_E_ARG, "ev_slice_track: bad LK parameters");
+    if (c->l1_nref < 0) return set_err(c, EORB_E_NOTCONF, "ev_slice_track: no reference frame (eorb_ev_slice_extract sets it)");
+    if (nref != c->l1_nref) return set_err(c, EORB_E_ARG, "ev_slice_track: %d points, the reference frame has %d", nref, c->l1_nref);
+    hipSetDevice(c->device);
+    const int W = c->l1_W, H = c->l1_H;
+    const size_t npix = (size_t)W * H;
+    int rc, is_raw = 0;
+    Arena A(c);
+    std::vector<eorb_event16> packed;
+    size_t o_ev = 0;
+    if ((rc = slice_events_in(c, A, ev, raw, n, packed, &o_ev, &is_raw, "ev_slice_track"))) return rc;
+    // in / out: the points (initial flow in, tracked points out); outputs behind them: status | err | u8 image; then device-only
+    const size_t o_pts = A.in(pts, sizeof(float) * 2 * (size_t)nref);
+    const size_t o_st = A.reserve((size_t)nref + 16), o_err = A.reserve(sizeof(float) * (size_t)nref), o_u8 = A.reserve(npix);
+    const size_t o_mm = A.reserve(64), o_f32 = A.reserve(sizeof(float) * npix);
+    if ((rc = A.upload())) return rc;
+    int64_t offs[2] = {0, (int64_t)n};
+    uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
+    if ((rc = ev_accumulate_dev(c, A.dev<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 1, A.dev<uint32_t>(o_mm)))) return rc;
+    c->l1_img_off = o_u8; c->l1_img_gen = c->arena_gen;
+    // ELK_Tracker::trackCurrImage (KLT_Tracker.cpp:49-74): calcOpticalFlowPyrLK(mRefFrame, currImage, mRefPoints, kpts, ..., OPTFLOW_USE_INITIAL_FLOW)
+    if (nref && (rc = klt_track_dev(c, (const uint8_t*)c->l1_ref_img.p, d_u8, W, H, W, (const float*)c->l1_ref_pts.p, A.dev<float>(o_pts), nref, klt->win,
+                                    klt->maxLevel, klt->maxCount, klt->epsilon, 4 /* OPTFLOW_USE_INITIAL_FLOW */, klt->minEigThreshold,
+                                    A.dev<uint8_t>(o_st), A.dev<float>(o_err), c->klt_ref_serial))) return rc;
+    const size_t end = out_u8 ? o_u8 + npix : o_err + sizeof(float) * (size_t)nref;
+    const char* h;
+    if ((rc = A.download(o_pts, end - o_pts, &h))) return rc;
+    if (nref) {
+        memcpy(pts, h + o_pts, sizeof(float) * 2 * (size_t)nref);
+        memcpy(status, h + o_st, (size_t)nref);
+        memcpy(err, h + o_err, sizeof(float) * (size_t)nref);
+    }
+    if (out_u8) memcpy(out_u8, h + o_u8, npix);
+    return EORB_OK;
+}
+
+int eorb_ev_slice_image(eorb_ctx* c, uint8_t* out_u8)
+{
+    if (!c || !out_u8) return EORB_E_ARG;
+    if (c->l1_img_gen != c->arena_gen || !c->arena.p || !c->l1_W) return set_err(c, EORB_E_NOTCONF, "ev_slice_image: the image of the last slice call is gone");
+    hipSetDevice(c->device);
+    EORB_HIP(c, hipMemcpyAsync(out_u8, (const char*)c->arena.p + c->l1_img_off, (size_t)c->l1_W * c->l1_H, hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    return EORB_OK;
+}
+
+int eorb_ev_mc_contest(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_camera* cam, const eorb_se3_motion* dp, const eorb_se3_motion* ba,
+                       const float* se2_params, int nparams, int W, int H, float sigma, float focus[5], int* winner, uint8_t* out_u8,
+                       eorb_ctx* l2, int lap0, int lap1, eorb_keypoint* kps, int cap, int* n_out)
+{
+    if (!c) return EORB_E_ARG;
+    if (winner) *winner = -1;
+    if (n_out) *n_out = 0;
+    if (W <= 0 || H <= 0 || (n && !ev) || !(sigma > 0.f) || !focus || !winner) return set_err(c, EORB_E_ARG, "ev_mc_contest: bad arguments");
+    if ((dp || ba || se2_params) && !cam) return set_err(c, EORB_E_ARG, "ev_mc_contest: the motion-compensated methods need the camera");
+    if (cam && cam->model != 0 && cam->model != 1) return set_err(c, EORB_E_ARG, "ev_mc_contest: camera model %d unknown", cam->model);
+    if (se2_params && nparams < 3) return set_err(c, EORB_E_ARG, "ev_mc_contest: need at least 3 SE2 parameters");
+    for (int k = 0; k < 5; k++) focus[k] = -1.f;
+    if (n == 0) return EORB_OK;                          // "Empty ev buffer, abort" (:1149-1152)
+    if (n > 0x3fffffff) return set_err(c, EORB_E_CAPACITY, "ev_mc_contest: too many events");
+    if (l2) {
+        if (l2->device != c->device) return set_err(c, EORB_E_ARG, "ev_mc_contest: the L2 context sits on another device");
+        if (!l2->orb.configured || l2->orb.W != W || l2->orb.H != H) return set_err(c, EORB_E_NOTCONF, "ev_mc_contest: the L2 context's extractor is not configured for %dx%d", W, H);
+    }
+    hipSetDevice(c->device);
+    const size_t npix = (size_t)W * H;
+    int rc;
+    // methods in the reference's insertion order (:1207-1211): 0 "DP", 1 "BA", 2 "EH", 3 "Opt"; image 4 = the event histogram of the
+    // later half of the window (:1214-1216), built alongside so that the call waits once
+    const eorb_se3_motion* se3[2] = {dp, ba};
+    int img_of[4] = {-1, -1, -1, -1}, nimg = 0;
+    for (int m = 0; m < 4; m++) if (m == 2 || (m < 2 && se3[m]) || (m == 3 && se2_params)) img_of[m] = nimg++;
+    const int half_img = nimg++;
+    const size_t nh = n / 2;                             // prefSize = evs.size() / 2: the window's last nh events (:1062-1066); 0 -> the whole window
+    std::vector<eorb_event16> packed(n);
+    eorb_pack_events(ev, n, packed.data());
+    Arena A(c);
+    const size_t o_ev = A.in(packed.data(), sizeof(eorb_event16) * n);
+    const size_t o_warp = A.reserve(sizeof(eorb_event16) * n * 3);
+    const size_t o_mm = A.reserve(256), o_f32 = A.reserve(sizeof(float) * npix * (size_t)nimg), o_u8s = A.reserve(npix * (size_t)nimg);
+    const size_t o_fimg = A.reserve(64);
+    const size_t mo = l2 ? (size_t)l2->orb.max_out : 0;
+    // outputs, contiguous: focus[5] + winner | the winner's u8 image | {n, mono, flag} | keypoints
+    const size_t o_res = A.reserve(64), o_win = A.reserve(npix), o_n = A.reserve(16), o_kp = A.reserve(sizeof(eorb_keypoint) * std::max<size_t>(mo, 1));
+    if ((rc = A.upload())) return rc;
+    const eorb_event16* d_ev = A.dev<eorb_event16>(o_ev);
+    eorb_event16* d_warp = A.dev<eorb_event16>(o_warp);
+    const int64_t wbase = (int64_t)((o_warp - o_ev) / sizeof(eorb_event16));      // (arena offsets are multiples of 256)
+    int64_t beg[8], end[8];
+    int nw = 0;
+    for (int m = 0; m < 4; m++) {
+        if (img_of[m] < 0) continue;
+        const int j = img_of[m];
+        if (m == 2) { beg[j] = 0; end[j] = (int64_t)n; continue; }                // getEvHist :1060-1079
+        eorb_event16* dst = d_warp + (size_t)nw * n;
+        if (m < 2) rc = ev_warp_se3_dev(c, d_ev, dst, (int)n, cam, se3[m]->angle, se3[m]->axis, se3[m]->t, se3[m]->medDepth, nullptr);       // getDPoseMCI :969 / getBAMCI :1043
+        else rc = ev_warp_se2_dev(c, d_ev, dst, (int)n, cam, se2_params, nparams);                                                           // getAff2DMCI :1133
+        if (rc) return rc;
+        beg[j] = wbase + (int64_t)nw * (int64_t)n; end[j] = beg[j] + (int64_t)n;
+        nw++;
+    }
+    beg[half_img] = nh ? (int64_t)(n - nh) : 0; end[half_img] = (int64_t)n;
+    float* d_f32 = A.dev<float>(o_f32);
+    uint32_t* d_mm = A.dev<uint32_t>(o_mm);
+    if (n <= 16384) {
+        // every reconstruction of the window in ONE launch of the binning-free kernel (float events, normalized = false)
+        if ((rc = ev_direct_slices_dev(c, d_ev, 0, beg, end, nimg, W, H, sigma, 0, d_f32, nullptr, 0, d_mm))) return rc;
+    } else {
+        const int64_t dd_saved = c->dbg_dd_min; c->dbg_dd_min = 0;     // (warped events: no two share a position)
+        for (int j = 0; j < nimg && !rc; j++) {
+            int64_t offs[2] = {0, end[j] - beg[j]};
+            rc = ev_accumulate_dev(c, d_ev + beg[j], 0, offs, 1, W, H, sigma, 0, 0, d_f32 + (size_t)j * npix, nullptr, 0, d_mm + 2 * j);
+        }
+        c->dbg_dd_min = dd_saved;
+        if (rc) return rc;
+    }
+    // measureImageFocus of every image, then cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1) of every image (:972-976, :1052-1055, :1073-1076, :1137-1140)
+    if ((rc = ev_focus_dev(c, d_f32, nimg, W, H, A.dev<float>(o_fimg)))) return rc;
+    if ((rc = ev_cvnormalize_n_dev(c, d_f32, nimg, (int)npix, d_mm + 32, A.dev<uint8_t>(o_u8s)))) return rc;
+    float* d_res = A.dev<float>(o_res);
+    if ((rc = ev_contest_select_dev(c, A.dev<float>(o_fimg), img_of, half_img, A.dev<uint8_t>(o_u8s), (int)npix, d_res, (int*)(d_res + 8), A.dev<uint8_t>(o_win)))) return rc;
+    int32_t* dn = A.dev<int32_t>(o_n);
+    if (l2) {
+        // isMcImageGood (:260-267): the L2 tracker's makeFrame on the winner = its detect-only extraction.  The L2 context's kernels run on
+        // THIS context's stream for the call (both contexts belong to the calling thread), so the call still waits once.
+        if (l2 != c) EORB_HIP(c, hipStreamSynchronize(l2->stream));
+        hipStream_t saved = l2->stream; l2->stream = c->stream;
+        rc = orb_extract_dev(l2, A.dev<uint8_t>(o_win), W, npix, 1, lap0, lap1, 0, A.dev<eorb_keypoint>(o_kp), nullptr, nullptr, dn, dn + 1, dn + 2);
+        l2->stream = saved;
+        if (rc) { if (l2 != c) c->err = l2->err; return rc; }
+    }
+    const size_t ncopy = l2 ? std::min<size_t>(mo, (size_t)std::max(cap, 0)) : 0;
+    const size_t end_off = l2 ? (ncopy && kps ? o_kp + sizeof(eorb_keypoint) * ncopy : o_n + 16) : (out_u8 ? o_win + npix : o_res + 64);
+    const char* h;
+    if ((rc = A.download(o_res, end_off - o_res, &h))) return rc;
+    memcpy(focus, h + o_res, sizeof(float) * 5);
+    int32_t w; memcpy(&w, h + o_res + 32, 4);
+    *winner = w;
+    if (out_u8) memcpy(out_u8, h + o_win, npix);
+    if (l2) {
+        const int32_t* hn = (const int32_t*)(h + o_n);
+        if (hn[2]) return set_err(c, EORB_E_CAPACITY, "ev_mc_contest: the L2 extraction exceeded an internal capacity (flag %d)", hn[2]);
+        if (hn[0] > cap) return set_err(c, EORB_E_CAPACITY, "ev_mc_contest: %d keypoints > caller capacity %d", hn[0], cap);
+        if (hn[0] > 0 && kps) memcpy(kps, h + o_kp, sizeof(eorb_keypoint) * (size_t)hn[0]);
+        if (n_out) *n_out = hn[0];
+    }
     return EORB_OK;
 }
 

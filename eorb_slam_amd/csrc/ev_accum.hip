@@ -1122,7 +1122,8 @@ __global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(con
 // and a descriptor upload there; instead every tile's wave reads ALL events of its slice (690 waves x 2 000 events: nothing),
 // keeps those whose stamp reaches the tile -- in event order, ballot-compacted into a small LDS list -- and adds them as K2s does.
 // Same entries in the same order as the binned lists, hence the same image.
-struct DirectSlices { int64_t off[5]; };            // event offsets of up to 4 slices
+constexpr int kDirectSlices = 8;
+struct DirectSlices { int64_t beg[kDirectSlices], end[kDirectSlices]; };      // the slices' event ranges (they may overlap: the contest's later-half histogram)
 constexpr int kDirectList = 1024;                   // entries of the LDS list (flushed when full)
 // FLT: float events (eorb_event16: the reference's own seam, ev2im_gauss(vector<EventData>)) -- the value of a tap is evaluated as K2
 // evaluates it (exp_XY2f :59-65: the general division form; K2's reciprocal form is proven equal by tests/test_gpu_math.py) instead
@@ -1141,8 +1142,8 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_eve
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
     const bool inimg = px < P.W && py < P.H;
     const int SW = 2 * P.h + 1, SWP = P.stamp_colstride;
-    const eorb_raw_event* e = ev + S.off[slice];
-    const int n = (int)(S.off[slice + 1] - S.off[slice]);
+    const eorb_raw_event* e = ev + S.beg[slice];
+    const int n = (int)(S.end[slice] - S.beg[slice]);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
     bool touched = false, any = false;
@@ -1569,6 +1570,86 @@ int ev_cvnormalize_dev(eorb_ctx* c, const float* d_img, int npix, uint32_t* d_mm
     return EORB_OK;
 }
 
+// the same for nimg images back to back (the reconstructions of one motion-compensation dispatch): blockIdx.y = image, mm[2 * image]
+__global__ void ev_mm_reset_n_kernel(uint32_t* mm, int nimg) { const int i = threadIdx.x; if (i < nimg) { mm[2 * i] = 0xffffffffu; mm[2 * i + 1] = 0u; } }
+__global__ void ev_minmax_final_n_kernel(const float* __restrict__ imgs, int npix, uint32_t* __restrict__ mm)
+{
+    const float* img = imgs + (size_t)blockIdx.y * npix;
+    float lo = img[0], hi = img[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) { lo = fminf(lo, img[i]); hi = fmaxf(hi, img[i]); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[2 * blockIdx.y], enc_f32(lo)); atomicMax(&mm[2 * blockIdx.y + 1], enc_f32(hi)); }
+}
+__global__ void ev_cvnormalize_n_kernel(const float* __restrict__ imgs, int npix, const uint32_t* __restrict__ mm, uint8_t* __restrict__ outs)
+{
+    const float* img = imgs + (size_t)blockIdx.y * npix; uint8_t* out = outs + (size_t)blockIdx.y * npix;
+    const double smin = (double)dec_f32(mm[2 * blockIdx.y]), smax = (double)dec_f32(mm[2 * blockIdx.y + 1]);
+    const double scale = 255.0 * (smax - smin > 2.2204460492503131e-16 ? 1. / (smax - smin) : 0);
+    const double shift = 0.0 - smin * scale;
+    const float fs = (float)scale, fh = (float)shift;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const float m = img[i] * fs;
+        const float v = m + fh;
+        out[i] = (uint8_t)min(max(__float2int_rn(v), 0), 255);
+    }
+}
+int ev_cvnormalize_n_dev(eorb_ctx* c, const float* d_imgs, int nimg, int npix, uint32_t* d_mm, uint8_t* d_outs)
+{
+    ProfScope ps(c, "ev_cvnormalize");
+    ev_mm_reset_n_kernel<<<1, 64, 0, c->stream>>>(d_mm, nimg);
+    ev_minmax_final_n_kernel<<<dim3(32, nimg), 256, 0, c->stream>>>(d_imgs, npix, d_mm);
+    ev_cvnormalize_n_kernel<<<dim3(32, nimg), 256, 0, c->stream>>>(d_imgs, npix, d_mm, d_outs);
+    EORB_LAUNCH_CHECK(c, "cv::normalize kernels");
+    return EORB_OK;
+}
+
+// generateMCImage's decision (EvImBuilder.cpp:1205-1216): the reconstruction with the largest focus wins, the first of equals in
+// insertion order (MciInfo = std::multimap<float, ..., std::greater<float>>, include/Utils/Visualization.h:29); a winning event
+// histogram is replaced by the histogram of the later half of the window (image `half_img`).  focus[m] = measureImageFocus of
+// method m's image (image index img_of[m]) or -1 when the method is absent.  Writes the winner's method to *winner and its u8 image to out.
+struct ContestSel { int img_of[4]; int eh_method, half_img; };
+__global__ void ev_contest_select_kernel(const float* __restrict__ focus_img, ContestSel S, const uint8_t* __restrict__ u8s, int npix,
+                                         float* __restrict__ focus_out /* 5: per method, then the later-half histogram's */, int* __restrict__ winner, uint8_t* __restrict__ out)
+{
+    float best = 0.f; int w = -1;
+    for (int m = 0; m < 4; m++) {
+        if (S.img_of[m] < 0) continue;
+        const float f = focus_img[S.img_of[m]];
+        if (w < 0 || f > best) { best = f; w = m; }
+    }
+    const int src = (w == S.eh_method) ? S.half_img : S.img_of[w];
+    const uint8_t* im = u8s + (size_t)src * npix;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) out[i] = im[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int m = 0; m < 4; m++) focus_out[m] = S.img_of[m] >= 0 ? focus_img[S.img_of[m]] : -1.0f;
+        focus_out[4] = focus_img[S.half_img];
+        *winner = w;
+    }
+}
+int ev_contest_select_dev(eorb_ctx* c, const float* d_focus_img, const int img_of[4], int half_img, const uint8_t* d_u8s, int npix,
+                          float* d_focus_out, int* d_winner, uint8_t* d_out)
+{
+    ContestSel S; for (int m = 0; m < 4; m++) S.img_of[m] = img_of[m];
+    S.eh_method = 2; S.half_img = half_img;
+    ev_contest_select_kernel<<<16, 256, 0, c->stream>>>(d_focus_img, S, d_u8s, npix, d_focus_out, d_winner, d_out);
+    EORB_LAUNCH_CHECK(c, "ev_contest_select_kernel");
+    return EORB_OK;
+}
+
+// cv::KeyPoint records -> their points (the reference points of the LK tracker, ELK_Tracker::setRefImage KLT_Tracker.cpp:36-44)
+__global__ void ev_kp_points_kernel(const eorb_keypoint* __restrict__ kps, const int32_t* __restrict__ n, int cap, float* __restrict__ pts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap && i < *n) { pts[2 * i] = kps[i].x; pts[2 * i + 1] = kps[i].y; }
+}
+int ev_kp_points_dev(eorb_ctx* c, const eorb_keypoint* d_kps, const int32_t* d_n, int cap, float* d_pts)
+{
+    ev_kp_points_kernel<<<(cap + 255) / 256, 256, 0, c->stream>>>(d_kps, d_n, cap, d_pts);
+    EORB_LAUNCH_CHECK(c, "ev_kp_points_kernel");
+    return EORB_OK;
+}
+
 // ---- raw sensor events: tables derived from the undistortion maps (MyCalibrator::mUndistMapX/Y, Utils/MyCalibrator.cpp:164-180) ----
 // per sensor pixel: integer image position floor(x) (breakFloatCoords :51-57) or round (roundFloatCoord :46-49); -32768 when the
 // undistorted point fails MyCalibrator::isInImage (:31-34) and the loader would have dropped the event (EventLoader.cpp:295-296)
@@ -1960,6 +2041,50 @@ __global__ void ev_unpack4_kernel(const uint32_t* __restrict__ in, int64_t n, eo
     }
 }
 
+// K2d on its own: up to 8 slices given by their event ranges [beg, end) inside one array (the ranges may overlap), float or raw events,
+// Gaussian stamp.  ev_accumulate_dev takes this path for the live per-slice calls; the motion-compensation contest
+// (eorb_ev_mc_contest) hands it the reconstructions of one window in one launch.
+int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* beg, const int64_t* end, int B, int W, int H,
+                         float sigma, int pol, float* d_f32, uint8_t* d_u8, int normalized, uint32_t* d_minmax_enc)
+{
+    if (B < 1 || B > kDirectSlices) return set_err(c, EORB_E_ARG, "direct slices: %d slices", B);
+    const int h = (int)ceil((double)sigma * 3.0);
+    if (h > 8) return set_err(c, EORB_E_CONFIG, "ev_accumulate: sigma %.3f gives half window %d > 8", sigma, h);
+    const int R = (2 * h <= kTile) ? ((h == 0) ? 1 : 2) : 3;
+    const int TX = (W + kTile - 1) / kTile, TY = (H + kTile - 1) / kTile, NT = TX * TY;
+    int nbits = 1; while ((1 << nbits) < NT) nbits++;
+    const int dup = R * R;
+    DirectSlices S{};
+    for (int b = 0; b < B; b++) {
+        if (end[b] < beg[b]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
+        if ((end[b] - beg[b]) * dup >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)(end[b] - beg[b]));
+        S.beg[b] = beg[b]; S.end[b] = end[b];
+    }
+    int rc;
+    GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, 0, B * NT, sigma);
+    if (raw && (rc = ev_raw_tables(c, W, H, h, sigma, 0, G))) return rc;
+    BinParams P{W, H, h, TX, TY, NT, nbits, dup, 0, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
+    {
+        ProfScope ps(c, "ev_minmax_init");
+        ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
+    }
+    {
+        ProfScope ps(c, "ev_gather");
+#define LAUNCH_D(PP, FF) ev_gather_direct_kernel<PP, FF><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc)
+        if (raw) { if (pol) LAUNCH_D(true, false); else LAUNCH_D(false, false); }
+        else { if (pol) LAUNCH_D(true, true); else LAUNCH_D(false, true); }
+#undef LAUNCH_D
+        EORB_LAUNCH_CHECK(c, "ev_gather_direct_kernel");
+    }
+    if (normalized && d_u8) {
+        ProfScope ps(c, "ev_normalize");
+        dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
+        ev_normalize_kernel<<<grid, 256, 0, c->stream>>>(d_f32, d_minmax_enc, d_u8, W * H, 0);
+        EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
+    }
+    return EORB_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
@@ -2053,35 +2178,12 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         // one or a few small slices of raw events (the live per-slice call): no binning at all, K2d
         const int64_t nev0 = h_offsets[B] - h_offsets[0];
         if (!hashed && !packed4 && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
-            DirectSlices S;
-            for (int b = 0; b <= B; b++) {
-                if (b && h_offsets[b] < h_offsets[b - 1]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
-                S.off[b] = h_offsets[b];
+            int64_t beg[kDirectSlices], end[kDirectSlices];
+            for (int b = 0; b < B; b++) {
+                if (h_offsets[b + 1] < h_offsets[b]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
+                beg[b] = h_offsets[b]; end[b] = h_offsets[b + 1];
             }
-            if (nev0 * dup >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)nev0);
-            int rc;
-            GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, mode_count, B * NT, sigma);
-            if (raw && (rc = ev_raw_tables(c, W, H, h, sigma, mode_count, G))) return rc;
-            BinParams P{W, H, h, TX, TY, NT, nbits, dup, mode_count, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
-            {
-                ProfScope ps(c, "ev_minmax_init");
-                ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
-            }
-            {
-                ProfScope ps(c, "ev_gather");
-#define LAUNCH_D(PP, FF) ev_gather_direct_kernel<PP, FF><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc)
-                if (raw) { if (pol) LAUNCH_D(true, false); else LAUNCH_D(false, false); }
-                else { if (pol) LAUNCH_D(true, true); else LAUNCH_D(false, true); }
-#undef LAUNCH_D
-                EORB_LAUNCH_CHECK(c, "ev_gather_direct_kernel");
-            }
-            if (normalized && d_u8) {
-                ProfScope ps(c, "ev_normalize");
-                dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
-                ev_normalize_kernel<<<grid, 256, 0, c->stream>>>(d_f32, d_minmax_enc, d_u8, W * H, mode_count);
-                EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
-            }
-            return EORB_OK;
+            return ev_direct_slices_dev(c, d_events, raw, beg, end, B, W, H, sigma, pol, d_f32, d_u8, normalized, d_minmax_enc);
         }
     }
     // dense batches of raw events without polarity: two-byte slot lists, a tile position's rows in LDS (ev_slots.hip)

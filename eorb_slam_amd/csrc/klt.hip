@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
 // d_prev / d_next: W x H u8 images (row stride `stride`); d_prev_pts, d_next_pts: n x 2 floats; everything device resident
 int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int W, int H, int stride, const float* d_prev_pts,
                   float* d_next_pts, int n, int win, int maxLevel, int maxCount, double epsilon, int flags, float minEig,
-                  uint8_t* d_status, float* d_err)
+                  uint8_t* d_status, float* d_err, unsigned long long ref_key)
 {
     if (win > kKltMaxWin) return set_err(c, EORB_E_CAPACITY, "klt: window %d exceeds the %d-pixel LDS patch", win, kKltMaxWin);
     KltPyr P{}; P.win = win;
@@ -265,8 +265,13 @@ int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int
     if ((rc = ensure(c, c->klt_der, sizeof(int16_t) * 2 * one))) return rc;
     uint8_t* pyr = (uint8_t*)c->klt_pyr.p; int16_t* der = (int16_t*)c->klt_der.p;
     ProfScope ps(c, "klt_track");
-    EORB_HIP(c, hipMemsetAsync(der, 0, sizeof(int16_t) * 2 * one, c->stream));           // derivative padding = BORDER_CONSTANT 0
-    for (int f = 0; f < 2; f++) {
+    // the reference frame of an LK tracker does not change between its frames (ELK_Tracker::mRefFrame, KLT_Tracker.cpp:22-46): with a
+    // key, its pyramid and derivatives are built by the first call and reused by the following ones
+    const unsigned long long geo = ((unsigned long long)W << 40) | ((unsigned long long)H << 20) | ((unsigned long long)win << 8) | (unsigned long long)P.levels;
+    const bool reuse = ref_key && c->klt_ref_key == ref_key && c->klt_ref_geo == geo;
+    c->klt_ref_key = ref_key; c->klt_ref_geo = geo;
+    if (!reuse) EORB_HIP(c, hipMemsetAsync(der, 0, sizeof(int16_t) * 2 * one, c->stream));           // derivative padding = BORDER_CONSTANT 0
+    for (int f = reuse ? 1 : 0; f < 2; f++) {
         uint8_t* base = pyr + (size_t)f * one;
         const uint8_t* img = f ? d_next : d_prev;
         for (int lv = 0; lv < P.levels; lv++) {

@@ -550,6 +550,191 @@ class ELK_Tracker:
         return nMatches - int(bad.sum()), m, cnt
 
 
+class EvImBuilder:
+    """The chunk loop of EORB_SLAM::EvImBuilder::Track (src/Event/EvImBuilder.cpp:1300-1515) over the one-call seams
+    eorb_ev_slice_extract / eorb_ev_slice_track / eorb_ev_mc_contest: per chunk of l1ChunkSize events the event image and its frame
+    (INIT: detect-only ORBextractor + ELK_Tracker::setRefImage; TRACKING: ELK_Tracker::trackAndMatchCurrImage), the window-size rule
+    (resolveEvWinSize :209-232) and, on a dispatch, the four-way reconstruction contest with the L2 detection of the winner
+    (generateMCImage :1146-1247, isMcImageGood :260-267).  What stays with the caller, as in the reference: the optimisers that
+    produce the poses of the motion-compensated reconstructions (`mci_poses`), the two-view RANSAC refinement of step() (:600-668,
+    `reconstruct`), the IMU and the L2 tracker's queue."""
+    IDLE, INIT, TRACKING = 0, 1, 2
+    DEF_TH_MIN_KPTS, DEF_TH_MIN_MATCHES = 100, 50                     # include/Event/EventData.h:24-26
+
+    def __init__(self, W=240, H=180, l1ChunkSize=2000, l1NumLoop=3, l1FixedWinSz=False, continTracking=True, maxPixelDisp=3.0,
+                 l1WinOverlap=0.5, minEvGenRate=1.0, l1ImSigma=1.0, maxNumPts=400, fastTh=0, imMargin=9, klt=(23, 1, 10, 0.03),
+                 cam=None, raw_events=False, keep_images=True):
+        self.W, self.H, self.sigma = W, H, float(l1ImSigma)
+        self.mbContTracking, self.mbFixedWinSize = bool(continTracking), bool(l1FixedWinSz)
+        self.mL1EvWinSize = self.mInitL1EvWinSize = int(l1ChunkSize)
+        self.mL1NumLoop, self.mL1MaxPxDisp, self.l1WinOverlap, self.minEvGenRate = int(l1NumLoop), float(maxPixelDisp), float(l1WinOverlap), float(minEvGenRate)
+        self.mnWinOverlap = int(self.l1WinOverlap * float(self.mL1NumLoop * self.mL1EvWinSize))          # :40
+        self.cam, self.raw, self.keep_images = cam, bool(raw_events), keep_images
+        # the L1 builder's own extractor (FAST = ORB with one level, :49-54 + EvBaseTracker.cpp:150-164) and the L2 tracker's
+        # (2 x maxNumPts, src/Event/EvAsynchTracker.cpp:51,59-62), one context each as the reference has one extractor object each
+        self.ctx = Context(); self.ctx_l2 = Context()
+        self.l1 = ORBextractor(maxNumPts, 1.0, 1, fastTh, 0, imMargin, imSize=(W, H), ctx=self.ctx)
+        self.l2 = ORBextractor(2 * maxNumPts, 1.0, 1, fastTh, 0, imMargin, imSize=(W, H), ctx=self.ctx_l2)
+        self.klt = _lib.KltParams(int(klt[0]), int(klt[1]), int(klt[2]), float(klt[3]), 1e-4)
+        self.mStat = self.IDLE
+        self.reset()
+
+    def close(self):
+        self.ctx.close(); self.ctx_l2.close()
+
+    def set_undistort_maps(self, mapX, mapY, checkInImage=True):
+        EvImConverter.set_undistort_maps(mapX, mapY, checkInImage, ctx=self.ctx)
+
+    def reset(self):                                                 # :95-139
+        self.mCurrIdx = 0
+        self.mCntLowEvGenRate = 0
+        self.mvSharedL2Evs = []
+        self.mvMatchesCnt = None
+        self.nref = -1
+
+    def updateL1ChunkSize(self, newSz):                              # :188-195
+        self.mL1EvWinSize = int(newSz)
+
+    def _events(self, evs):
+        if self.raw:
+            return None, np.ascontiguousarray(evs, RAW_DTYPE)
+        return np.ascontiguousarray(evs, EVENT_DTYPE), None
+
+    def _slice_extract(self, evs):
+        c = self.ctx
+        ev, raw = self._events(evs)
+        cap = c.L.eorb_orb_max_keypoints(c.h)
+        kps = np.zeros(cap, KP_DTYPE); n = C.c_int(0); mono = C.c_int(0)
+        img = np.zeros((self.H, self.W), np.uint8) if self.keep_images else None
+        c.check(c.L.eorb_ev_slice_extract(c.h, _p(ev), _p(raw), len(evs), self.sigma, 0, 1000, 0, _p(kps), None, None, cap, C.byref(n), C.byref(mono), _p(img)))
+        return kps[:n.value].copy(), img
+
+    def _slice_track(self, evs, pts):
+        c = self.ctx
+        ev, raw = self._events(evs)
+        pts = np.ascontiguousarray(pts, np.float32).copy()
+        n = len(pts)
+        st = np.zeros(max(n, 1), np.uint8); er = np.zeros(max(n, 1), np.float32)
+        img = np.zeros((self.H, self.W), np.uint8) if self.keep_images else None
+        c.check(c.L.eorb_ev_slice_track(c.h, _p(ev), _p(raw), len(evs), self.sigma, C.byref(self.klt), _p(pts), _p(st), _p(er), n, _p(img)))
+        return pts, st[:n], er[:n], img
+
+    def generateMCImage(self, evs, poses):                           # :1146-1247 + isMcImageGood :260-267
+        c = self.ctx
+        ev = np.ascontiguousarray(evs, EVENT_DTYPE)
+        poses = poses or {}
+        dp, ba = _lib.se3_motion(poses.get("dp")), _lib.se3_motion(poses.get("ba"))
+        se2 = None if poses.get("se2") is None else np.ascontiguousarray(poses["se2"], np.float32)
+        cam = None if self.cam is None else _lib.camera(self.cam)
+        focus = np.zeros(5, np.float32); win = C.c_int(-1)
+        img = np.zeros((self.H, self.W), np.uint8)
+        cap = self.ctx_l2.L.eorb_orb_max_keypoints(self.ctx_l2.h)
+        kps = np.zeros(cap, KP_DTYPE); n = C.c_int(0)
+        c.check(c.L.eorb_ev_mc_contest(c.h, _p(ev), len(ev), C.byref(cam) if cam is not None else None, C.byref(dp) if dp is not None else None,
+                                       C.byref(ba) if ba is not None else None, _p(se2), 0 if se2 is None else len(se2), self.W, self.H, self.sigma,
+                                       _p(focus), C.byref(win), _p(img), self.ctx_l2.h, 0, 1000, _p(kps), cap, C.byref(n)))
+        return dict(focus=focus, winner=win.value, image=img, l2_kps=kps[:n.value].copy())
+
+    def Track(self, l1Evs, mci_poses=None, reconstruct=None):
+        """One pass of the loop body for the chunk `l1Evs` (float EventData, or raw sensor records when raw_events): returns what the
+        chunk produced.  mci_poses(window events) -> dict(dp=..., ba=..., se2=...) stands where resolveLastDPose / resolveLastPoseMap /
+        resolveLastAtt2Params deliver the optimisers' results; reconstruct(p0, p1, matches12) -> (ok, inlier flags) is the two-view
+        refinement of step(), skipped when None (step returns 1, :609-611)."""
+        out = dict(state=None, dispatched=False)
+        if self.mStat == self.IDLE:
+            self.mStat = self.INIT
+        if self.mStat == self.INIT:
+            self.reset()
+        if len(l1Evs) == 0:
+            return out
+        ts = l1Evs["ts"] if not self.raw else l1Evs["t"]
+        evTspan = float(ts[-1]) - float(ts[0])                        # calcEventGenRate, src/Event/EventData.cpp:14-19
+        with np.errstate(divide="ignore", invalid="ignore"):
+            evGenRate = np.float64(len(l1Evs)) / (np.float64(evTspan) * self.W * self.H)
+        rate = self.checkEvGenRate(evGenRate)
+        out["state"] = self.mStat
+        if rate != 0:
+            if rate == -1:
+                self.mStat = self.INIT
+            elif rate == 1:
+                self.mvSharedL2Evs.append(l1Evs)
+            out["skipped"] = rate
+            return out
+        sendMCF = False
+        if self.mStat == self.INIT:
+            kps, img = self._slice_extract(l1Evs)                    # :1345 + :1348 (INIT branch of makeFrame :507-523)
+            out.update(kps=kps, image=img)
+            nKpts = len(kps)                                         # init() :568-592
+            self.mvMatchesCnt = np.ones(nKpts, np.int32)
+            self.mRefKPoints = kps
+            self.mRefPoints = np.stack([kps["x"], kps["y"]], axis=1).astype(np.float32)
+            self.mLastTrackedPts = self.mRefPoints.copy()
+            if nKpts > self.DEF_TH_MIN_KPTS or (self.mbContTracking and self.mbFixedWinSize):
+                self.updateState(l1Evs)
+                self.mStat = self.TRACKING
+            else:
+                self.updateL1ChunkSize(self.mInitL1EvWinSize)
+        elif self.mStat == self.TRACKING:
+            nref = len(self.mRefPoints)
+            pts, st, err, img = self._slice_track(l1Evs, self.mLastTrackedPts)      # :1348 (makeFrame :528-548) -> trackAndMatchCurrImage
+            self.mLastTrackedPts = pts
+            ok = (st == 1) & (pts[:, 0] >= 0) & (pts[:, 0] < np.float32(self.W)) & (pts[:, 1] >= 0) & (pts[:, 1] < np.float32(self.H))    # refineTrackedPts :104-151
+            self.mvMatchesCnt = self.mvMatchesCnt + ok.astype(np.int32)
+            vMatches12 = np.where(ok, np.arange(nref), -1).astype(np.int32)
+            d = pts[ok] - self.mRefPoints[ok]
+            vPxDisp = np.sort(np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)))
+            nMatches = int(ok.sum())
+            medPxDisp = float(vPxDisp[len(vPxDisp) // 2]) if len(vPxDisp) else 0.0      # (:540-541; the reference indexes an empty vector here)
+            if reconstruct is not None and nMatches >= self.DEF_TH_MIN_MATCHES:          # step() :600-668
+                res, inl = reconstruct(self.mRefKPoints, pts, vMatches12)
+                drop = (vMatches12 >= 0) & ~np.asarray(inl, bool)
+                vMatches12[drop] = -1; self.mvMatchesCnt[drop] -= 1; nMatches -= int(drop.sum())
+            out.update(pts=pts, status=st, err=err, image=img, matches12=vMatches12, nMatches=nMatches, medPxDisp=medPxDisp)
+            if nMatches < self.DEF_TH_MIN_MATCHES and not self.mbContTracking and self.mCurrIdx < 3:       # :1389-1402
+                self.updateL1ChunkSize(self.mInitL1EvWinSize)
+                self.mStat = self.INIT
+                return out
+            self.updateState(l1Evs)
+            dispatchMCI = self.resolveEvWinSize(medPxDisp)
+            if dispatchMCI or nMatches < self.DEF_TH_MIN_MATCHES:
+                self.mStat = self.INIT
+                sendMCF = True
+        out["chunk_size"] = self.mL1EvWinSize
+        if sendMCF:                                                  # :1433-1470
+            vAccEvs = np.concatenate(self.mvSharedL2Evs)
+            if self.raw:
+                raise EorbError(_lib.EORB_E_ARG, "EvImBuilder: the reconstruction contest warps float EventData (time stamps); run the builder on float events")
+            mc = self.generateMCImage(vAccEvs, mci_poses(vAccEvs) if mci_poses else None)
+            good = len(mc["l2_kps"]) > self.DEF_TH_MIN_KPTS or self.mbContTracking
+            out.update(dispatched=True, mci=mc, mci_good=good, window=len(vAccEvs))
+            if self.mbContTracking:                                  # the overlap goes back to the front of the event queue (:1465-1469)
+                nWinOverlap = self.mnWinOverlap if self.mbFixedWinSize else int(len(vAccEvs) * self.l1WinOverlap)
+                out["overlap"] = vAccEvs[len(vAccEvs) - nWinOverlap:]
+        return out
+
+    def checkEvGenRate(self, eventRate):                             # :284-328
+        if eventRate > self.minEvGenRate:
+            self.mCntLowEvGenRate = 0
+            return 0
+        if self.mbContTracking:
+            return -1 if (not self.mbFixedWinSize and self.mStat == self.INIT) else 0
+        if self.mStat == self.INIT:
+            return -1
+        self.mCntLowEvGenRate += 1
+        return -1 if self.mCntLowEvGenRate > 3 else 1                # DEF_L1_MAX_TRACK_LOST
+
+    def updateState(self, l1Evs):                                    # :427-435
+        self.mCurrIdx += 1
+        self.mvSharedL2Evs.append(l1Evs)
+
+    def resolveEvWinSize(self, medPxDisp):                           # :209-232
+        if not self.mbFixedWinSize and np.float32(medPxDisp) > np.float32(self.mL1MaxPxDisp):
+            new = int(np.floor(np.float32(np.float32(self.mCurrIdx + 1) / np.float32(medPxDisp)) * np.float32(self.mL1EvWinSize)))     # calcNewL1ChunkSize :197-201
+            self.updateL1ChunkSize(new)
+            return True
+        return self.mbFixedWinSize and self.mCurrIdx >= self.mL1NumLoop
+
+
 class ORBVocabulary:
     """DBoW2 vocabulary resident on the device (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h); voc = dict(L, child_off, child_ids,
     node_desc, word_id, weight) as TemplatedVocabulary::loadFromTextFile leaves m_nodes (node 0 = root)."""

@@ -411,6 +411,61 @@ int eorb_fe_run_batch_dev(eorb_ctx* ctx, const eorb_event16* d_events, const int
                           uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                           int32_t* d_matches12, int32_t* d_nmatches);
 
+/* ---- the L1 image builder's per-chunk path, one call per chunk ----------------------------------------------------------------
+ * EvImBuilder::Track (src/Event/EvImBuilder.cpp:1300-1515) makes, per chunk of l1ChunkSize events, the event image (:1345) and a frame
+ * from it (:1348); the frame of an INIT chunk runs the detect-only ORBextractor (EvBaseTracker::makeFrame -> EvFrame ctor,
+ * src/Event/EventFrame.cpp:199-247) and becomes the reference of the LK tracker (init :568-592 -> ELK_Tracker::setRefImage), the frame
+ * of a TRACKING chunk tracks the reference points into the new image (makeFrame :528-548 -> ELK_Tracker::trackAndMatchCurrImage,
+ * src/Event/KLT_Tracker.cpp:215-234).  Through eorb_ev2im_gauss + eorb_orb_extract / eorb_calc_optical_flow_pyr_lk that is two or three
+ * host-buffer calls, each with its own upload, wait and download, and the image crosses the link three times; the calls below take the
+ * chunk's events and hand back keypoints / tracked points with ONE upload, ONE wait and ONE download.  The u8 image stays on the device
+ * (out_u8 != NULL downloads it with the results; eorb_ev_slice_image fetches it later, until the next call on the context).
+ * Events: `ev` (the reference's float EventData) or `raw` (sensor events resolved through eorb_set_undistort_maps), not both.
+ * The image size is the extractor's (eorb_orb_configure). */
+typedef struct eorb_klt_params {      /* Event.klt.* of Examples/Event/EvETHZ.yaml:205-208 -> ELK_Tracker (KLT_Tracker.cpp:14-20) */
+    int    win;                       /* kltWinSize (23) */
+    int    maxLevel;                  /* maxLevel (1) */
+    int    maxCount;                  /* kltMaxItr (10) */
+    double epsilon;                   /* kltEps (0.03) */
+    float  minEigThreshold;           /* cv::calcOpticalFlowPyrLK's default 1e-4 */
+} eorb_klt_params;
+
+/* INIT chunk: ev2im_gauss(events, W, H, sigma) -> ORBextractor::operator() (both overloads: want_desc) -> the image and its keypoints
+ * become the LK reference kept on the device.  Outputs as eorb_orb_extract. */
+int eorb_ev_slice_extract(eorb_ctx* ctx, const eorb_event* ev, const eorb_raw_event* raw, size_t n, float sigma, int lap0, int lap1,
+                          int want_desc, eorb_keypoint* kps, uint8_t* desc, uint8_t* oob, int cap, int* n_out, int* mono_index,
+                          uint8_t* out_u8);
+
+/* TRACKING chunk: ev2im_gauss(events) -> cv::calcOpticalFlowPyrLK(reference image, image, reference points, pts, status, err, win,
+ * maxLevel, criteria, OPTFLOW_USE_INITIAL_FLOW) (ELK_Tracker::trackCurrImage, KLT_Tracker.cpp:49-74).  pts[2 * nref]: in = the last
+ * tracked points (mLastTrackedPts: the reference points on the first tracking chunk), out = the tracked points; nref = the number of
+ * keypoints the last eorb_ev_slice_extract returned.  The reference frame's pyramid and derivatives are built once per reference. */
+int eorb_ev_slice_track(eorb_ctx* ctx, const eorb_event* ev, const eorb_raw_event* raw, size_t n, float sigma, const eorb_klt_params* klt,
+                        float* pts, uint8_t* status, float* err, int nref, uint8_t* out_u8);
+
+/* the u8 image of the context's last eorb_ev_slice_extract / _track call (W x H of the extractor), while no other host-buffer call
+ * has run on the context since: the adapter's lazy download behind the cv::Mat seam */
+int eorb_ev_slice_image(eorb_ctx* ctx, uint8_t* out_u8);
+
+/* The reconstruction contest of a dispatch, EvImBuilder::generateMCImage (src/Event/EvImBuilder.cpp:1146-1247), in one call: for the
+ * accumulated window `ev` (float EventData with their time stamps) the reconstructions
+ *   0 "DP"  ev2mci_gg_f(evs, camera, Tcw, medDepth)     getDPoseMCI :958-979    present when dp != NULL
+ *   1 "BA"  the same with the BA pose                   getBAMCI :1033-1058     present when ba != NULL
+ *   2 "EH"  ev2im_gauss(evs, normalized = false)        getEvHist :1060-1079    always
+ *   3 "Opt" ev2mci_gg_f(evs, camera, paramsSE2)         getAff2DMCI :1124-1143  present when se2_params != NULL
+ * each with measureImageFocus and cv::normalize(img, img, 255, 0, NORM_MINMAX, CV_8UC1); the winner is the largest focus, the first
+ * of equals in that order (MciInfo = std::multimap<float, PoseImagePtr, std::greater<float>>, include/Utils/Visualization.h:29); a
+ * winning "EH" is replaced by the histogram of the later half of the window (:1214-1216).  The poses come from the optimisers (out of
+ * this library's scope): AngleAxisd(R) of Tcw's rotation, its translation and the median depth, exactly what eorb_ev2mci_se3 takes.
+ * focus[0..3] = the methods' focus (-1: absent), focus[4] = the later-half histogram's; *winner = the winning method; out_u8
+ * (optional) = the winner's image; with `l2` (a context on the same device whose extractor is the L2 tracker's; the contexts belong to
+ * the calling thread) the winner goes through its detect-only extraction (isMcImageGood :260-267 = the L2 frame): kps / cap / n_out.
+ * No events: returns with *winner = -1 (:1149-1152). */
+typedef struct eorb_se3_motion { double angle; double axis[3]; double t[3]; float medDepth; } eorb_se3_motion;
+int eorb_ev_mc_contest(eorb_ctx* ctx, const eorb_event* ev, size_t n, const eorb_camera* cam, const eorb_se3_motion* dp,
+                       const eorb_se3_motion* ba, const float* se2_params, int nparams, int W, int H, float sigma, float focus[5],
+                       int* winner, uint8_t* out_u8, eorb_ctx* l2, int lap0, int lap1, eorb_keypoint* kps, int cap, int* n_out);
+
 /* The float images of the context's last eorb_fe_run_batch_*_dev call (what ev2im_gauss(..., normalized = false) returns,
  * src/Event/EventConversion.cc:264-268: the CV_32FC1 sums before normaliseImage): *d_f32 = device pointer to B x H x W floats, valid
  * until the next batch call on the context; h_minmax (optional, 2 * B floats: min, max per slice = the running extremes of
