@@ -90,6 +90,7 @@ struct eorb_ctx {
     eorb::DevBuf ev16, chunks, segoff, entries, img_f32, img_u8, minmax, tile_order, order_hist;
     // raw sensor events: undistortion maps (float2 per sensor pixel) and the tables derived from them
     eorb::DevBuf lut, src_info, stamps;
+    eorb::DevBuf ev_info, ev_stamps;              // float events of the per-slice calls: the same tables per EVENT (ev_direct_slices_dev)
     // slot form of the raw accumulation (ev_slots.hip): per sensor pixel its tiles / slot numbers, per tile its rows; valid when sl_ok
     eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_plan, sl_trace, sl_hot; long long sl_trace_n = 0;
     hipStream_t sl_side = nullptr; hipEvent_t sl_ev_fork = nullptr, sl_ev_join = nullptr, sl_ev_plan = nullptr, sl_ev_scat = nullptr;      // the long lists run beside the gather
@@ -117,6 +118,8 @@ struct eorb_ctx {
     eorb::DevBuf win_ws;                 // candidate lists of the two-phase window matchers
     eorb::DevBuf arena;                  // host-buffer entry points: all inputs / outputs of one call, one H2D and one D2H copy
     void* dl_pinned = nullptr; size_t dl_cap = 0;      // pinned landing buffer of the D2H copy (the call synchronises before reading it)
+    hipEvent_t dl_event = nullptr;                     // recorded behind that copy: what the call waits for
+    bool mm_preset = false;                            // the next ev_accumulate_dev finds its running extremes initialised (per-slice calls)
     // pyramidal LK workspaces; klt_ref_key: the reference frame whose pyramid and derivatives the buffers hold (0 = none)
     eorb::DevBuf klt_pyr, klt_der, klt_scratch;
     unsigned long long klt_ref_key = 0, klt_ref_geo = 0, klt_ref_serial = 0;
@@ -174,7 +177,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
                       uint32_t* d_minmax_enc);
 int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* beg, const int64_t* end, int B, int W, int H,
-                         float sigma, int pol, float* d_f32, uint8_t* d_u8, int normalized, uint32_t* d_minmax_enc);
+                         float sigma, int pol, float* d_f32, uint8_t* d_u8, int normalized, uint32_t* d_minmax_enc, bool mm_preset = false);
 int ev_undistort_dev(eorb_ctx* c, const eorb_raw_event* d_raw, size_t n, int W, int H, double tsFactor, eorb_event* d_out, uint32_t* d_blk);
 int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* d_lineend, eorb_raw_event* d_ev, uint8_t* d_status,
                       eorb_raw_event* d_out, uint32_t* d_blk, size_t max_lines, uint32_t h_res[3]);

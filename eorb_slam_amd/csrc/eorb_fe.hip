@@ -181,8 +181,11 @@ struct Arena {
         pinned_commit(c);
         return EORB_OK;
     }
-    // one D2H copy of arena[off, off + bytes) + stream sync; returns the host view of arena offset `off` (valid until the next call)
-    int download(size_t off, size_t bytes, const char** host)
+    // one D2H copy of arena[off, off + bytes) + a wait for it; returns the host view of arena offset `off` (valid until the next call).
+    // download_begin / download_wait: the same in two halves -- what the caller launches in between (work the results do not depend on:
+    // the LK reference kept for the next call) runs after the copy and is not waited for.
+    size_t dl_off = 0;
+    int download_begin(size_t off, size_t bytes)
     {
         if (c->dl_cap < bytes) {
             if (c->dl_pinned) { hipHostFree(c->dl_pinned); c->dl_pinned = nullptr; c->dl_cap = 0; }
@@ -191,17 +194,31 @@ struct Arena {
             c->dl_cap = want;
         }
         EORB_HIP(c, hipMemcpyAsync(c->dl_pinned, (char*)c->arena.p + off, bytes, hipMemcpyDeviceToHost, c->stream));
-        // EORB_SYNC_SPIN=1: poll the stream instead of blocking (one 2 000-event slice through ev2im_gauss + detect: p50 0.260 ->
+        if (!c->dl_event && hipEventCreateWithFlags(&c->dl_event, hipEventDisableTiming) != hipSuccess) { c->dl_event = nullptr; return set_err(c, EORB_E_HIP, "event"); }
+        EORB_HIP(c, hipEventRecord(c->dl_event, c->stream));
+        dl_off = off;
+        return EORB_OK;
+    }
+    int download_wait(const char** host)
+    {
+        // EORB_SYNC_SPIN=1: poll instead of blocking (one 2 000-event slice through ev2im_gauss + detect: p50 0.260 ->
         // 0.237 ms, p95 0.277 -> 0.326 ms, and a CPU core kept busy: off by default)
         static const int spin = [] { const char* e = getenv("EORB_SYNC_SPIN"); return e ? atoi(e) : 0; }();
         if (spin) {
             hipError_t q;
-            while ((q = hipStreamQuery(c->stream)) == hipErrorNotReady) {}
-            if (q != hipSuccess) return hip_check(c, q, "hipStreamQuery");
+            while ((q = hipEventQuery(c->dl_event)) == hipErrorNotReady) {}
+            if (q != hipSuccess) return hip_check(c, q, "hipEventQuery");
         } else
-            EORB_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->prof) prof_collect(c);               // the stream is idle: the scopes' events go back to the pool
-        *host = (const char*)c->dl_pinned - off;
+            EORB_HIP(c, hipEventSynchronize(c->dl_event));
+        *host = (const char*)c->dl_pinned - dl_off;
+        return EORB_OK;
+    }
+    int download(size_t off, size_t bytes, const char** host)
+    {
+        int rc = download_begin(off, bytes);
+        if (rc) return rc;
+        if ((rc = download_wait(host))) return rc;
+        // (profiling: the scopes' events are collected when the stream is idle -- eorb_prof_* synchronise before they read)
         return EORB_OK;
     }
 };
@@ -244,11 +261,12 @@ void eorb_destroy(eorb_ctx* c)
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
-                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena, &c->l1_ref_img, &c->l1_ref_pts};
+                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena, &c->l1_ref_img, &c->l1_ref_pts, &c->ev_info, &c->ev_stamps};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->dl_pinned) hipHostFree(c->dl_pinned);
+    if (c->dl_event) hipEventDestroy(c->dl_event);
     if (c->rb_pinned) hipHostFree(c->rb_pinned);
     if (c->sl_ev_fork) hipEventDestroy(c->sl_ev_fork);
     if (c->sl_ev_join) hipEventDestroy(c->sl_ev_join);
@@ -676,6 +694,10 @@ int eorb_normalize_minmax_u8(eorb_ctx* c, const float* img, int W, int H, uint8_
 }
 
 // ---- the L1 image builder's per-chunk path, one call per chunk (src/Event/EvImBuilder.cpp:1300-1515) ----------------------------
+// resolveMinMaxVals' start values (min 0, max -1e6: src/Event/EventConversion.cc:224-225) in the order-preserving encoding of the
+// gather kernels' atomics (enc_f32), uploaded with a call's events instead of being written by a kernel
+static const uint32_t kMinMaxPreset[16] = {0x80000000u, 0x368bdbffu, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
 // events of a chunk -> arena; float EventData are packed to the 16-byte record on the host, raw sensor events go as they are
 static int slice_events_in(eorb_ctx* c, Arena& A, const eorb_event* ev, const eorb_raw_event* raw, size_t n, std::vector<eorb_event16>& packed,
                            size_t* o_ev, int* is_raw, const char* who)
@@ -714,29 +736,33 @@ int eorb_ev_slice_extract(eorb_ctx* c, const eorb_event* ev, const eorb_raw_even
     std::vector<eorb_event16> packed;
     size_t o_ev = 0;
     if ((rc = slice_events_in(c, A, ev, raw, n, packed, &o_ev, &is_raw, "ev_slice_extract"))) return rc;
-    // device-only: extremes, float image; outputs, contiguous: u8 image | {n, mono, flag, pad} | keypoints | descriptors | oob
-    const size_t o_mm = A.reserve(64), o_f32 = A.reserve(sizeof(float) * npix);
+    // the running extremes travel initialised with the events (no launch for them); device-only: float image; outputs, contiguous:
+    // u8 image | {n, mono, flag, pad} | keypoints | descriptors | oob
+    const size_t o_mm = A.in(kMinMaxPreset, sizeof(kMinMaxPreset)), o_f32 = A.reserve(sizeof(float) * npix);
     const size_t o_u8 = A.reserve(npix), o_n = A.reserve(16), o_kp = A.reserve(sizeof(eorb_keypoint) * mo), o_desc = A.reserve(32 * mo), o_oob = A.reserve(mo);
     if ((rc = A.upload())) return rc;
     int64_t offs[2] = {0, (int64_t)n};
     uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
     int32_t* dn = A.dev<int32_t>(o_n);
     // EvImConverter::ev2im_gauss(l1Evs, W, H, sigma) :1345 (pol = false, normalized = true)
+    c->mm_preset = true;
     if ((rc = ev_accumulate_dev(c, A.dev<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 1, A.dev<uint32_t>(o_mm)))) return rc;
     // makeFrame :1348 -> EvFrame ctor -> ORBextractor::operator() (EventFrame.cpp:220)
     if ((rc = orb_extract_dev(c, d_u8, W, npix, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp), A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob),
                               dn, dn + 1, dn + 2))) return rc;
-    // ELK_Tracker::setRefImage(image, keypoints) (:1363 init -> KLT_Tracker.cpp:22-46): the image and its points stay on the device
     if ((rc = ensure(c, c->l1_ref_img, npix)) || (rc = ensure(c, c->l1_ref_pts, sizeof(float) * 2 * mo))) return rc;
-    EORB_HIP(c, hipMemcpyAsync(c->l1_ref_img.p, d_u8, npix, hipMemcpyDeviceToDevice, c->stream));
-    if ((rc = ev_kp_points_dev(c, A.dev<eorb_keypoint>(o_kp), dn, (int)mo, (float*)c->l1_ref_pts.p))) return rc;
     c->l1_nref = -1; c->l1_W = W; c->l1_H = H; c->klt_ref_serial++;
     c->l1_img_off = o_u8; c->l1_img_gen = c->arena_gen;
     const size_t ncopy = std::min<size_t>(mo, (size_t)std::max(cap, 0));
     const size_t first = out_u8 ? o_u8 : o_n;
     const size_t end = !ncopy ? o_n + 16 : (oob ? o_oob + ncopy : ((want_desc && desc) ? o_desc + 32 * ncopy : (kps ? o_kp + sizeof(eorb_keypoint) * ncopy : o_n + 16)));
     const char* h;
-    if ((rc = A.download(first, end - first, &h))) return rc;
+    if ((rc = A.download_begin(first, end - first))) return rc;
+    // ELK_Tracker::setRefImage(image, keypoints) (:1363 init -> KLT_Tracker.cpp:22-46): the image and its points stay on the device --
+    // queued behind the download, which does not wait for them (the next call on the stream is ordered behind them)
+    EORB_HIP(c, hipMemcpyAsync(c->l1_ref_img.p, d_u8, npix, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = ev_kp_points_dev(c, A.dev<eorb_keypoint>(o_kp), dn, (int)mo, (float*)c->l1_ref_pts.p))) return rc;
+    if ((rc = A.download_wait(&h))) return rc;
     const int32_t* hn = (const int32_t*)(h + o_n);
     if (hn[2]) return set_err(c, EORB_E_CAPACITY, "ev_slice_extract: internal capacity exceeded (flag %d)", hn[2]);
     c->l1_nref = hn[0];
@@ -768,13 +794,16 @@ int eorb_ev_slice_track(eorb_ctx* c, const eorb_event* ev, const eorb_raw_event*
     std::vector<eorb_event16> packed;
     size_t o_ev = 0;
     if ((rc = slice_events_in(c, A, ev, raw, n, packed, &o_ev, &is_raw, "ev_slice_track"))) return rc;
-    // in / out: the points (initial flow in, tracked points out); outputs behind them: status | err | u8 image; then device-only
+    // in: the running extremes, initialised; in / out: the points (initial flow in, tracked points out); outputs behind them:
+    // status | err | u8 image; then device-only
+    const size_t o_mm = A.in(kMinMaxPreset, sizeof(kMinMaxPreset));
     const size_t o_pts = A.in(pts, sizeof(float) * 2 * (size_t)nref);
     const size_t o_st = A.reserve((size_t)nref + 16), o_err = A.reserve(sizeof(float) * (size_t)nref), o_u8 = A.reserve(npix);
-    const size_t o_mm = A.reserve(64), o_f32 = A.reserve(sizeof(float) * npix);
+    const size_t o_f32 = A.reserve(sizeof(float) * npix);
     if ((rc = A.upload())) return rc;
     int64_t offs[2] = {0, (int64_t)n};
     uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
+    c->mm_preset = true;
     if ((rc = ev_accumulate_dev(c, A.dev<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 1, A.dev<uint32_t>(o_mm)))) return rc;
     c->l1_img_off = o_u8; c->l1_img_gen = c->arena_gen;
     // ELK_Tracker::trackCurrImage (KLT_Tracker.cpp:49-74): calcOpticalFlowPyrLK(mRefFrame, currImage, mRefPoints, kpts, ..., OPTFLOW_USE_INITIAL_FLOW)

@@ -1123,69 +1123,87 @@ __global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(con
 // keeps those whose stamp reaches the tile -- in event order, ballot-compacted into a small LDS list -- and adds them as K2s does.
 // Same entries in the same order as the binned lists, hence the same image.
 constexpr int kDirectSlices = 8;
-struct DirectSlices { int64_t beg[kDirectSlices], end[kDirectSlices]; };      // the slices' event ranges (they may overlap: the contest's later-half histogram)
+struct DirectSlices { int64_t beg[kDirectSlices], end[kDirectSlices]; int64_t tab_base; };      // the slices' event ranges (they may overlap: the contest's later-half histogram)
 constexpr int kDirectList = 1024;                   // entries of the LDS list (flushed when full)
-// FLT: float events (eorb_event16: the reference's own seam, ev2im_gauss(vector<EventData>)) -- the value of a tap is evaluated as K2
-// evaluates it (exp_XY2f :59-65: the general division form; K2's reciprocal form is proven equal by tests/test_gpu_math.py) instead
-// of being read from the stamp table of a sensor pixel.
-template <bool POL, bool FLT>
-__global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_event* __restrict__ ev, DirectSlices S, BinParams B, GatherParams P,
+// ev_direct_slices_dev resolves every event of the call ONCE, in parallel, into the entry it would contribute to a tile's list
+// (ev_pre_kernel): { table row | negative polarity << 31, xi | yi << 16 } -- raw sensor events: row = the sensor pixel (its stamp in
+// the maps' table), integer position from src_info; float events (eorb_event16: the reference's own seam, ev2im_gauss(vector<
+// EventData>)): row = the event itself, whose integer position and (2h+1)^2 taps are tabulated per EVENT by the same kernels that
+// tabulate them per sensor pixel (ev_stamp_kernel: the arithmetic of exp_XY2f :59-65 as every other path evaluates it).  The tile
+// wavefronts then only test and copy: with the map lookup (raw) or an f64 expf chain per listed entry (float) inside this kernel a
+// 2 000 ... 5 000-event chunk took 76 / 140 us.
+template <bool FLT>
+__global__ void ev_pre_kernel(const eorb_raw_event* __restrict__ ev, int n, int W, int H, int LW, int LH, const uint32_t* __restrict__ src_info,
+                              uint32_t row0, uint2* __restrict__ pre)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t row, neg, info = 0x80008000u;
+    if (FLT) {
+        const uint4 q = *(const uint4*)&ev[k];                             // { x, y } float bits, t
+        const float ex = __uint_as_float(q.x), ey = __uint_as_float(q.y);
+        row = row0 + (uint32_t)k; neg = q.w >> 31;                           // negative polarity = the sign bit of t (eorb_pack_events)
+        if (ex == ex && ey == ey) {                                          // NaN coordinates are never in the image (ev_tile_range)
+            const int xi = (int)fminf(fmaxf(floorf(ex), -32000.f), 32000.f), yi = (int)fminf(fmaxf(floorf(ey), -32000.f), 32000.f);   // breakFloatCoords :51-57
+            info = (uint32_t)(xi & 0xffff) | ((uint32_t)(yi & 0xffff) << 16);
+        }
+    } else {
+        const uint2 q = *(const uint2*)&ev[k];                             // { x | y << 16, p }
+        const uint32_t x = q.x & 0xffff, y = q.x >> 16;
+        row = y * (uint32_t)LW + x; neg = q.y ? 0u : 1u;
+        if (x < (uint32_t)LW && y < (uint32_t)LH) info = src_info[row]; else row = 0u;
+    }
+    pre[k] = make_uint2(row | (neg << 31), info);
+}
+
+template <bool POL>
+__global__ __launch_bounds__(64) void ev_gather_direct_kernel(const uint2* __restrict__ pre, DirectSlices S, GatherParams P,
                                                               float* __restrict__ img, uint32_t* __restrict__ minmax_enc)
 {
     __shared__ uint2 lst[kDirectList];
-    __shared__ uint8_t lneg[FLT ? kDirectList : 4];          // FLT: negative polarity of the listed event (raw entries carry it in word 0)
-    __shared__ uint64_t tab[32];
     const int lane = threadIdx.x;
-    if (FLT) { if (lane < 32) tab[lane] = kExp2Tab[lane]; __syncthreads(); }
     const int slice = blockIdx.x / P.NT, tile = blockIdx.x - slice * P.NT;
     const int tx0 = (tile % P.TX) * kTile, ty0 = (tile / P.TX) * kTile;
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
     const bool inimg = px < P.W && py < P.H;
     const int SW = 2 * P.h + 1, SWP = P.stamp_colstride;
-    const eorb_raw_event* e = ev + S.beg[slice];
+    const uint2* e = pre + (S.beg[slice] - S.tab_base);
     const int n = (int)(S.end[slice] - S.beg[slice]);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     float acc = 0.0f, vmax = -1000000.0f, vmin = 0.0f;
     bool touched = false, any = false;
     int nl = 0;
-    // the adds of the listed entries (K2s' loop over a list in LDS)
+    // the adds of the listed entries (K2s' loop over a list in LDS).  The taps of a group of 16 entries are requested while the previous
+    // group's are added.
     auto flush = [&]() {
+        constexpr int U = 16;
         for (int e0 = 0; e0 < nl; e0 += 64) {
             const int cnt = min(64, nl - e0);
             const uint2 mine = lst[e0 + min(lane, cnt - 1)];
-            const uint32_t mneg = FLT ? (uint32_t)lneg[e0 + min(lane, cnt - 1)] : 0u;
-            constexpr int U = 8;
-            for (int k0 = 0; k0 < cnt; k0 += U) {
-                float v[U]; bool in[U]; uint32_t sgn[U];
+            float v[U]; bool in[U]; uint32_t sgn[U];
+            auto fetch = [&](int k0) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int k = min(k0 + u, cnt - 1);
                     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, k), w1 = (uint32_t)__builtin_amdgcn_readlane((int)mine.y, k);
-                    if (FLT) {
-                        const float ex = __uint_as_float(w0), ey = __uint_as_float(w1);
-                        const int xi = (int)floorf(ex), yi = (int)floorf(ey);               // breakFloatCoords :51-57
-                        const float xr = ex - (float)xi, yr = ey - (float)yi;
-                        const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
-                        in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
-                        sgn[u] = (uint32_t)__builtin_amdgcn_readlane((int)mneg, k) << 31;
-                        const float fx = (float)(px - xi) - xr, fy = (float)(py - yi) - yr;
-                        const float xx = fx * fx, yy = fy * fy;
-                        float dd = xx + yy;
-                        dd = dd / P.two_sig2;
-                        v[u] = in[u] ? dev_expf_nonpos<true>(-dd, tab) / P.norm : 0.0f;
-                    } else {
-                        const int xi = (int)(int16_t)(w1 & 0xffff), yi = (int)(int16_t)(w1 >> 16);
-                        const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
-                        in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
-                        sgn[u] = w0 & 0x80000000u;
-                        const uint32_t off = (w0 & 0x7fffffffu) * (uint32_t)P.stamp_stride + i * (uint32_t)SWP + j;
-                        v[u] = in[u] ? P.stamps[off] : 0.0f;
-                    }
+                    const int xi = (int)(int16_t)(w1 & 0xffff), yi = (int)(int16_t)(w1 >> 16);
+                    const uint32_t i = (uint32_t)(px - xi + P.h), j = (uint32_t)(py - yi + P.h);
+                    in[u] = (k0 + u < cnt) && i < (uint32_t)SW && j < (uint32_t)SW && inimg;
+                    sgn[u] = w0 & 0x80000000u;
+                    const uint32_t off = (w0 & 0x7fffffffu) * (uint32_t)P.stamp_stride + i * (uint32_t)SWP + j;
+                    v[u] = in[u] ? P.stamps[off] : 0.0f;
                 }
+            };
+            fetch(0);
+            for (int k0 = 0; k0 < cnt; k0 += U) {
+                float a[U]; bool ain[U]; uint32_t asg[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { a[u] = v[u]; ain[u] = in[u]; asg[u] = sgn[u]; }
+                if (k0 + U < cnt) fetch(k0 + U);
 #pragma unroll
                 for (int u = 0; u < U; u++)
-                    if (in[u]) {
-                        acc = acc + (POL ? __uint_as_float(__float_as_uint(v[u]) ^ sgn[u]) : v[u]);
+                    if (ain[u]) {
+                        acc = acc + (POL ? __uint_as_float(__float_as_uint(a[u]) ^ asg[u]) : a[u]);
                         if (POL) { vmax = fmaxf(vmax, acc); vmin = fminf(vmin, acc); }
                         touched = true;
                     }
@@ -1195,50 +1213,22 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const eorb_raw_eve
     };
     constexpr int G = 8;                                     // sub-batches of 64 events whose loads are in flight together
     for (int k0 = 0; k0 < n; k0 += 64 * G) {
-        uint32_t xy[G], pp[G], info[G];
+        uint2 q[G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int k = k0 + g * 64 + lane;
-            if (FLT) {
-                // { x, y } as float bits in xy / info, negative polarity (sign bit of t) in pp
-                const uint4 q = k < n ? *(const uint4*)&e[k] : make_uint4(0x7fc00000u, 0x7fc00000u, 0u, 0u);
-                xy[g] = q.x; info[g] = q.y; pp[g] = q.w >> 31;
-            } else {
-                const uint2 q = k < n ? *(const uint2*)&e[k] : make_uint2(0xffffffffu, 0u);    // { x | y << 16, p }
-                xy[g] = q.x; pp[g] = q.y;
-            }
-        }
-        if (!FLT) {
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-                const int x = (int)(xy[g] & 0xffff), y = (int)(xy[g] >> 16);
-                info[g] = (x < B.LW && y < B.LH) ? B.src_info[(uint32_t)y * (uint32_t)B.LW + x] : 0x80008000u;    // (-32768, -32768): dropped
-            }
+            q[g] = k < n ? e[k] : make_uint2(0u, 0x80008000u);
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (k0 + g * 64 >= n) break;
-            int xi, yi; bool live;
-            if (FLT) {
-                const float ex = __uint_as_float(xy[g]), ey = __uint_as_float(info[g]);
-                live = ex == ex && ey == ey;                                        // NaN coordinates are never in the image (ev_tile_range)
-                xi = (int)fminf(fmaxf(floorf(ex), -1048576.f), 1048576.f); yi = (int)fminf(fmaxf(floorf(ey), -1048576.f), 1048576.f);
-            } else {
-                live = info[g] != 0x80008000u;
-                xi = (int)(int16_t)(info[g] & 0xffff); yi = (int)(int16_t)(info[g] >> 16);
-            }
+            const bool live = q[g].y != 0x80008000u;                          // (-32768, -32768): dropped by checkInImage / not a position
+            const int xi = (int)(int16_t)(q[g].y & 0xffff), yi = (int)(int16_t)(q[g].y >> 16);
             // the event has an entry in this tile's list iff the tile lies in its tile range (ev_tile_range / ev_tile_range_raw)
             const bool hit = live && xi - P.h <= tx0 + kTile - 1 && xi + P.h >= tx0 && yi - P.h <= ty0 + kTile - 1 && yi + P.h >= ty0;
             const uint64_t m = __ballot(hit);
             if (m) {
-                if (hit) {
-                    const int pos = nl + __popcll(m & lt_mask);
-                    if (FLT) { lst[pos] = make_uint2(xy[g], info[g]); lneg[pos] = (uint8_t)pp[g]; }
-                    else {
-                        const uint32_t src = (xy[g] >> 16) * (uint32_t)B.LW + (xy[g] & 0xffff);
-                        lst[pos] = make_uint2(src | (pp[g] ? 0u : 0x80000000u), info[g]);
-                    }
-                }
+                if (hit) lst[nl + __popcll(m & lt_mask)] = q[g];
                 nl += __popcll(m); any = true;
                 if (nl > kDirectList - 64) flush();
             }
@@ -1653,11 +1643,12 @@ int ev_kp_points_dev(eorb_ctx* c, const eorb_keypoint* d_kps, const int32_t* d_n
 // ---- raw sensor events: tables derived from the undistortion maps (MyCalibrator::mUndistMapX/Y, Utils/MyCalibrator.cpp:164-180) ----
 // per sensor pixel: integer image position floor(x) (breakFloatCoords :51-57) or round (roundFloatCoord :46-49); -32768 when the
 // undistorted point fails MyCalibrator::isInImage (:31-34) and the loader would have dropped the event (EventLoader.cpp:295-296)
-__global__ void ev_src_info_kernel(const float2* __restrict__ lut, int n, int W, int H, int check, int mode_count, uint32_t* __restrict__ info)
+__global__ void ev_src_info_kernel(const float2* __restrict__ lut, int n, int W, int H, int check, int mode_count, uint32_t* __restrict__ info,
+                                   int stride2 = 1 /* float2 per entry: 1 = the maps, 2 = eorb_event16 records (their x, y lead) */)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float2 q = lut[i];
+    const float2 q = lut[(size_t)i * stride2];
     const bool in = (q.x >= 0 && q.x < (float)W) && (q.y >= 0 && q.y < (float)H);
     int xi = -32768, yi = -32768;
     if ((in || !check) && q.x == q.x && q.y == q.y) {
@@ -1669,7 +1660,7 @@ __global__ void ev_src_info_kernel(const float2* __restrict__ lut, int n, int W,
 
 // stamp table: S[src][i][j] = exp_XY2f(i - h - xRes, j - h - yRes) (:59-65, :236-249), evaluated exactly as K2's value waves do
 __global__ void ev_stamp_kernel(const float2* __restrict__ lut, const uint32_t* __restrict__ info, int n, GatherParams P,
-                                float* __restrict__ stamps)
+                                float* __restrict__ stamps, int stride2 = 1, int info_stride = 1, int info_off = 0)
 {
     __shared__ uint64_t tab[32];
     if (threadIdx.x < 32) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
@@ -1679,13 +1670,13 @@ __global__ void ev_stamp_kernel(const float2* __restrict__ lut, const uint32_t* 
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
         const int src = (int)(k / (SW * SWP)), r = (int)(k - (size_t)src * SW * SWP);
         const int i = r / SWP, j = r - i * SWP;
-        const uint32_t w = info[src];
+        const uint32_t w = info[(size_t)src * info_stride + info_off];
         const int xi = (int)(int16_t)(w & 0xffff), yi = (int)(int16_t)(w >> 16);
         if (xi == -32768) continue;                   // a dropped pixel has no entries: its rows are never selected (K2r's reads past a
                                                       // column's ends may touch them, but only under a zero row mask)
         float v = 0.f;
         if (j < SW) {
-            const float2 q = lut[src];
+            const float2 q = lut[(size_t)src * stride2];
             const float xr = q.x - (float)xi, yr = q.y - (float)yi;
             const float fx = (float)(i - P.h) - xr, fy = (float)(j - P.h) - yr;
             const float xx = fx * fx, yy = fy * fy;
@@ -2045,7 +2036,7 @@ __global__ void ev_unpack4_kernel(const uint32_t* __restrict__ in, int64_t n, eo
 // Gaussian stamp.  ev_accumulate_dev takes this path for the live per-slice calls; the motion-compensation contest
 // (eorb_ev_mc_contest) hands it the reconstructions of one window in one launch.
 int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* beg, const int64_t* end, int B, int W, int H,
-                         float sigma, int pol, float* d_f32, uint8_t* d_u8, int normalized, uint32_t* d_minmax_enc)
+                         float sigma, int pol, float* d_f32, uint8_t* d_u8, int normalized, uint32_t* d_minmax_enc, bool mm_preset)
 {
     if (B < 1 || B > kDirectSlices) return set_err(c, EORB_E_ARG, "direct slices: %d slices", B);
     const int h = (int)ceil((double)sigma * 3.0);
@@ -2063,17 +2054,42 @@ int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64
     int rc;
     GatherParams G = ev_gather_params(W, H, h, TX, TY, NT, 0, B * NT, sigma);
     if (raw && (rc = ev_raw_tables(c, W, H, h, sigma, 0, G))) return rc;
-    BinParams P{W, H, h, TX, TY, NT, nbits, dup, 0, pol, raw, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p};
-    {
+    // every event of the call resolved once into its list entry (ev_pre_kernel), over the span of the slices
+    int64_t lo = S.beg[0], hi = S.end[0];
+    for (int b = 1; b < B; b++) { lo = std::min(lo, S.beg[b]); hi = std::max(hi, S.end[b]); }
+    const int64_t span = std::max<int64_t>(hi - lo, 0);
+    if (span >= (int64_t)1 << 30) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one direct call", (long long)span);
+    if ((rc = ensure(c, c->ev_info, sizeof(uint2) * (size_t)std::max<int64_t>(span, 1)))) return rc;
+    S.tab_base = lo;
+    uint2* d_pre = (uint2*)c->ev_info.p;
+    const eorb_raw_event* d_first = (const eorb_raw_event*)d_events + lo;
+    if (!raw) {
+        // float events: the taps per EVENT (row = the event's index in the span), as the maps' table holds them per sensor pixel
+        const int SW = 2 * h + 1, SWP = (SW + 3) & ~3;
+        if (span * SW * SWP * 4 >= (int64_t)1 << 32) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld float events x %d taps exceed the per-event stamp table", (long long)span, SW * SWP);
+        G.stamp_stride = SW * SWP; G.stamp_colstride = SWP;
+        if ((rc = ensure(c, c->ev_stamps, sizeof(float) * (size_t)std::max<int64_t>(span, 1) * SW * SWP))) return rc;
+        if (span) {
+            ProfScope ps(c, "ev_stamp_tables");
+            ev_pre_kernel<true><<<(int)((span + 255) / 256), 256, 0, c->stream>>>(d_first, (int)span, W, H, 0, 0, nullptr, 0u, d_pre);
+            ev_stamp_kernel<<<(int)std::min<int64_t>((span * SW * SWP + 255) / 256, 4096), 256, 0, c->stream>>>((const float2*)d_first, (const uint32_t*)d_pre, (int)span, G,
+                                                                                                          (float*)c->ev_stamps.p, 2, 2, 1);
+            EORB_LAUNCH_CHECK(c, "per-event tables");
+        }
+        G.stamps = (const float*)c->ev_stamps.p;
+    } else if (span) {
+        ProfScope ps(c, "ev_stamp_tables");
+        ev_pre_kernel<false><<<(int)((span + 255) / 256), 256, 0, c->stream>>>(d_first, (int)span, W, H, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p, 0u, d_pre);
+        EORB_LAUNCH_CHECK(c, "ev_pre_kernel");
+    }
+    if (!mm_preset) {
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
     }
     {
         ProfScope ps(c, "ev_gather");
-#define LAUNCH_D(PP, FF) ev_gather_direct_kernel<PP, FF><<<B * NT, 64, 0, c->stream>>>((const eorb_raw_event*)d_events, S, P, G, d_f32, d_minmax_enc)
-        if (raw) { if (pol) LAUNCH_D(true, false); else LAUNCH_D(false, false); }
-        else { if (pol) LAUNCH_D(true, true); else LAUNCH_D(false, true); }
-#undef LAUNCH_D
+        if (pol) ev_gather_direct_kernel<true><<<B * NT, 64, 0, c->stream>>>(d_pre, S, G, d_f32, d_minmax_enc);
+        else ev_gather_direct_kernel<false><<<B * NT, 64, 0, c->stream>>>(d_pre, S, G, d_f32, d_minmax_enc);
         EORB_LAUNCH_CHECK(c, "ev_gather_direct_kernel");
     }
     if (normalized && d_u8) {
@@ -2090,6 +2106,8 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
                       uint32_t* d_minmax_enc)
 {
+    const bool mm_preset = c->mm_preset;                 // (only the binning-free form takes the caller's word for it; the others initialise the extremes themselves)
+    c->mm_preset = false;
     if (B <= 0 || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "ev_accumulate: bad size");
     if (raw && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "ev_accumulate: raw events need eorb_set_undistort_maps first");
     const eorb_event16* d_ev = (const eorb_event16*)d_events;          // eorb_raw_event has the same 16-byte stride
@@ -2183,7 +2201,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                 if (h_offsets[b + 1] < h_offsets[b]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
                 beg[b] = h_offsets[b]; end[b] = h_offsets[b + 1];
             }
-            return ev_direct_slices_dev(c, d_events, raw, beg, end, B, W, H, sigma, pol, d_f32, d_u8, normalized, d_minmax_enc);
+            return ev_direct_slices_dev(c, d_events, raw, beg, end, B, W, H, sigma, pol, d_f32, d_u8, normalized, d_minmax_enc, mm_preset);
         }
     }
     // dense batches of raw events without polarity: two-byte slot lists, a tile position's rows in LDS (ev_slots.hip)

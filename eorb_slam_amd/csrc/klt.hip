@@ -98,8 +98,16 @@ constexpr int kKltMaxWin = 31;         // window side handled by the LDS patch b
 // float sum of v[0..n) in index order, by ONE lane (the order is part of the result); four values per LDS read
 __device__ __forceinline__ float klt_ordered_sum(const float* v, int n)
 {
+    // sixteen values in flight ahead of their adds (one wavefront per point and mostly one per CU: nothing else hides the LDS latency)
     float s = 0.f;
     int k = 0;
+    for (; k + 16 <= n; k += 16) {
+        const float4 q0 = *(const float4*)(v + k), q1 = *(const float4*)(v + k + 4), q2 = *(const float4*)(v + k + 8), q3 = *(const float4*)(v + k + 12);
+        s = s + q0.x; s = s + q0.y; s = s + q0.z; s = s + q0.w;
+        s = s + q1.x; s = s + q1.y; s = s + q1.z; s = s + q1.w;
+        s = s + q2.x; s = s + q2.y; s = s + q2.z; s = s + q2.w;
+        s = s + q3.x; s = s + q3.y; s = s + q3.z; s = s + q3.w;
+    }
     for (; k + 4 <= n; k += 4) {
         const float4 q = *(const float4*)(v + k);
         s = s + q.x; s = s + q.y; s = s + q.z; s = s + q.w;
@@ -162,10 +170,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
             sP0[k] = (float)(ixval * ixval); sP1[k] = (float)(ixval * iyval); sP2[k] = (float)(iyval * iyval);
         }
         __syncthreads();
+        // the three raster-order chains side by side on lanes 0..2 (one branch per lane would run them one after the other)
         float acc = 0.f;
-        if (lane == 0) acc = klt_ordered_sum(sP0, WW);
-        else if (lane == 1) acc = klt_ordered_sum(sP1, WW);
-        else if (lane == 2) acc = klt_ordered_sum(sP2, WW);
+        if (lane < 3) acc = klt_ordered_sum(lane == 0 ? sP0 : (lane == 1 ? sP1 : sP2), WW);
         const float A11 = __shfl(acc, 0, 64) * FLT_SCALE, A12 = __shfl(acc, 1, 64) * FLT_SCALE, A22 = __shfl(acc, 2, 64) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float dif = A11 - A22;
@@ -190,16 +197,32 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
             iw10 = dev_cvround((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             __syncthreads();                                      // last iteration's sums have been read
-            for (int k = lane; k < WW; k += 64) {
-                const int y = k / win, x = k - y * win;
-                const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx + x;
-                const int diff = KLT_DESCALE(Jp[0] * iw00 + Jp[1] * iw01 + Jp[stp] * iw10 + Jp[stp + 1] * iw11, W_BITS1 - 5) - sI[k];
-                sP0[k] = (float)(diff * sDx[k]); sP1[k] = (float)(diff * sDy[k]);
+            {
+                // all of the window's pixel reads in flight before the first is used (the window's size is a run-time value: left to
+                // itself the loop waits for every trip's four loads, 9 round trips per iteration for a 23 x 23 window)
+                constexpr int T = (kKltMaxWin * kKltMaxWin + 63) / 64;
+                uint32_t j00[T], j01[T], j10[T], j11[T];
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const int k = lane + 64 * t;
+                    if (k < WW) {
+                        const int y = k / win, x = k - y * win;
+                        const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx + x;
+                        j00[t] = Jp[0]; j01[t] = Jp[1]; j10[t] = Jp[stp]; j11[t] = Jp[stp + 1];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const int k = lane + 64 * t;
+                    if (k < WW) {
+                        const int diff = KLT_DESCALE((int)j00[t] * iw00 + (int)j01[t] * iw01 + (int)j10[t] * iw10 + (int)j11[t] * iw11, W_BITS1 - 5) - sI[k];
+                        sP0[k] = (float)(diff * sDx[k]); sP1[k] = (float)(diff * sDy[k]);
+                    }
+                }
             }
             __syncthreads();
             float sb = 0.f;
-            if (lane == 0) sb = klt_ordered_sum(sP0, WW);
-            else if (lane == 1) sb = klt_ordered_sum(sP1, WW);
+            if (lane < 2) sb = klt_ordered_sum(lane == 0 ? sP0 : sP1, WW);
             const float b1 = __shfl(sb, 0, 64) * FLT_SCALE, b2 = __shfl(sb, 1, 64) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
             nextx += dx; nexty += dy;

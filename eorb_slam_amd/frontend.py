@@ -585,6 +585,11 @@ class EvImBuilder:
     def set_undistort_maps(self, mapX, mapY, checkInImage=True):
         EvImConverter.set_undistort_maps(mapX, mapY, checkInImage, ctx=self.ctx)
 
+    def resetAll(self):                                              # :70-93
+        self.mStat = self.IDLE
+        self.updateL1ChunkSize(self.mInitL1EvWinSize)
+        self.reset()
+
     def reset(self):                                                 # :95-139
         self.mCurrIdx = 0
         self.mCntLowEvGenRate = 0
@@ -733,6 +738,25 @@ class EvImBuilder:
             self.updateL1ChunkSize(new)
             return True
         return self.mbFixedWinSize and self.mCurrIdx >= self.mL1NumLoop
+
+
+def feed_chunks(builder, events, mci_poses=None, max_chunks=10 ** 9):
+    """The track manager's feed of the L1 builder (src/Event/EvTrackManager.cpp:272-286 consumeEventsBegin(l1ChunkSize), and
+    injectEventsBegin for the overlap a dispatch hands back, src/Event/EvImBuilder.cpp:1465-1469): chunks of the builder's CURRENT
+    chunk size off the front of the queue.  Returns the chunks' results."""
+    queue = events
+    res = []
+    size = builder.mL1EvWinSize
+    while len(queue) >= max(size, 1) and len(res) < max_chunks:
+        chunk, queue = queue[:size], queue[size:]
+        r = builder.Track(chunk, mci_poses)
+        res.append(r)
+        if r.get("overlap") is not None and len(r["overlap"]):
+            queue = np.concatenate([r["overlap"], queue])
+        size = builder.mL1EvWinSize
+        if size < 1:
+            break
+    return res
 
 
 class ORBVocabulary:

@@ -199,3 +199,23 @@ def random_vocabulary(k=10, L=3, seed=0, ragged=False, stop_frac=0.02):
     weight[stop] = 0.0                                                  # stopWords()
     return dict(L=L, child_off=np.array(child_off, np.int32), child_ids=np.array(child_ids, np.int32), node_desc=node_desc,
                 word_id=word_id, weight=weight)
+
+
+# ---- config 1 as the reference executes it (EvImBuilder::Track): a stream with enough motion for the window-size rule to fire, and
+# stand-ins for what the optimisers hand the motion-compensated reconstructions (they are outside the front end) ----
+EVETHZ_PINHOLE = (EVETHZ_K["fx"], EVETHZ_K["fy"], EVETHZ_K["cx"], EVETHZ_K["cy"])       # rectified events: a calibrated pinhole camera
+
+
+def l1_stream(n_chunks=60, chunk=2000, seed=5, motion=14.0, W=240, H=180):
+    """One long time-ordered slice of the shapes generator (float EventData, monotone time stamps 1 us apart)."""
+    return shapes_events(n_chunks * chunk, W, H, seed=seed, motion=motion, undistort=True)
+
+
+def l1_mci_poses(window):
+    """What resolveLastDPose / resolveLastPoseMap / resolveLastAtt2Params would hand generateMCImage (src/Event/EvImBuilder.cpp:958-1143):
+    fixed small motions scaled by the window's length.  Deterministic in the window."""
+    n = len(window)
+    s = min(n / 6000.0, 2.0)
+    return dict(dp=dict(angle=0.010 * s, axis=(0.1, -0.2, 0.97), t=(0.004 * s, -0.003 * s, 0.001), medDepth=1.0),
+                ba=dict(angle=0.016 * s, axis=(-0.3, 0.1, 0.95), t=(-0.002 * s, 0.005 * s, 0.0), medDepth=1.3),
+                se2=np.array([0.012 * s, 1.5 * s, -0.8 * s], np.float32))

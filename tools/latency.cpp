@@ -155,6 +155,32 @@ int main()
     }
     std::printf("keypoints %d\n", n);
     pct("eorb_ev2im_gauss_raw (2000)", a); pct("eorb_orb_extract (detect)", b); pct("both", t); pct("eorb_ev2im_gauss_raw (1 ev)", one);
+    // the same chunk through the one-call seams (EvImBuilder::Track's per-chunk path): events in -> keypoints out / tracked points out
+    {
+        std::vector<eorb_event> fev(N);
+        for (int i = 0; i < N; i++) { fev[i].ts = ev[i].t; fev[i].x = mx[ev[i].y * W + ev[i].x]; fev[i].y = my[ev[i].y * W + ev[i].x]; fev[i].p = ev[i].p != 0; }
+        std::vector<eorb_raw_event> ev2(ev);
+        for (int i = 0; i < N; i++) ev2[i].x = (uint16_t)(ev2[i].x + 1);                  // the next chunk: the edges moved by a pixel
+        eorb_klt_params klt{23, 1, 10, 0.03, 1e-4f};
+        std::vector<double> xr, xf, tr;
+        std::vector<float> pts((size_t)cap * 2), err(cap); std::vector<uint8_t> st(cap);
+        int nk = 0;
+        for (int r = 0; r < REP + 20; r++) {
+            const double t0 = now();
+            if (eorb_ev_slice_extract(c, nullptr, ev.data(), N, 1.0f, 0, 1000, 0, kps.data(), nullptr, nullptr, cap, &nk, &mono, nullptr)) { std::printf("slice_extract: %s\n", eorb_last_error(c)); return 1; }
+            const double t1 = now();
+            for (int i = 0; i < nk; i++) { pts[2 * i] = kps[i].x; pts[2 * i + 1] = kps[i].y; }
+            const double t2 = now();
+            if (eorb_ev_slice_track(c, nullptr, ev2.data(), N, 1.0f, &klt, pts.data(), st.data(), err.data(), nk, nullptr)) { std::printf("slice_track: %s\n", eorb_last_error(c)); return 1; }
+            const double t3 = now();
+            if (eorb_ev_slice_extract(c, fev.data(), nullptr, N, 1.0f, 0, 1000, 0, kps.data(), nullptr, nullptr, cap, &nk, &mono, nullptr)) { std::printf("slice_extract: %s\n", eorb_last_error(c)); return 1; }
+            const double t4 = now();
+            if (r >= 20) { xr.push_back(t1 - t0); tr.push_back(t3 - t2); xf.push_back(t4 - t3); }
+        }
+        int ok = 0; for (int i = 0; i < nk; i++) ok += st[i];
+        std::printf("one-call seams: %d keypoints, %d tracked\n", nk, ok);
+        pct("eorb_ev_slice_extract (raw)", xr); pct("eorb_ev_slice_extract (float)", xf); pct("eorb_ev_slice_track (raw)", tr);
+    }
     if (run_w3(c) || run_w4(c)) return 1;
     eorb_destroy(c);
     return 0;
