@@ -253,8 +253,15 @@ def gen_slices(NEV, W, H, seeds, use_raw, world):
     are drawn by a pool of processes -- same seeds, same events as the serial loop -- started before this process touches the GPU
     any further; N > 1 ranks share the host's cores."""
     jobs = [(NEV, W, H, int(sd), use_raw) for sd in seeds]
-    if NEV * len(seeds) < 8000000:
-        return [_gen_slice(j) for j in jobs]
+    # (under rocprofv3 the tool library is preloaded into every child process and initialises the GPU there: no pool then)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
+    if NEV * len(seeds) < 8000000 or profiled:
+        out = []
+        for i, j in enumerate(jobs):
+            out.append(_gen_slice(j))
+            if profiled and i % 16 == 15:
+                print("bench.py: drew %d of %d slices" % (i + 1, len(jobs)), file=sys.stderr, flush=True)
+        return out
     import multiprocessing as mp
     nproc = max(2, min(CPU_POOL, (os.cpu_count() or 2) // max(world, 1), len(jobs)))
     with mp.get_context("spawn").Pool(nproc) as p:

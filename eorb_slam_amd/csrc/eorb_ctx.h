@@ -92,8 +92,15 @@ struct eorb_ctx {
     eorb::DevBuf lut, src_info, stamps;
     eorb::DevBuf ev_info, ev_stamps;              // float events of the per-slice calls: the same tables per EVENT (ev_direct_slices_dev)
     // slot form of the raw accumulation (ev_slots.hip): per sensor pixel its tiles / slot numbers, per tile its rows; valid when sl_ok
-    eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_plan, sl_trace, sl_hot; long long sl_trace_n = 0;
-    hipStream_t sl_side = nullptr; hipEvent_t sl_ev_fork = nullptr, sl_ev_join = nullptr, sl_ev_plan = nullptr, sl_ev_scat = nullptr;      // the long lists run beside the gather
+    eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_trace; long long sl_trace_n = 0;
+    // per-batch workspaces of the slot form, one set per part of a batch (a batch of 64 slices or more runs as two halves)
+    struct SlotWS { eorb::DevBuf chunks, segoff, entries, tile_order, plan, hot; };
+    SlotWS sl_ws[2];
+    // its streams (made together, ev_slots.hip sl_streams): sl_side = the register-row kernel (high priority), sl_pstream = the plan,
+    // sl_gstream = the LDS gather of one half while the next half is binned; five events per part
+    static constexpr int kSlotEvents = 10;
+    hipStream_t sl_side = nullptr, sl_pstream = nullptr, sl_gstream = nullptr; hipEvent_t sl_ev[kSlotEvents] = {};
+    int sl_last_parts = 0;
     int sl_ok = 0, sl_null = 0, sl_rank_ok = -1;
     int ncu = 0;                                 // compute units of c->device (per context: a second context may sit on another GPU)
     unsigned sl_attr = 0;                        // bit per kernel instantiation whose dynamic-LDS opt-in was made on c->device
@@ -151,6 +158,7 @@ struct eorb_ctx {
     int dbg_slot_rank = -1;                      // slot form: -1 by the device check / EORB_SLOT_RANK, 0 ballot scatter, 1 rank scatter (if the check passed)
     long long dbg_slot_hot_min = -1;             // slot form: list length from which the register-row kernel takes a list (-1: default / EORB_SLOT_HOT_MIN)
     int dbg_slot_hot_cap = 0;                    // slot form: lists per length bucket of the register-row kernel (0: kHotCap), to force the overflow branch
+    int dbg_slot_halves = -1;                    // slot form: -1 by the batch's shape / EORB_SLOT_HALVES, 0 one part, 1 two halves whatever the shape
 };
 
 namespace eorb {
@@ -164,8 +172,8 @@ int* readback_buf(eorb_ctx* c);                 // c->rb_pinned, allocated on fi
 
 // scoped per-kernel timing (HIP events on the ctx stream) when profiling is enabled
 struct ProfScope {
-    eorb_ctx* c; int idx; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(eorb_ctx* c, const char* name);
+    eorb_ctx* c; int idx; hipEvent_t a = nullptr, b = nullptr; hipStream_t st = nullptr;
+    ProfScope(eorb_ctx* c, const char* name, hipStream_t stream = nullptr);      // stream: where the scope's kernels run (default: the context's)
     ~ProfScope();
 };
 

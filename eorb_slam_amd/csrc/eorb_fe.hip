@@ -103,7 +103,7 @@ void pinned_commit(eorb_ctx* c)
     s.busy = true;
 }
 
-ProfScope::ProfScope(eorb_ctx* cc, const char* name) : c(cc), idx(-1)
+ProfScope::ProfScope(eorb_ctx* cc, const char* name, hipStream_t stream) : c(cc), idx(-1), st(stream ? stream : cc->stream)
 {
     if (!c->prof) return;
     if (!c->prof_only.empty() && c->prof_only.find(std::string(",") + name + ",") == std::string::npos) return;
@@ -112,12 +112,12 @@ ProfScope::ProfScope(eorb_ctx* cc, const char* name) : c(cc), idx(-1)
     // events come from a pool (creating a pair costs several microseconds: visible on the one-frame-per-call paths)
     auto take = [&](hipEvent_t& e) { if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); } else hipEventCreate(&e); };
     take(a); take(b);
-    hipEventRecord(a, c->stream);
+    hipEventRecord(a, st);
 }
 ProfScope::~ProfScope()
 {
     if (idx < 0) return;
-    hipEventRecord(b, c->stream);
+    hipEventRecord(b, st);
     c->profs[idx].pending.emplace_back(a, b);
     c->profs[idx].launches++;
 }
@@ -257,7 +257,7 @@ void eorb_destroy(eorb_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
-    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_plan, &c->sl_trace, &c->sl_hot, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_sl_tab, &c->dd_sl_tile, &c->dd_sl_rows, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
+    DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_trace, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_sl_tab, &c->dd_sl_tile, &c->dd_sl_rows, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
@@ -268,11 +268,11 @@ void eorb_destroy(eorb_ctx* c)
     if (c->dl_pinned) hipHostFree(c->dl_pinned);
     if (c->dl_event) hipEventDestroy(c->dl_event);
     if (c->rb_pinned) hipHostFree(c->rb_pinned);
-    if (c->sl_ev_fork) hipEventDestroy(c->sl_ev_fork);
-    if (c->sl_ev_join) hipEventDestroy(c->sl_ev_join);
-    if (c->sl_ev_plan) hipEventDestroy(c->sl_ev_plan);
-    if (c->sl_ev_scat) hipEventDestroy(c->sl_ev_scat);
+    for (hipEvent_t e : c->sl_ev) if (e) hipEventDestroy(e);
     if (c->sl_side) hipStreamDestroy(c->sl_side);
+    if (c->sl_pstream) hipStreamDestroy(c->sl_pstream);
+    if (c->sl_gstream) hipStreamDestroy(c->sl_gstream);
+    for (auto& w : c->sl_ws) { free_buf(w.chunks); free_buf(w.segoff); free_buf(w.entries); free_buf(w.tile_order); free_buf(w.plan); free_buf(w.hot); }
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -308,6 +308,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "slot_rank")) { c->dbg_slot_rank = value; return EORB_OK; }
     if (!strcmp(name, "slot_hot_min")) { c->dbg_slot_hot_min = value; return EORB_OK; }
     if (!strcmp(name, "slot_hot_cap")) { c->dbg_slot_hot_cap = value; return EORB_OK; }
+    if (!strcmp(name, "slot_halves")) { c->dbg_slot_halves = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
 
@@ -318,18 +319,25 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
     if (!strcmp(name, "slot_rank_ok")) return c->sl_rank_ok;
     if (!strcmp(name, "slot_scatter_form")) return c->sl_last_rank;       // the scatter of the last slot-form call: 1 rank form, 0 ballot form
     if (!strcmp(name, "slot_chunk")) return c->sl_last_chunk;
+    if (!strcmp(name, "slot_parts")) return c->sl_last_parts;              // 2: the last slot-form call ran its batch as two halves
     if (!strcmp(name, "slot_hot_overflow")) {           // lists the last slot-form call handed back to the LDS gather because their length bucket was full (synchronises)
-        if (!c->sl_hot.p) return 0;
-        uint32_t h = 0;
-        if (hipMemcpyAsync(&h, (uint32_t*)c->sl_hot.p + 33, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
-        return h;
+        long long n = 0;
+        for (int part = 0; part < std::max(c->sl_last_parts, 1); part++) {
+            if (!c->sl_ws[part].hot.p) continue;
+            uint32_t h = 0;
+            if (hipMemcpyAsync(&h, (uint32_t*)c->sl_ws[part].hot.p + 33, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+            n += h;
+        }
+        return n;
     }
     if (!strcmp(name, "slot_hot_items")) {              // lists the last slot-form call handed to the register-row kernel (synchronises)
-        if (!c->sl_hot.p) return 0;
-        uint32_t h[16];
-        if (hipMemcpyAsync(h, c->sl_hot.p, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
         long long n = 0;
-        for (int i = 0; i < 16; i++) n += h[i];      // (sl_tasks_kernel capped the counts at the buckets' capacity)
+        for (int part = 0; part < std::max(c->sl_last_parts, 1); part++) {
+            if (!c->sl_ws[part].hot.p) continue;
+            uint32_t h[16];
+            if (hipMemcpyAsync(h, c->sl_ws[part].hot.p, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+            for (int i = 0; i < 16; i++) n += h[i];      // (sl_tasks_kernel capped the counts at the buckets' capacity)
+        }
         return n;
     }
     if (!strcmp(name, "slot_flags")) {

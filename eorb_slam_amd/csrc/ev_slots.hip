@@ -1070,23 +1070,41 @@ static bool sl_choose_scatter(const eorb_ctx* c, int NT, int64_t per_slice, bool
     return false;
 }
 
-// count -> scan -> scatter -> order -> gather for B slices of raw events (no polarity, Gaussian stamp).
-// Returns kSlotDeclined (> 0, nothing launched) when the batch's shape does not fit: the caller goes on with the batch pipeline.
-int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
-                        float* d_f32, uint32_t* d_minmax_enc)
+// The streams and events of the slot form, made once per context, all or nothing: P = the gather's plan (single-block kernels beside
+// the scatter), H = the register-row kernel (high priority: its lists are the launch's longest chains), G = the LDS gather of a
+// half batch while the main stream bins the next half.
+static int sl_streams(eorb_ctx* c)
+{
+    if (c->sl_side) return EORB_OK;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[eorb_ctx::kSlotEvents];
+    for (auto& e : ev) e = nullptr;
+    bool ok = hipStreamCreateWithPriority(&st[0], hipStreamNonBlocking, hi) == hipSuccess && hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&st[2], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < eorb_ctx::kSlotEvents; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {                                       // a half-made set must not be used by a later call
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& q : st) if (q) (void)hipStreamDestroy(q);
+        return set_err(c, EORB_E_HIP, "slot form: streams / events");
+    }
+    c->sl_side = st[0]; c->sl_pstream = st[1]; c->sl_gstream = st[2];
+    for (int i = 0; i < eorb_ctx::kSlotEvents; i++) c->sl_ev[i] = ev[i];
+    return EORB_OK;
+}
+
+// count -> scan -> scatter -> plan -> gather for the B slices of one PART of a batch (the whole batch, or one of its halves), on the
+// part's own workspaces.  Streams: binning on the context's stream; the plan on P; the long lists on H; the LDS gather on G when the
+// batch runs in halves (so that the next half's binning, HBM- and LDS-atomic-bound, runs under it), else on the context's stream.
+static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, const void* d_events, int stride, const int64_t* h_offsets, int B,
+                      int W, int H, int TX, int TY, float* d_f32, uint32_t* d_minmax_enc, const SlotScatterChoice& sc)
 {
     const int NT = TX * TY;
     const int64_t nev = h_offsets[B] - h_offsets[0];
-    const int64_t per_slice = nev / B;
-    static const int rank_env0 = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
-    const bool rank_allowed = c->sl_rank_ok == 1 && (c->dbg_slot_rank < 0 ? rank_env0 != 0 : c->dbg_slot_rank != 0);
-    SlotScatterChoice sc;
-    // sl_plan_kernel keeps two words per slice in LDS and ranks a position's lists by an O(B^2) loop, sl_scan_kernel is one workgroup
-    // per slice: batches of more than 2 048 slices take the batch pipeline; so do tile grids whose count rows do not fit the LDS
-    if (B > 2048 || (size_t)NT * 4 > 64 * 1024 || !sl_choose_scatter(c, NT, per_slice, rank_allowed, &sc)) return kSlotDeclined;
     const int chunk = sc.chunk;
-    c->sl_calls++;
-    c->sl_last_rank = sc.rank ? 1 : 0; c->sl_last_chunk = chunk;
+    hipStream_t M = c->stream, P = c->sl_pstream, Hs = c->sl_side, G = nparts > 1 ? c->sl_gstream : c->stream;
+    hipEvent_t* E = c->sl_ev + 5 * part;             // fork (scan done), plan, scat, hot done, gather done
     // up to 256 slices: the descriptors are made on the device from the offsets (sl_chunks_kernel); more: on the host, one copy
     const bool on_dev = B <= kOffsetsInArg;
     std::vector<ChunkDesc> cds;
@@ -1096,8 +1114,6 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     for (int b = 0; b < B; b++) {
         if (!on_dev) slice_c0[b] = (int)nch;
         const int64_t s = h_offsets[b], e = h_offsets[b + 1];
-        if (e < s) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
-        if ((e - s) * 4 + (int64_t)NT * 16 >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)(e - s));
         if (!on_dev) slice_eb[b] = eb;
         eb = (eb + (e - s) * 4 + (int64_t)NT * 16 + 15) & ~(int64_t)15;   // <= 4 entries per event, every list rounded up to 16
         nch += (e - s + chunk - 1) / chunk;
@@ -1115,16 +1131,16 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     const size_t eb_bytes = sizeof(int64_t) * (size_t)B;
     const int nb = B * NT;
     int rc;
-    if ((rc = ensure(c, c->chunks, cd_bytes + sc_bytes + eb_bytes))) return rc;
+    if ((rc = ensure(c, ws.chunks, cd_bytes + sc_bytes + eb_bytes))) return rc;
     const size_t cnt_bytes = (sizeof(uint16_t) * (size_t)std::max(nchunks, 1) * NT + 15) & ~(size_t)15;
-    if ((rc = ensure(c, c->segoff, cnt_bytes + sizeof(uint32_t) * (size_t)std::max(nchunks, 1) * NT))) return rc;
-    if ((rc = ensure(c, c->entries, (size_t)eb + 8192))) return rc;      // + slack: the gather requests blocks past a list's end
-    if ((rc = ensure(c, c->tile_order, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
+    if ((rc = ensure(c, ws.segoff, cnt_bytes + sizeof(uint32_t) * (size_t)std::max(nchunks, 1) * NT))) return rc;
+    if ((rc = ensure(c, ws.entries, (size_t)eb + 8192))) return rc;      // + slack: the gather requests blocks past a list's end
+    if ((rc = ensure(c, ws.tile_order, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
     if (on_dev) {
         SliceOffsets so;
         for (int b = 0; b <= B; b++) so.off[b] = h_offsets[b];
-        sl_chunks_kernel<<<std::max(1, (nchunks + 255) / 256), 256, 0, c->stream>>>(so, B, chunk == 4096 ? 12 : (chunk == 2048 ? 11 : (chunk == 1024 ? 10 : 8)), NT, nchunks, (ChunkDesc*)c->chunks.p, (int*)((char*)c->chunks.p + cd_bytes),
-                                                                                  (int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes));
+        sl_chunks_kernel<<<std::max(1, (nchunks + 255) / 256), 256, 0, M>>>(so, B, chunk == 4096 ? 12 : (chunk == 2048 ? 11 : (chunk == 1024 ? 10 : 8)), NT, nchunks, (ChunkDesc*)ws.chunks.p, (int*)((char*)ws.chunks.p + cd_bytes),
+                                                                                  (int64_t*)((char*)ws.chunks.p + cd_bytes + sc_bytes));
     }
     else {
         char* hp = (char*)pinned(c, cd_bytes + sc_bytes + eb_bytes);
@@ -1132,143 +1148,177 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
         if (nchunks) memcpy(hp, cds.data(), sizeof(ChunkDesc) * nchunks);
         memcpy(hp + cd_bytes, slice_c0.data(), sizeof(int) * (size_t)(B + 1));
         memcpy(hp + cd_bytes + sc_bytes, slice_eb.data(), eb_bytes);
-        EORB_HIP(c, hipMemcpyAsync(c->chunks.p, hp, cd_bytes + sc_bytes + eb_bytes, hipMemcpyHostToDevice, c->stream));
+        EORB_HIP(c, hipMemcpyAsync(ws.chunks.p, hp, cd_bytes + sc_bytes + eb_bytes, hipMemcpyHostToDevice, M));
         pinned_commit(c);
     }
-    const ChunkDesc* d_chunks = (const ChunkDesc*)c->chunks.p;
-    const int* d_slice_c0 = (const int*)((char*)c->chunks.p + cd_bytes);
-    const int64_t* d_slice_eb = (const int64_t*)((char*)c->chunks.p + cd_bytes + sc_bytes);
-    uint16_t* d_segcnt = (uint16_t*)c->segoff.p;
-    uint32_t* d_segbase = (uint32_t*)((char*)c->segoff.p + cnt_bytes);
-    uint32_t* d_tile_cnt = (uint32_t*)c->tile_order.p;
+    const ChunkDesc* d_chunks = (const ChunkDesc*)ws.chunks.p;
+    const int* d_slice_c0 = (const int*)((char*)ws.chunks.p + cd_bytes);
+    const int64_t* d_slice_eb = (const int64_t*)((char*)ws.chunks.p + cd_bytes + sc_bytes);
+    uint16_t* d_segcnt = (uint16_t*)ws.segoff.p;
+    uint32_t* d_segbase = (uint32_t*)((char*)ws.segoff.p + cnt_bytes);
+    uint32_t* d_tile_cnt = (uint32_t*)ws.tile_order.p;
     uint32_t* d_tile_base = d_tile_cnt + nb;
     uint32_t* d_nslots = (uint32_t*)c->sl_tile.p;
     uint32_t* d_rowbase = d_nslots + NT;
-    uint32_t* d_tile_w = d_nslots + 2 * (size_t)NT;
-    uint32_t* d_ctr = d_nslots + 3 * (size_t)NT;
     int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
     const eorb_raw_event* d_ev = (const eorb_raw_event*)d_events;
     const uint2* d_tab = (const uint2*)c->sl_tab.p;
-    int ncu_g = 256; uint32_t hot_min = 0; uint32_t* d_hot_cnt = nullptr; HotDesc* d_hot_items = nullptr;
-    size_t lds_g = 0; int nw = 1, G = 0; uint4* d_items = nullptr; uint32_t* d_task = nullptr; uint32_t prio_ref = 0;
+    const int ncu = sl_ncu(c);
+    const int NTp = (NT + 1) & ~1;
+    // ---- the gather's plan: sizes first (its buffers are allocated before anything of the part is launched) ----
+    const size_t lds_g = (size_t)(c->sl_null + 1) * 256;
+    const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds_g));
+    static const int nw_env = [] { const char* e = getenv("EORB_SLOT_WAVES"); return e ? atoi(e) : 0; }();
+    static const int ns_env = [] { const char* e = getenv("EORB_SLOT_ROUNDS"); return e ? atoi(e) : 0; }();
+    // four wavefronts per SIMD saturate the vector ALUs and leave every list about full single-wave speed (measured: 8 per SIMD
+    // process the same entries per second, each list at half the pace)
+    int nw = std::min(16, std::max(1, 16 / wg_per_cu));
+    if (nw_env >= 1 && nw_env <= 16) nw = nw_env;
+    nw = std::min(nw, std::max(1, B));
+    // one task per tile position plus a few rounds of spare ones shared out by weight; a position never gets more wavefronts than slices
+    const int rounds = ns_env >= 1 ? ns_env : 4;
+    const int Gt = NT + rounds * ncu * wg_per_cu;
+    const int max_per_tile = (B + nw - 1) / nw;
+    // items | task table | longest lists | scratch (2 NT) | tile weights | tickets
+    if ((rc = ensure(c, ws.plan, sizeof(uint4) * (size_t)nb + sizeof(uint32_t) * ((size_t)Gt + 5 * (size_t)NT)))) return rc;
+    uint4* d_items = (uint4*)ws.plan.p;
+    uint32_t* d_task = (uint32_t*)(d_items + nb);
+    uint32_t* d_tile_m = d_task + Gt;
+    uint32_t* d_scr = d_tile_m + NT;
+    uint32_t* d_tile_w = d_scr + 2 * (size_t)NT;
+    uint32_t* d_ctr = d_tile_w + NT;
+    const uint32_t prio_ref = (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 2000), 0x7fffffff);   // lists this long go first at the issue arbiter
+    // lists of a few thousand entries or more go to the register-row kernel (when every tile's rows fit its 240 registers): 13
+    // cycles per entry instead of 29, which shortens the launch's longest chains AND moves more entries per second; shorter lists
+    // would not repay the 240 row loads per list (measured at 128 x 1 Mev: threshold 4 096 ... 8 192 1.40-1.45 ms, 16 384 1.53, none 2.44)
+    static const long long hot_env = [] { const char* e = getenv("EORB_SLOT_HOT_MIN"); return e ? atoll(e) : -1ll; }();
+    uint32_t hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev * nparts / 16000), 0x7fffffff) : 0u;
+    const long long hot_over = c->dbg_slot_hot_min >= 0 ? c->dbg_slot_hot_min : hot_env;
+    // (never below 64: the register-row kernel's tail load reads the 64 bytes that END at the list's end; 0 = that kernel off)
+    if (hot_over >= 0) hot_min = (c->sl_null <= SL_HOT_NROWS && hot_over > 0) ? (uint32_t)std::min<long long>(std::max<long long>(hot_over, 64), 0x7fffffff) : 0u;
+    const uint32_t hot_cap = c->dbg_slot_hot_cap > 0 ? (uint32_t)std::min(c->dbg_slot_hot_cap, kHotCap) : (uint32_t)kHotCap;
+    if ((rc = ensure(c, ws.hot, sizeof(HotDesc) * (size_t)kHotBuckets * kHotCap + 256))) return rc;
+    uint32_t* d_hot_cnt = (uint32_t*)ws.hot.p;                           // 16 bucket counts | ticket (at word 32) | overflow count (33) | descriptors (from byte 256)
+    HotDesc* d_hot_items = (HotDesc*)((char*)ws.hot.p + 256);
     {
         ProfScope ps(c, "ev_bin");
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
-        const int NTp = (NT + 1) & ~1;
         // the tile ranges of all sensor pixels + one set of counters per wavefront in the LDS of one workgroup per CU?
         const size_t nsrc = (size_t)c->lut_w * (size_t)c->lut_h;
         const size_t lds_c = 4 * ((nsrc + 2) / 2) + (size_t)kCountWaves * NTp * 2;
         static const int cl_env = [] { const char* e = getenv("EORB_SLOT_COUNT_LDS"); return e ? atoi(e) : 1; }();
         if (nchunks && cl_env && TX <= 127 && TY <= 127 && lds_c <= 159 * 1024) {
-            const int ncu_c = sl_ncu(c);
             const uint16_t* d_geo = (const uint16_t*)((const char*)c->sl_tab.p + sizeof(uint2) * nsrc);
-            const int g = std::min(ncu_c, (nchunks + kCountWaves - 1) / kCountWaves);
+            const int g = std::min(ncu, (nchunks + kCountWaves - 1) / kCountWaves);
 #define SL_COUNT(ST, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_count_lds_kernel<ST>, 159 * 1024))) return rc; \
-                sl_count_lds_kernel<ST><<<g, 64 * kCountWaves, lds_c, c->stream>>>(d_ev, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt); } while (0)
+                sl_count_lds_kernel<ST><<<g, 64 * kCountWaves, lds_c, M>>>(d_ev, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt); } while (0)
             if (stride == 16) SL_COUNT(16, 0); else if (stride == 4) SL_COUNT(4, 1); else SL_COUNT(-4, 2);
 #undef SL_COUNT
         }
         else if (nchunks) {
-            if (stride == 16) sl_count_kernel<16><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
-            else if (stride == 4) sl_count_kernel<4><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
-            else sl_count_kernel<-4><<<nchunks, 256, lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+            if (stride == 16) sl_count_kernel<16><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+            else if (stride == 4) sl_count_kernel<4><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+            else sl_count_kernel<-4><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
         }
-        sl_scan_kernel<<<B, 1024, 0, c->stream>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
-        // ---- the gather's plan needs the scan's counts only: it runs on the side stream BESIDE the scatter (50 us of single-block
-        //      kernels off the critical path); the side stream goes on to the long lists once the scatter's entries are there ----
-        if (!c->sl_side) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            hipStream_t st = nullptr; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-            bool ok = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi) == hipSuccess;
-            for (int i = 0; ok && i < 4; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
-            if (!ok) {                                   // all or nothing: a half-made side stream must not be used by a later call
-                for (int i = 0; i < 4; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
-                if (st) (void)hipStreamDestroy(st);
-                return set_err(c, EORB_E_HIP, "side stream / events");
-            }
-            c->sl_side = st; c->sl_ev_fork = ev[0]; c->sl_ev_join = ev[1]; c->sl_ev_plan = ev[2]; c->sl_ev_scat = ev[3];
-        }
-        lds_g = (size_t)(c->sl_null + 1) * 256;
-        const int wg_per_cu = std::max(1, (int)((160 * 1024) / lds_g));
-        static const int nw_env = [] { const char* e = getenv("EORB_SLOT_WAVES"); return e ? atoi(e) : 0; }();
-        static const int ns_env = [] { const char* e = getenv("EORB_SLOT_ROUNDS"); return e ? atoi(e) : 0; }();
-        // four wavefronts per SIMD saturate the vector ALUs and leave every list about full single-wave speed (measured: 8 per SIMD
-        // process the same entries per second, each list at half the pace)
-        nw = std::min(16, std::max(1, 16 / wg_per_cu));
-        if (nw_env >= 1 && nw_env <= 16) nw = nw_env;
-        nw = std::min(nw, std::max(1, B));
-        const int ncu = sl_ncu(c);
-        ncu_g = ncu;
-        // one task per tile position plus a few rounds of spare ones shared out by weight; a position never gets more wavefronts than slices
-        const int rounds = ns_env >= 1 ? ns_env : 4;
-        G = NT + rounds * ncu * wg_per_cu;
-        const int max_per_tile = (B + nw - 1) / nw;
-        if ((rc = ensure(c, c->sl_plan, sizeof(uint4) * (size_t)nb + sizeof(uint32_t) * ((size_t)G + 3 * (size_t)NT)))) return rc;
-        d_items = (uint4*)c->sl_plan.p;
-        d_task = (uint32_t*)(d_items + nb);
-        uint32_t* d_tile_m = d_task + G;
-        uint32_t* d_scr = d_tile_m + NT;
-        prio_ref = (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 2000), 0x7fffffff);   // lists this long go first at the issue arbiter
-        // lists of a few thousand entries or more go to the register-row kernel (when every tile's rows fit its 240 registers): 13
-        // cycles per entry instead of 29, which shortens the launch's longest chains AND moves more entries per second; shorter lists
-        // would not repay the 240 row loads per list (measured at 128 x 1 Mev: threshold 4 096 ... 8 192 1.40-1.45 ms, 16 384 1.53, none 2.44)
-        static const long long hot_env = [] { const char* e = getenv("EORB_SLOT_HOT_MIN"); return e ? atoll(e) : -1ll; }();
-        hot_min = c->sl_null <= SL_HOT_NROWS ? (uint32_t)std::min<int64_t>(std::max<int64_t>(4096, nev / 16000), 0x7fffffff) : 0u;
-        const long long hot_over = c->dbg_slot_hot_min >= 0 ? c->dbg_slot_hot_min : hot_env;
-        // (never below 64: the register-row kernel's tail load reads the 64 bytes that END at the list's end; 0 = that kernel off)
-        if (hot_over >= 0) hot_min = (c->sl_null <= SL_HOT_NROWS && hot_over > 0) ? (uint32_t)std::min<long long>(std::max<long long>(hot_over, 64), 0x7fffffff) : 0u;
-        const uint32_t hot_cap = c->dbg_slot_hot_cap > 0 ? (uint32_t)std::min(c->dbg_slot_hot_cap, kHotCap) : (uint32_t)kHotCap;
-        if ((rc = ensure(c, c->sl_hot, sizeof(HotDesc) * (size_t)kHotBuckets * kHotCap + 256))) return rc;
-        d_hot_cnt = (uint32_t*)c->sl_hot.p;                                  // 16 bucket counts | ticket (at word 32) | descriptors (from byte 256)
-        d_hot_items = (HotDesc*)((char*)c->sl_hot.p + 256);
-        EORB_HIP(c, hipEventRecord(c->sl_ev_fork, c->stream));
-        EORB_HIP(c, hipStreamWaitEvent(c->sl_side, c->sl_ev_fork, 0));
-        EORB_HIP(c, hipMemsetAsync(c->sl_hot.p, 0, 256, c->sl_side));
-        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, c->sl_side>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, TX, hot_min, d_nslots, d_rowbase,
+        sl_scan_kernel<<<B, 1024, 0, M>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
+        // ---- the gather's plan needs the scan's counts only: it runs on its own stream BESIDE the scatter (50 us of single-block
+        //      kernels off the critical path) ----
+        EORB_HIP(c, hipEventRecord(E[0], M));
+        EORB_HIP(c, hipStreamWaitEvent(P, E[0], 0));
+        EORB_HIP(c, hipMemsetAsync(ws.hot.p, 0, 256, P));
+        sl_plan_kernel<<<NT, 256, sizeof(uint32_t) * 2 * (size_t)B, P>>>(d_tile_cnt, d_tile_base, d_slice_eb, B, NT, TX, hot_min, d_nslots, d_rowbase,
                                                                                d_items, d_tile_w, d_tile_m, d_ctr, d_hot_cnt, d_hot_items, hot_cap);
-        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, c->sl_side>>>(d_tile_w, d_tile_m, NT, G, max_per_tile, d_scr, d_task, d_hot_cnt, hot_cap);
-        EORB_HIP(c, hipEventRecord(c->sl_ev_plan, c->sl_side));
+        sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, P>>>(d_tile_w, d_tile_m, NT, Gt, max_per_tile, d_scr, d_task, d_hot_cnt, hot_cap);
+        EORB_HIP(c, hipEventRecord(E[1], P));
         // ---- the scatter (form and chunk size chosen up front: sl_choose_scatter) ----
         if (nchunks && sc.rank) {
 #define SL_SCAT(ST, NW, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_scatter_rank_kernel<ST, NW>, 159 * 1024))) return rc; \
-                sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, sc.lds, c->stream>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
-                                                                                   d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p); } while (0)
+                sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, sc.lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
+                                                                                   d_slice_eb, d_segbase, d_tile_base, (uint8_t*)ws.entries.p); } while (0)
             if (sc.waves == 16) { if (stride == 16) SL_SCAT(16, 16, 3); else if (stride == 4) SL_SCAT(4, 16, 4); else SL_SCAT(-4, 16, 5); }
             else { if (stride == 16) SL_SCAT(16, 8, 6); else if (stride == 4) SL_SCAT(4, 8, 7); else SL_SCAT(-4, 8, 8); }
 #undef SL_SCAT
         }
         else if (nchunks)
-            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, sc.lds, c->stream>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
-                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)c->entries.p);
+            sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, sc.lds, M>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
+                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)ws.entries.p);
         EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
     }
+    EORB_HIP(c, hipEventRecord(E[2], M));                                // the part's entries are in place
     {
-        ProfScope ps(c, "ev_gather");
-        SlotGather P{d_task, d_items, (const uint8_t*)c->entries.p, d_nslots, d_rowbase, (const float*)c->sl_rows.p,
-                     d_tile_w, d_ctr, d_f32, d_minmax_enc, d_info, (int*)c->status.p, B, W, H, TX, NT, c->sl_null, prio_ref, nullptr};
+        SlotGather Pg{d_task, d_items, (const uint8_t*)ws.entries.p, d_nslots, d_rowbase, (const float*)c->sl_rows.p,
+                      d_tile_w, d_ctr, d_f32, d_minmax_enc, d_info, (int*)c->status.p, B, W, H, TX, NT, c->sl_null, prio_ref, nullptr};
 #ifdef EORB_SLOT_TRACE
-        if ((rc = ensure(c, c->sl_trace, sizeof(unsigned long long) * 6 * 16 * (size_t)G + 64))) return rc;
-        EORB_HIP(c, hipMemsetAsync(c->sl_trace.p, 0, sizeof(unsigned long long) * 6 * 16 * (size_t)G + 64, c->stream));
-        P.trace = (unsigned long long*)c->sl_trace.p + 8;
-        c->sl_trace_n = (long long)G * 16;
+        if ((rc = ensure(c, c->sl_trace, sizeof(unsigned long long) * 6 * 16 * (size_t)Gt + 64))) return rc;
+        EORB_HIP(c, hipMemsetAsync(c->sl_trace.p, 0, sizeof(unsigned long long) * 6 * 16 * (size_t)Gt + 64, M));
+        Pg.trace = (unsigned long long*)c->sl_trace.p + 8;
+        c->sl_trace_n = (long long)Gt * 16;
 #endif
         if ((rc = sl_optin(c, 9, (const void*)sl_gather_kernel, 160 * 1024))) return rc;
         if (hot_min) {
-            // the long lists on the side (high-priority) stream beside the gather: they need the scatter's entries
+            // the long lists on the high-priority stream beside the gather: they need the scatter's entries and the plan's descriptors
             static const int hw_env = [] { const char* e = getenv("EORB_SLOT_HOT_WAVES"); return e ? atoi(e) : 0; }();
-            const int hw = hw_env > 0 ? hw_env : 8 * ncu_g;               // two per SIMD: all of its registers
-            EORB_HIP(c, hipEventRecord(c->sl_ev_scat, c->stream));
-            EORB_HIP(c, hipStreamWaitEvent(c->sl_side, c->sl_ev_scat, 0));
-            sl_hot_kernel<<<hw, 64, 0, c->sl_side>>>(d_hot_cnt, d_hot_cnt + 32, d_hot_items, kHotCap, (const float*)c->sl_rows.p, (const uint8_t*)c->entries.p,
-                                                     d_f32, d_minmax_enc, W, H);
+            const int hw = hw_env > 0 ? hw_env : 8 * ncu;                 // two per SIMD: all of its registers
+            EORB_HIP(c, hipStreamWaitEvent(Hs, E[2], 0));
+            EORB_HIP(c, hipStreamWaitEvent(Hs, E[1], 0));
+            sl_hot_kernel<<<hw, 64, 0, Hs>>>(d_hot_cnt, d_hot_cnt + 32, d_hot_items, kHotCap, (const float*)c->sl_rows.p, (const uint8_t*)ws.entries.p,
+                                             d_f32, d_minmax_enc, W, H);
         }
-        EORB_HIP(c, hipEventRecord(c->sl_ev_join, c->sl_side));
-        EORB_HIP(c, hipStreamWaitEvent(c->stream, c->sl_ev_plan, 0));       // the plan and the task table
-        sl_gather_kernel<<<G, 64 * nw, lds_g, c->stream>>>(P);
-        EORB_HIP(c, hipStreamWaitEvent(c->stream, c->sl_ev_join, 0));       // (whatever the side stream did is done before the images are read)
+        EORB_HIP(c, hipEventRecord(E[3], Hs));
+        if (G != M) EORB_HIP(c, hipStreamWaitEvent(G, E[2], 0));
+        EORB_HIP(c, hipStreamWaitEvent(G, E[1], 0));                       // the plan and the task table
+        {
+            ProfScope ps(c, "ev_gather", G);
+            sl_gather_kernel<<<Gt, 64 * nw, lds_g, G>>>(Pg);
+        }
+        EORB_HIP(c, hipEventRecord(E[4], G));
         EORB_LAUNCH_CHECK(c, "sl_gather_kernel");
     }
+    return EORB_OK;
+}
+
+// The slot form for B slices of raw events (no polarity, Gaussian stamp).  On request a batch runs as two halves: the LDS gather and
+// the register-row kernel of the first half (vector-ALU / LDS-read / scalar-ALU bound) beside the count and scatter passes of the
+// second (HBM- and LDS-atomic bound).  Returns kSlotDeclined (> 0, nothing launched) when the batch's shape does not
+// fit: the caller goes on with the batch pipeline.
+int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
+                        float* d_f32, uint32_t* d_minmax_enc)
+{
+    const int NT = TX * TY;
+    const int64_t nev = h_offsets[B] - h_offsets[0];
+    static const int rank_env0 = [] { const char* e = getenv("EORB_SLOT_RANK"); return e ? atoi(e) : 1; }();
+    const bool rank_allowed = c->sl_rank_ok == 1 && (c->dbg_slot_rank < 0 ? rank_env0 != 0 : c->dbg_slot_rank != 0);
+    static const int halves_env = [] { const char* e = getenv("EORB_SLOT_HALVES"); return e ? atoi(e) : -1; }();
+    const int halves_opt = c->dbg_slot_halves >= 0 ? c->dbg_slot_halves : halves_env;
+    // Off by default.  Measured at 128 x 1 Mev: 3.94 ms per step in halves against 3.34 in one part -- each half's gather phase is bounded
+    // from below by the serial chain of its own longest list (200 000 entries x 13 cycles = 1.1 ms on the register-row kernel's
+    // wavefront), so two halves pay that chain twice; the overlap of the second half's binning with the first half's gather does not
+    // buy it back.  The parts machinery stays (test hook "slot_halves", EORB_SLOT_HALVES=1) for batches without such chains.
+    const int nparts = (halves_opt > 0 && B >= 2) ? 2 : 1;
+    const int64_t per_slice = nev / B;
+    SlotScatterChoice sc;
+    // sl_plan_kernel keeps two words per slice in LDS and ranks a position's lists by an O(B^2) loop, sl_scan_kernel is one workgroup
+    // per slice: batches of more than 2 048 slices take the batch pipeline; so do tile grids whose count rows do not fit the LDS
+    if (B > 2048 || (size_t)NT * 4 > 64 * 1024 || !sl_choose_scatter(c, NT, per_slice, rank_allowed, &sc)) return kSlotDeclined;
+    for (int b = 0; b < B; b++) {
+        const int64_t s = h_offsets[b], e = h_offsets[b + 1];
+        if (e < s) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
+        if ((e - s) * 4 + (int64_t)NT * 16 >= (int64_t)1 << 31) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one slice", (long long)(e - s));
+    }
+    int rc;
+    if ((rc = sl_streams(c))) return rc;
+    c->sl_calls++;
+    c->sl_last_rank = sc.rank ? 1 : 0; c->sl_last_chunk = sc.chunk; c->sl_last_parts = nparts;
+    const int B0 = nparts == 2 ? B / 2 : B;
+    for (int part = 0; part < nparts; part++) {
+        const int b0 = part ? B0 : 0, nb_ = part ? B - B0 : B0;
+        if ((rc = slots_part(c, c->sl_ws[part], part, nparts, d_events, stride, h_offsets + b0, nb_, W, H, TX, TY,
+                             d_f32 + (size_t)b0 * W * H, d_minmax_enc + 2 * (size_t)b0, sc))) return rc;
+    }
+    // whatever the other streams did is done before the images are read (streams are in order: the last part's events cover the first's)
+    hipEvent_t* E = c->sl_ev + 5 * (nparts - 1);
+    EORB_HIP(c, hipStreamWaitEvent(c->stream, E[3], 0));
+    if (nparts > 1) EORB_HIP(c, hipStreamWaitEvent(c->stream, E[4], 0));
     return EORB_OK;
 }
 

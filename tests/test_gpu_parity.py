@@ -1200,7 +1200,7 @@ def _raw_batch(fe, raws, W, H, mx, my, opts=(), check=True, sigma=1.0):
     imgs = np.zeros((B, H, W), np.uint8); c.download(imgs, d_img)
     p32, mm = fb.last_f32(B)
     f32 = np.zeros((B, H, W), np.float32); c.download(f32, p32)
-    cnt = {k: c.debug_counter(k) for k in ("slot_calls", "slot_flags", "slot_hot_items", "slot_hot_overflow", "slot_scatter_form", "slot_chunk", "slot_rank_ok")}
+    cnt = {k: c.debug_counter(k) for k in ("slot_calls", "slot_flags", "slot_hot_items", "slot_hot_overflow", "slot_scatter_form", "slot_chunk", "slot_rank_ok", "slot_parts")}
     for p_ in (d_ev, d_img, d_kp, d_n):
         c.dev_free(p_)
     c.close()
@@ -1237,7 +1237,8 @@ def test_slot_hot_bucket_overflow_many_slices(oracle, fe):
     """The slot form at the benchmark's batch shape in small: 160 slices whose long lists compete for the register-row kernel's length
     buckets.  (a) the buckets as shipped; (b) buckets of 8 lists (test hook "slot_hot_cap"): the lists that find their bucket full are
     handed back to the LDS gather (ev_slots.hip, sl_plan_kernel: `the bucket is full`), counted by "slot_hot_overflow"; (c) the
-    register-row kernel off: 160 lists per tile position through the LDS gather's longest-first tickets.  Every slice of every run:
+    register-row kernel off: 160 lists per tile position through the LDS gather's longest-first tickets; (d) the batch as two halves on
+    their own workspaces and streams (the second half binned under the first half's gather).  Every slice of every run:
     float image, running extremes and u8 image against the oracle, bit for bit (the `for k` loop of src/Event/EventConversion.cc:231-263)."""
     W, H, B = 240, 180, 160
     mx, my = _maps(W, H)
@@ -1246,10 +1247,11 @@ def test_slot_hot_bucket_overflow_many_slices(oracle, fe):
     for name, opts, expect in (
             ("buckets as shipped", (("gather_form", 4), ("slot_hot_min", 256)), dict(hot=True, over=False)),
             ("buckets of 8", (("gather_form", 4), ("slot_hot_min", 256), ("slot_hot_cap", 8)), dict(hot=True, over=True)),
-            ("register-row kernel off", (("gather_form", 4), ("slot_hot_min", 0)), dict(hot=False, over=False))):
+            ("register-row kernel off", (("gather_form", 4), ("slot_hot_min", 0)), dict(hot=False, over=False)),
+            ("two halves in flight", (("gather_form", 4), ("slot_hot_min", 256), ("slot_halves", 1)), dict(hot=True, over=False))):
         got = _raw_batch(fe, raws, W, H, mx, my, opts)
         cnt = got[3]
-        assert cnt["slot_calls"] == 1 and cnt["slot_flags"] == 0, (name, cnt)
+        assert cnt["slot_calls"] == 1 and cnt["slot_flags"] == 0 and cnt["slot_parts"] == (2 if "halves" in name else 1), (name, cnt)
         assert (cnt["slot_hot_items"] > 0) == expect["hot"] and (cnt["slot_hot_overflow"] > 0) == expect["over"], (name, cnt)
         if expect["over"]:
             assert cnt["slot_hot_items"] <= 16 * 8, cnt

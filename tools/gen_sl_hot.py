@@ -19,6 +19,7 @@ def process(buf0, lab=None):
             a("s_lshr_b32 s33, %s, %d" % (s, sh)); a("s_set_gpr_idx_idx s33"); a("v_add_f32 v241, v0, v241")
 
 # ---- prologue ----
+a("s_setprio 3")                                                           # a long list is a serial chain: its wave goes first at the issue arbiter
 a("v_mbcnt_lo_u32_b32 v242, -1, 0"); a("v_mbcnt_hi_u32_b32 v242, -1, v242")
 a("v_and_b32 v243, 7, v242"); a("v_lshrrev_b32 v244, 3, v242"); a("v_lshlrev_b32 v242, 2, v242")
 a("v_mov_b32 v246, v243"); a("v_mov_b32 v247, v244")                      # lx, ly
