@@ -349,16 +349,41 @@ def profile_inputs(key):
     return (e, "%s (sources %s)" % (PROFILE_INPUTS, doc["src_hash"])) if e else (None, "%s has no entry %s" % (PROFILE_INPUTS, key))
 
 
+# HIP-event scope -> the kernel it brackets (one launch per scope where a single name is given)
+SCOPE_KERNEL = {"ev_gather": "eorb::sl_gather_kernel", "ev_count": "eorb::sl_count_lds_kernel", "ev_scan": "eorb::sl_scan_kernel",
+                "ev_scatter": "eorb::sl_scatter_rank_kernel", "ev_dedupe": "eorb::dd_insert_kernel", "orb_octree": "eorb::octree_kernel",
+                "orb_fast_cells": "eorb::fast_cells_kernel", "orb_blur": "eorb::blur_kernel", "orb_brief": "eorb::brief_kernel",
+                "orb_orient": "eorb::orient_kernel", "orb_assemble": "eorb::assemble_kernel", "bf_knn2": "eorb::bf_knn2_kernel",
+                "klt_track": "eorb::klt_track_kernel (+ pyramid kernels)", "search_init": "eorb::win_cand_kernel<0> + eorb::win_resolve_kernel<0>",
+                "search_proj_last": "eorb::win_cand_kernel<1> + eorb::win_resolve_kernel<1>", "orb_pyr": "eorb::pyr_level0_kernel + eorb::pyr_resize_kernel"}
+GPU_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: peak engine clock
+N_CU = 256
+
+
+def issue_floor(entries, hot_entries, measured_gather_ms):
+    """What the two gather kernels' binding pipes allow for the entries they walked: the LDS-row gather reads one 256-byte
+    row per entry = 2 LDS-array cycles per entry and CU (ds_read_b32 of 64 lanes at 128 B/clk; tools/mb/slot_loop.hip measures 2.05);
+    the register-row kernel issues 1.75 scalar instructions per entry on the CU's scalar ALU (s_set_gpr_idx_idx per entry + 3 shifts per 4)."""
+    lds_entries = max(entries - hot_entries, 0)
+    f_lds = lds_entries * 2.0 / (N_CU * GPU_CLOCK_HZ) * 1e3
+    f_salu = hot_entries * 1.75 / (N_CU * GPU_CLOCK_HZ) * 1e3
+    return {"entries_per_step": int(entries), "register_row_entries": int(hot_entries), "lds_row_entries": int(lds_entries),
+            "sl_gather_kernel": {"lds_cycles_per_entry": 2, "floor_ms": f_lds},
+            "sl_hot_kernel": {"salu_instructions_per_entry": 1.75, "floor_ms": f_salu},
+            "floor_ms": max(f_lds, f_salu), "measured_ms": measured_gather_ms,
+            "note": "the two kernels run side by side (LDS array / scalar ALU): the stage cannot beat the larger floor; measured = the live launch time of sl_gather_kernel, which the register-row kernel overlaps"}
+
+
 def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, inputs_key=None):
     """`roofline` of the dominant kernel: algorithmic bytes per launch / its live HIP-event launch time; HBM traffic and the
     issue-pipe utilisation of that kernel from the rocprofv3 passes of the same sources (see PROFILE_INPUTS)."""
     tot = {k: v[0] for k, v in prof.items()}
-    dom = max(tot, key=tot.get)
+    dom = max(tot, key=tot.get)                     # (slot form: every accumulation scope brackets ONE kernel's launch)
     ms, launches = prof[dom]
     avg_ms = ms / max(launches, 1)
     ub = unit_bytes_by_kernel(dom)
     achieved = ub * units_per_launch / (avg_ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+    r = {"bound": "hbm", "kernel": SCOPE_KERNEL.get(dom, dom), "scope": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": ub * units_per_launch}
     if inputs_key:
         e, src = profile_inputs(inputs_key)
@@ -375,7 +400,8 @@ def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, inputs_key=
                                         "SQ_WAIT_ANY / SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; " + src}
             stage = sum(v["traffic_bytes"] for k, v in e["scopes"].items() if k.startswith("ev_"))
             alg = unit_bytes_by_kernel("ev_") * units_per_launch
-            r["stage"] = {"what": "all accumulation kernels (ev_*) of a step", "traffic": stage, "algorithmic": alg, "ratio": stage / alg,
+            if stage > 0 and dom.startswith("ev_"):
+              r["stage"] = {"what": "all accumulation kernels (ev_*) of a step", "traffic": stage, "algorithmic": alg, "ratio": stage / alg,
                           "scopes": {k: {"live_ms": prof[k][0] / max(prof[k][1], 1), "rocprof_ms": v["rocprof_ms"], "traffic": v["traffic_bytes"],
                                          "algorithmic_GBps": alg / (prof[k][0] / max(prof[k][1], 1) * 1e-3) / 1e9,
                                          **({"issue_by_kernel": v["issue_by_kernel"]} if "issue_by_kernel" in v else {}),
@@ -656,7 +682,7 @@ def run_batch(env):
 
     # Inside the timed steps only the accumulation scopes are bracketed by HIP events (the roofline's kernels: two event records per
     # scope and call cost a step of 14 scopes 0.1-0.18 ms of 3.6); the other scopes are timed in a few further steps afterwards.
-    TIMED_SCOPES = ("ev_bin", "ev_gather", "ev_dedupe")
+    TIMED_SCOPES = ("ev_count", "ev_scan", "ev_scatter", "ev_bin", "ev_gather", "ev_dedupe")
 
     def arm_prof():
         if not a.no_prof:
@@ -722,6 +748,11 @@ def run_batch(env):
             ext_bytes = 7.0 * P + 1321.0 * float(nk.mean())  # 7*P + 1321*K per frame
             r, per_step = roofline_of(prof, a.steps, lambda k: acc_bytes if k.startswith("ev_") else ext_bytes, B,
                                       "%s:%s:%d:%d" % (a.workload, a.input, B, NEV))
+            if a.workload == "w2" and use_raw:
+                c0 = seqs[0][0]
+                ent, hot = c0.debug_counter("slot_entries"), c0.debug_counter("slot_hot_entries")
+                if ent > 0 and "ev_gather" in prof:
+                    r["issue_floor"] = issue_floor(ent, max(hot, 0), prof["ev_gather"][0] / max(prof["ev_gather"][1], 1))
             r["note"] = ("the accumulation is bound by instruction issue (vector ALU / LDS), not by HBM: every pixel adds its taps in event "
                          "order (49 taps per 16 B event, DESIGN.md section 4); `issue` carries the utilisation of the binding pipes, the HBM "
                          "fraction is reported as the contract asks")
@@ -889,7 +920,7 @@ def run_frames(env):
         if prof:
             ext_bytes = 7.0 * P + 1321.0 * K
             bfb = (2000 + 2000) * 32 + 2000 * 16.0
-            r, per_step = roofline_of(prof, a.steps, lambda k: bfb if k.startswith("bf_") else ext_bytes, 1)
+            r, per_step = roofline_of(prof, a.steps, lambda k: bfb if k.startswith("bf_") else ext_bytes, 1, "%s:frames" % a.workload)
             r["note"] = ("one frame per call: the working set (< 1 MB) lives in L2 / Infinity Cache and every kernel is launch- or "
                          "latency-bound; the HBM fraction is reported as the contract asks; kernel times from a second, profiled "
                          "pass over the same steps")
@@ -984,7 +1015,7 @@ def run_chain(env):
         out["ms_per_chunk"] = dt / a.steps / nchunks * 1e3
         if prof:
             acc_bytes = 16.0 * CH + W * H * 9.0
-            r, per_step = roofline_of(prof, 1, lambda k: acc_bytes, 1)
+            r, per_step = roofline_of(prof, 1, lambda k: acc_bytes, 1, "w1full:chain")
             r["note"] = ("one chunk per call: every kernel is launch- or latency-bound (a 2 000-event chunk is 0.4 MB of algorithmic traffic); "
                          "the HBM fraction is reported as the contract asks; kernel times from a second, profiled pass")
             out["roofline"] = r

@@ -100,7 +100,7 @@ struct eorb_ctx {
     // sl_gstream = the LDS gather of one half while the next half is binned; five events per part
     static constexpr int kSlotEvents = 10;
     hipStream_t sl_side = nullptr, sl_pstream = nullptr, sl_gstream = nullptr; hipEvent_t sl_ev[kSlotEvents] = {};
-    int sl_last_parts = 0;
+    int sl_last_parts = 0, sl_last_nb[2] = {0, 0};      // the last slot-form call: its parts, (slices x tiles) of each
     int sl_ok = 0, sl_null = 0, sl_rank_ok = -1;
     int ncu = 0;                                 // compute units of c->device (per context: a second context may sit on another GPU)
     unsigned sl_attr = 0;                        // bit per kernel instantiation whose dynamic-LDS opt-in was made on c->device
@@ -158,6 +158,7 @@ struct eorb_ctx {
     int dbg_slot_rank = -1;                      // slot form: -1 by the device check / EORB_SLOT_RANK, 0 ballot scatter, 1 rank scatter (if the check passed)
     long long dbg_slot_hot_min = -1;             // slot form: list length from which the register-row kernel takes a list (-1: default / EORB_SLOT_HOT_MIN)
     int dbg_slot_hot_cap = 0;                    // slot form: lists per length bucket of the register-row kernel (0: kHotCap), to force the overflow branch
+    int dbg_slot_hot_waves = 0;                  // slot form: wavefronts of the register-row kernel (0: default / EORB_SLOT_HOT_WAVES)
     int dbg_slot_halves = -1;                    // slot form: -1 by the batch's shape / EORB_SLOT_HALVES, 0 one part, 1 two halves whatever the shape
 };
 

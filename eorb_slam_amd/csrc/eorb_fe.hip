@@ -309,6 +309,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "slot_hot_min")) { c->dbg_slot_hot_min = value; return EORB_OK; }
     if (!strcmp(name, "slot_hot_cap")) { c->dbg_slot_hot_cap = value; return EORB_OK; }
     if (!strcmp(name, "slot_halves")) { c->dbg_slot_halves = value; return EORB_OK; }
+    if (!strcmp(name, "slot_hot_waves")) { c->dbg_slot_hot_waves = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
 
@@ -337,6 +338,32 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
             uint32_t h[16];
             if (hipMemcpyAsync(h, c->sl_ws[part].hot.p, sizeof(h), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
             for (int i = 0; i < 16; i++) n += h[i];      // (sl_tasks_kernel capped the counts at the buckets' capacity)
+        }
+        return n;
+    }
+    if (!strcmp(name, "slot_entries") || !strcmp(name, "slot_hot_entries")) {
+        // list entries the last slot-form call's gather kernels walked: all of them / those of the lists handed to the register-row kernel
+        // (synchronises; reads the scan's per-(slice, tile) counts and the hot descriptors back)
+        const bool hot = name[5] == 'h';
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+        long long n = 0;
+        for (int part = 0; part < std::max(c->sl_last_parts, 1); part++) {
+            const eorb_ctx::SlotWS& w = c->sl_ws[part];
+            if (hot) {
+                if (!w.hot.p) continue;
+                uint32_t cnt[16];
+                if (hipMemcpy(cnt, w.hot.p, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                for (int b = 0; b < 16; b++) {
+                    std::vector<uint32_t> d(8 * (size_t)cnt[b]);
+                    if (cnt[b] && hipMemcpy(d.data(), (const char*)w.hot.p + 256 + (size_t)b * 8192 * 32, 32 * (size_t)cnt[b], hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                    for (uint32_t k = 0; k < cnt[b]; k++) n += d[8 * (size_t)k + 2];
+                }
+            } else {
+                if (!w.tile_order.p || !c->sl_last_nb[part]) continue;
+                std::vector<uint32_t> t((size_t)c->sl_last_nb[part]);
+                if (hipMemcpy(t.data(), w.tile_order.p, sizeof(uint32_t) * t.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                for (uint32_t v : t) n += v;
+            }
         }
         return n;
     }

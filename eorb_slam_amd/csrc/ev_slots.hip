@@ -28,6 +28,7 @@
 #include "dev_math.h"
 #include "sl_hot_asm.h"
 #include <algorithm>
+#include <memory>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -1130,6 +1131,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
     const size_t sc_bytes = (sizeof(int) * (size_t)(B + 1) + 7) & ~(size_t)7;
     const size_t eb_bytes = sizeof(int64_t) * (size_t)B;
     const int nb = B * NT;
+    c->sl_last_nb[part] = nb;
     int rc;
     if ((rc = ensure(c, ws.chunks, cd_bytes + sc_bytes + eb_bytes))) return rc;
     const size_t cnt_bytes = (sizeof(uint16_t) * (size_t)std::max(nchunks, 1) * NT + 15) & ~(size_t)15;
@@ -1201,7 +1203,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
     uint32_t* d_hot_cnt = (uint32_t*)ws.hot.p;                           // 16 bucket counts | ticket (at word 32) | overflow count (33) | descriptors (from byte 256)
     HotDesc* d_hot_items = (HotDesc*)((char*)ws.hot.p + 256);
     {
-        ProfScope ps(c, "ev_bin");
+        std::unique_ptr<ProfScope> ps(new ProfScope(c, "ev_count"));      // (one scope per kernel of the binning: count, scan, scatter)
         const size_t lds = sizeof(uint32_t) * (size_t)NT;
         // the tile ranges of all sensor pixels + one set of counters per wavefront in the LDS of one workgroup per CU?
         const size_t nsrc = (size_t)c->lut_w * (size_t)c->lut_h;
@@ -1220,7 +1222,9 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
             else if (stride == 4) sl_count_kernel<4><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
             else sl_count_kernel<-4><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
         }
+        ps.reset(); ps.reset(new ProfScope(c, "ev_scan"));
         sl_scan_kernel<<<B, 1024, 0, M>>>(d_slice_c0, d_segcnt, NT, d_segbase, d_tile_cnt, d_tile_base);
+        ps.reset();
         // ---- the gather's plan needs the scan's counts only: it runs on its own stream BESIDE the scatter (50 us of single-block
         //      kernels off the critical path) ----
         EORB_HIP(c, hipEventRecord(E[0], M));
@@ -1231,6 +1235,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
         sl_tasks_kernel<<<1, 1024, sizeof(uint32_t) * (size_t)NT, P>>>(d_tile_w, d_tile_m, NT, Gt, max_per_tile, d_scr, d_task, d_hot_cnt, hot_cap);
         EORB_HIP(c, hipEventRecord(E[1], P));
         // ---- the scatter (form and chunk size chosen up front: sl_choose_scatter) ----
+        ProfScope ps2(c, "ev_scatter");
         if (nchunks && sc.rank) {
 #define SL_SCAT(ST, NW, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_scatter_rank_kernel<ST, NW>, 159 * 1024))) return rc; \
                 sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, sc.lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
@@ -1258,7 +1263,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
         if (hot_min) {
             // the long lists on the high-priority stream beside the gather: they need the scatter's entries and the plan's descriptors
             static const int hw_env = [] { const char* e = getenv("EORB_SLOT_HOT_WAVES"); return e ? atoi(e) : 0; }();
-            const int hw = hw_env > 0 ? hw_env : 8 * ncu;                 // two per SIMD: all of its registers
+            const int hw = c->dbg_slot_hot_waves > 0 ? c->dbg_slot_hot_waves : (hw_env > 0 ? hw_env : 8 * ncu);     // two per SIMD: all of its registers
             EORB_HIP(c, hipStreamWaitEvent(Hs, E[2], 0));
             EORB_HIP(c, hipStreamWaitEvent(Hs, E[1], 0));
             sl_hot_kernel<<<hw, 64, 0, Hs>>>(d_hot_cnt, d_hot_cnt + 32, d_hot_items, kHotCap, (const float*)c->sl_rows.p, (const uint8_t*)ws.entries.p,

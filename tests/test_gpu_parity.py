@@ -1112,12 +1112,12 @@ def test_profiling_scopes_can_be_selected(fe):
     c.prof_reset(); c.prof_only(()); c.prof_enable(True)
     run(); run(); c.sync(); c.prof_enable(False)
     every = c.prof_results()
-    assert {"ev_bin", "ev_gather", "orb_fast_cells", "orb_octree", "search_init"} <= set(every)
+    assert {"ev_count", "ev_scan", "ev_scatter", "ev_gather", "orb_fast_cells", "orb_octree", "search_init"} <= set(every)
     assert all(cnt == 2 and ms > 0 for ms, cnt in every.values()), every
-    c.prof_reset(); c.prof_only(("ev_bin", "ev_gather")); c.prof_enable(True)
+    c.prof_reset(); c.prof_only(("ev_scatter", "ev_gather")); c.prof_enable(True)
     run(); c.sync(); c.prof_enable(False)
     some = {k: v for k, v in c.prof_results().items() if v[1]}
-    assert set(some) == {"ev_bin", "ev_gather"} and all(cnt == 1 and ms > 0 for ms, cnt in some.values()), some
+    assert set(some) == {"ev_scatter", "ev_gather"} and all(cnt == 1 and ms > 0 for ms, cnt in some.values()), some
     c.prof_only(())
     for p_ in (d_ev, d_img, d_kp, d_desc, d_n, d_m, d_nm):
         c.dev_free(p_)

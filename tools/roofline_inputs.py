@@ -5,7 +5,8 @@ sources it was measured on; bench.py reports the numbers only while that hash eq
 
 usage: roofline_inputs.py <out.json> <key> <stats_dir> <fetch_dir> <write_dir> <sq1_dir> <sq2_dir> -- <bench command line>
 key = "<workload>:<input>:<batch>:<events>".  Counters (separate --pmc passes, MI355X_MICROARCH.md):
-  traffic  = FETCH_SIZE x 1024 x 2 (gfx950: FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64 bytes) + WRITE_SIZE x 1024
+  traffic  = FETCH_SIZE x 1024 x f + WRITE_SIZE x 1024, f = 2 for the kernels whose reads are wide coalesced streams (gfx950: FETCH_SIZE counts
+             their 128-byte requests as 64 bytes; list WIDE_READ below), 1 for gathers / list walkers / per-keypoint kernels
   cycles    = GRBM_GUI_ACTIVE / 8                                          (summed over the 8 XCDs)
   valu_frac = SQ_INSTS_VALU x 4 cycles / (cycles x 1024 SIMDs)             (a wave64 VALU instruction holds its SIMD's ALU for 4 cycles)
   lds_frac  = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs)                       (LDS-array cycles)
@@ -15,12 +16,26 @@ key = "<workload>:<input>:<batch>:<events>".  Counters (separate --pmc passes, M
 import collections, csv, glob, hashlib, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCOPES = {   # HIP-event scope of bench.py -> kernels it brackets
+SCOPES = {   # HIP-event scope of bench.py -> kernels it brackets (substrings of the demangled names)
     "ev_gather": ["sl_gather_kernel", "sl_hot_kernel", "ev_gather_"],
-    "ev_bin": ["sl_chunks_kernel", "sl_count_kernel", "sl_count_lds_kernel", "sl_scan_kernel", "sl_scatter", "sl_plan_kernel", "sl_tasks_kernel", "ev_count_kernel", "ev_scan_kernel",
-               "ev_scatter", "ev_tile_hist", "ev_tile_order"],
-    "ev_normalize": ["ev_normalize_kernel"], "ev_dedupe": ["dd_insert_kernel"],
+    # slot form: one scope per kernel of the binning (the plan kernels run on their own stream beside the scatter)
+    "ev_count": ["sl_chunks_kernel", "sl_count_kernel", "sl_count_lds_kernel"], "ev_scan": ["sl_scan_kernel"],
+    "ev_scatter": ["sl_scatter", "sl_plan_kernel", "sl_tasks_kernel"],
+    # batch pipeline (polarity, wide stamps, sparse slices)
+    "ev_bin": ["ev_count_kernel", "ev_scan_kernel", "ev_scatter", "ev_tile_hist", "ev_tile_order"],
+    "ev_normalize": ["ev_normalize_kernel"], "ev_dedupe": ["dd_insert_kernel"], "ev_stamp_tables": ["ev_pre_kernel", "ev_stamp_kernel", "ev_src_info_kernel"],
+    "orb_pyr": ["pyr_level0_kernel", "pyr_resize_kernel"], "orb_fast_cells": ["fast_cells_kernel"], "orb_octree": ["octree_kernel"],
+    "orb_orient": ["orient_kernel"], "orb_blur": ["blur_kernel"], "orb_brief": ["brief_kernel"], "orb_assemble": ["assemble_kernel"],
+    "search_init": ["win_cand_kernel<0>", "win_resolve_kernel<0>", "win_histo_kernel<0>"],
+    "search_proj_last": ["win_cand_kernel<1>", "win_resolve_kernel<1>", "win_histo_kernel<1>"],
+    "bf_knn2": ["bf_knn2_kernel"], "klt_track": ["klt_"],
+    "ev_focus": ["ev_focus_"], "ev_cvnormalize": ["ev_mm_reset", "ev_minmax_final", "ev_cvnormalize"], "ev_warp_se3": ["ev_warp_se3_kernel"], "ev_warp_se2": ["ev_warp_se2_kernel"],
 }
+# FETCH_SIZE counts the 128-byte requests of WIDE COALESCED reads as 64 bytes on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section): the
+# x 2 applies to the kernels whose reads are such streams -- the passes over the event records and over whole images -- not to the
+# gathers / list walkers / per-keypoint kernels, whose reads are scalar loads, dword gathers or L2-resident tables
+WIDE_READ = ["sl_count", "sl_scatter", "sl_chunks", "ev_count_kernel", "ev_scatter", "dd_insert", "ev_unpack4", "ev_normalize", "ev_pre_kernel",
+             "pyr_level0", "pyr_resize", "blur_kernel", "ev_undistort", "txt_", "ev_minmax_final", "ev_cvnormalize", "ev_warp", "fe_publish"]
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
@@ -62,8 +77,9 @@ def main():
             continue
         e = {"kernels": {}, "traffic_bytes": 0.0, "rocprof_ms": 0.0}
         for k in ks:
-            fetch = cf.get(k, {}).get("FETCH_SIZE", 0.0) * 1024 * 2; write = cw.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
-            e["kernels"][k.split("(")[0]] = {"avg_ms": st[k][0], "calls": st[k][1], "fetch_bytes": fetch, "write_bytes": write}
+            ff = 2 if any(p in k for p in WIDE_READ) else 1
+            fetch = cf.get(k, {}).get("FETCH_SIZE", 0.0) * 1024 * ff; write = cw.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
+            e["kernels"][k.split("(")[0]] = {"avg_ms": st[k][0], "calls": st[k][1], "fetch_bytes": fetch, "fetch_factor": ff, "write_bytes": write}
             e["traffic_bytes"] += fetch + write; e["rocprof_ms"] += st[k][0]
         def issue_of(k):
             a, b = c1.get(k, {}), c2.get(k, {})
@@ -86,8 +102,8 @@ def main():
             e["concurrent"] = True
             e["rocprof_ms"] = max(st[k][0] for k in ks)
             e["issue_by_kernel"] = {k.split("(")[0]: {kk: vv for kk, vv in (issue_of(k) or {}).items() if kk != "counters"} for k in ks}
-        if scope == "ev_bin" and any("sl_scatter" in k for k in ks):
-            # sl_plan_kernel and sl_tasks_kernel run on the side stream beside the scatter: their traffic counts, their time does not
+        if scope == "ev_scatter" and any("sl_scatter" in k for k in ks):
+            # sl_plan_kernel and sl_tasks_kernel run on their own stream beside the scatter: their traffic counts, their time does not
             e["rocprof_ms"] = sum(st[k][0] for k in ks if "sl_plan_kernel" not in k and "sl_tasks_kernel" not in k)
             e["beside_the_scatter"] = [k.split("(")[0] for k in ks if "sl_plan_kernel" in k or "sl_tasks_kernel" in k]
         scopes[scope] = e
