@@ -1785,6 +1785,15 @@ int eorb_fe_run_batch_raw4_dev(eorb_ctx* c, const eorb_raw_event4* d_events, con
     return fe_run_batch_common(c, d_events, 3, h_offsets, B, d_images, d_kps, d_desc, d_nkps, d_matches12, d_nmatches);
 }
 
+int eorb_fe_run_batch_raw2_dev(eorb_ctx* c, const eorb_raw_event2* d_events, const int64_t* h_offsets, int B,
+                               uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                               int32_t* d_matches12, int32_t* d_nmatches)
+{
+    if (c && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "fe_run_batch_raw2: eorb_set_undistort_maps not called");
+    if (c && c->fe_configured && c->fe.pol) return set_err(c, EORB_E_ARG, "fe_run_batch_raw2: the 2-byte record carries no polarity");
+    return fe_run_batch_common(c, d_events, 4, h_offsets, B, d_images, d_kps, d_desc, d_nkps, d_matches12, d_nmatches);
+}
+
 int eorb_fe_run_batch_dev(eorb_ctx* c, const eorb_event16* d_events, const int64_t* h_offsets, int B,
                           uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                           int32_t* d_matches12, int32_t* d_nmatches)

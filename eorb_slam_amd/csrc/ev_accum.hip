@@ -2101,6 +2101,17 @@ int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64
     return EORB_OK;
 }
 
+// eorb_raw_event2 (the sensor pixel's linear index y * LW + x; 0xffff = no event: the 2-byte wire record of polarity-free images on
+// sensors of at most 65 535 pixels) -> eorb_raw_event
+__global__ void ev_unpack2_kernel(const uint16_t* __restrict__ in, int64_t n, int LW, eorb_raw_event* __restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t q = in[i];
+        eorb_raw_event e; e.x = (uint16_t)(q == 0xffffu ? 0xffffu : q % (uint32_t)LW); e.y = (uint16_t)(q == 0xffffu ? 0xffffu : q / (uint32_t)LW); e.p = 1u; e.t = 0.0;
+        out[i] = e;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
@@ -2122,6 +2133,8 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     const int dup = R * R;
     const bool hashed = raw == 2;                        // (recursion of the block below: d_events are 4-byte hashed records)
     const bool packed4 = raw == 3;                       // 4-byte sensor records (eorb_raw_event4)
+    const bool packed2 = raw == 4;                       // 2-byte sensor records (eorb_raw_event2: y * LW + x)
+    if (packed2 && (int64_t)c->lut_w * c->lut_h > 65535) return set_err(c, EORB_E_ARG, "ev_accumulate: 2-byte records need a sensor of at most 65 535 pixels (the maps are %dx%d)", c->lut_w, c->lut_h);
     if (!raw && !mode_count && c->dbg_gather_form != 1 && h_offsets[B] - h_offsets[0] >= c->dbg_dd_min && c->dbg_dd_min > 0) {
         // float events in bulk: tabulate their distinct positions, continue on the raw path (see dd_insert_kernel)
         const int64_t n0 = h_offsets[B] - h_offsets[0];
@@ -2195,7 +2208,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
     {
         // one or a few small slices of raw events (the live per-slice call): no binning at all, K2d
         const int64_t nev0 = h_offsets[B] - h_offsets[0];
-        if (!hashed && !packed4 && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
+        if (!hashed && !packed4 && !packed2 && !mode_count && B <= 4 && (c->dbg_gather_form == 3 || (c->dbg_gather_form == 0 && nev0 <= 16384))) {
             int64_t beg[kDirectSlices], end[kDirectSlices];
             for (int b = 0; b < B; b++) {
                 if (h_offsets[b + 1] < h_offsets[b]) return set_err(c, EORB_E_ARG, "ev_accumulate: offsets not monotone");
@@ -2219,7 +2232,7 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                 }
                 // > 0: the batch's shape does not fit the slot form (tile grids beyond the scatter's LDS, e.g. VGA-class sensors; more than
                 // 2 048 slices) and nothing was launched: the batch pipeline below serves it
-                if ((rc = ev_slots_accumulate(c, d_events, hashed ? -4 : (packed4 ? 4 : 16), h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc)) < 0) return rc;
+                if ((rc = ev_slots_accumulate(c, d_events, hashed ? -4 : (packed4 ? 4 : (packed2 ? 2 : 16)), h_offsets, B, W, H, TX, TY, d_f32, d_minmax_enc)) < 0) return rc;
                 if (rc == 0) {
                     if (normalized && d_u8) {
                         ProfScope ps(c, "ev_normalize");
@@ -2232,12 +2245,13 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
             }
         }
     }
-    if (packed4) {
+    if (packed4 || packed2) {
         // the other forms read 16-byte records: widen the batch's events once and go on with those
         const int64_t n0 = h_offsets[B] - h_offsets[0];
         int rc;
         if ((rc = ensure(c, c->ev16, sizeof(eorb_raw_event) * (size_t)std::max<int64_t>(n0, 1)))) return rc;
-        if (n0 > 0) ev_unpack4_kernel<<<(int)std::min<int64_t>((n0 + 255) / 256, 65536), 256, 0, c->stream>>>((const uint32_t*)d_events + h_offsets[0], n0, (eorb_raw_event*)c->ev16.p);
+        if (n0 > 0 && packed2) ev_unpack2_kernel<<<(int)std::min<int64_t>((n0 + 255) / 256, 65536), 256, 0, c->stream>>>((const uint16_t*)d_events + h_offsets[0], n0, c->lut_w, (eorb_raw_event*)c->ev16.p);
+        else if (n0 > 0) ev_unpack4_kernel<<<(int)std::min<int64_t>((n0 + 255) / 256, 65536), 256, 0, c->stream>>>((const uint32_t*)d_events + h_offsets[0], n0, (eorb_raw_event*)c->ev16.p);
         EORB_LAUNCH_CHECK(c, "ev_unpack4_kernel");
         std::vector<int64_t> off(B + 1);
         for (int b = 0; b <= B; b++) off[b] = h_offsets[b] - h_offsets[0];

@@ -182,7 +182,14 @@ __global__ __launch_bounds__(256) void sl_chunks_kernel(SliceOffsets S, int B, i
 }
 
 // ---- K1a: entries of every (chunk, tile) -----------------------------------------------------------------------------------------
-// (stride: 16 = eorb_raw_event, 4 = eorb_raw_event4, -4 = hashed records; a template parameter in the two hot kernels)
+// (stride: 16 = eorb_raw_event, 4 = eorb_raw_event4, 2 = eorb_raw_event2, -4 = hashed records; a template parameter in the two hot kernels)
+// the word of record k that names the sensor pixel: the first dword of the 16- / 4-byte records, the 16-bit linear index of the 2-byte one
+template <int stride>
+__device__ __forceinline__ uint32_t sl_load_rec(const unsigned char* e, int k)
+{
+    if (stride == 2) { const uint32_t v = *(const uint16_t*)(e + (size_t)k * 2); return v == 0xffffu ? 0x7fffffffu : v; }      // (0xffff: no event)
+    return *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride));
+}
 template <int stride>
 __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
                                                        const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
@@ -192,14 +199,16 @@ __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __r
     const ChunkDesc cd = chunks[blockIdx.x];
     for (int i = threadIdx.x; i < NT; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed, 2-byte eorb_raw_event2
     const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
-    const bool hashed = stride < 0;          // stride -4: 4-byte records { row of the position's table entry | polarity << 31 } (float events in bulk)
+    // records that name a table row instead of (x, y): stride -4 = { row of the position's table entry | polarity << 31 } (float events in
+    // bulk), stride 2 = the sensor pixel's linear index y * LW + x (the 2-byte wire record)
+    const bool hashed = stride < 0 || stride == 2;
     constexpr int U = 8;
     for (int k0 = threadIdx.x; k0 < cd.n; k0 += blockDim.x * U) {
         uint32_t xy[U], rg[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride)) : 0xffffffffu; }
+        for (int u = 0; u < U; u++) { const int k = k0 + u * blockDim.x; xy[u] = k < cd.n ? sl_load_rec<stride>(e, k) : 0xffffffffu; }
         // (whole 16-byte records per lane, non-temporal, were measured: 0.69 ms instead of 0.62)
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -251,11 +260,11 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
         for (int k0 = lane; k0 < cd.n; k0 += 64 * U) {
             uint32_t xy[U], g[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int k = k0 + u * 64; xy[u] = k < cd.n ? *(const uint32_t*)(e + (size_t)k * (size_t)astride) : 0xffffffffu; }
+            for (int u = 0; u < U; u++) { const int k = k0 + u * 64; xy[u] = k < cd.n ? sl_load_rec<stride>(e, k) : 0xffffffffu; }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t x = xy[u] & xmask, y = xy[u] >> 16, row = xy[u] & 0x7fffffffu;      // (hashed records: the row itself)
-                if (stride < 0) g[u] = row < (uint32_t)LW * (uint32_t)LH ? tab[row] : kNoGeo;
+                if (stride < 0 || stride == 2) g[u] = row < (uint32_t)LW * (uint32_t)LH ? tab[row] : kNoGeo;
                 else g[u] = (x < (uint32_t)LW && y < (uint32_t)LH) ? tab[y * (uint32_t)LW + x] : kNoGeo;
             }
 #pragma unroll
@@ -352,9 +361,9 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
     uint16_t* loff = cntw + kSlotScatWaves * NTp;                     // NT + 1 (+ 1 pad)
     uint32_t* gbase = (uint32_t*)(loff + NTp + 2);                    // NT
     for (int i = tid; i < kSlotScatWaves * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
-    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed, 2-byte eorb_raw_event2
     const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
-    const bool hashed = stride < 0;          // stride -4: 4-byte records { row of the position's table entry | polarity << 31 } (float events in bulk)
+    const bool hashed = stride < 0 || stride == 2;          // records that name a table row (see sl_count_kernel)
     const int Q = (((cd.n + kSlotScatWaves - 1) / kSlotScatWaves) + 63) & ~63;
     const int S = Q >> 6;
     constexpr int SMAX = 4;
@@ -366,7 +375,8 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         const int k = wave * Q + s * 64 + lane;
-        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride)) : 0xffffffffu;
+        uint32_t q = 0xffffffffu;
+        if (s < S && k < cd.n) q = stride == 2 ? sl_load_rec<2>(e, k) : *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride));
         const int x = q == 0xffffffffu ? 0xffff : (int)(q & xmask), y = (int)(q >> 16);
         if (hashed) { const uint32_t row = q & 0x7fffffffu; rsrc[s] = (row != 0x7fffffffu && row < (uint32_t)LW * (uint32_t)LH) ? row : 0xffffffffu; }
         else rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
@@ -495,9 +505,9 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
     uint16_t* loff = cntw + NW * NTp;                     // NT + 1 (+ 1 pad)
     uint8_t* sorted = (uint8_t*)(loff + NTp + 2);                     // chunk_cap * 4: the entry bytes in tile-sorted order
     for (int i = tid; i < NW * NTp / 2; i += NTHR) ((uint32_t*)cntw)[i] = 0u;
-    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed
+    const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)(stride < 0 ? -stride : stride);      // 16-byte eorb_raw_event, 4-byte eorb_raw_event4, 4-byte hashed, 2-byte eorb_raw_event2
     const uint32_t xmask = stride == 4 ? 0x7fffu : 0xffffu;
-    const bool hashed = stride < 0;          // stride -4: 4-byte records { row of the position's table entry | polarity << 31 } (float events in bulk)
+    const bool hashed = stride < 0 || stride == 2;          // records that name a table row (see sl_count_kernel)
     const int Q = (((cd.n + NW - 1) / NW) + 63) & ~63;
     const int S = Q >> 6;
     constexpr int SMAX = 4;
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
 #pragma unroll
     for (int s = 0; s < SMAX; s++) {
         const int k = wave * Q + s * 64 + lane;
-        const uint32_t q = (s < S && k < cd.n) ? *(const uint32_t*)(e + (size_t)k * (size_t)(stride < 0 ? -stride : stride)) : 0xffffffffu;
+        const uint32_t q = (s < S && k < cd.n) ? sl_load_rec<stride>(e, k) : 0xffffffffu;
         const int x = q == 0xffffffffu ? 0xffff : (int)(q & xmask), y = (int)(q >> 16);
         if (hashed) { const uint32_t row = q & 0x7fffffffu; rsrc[s] = (row != 0x7fffffffu && row < (uint32_t)LW * (uint32_t)LH) ? row : 0xffffffffu; }
         else rsrc[s] = (x < LW && y < LH) ? (uint32_t)y * (uint32_t)LW + x : 0xffffffffu;
@@ -1214,12 +1224,13 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
             const int g = std::min(ncu, (nchunks + kCountWaves - 1) / kCountWaves);
 #define SL_COUNT(ST, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_count_lds_kernel<ST>, 159 * 1024))) return rc; \
                 sl_count_lds_kernel<ST><<<g, 64 * kCountWaves, lds_c, M>>>(d_ev, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt); } while (0)
-            if (stride == 16) SL_COUNT(16, 0); else if (stride == 4) SL_COUNT(4, 1); else SL_COUNT(-4, 2);
+            if (stride == 16) SL_COUNT(16, 0); else if (stride == 4) SL_COUNT(4, 1); else if (stride == 2) SL_COUNT(2, 10); else SL_COUNT(-4, 2);
 #undef SL_COUNT
         }
         else if (nchunks) {
             if (stride == 16) sl_count_kernel<16><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
             else if (stride == 4) sl_count_kernel<4><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
+            else if (stride == 2) sl_count_kernel<2><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
             else sl_count_kernel<-4><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
         }
         ps.reset(); ps.reset(new ProfScope(c, "ev_scan"));
@@ -1240,8 +1251,8 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
 #define SL_SCAT(ST, NW, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_scatter_rank_kernel<ST, NW>, 159 * 1024))) return rc; \
                 sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, sc.lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
                                                                                    d_slice_eb, d_segbase, d_tile_base, (uint8_t*)ws.entries.p); } while (0)
-            if (sc.waves == 16) { if (stride == 16) SL_SCAT(16, 16, 3); else if (stride == 4) SL_SCAT(4, 16, 4); else SL_SCAT(-4, 16, 5); }
-            else { if (stride == 16) SL_SCAT(16, 8, 6); else if (stride == 4) SL_SCAT(4, 8, 7); else SL_SCAT(-4, 8, 8); }
+            if (sc.waves == 16) { if (stride == 16) SL_SCAT(16, 16, 3); else if (stride == 4) SL_SCAT(4, 16, 4); else if (stride == 2) SL_SCAT(2, 16, 11); else SL_SCAT(-4, 16, 5); }
+            else { if (stride == 16) SL_SCAT(16, 8, 6); else if (stride == 4) SL_SCAT(4, 8, 7); else if (stride == 2) SL_SCAT(2, 8, 12); else SL_SCAT(-4, 8, 8); }
 #undef SL_SCAT
         }
         else if (nchunks)

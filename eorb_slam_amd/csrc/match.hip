@@ -407,6 +407,7 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
     uint8_t* obs = (uint8_t*)(m21 + c2);                              // c2: KIND 1/2 "slot holds an observed map point"
     uint8_t* qobs = obs + c2;                                         // cq: KIND 1/2 mp_obs of the query's map point
     unsigned int* claim = (unsigned int*)(((uintptr_t)(qobs + cq) + 3) & ~(uintptr_t)3);   // c2: earliest query of the round matching the candidate
+    int* fx = (int*)(claim + c2);                                     // KIND 0 fixed point: 4 x cq (match / distance of the next sweep, chain links, distances)
     int32_t* M12 = A.matches12 ? A.matches12 + (size_t)pair * cq : nullptr;
     const uint64_t* gent = A.ent + (size_t)pair * A.ecap;
     const uint32_t total = min(A.total[pair], (uint32_t)A.ecap);
@@ -431,9 +432,10 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
     if (tid < 32) histo[tid] = 0;
     if (tid == 0) sh_nm[0] = 0;
     int over_any = 0;
-    if (KIND == 1) for (int i = tid; i < NQ; i += blockDim.x) over_any |= (A.cnt[(size_t)pair * cq + i] == kWinOver) ? 1 : 0;
-    const bool fixpoint = KIND == 1 && !__syncthreads_or(over_any);        // (also the barrier behind the LDS set-up)
-    if (KIND != 1) __syncthreads();
+    if (KIND != 2) for (int i = tid; i < NQ; i += blockDim.x) over_any |= (A.cnt[(size_t)pair * cq + i] == kWinOver) ? 1 : 0;
+    const bool no_over = KIND != 2 && !__syncthreads_or(over_any);         // (also the barrier behind the LDS set-up)
+    const bool fixpoint = KIND == 1 && no_over, fixpoint0 = KIND == 0 && no_over;
+    if (KIND == 2) __syncthreads();
 
     if (fixpoint) {
         // SearchByProjection(cur, last / KeyFrame): a query takes the FIRST entry of its sorted list whose candidate is free (no
@@ -473,6 +475,59 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
             if (pick >= 0) atomicMax(&st_a[pick], q);
             if (pick >= 0 && blocks) { obs[pick] = 1; claim[pick] = 0xFFFFFFFFu; }
             __syncthreads();
+        }
+        if (nm) atomicAdd(&sh_nm[0], nm);
+    } else if (fixpoint0) {
+        // SearchForInitialization (:714-831): query q skips a candidate whose vMatchedDistance is <= its distance (:755), i.e. a candidate
+        // that an EARLIER query matched at a distance <= its own; among the rest its best / second best decide whether it matches its
+        // best (:770-772), which then carries q's distance and loses its previous owner (:774-781).  So q's outcome is a function of the
+        // matches of the queries before it: D_q[i2] = min { dist(q', i2) : q' < q matched i2 }, and the walk is the fixed point of
+        // "every query decides against the D of the previous sweep's matches", iterated from "nobody matched": query 0 is final after
+        // one sweep, every sweep finalises at least the first query that still changed; dependency chains are short in practice (a
+        // handful of sweeps for 1 000 queries, where the round-based walk below took a round per conflict: 49 us).  Per candidate the
+        // sweep's matchers hang on a chain (head in st_a, links in fx): the minimum over the earlier ones is a walk of one or two links.
+        int* mcur = match_at; int* mnew = fx; int* dcur = fx + cq; int* dnew = fx + 2 * cq; int* nxt = fx + 3 * cq;
+        for (int i = tid; i < N2; i += blockDim.x) st_a[i] = -1;              // chain heads
+        for (int i = tid; i < NQ; i += blockDim.x) dcur[i] = 0;
+        __syncthreads();
+        for (int sweep = 0; sweep <= NQ; sweep++) {
+            int changed = 0;
+            for (int q = tid; q < NQ; q += blockDim.x) {
+                const uint32_t c = cnts[q], o = offs[q];
+                uint64_t k0 = ~0ull, k1 = ~0ull;
+                int found = 0;
+                for (uint32_t j = 0; j < c && found < 2; j++) {
+                    const uint32_t e = o + j;
+                    const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
+                    const int idx = (int)((key >> 8) & 0xffffffu), dist = (int)(key >> 44);
+                    int D = 0x7fffffff;                                       // vMatchedDistance[idx] as query q finds it
+                    for (int p2 = st_a[idx]; p2 >= 0; p2 = nxt[p2]) if (p2 < q) D = min(D, dcur[p2]);
+                    if (D > dist) { if (found == 0) k0 = key; else k1 = key; found++; }
+                }
+                int m = -1, d = 0;
+                if (k0 != ~0ull) {
+                    const int bestDist = (int)(k0 >> 44), bestDist2 = (k1 == ~0ull) ? 0x7fffffff : (int)(k1 >> 44);
+                    if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * A.nnratio) { m = (int)((k0 >> 8) & 0xffffffu); d = bestDist; }   // :770-772
+                }
+                mnew[q] = m; dnew[q] = d;
+                changed |= (m != mcur[q]) ? 1 : 0;
+            }
+            if (!__syncthreads_or(changed)) break;                            // (mnew == mcur: the chains already describe the final matches)
+            { int* t = mcur; mcur = mnew; mnew = t; t = dcur; dcur = dnew; dnew = t; }
+            for (int i = tid; i < N2; i += blockDim.x) st_a[i] = -1;
+            __syncthreads();
+            for (int q = tid; q < NQ; q += blockDim.x) { const int m = mcur[q]; if (m >= 0) nxt[q] = atomicExch(&st_a[m], q); }
+            __syncthreads();
+        }
+        // the walk's final state: every matched query pushed its rotation-histogram entry (match_at), a candidate belongs to the LAST of
+        // its matchers (each later one came with a strictly smaller distance and took it over, :774-781)
+        if (mcur != match_at) { for (int q = tid; q < NQ; q += blockDim.x) match_at[q] = mcur[q]; }
+        __syncthreads();
+        int nm = 0;
+        for (int i = tid; i < N2; i += blockDim.x) {
+            int owner = -1;
+            for (int p2 = st_a[i]; p2 >= 0; p2 = nxt[p2]) owner = max(owner, p2);
+            if (owner >= 0) { M12[owner] = i; nm++; }
         }
         if (nm) atomicAdd(&sh_nm[0], nm);
     } else if (wave == 0) {
@@ -662,7 +717,7 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
 static size_t win_cand_lds(int cap2, int wcap) { return ((size_t)cap2 * (32 + 4 + 4 + 4) + (size_t)4 * wcap * 8 + 15) & ~(size_t)15; }
 static size_t win_resolve_lds(int cap2, int capq)
 {
-    return ((size_t)kWinLdsEntries * 8 + (size_t)capq * (4 + 4 + 4 + 1) + (32 + 4) * 4 + (size_t)cap2 * (4 + 2 + 1 + 4) + 4 + 15) & ~(size_t)15;
+    return ((size_t)kWinLdsEntries * 8 + (size_t)capq * (4 + 4 + 4 + 1 + 16) + (32 + 4) * 4 + (size_t)cap2 * (4 + 2 + 1 + 4) + 8 + 15) & ~(size_t)15;
 }
 
 // smallest d in [lo, 256] for which pred(d) holds, else 257 (= keep every candidate)

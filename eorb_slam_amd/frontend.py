@@ -126,6 +126,12 @@ def pack_raw_events4(raw):
     return (raw["x"].astype(np.uint32) & 0x7fff) | ((raw["p"] != 0).astype(np.uint32) << 15) | (raw["y"].astype(np.uint32) << 16)
 
 
+def pack_raw_events2(raw, LW):
+    """eorb_raw_event[] (16 B) -> eorb_raw_event2[] (u16: y * LW + x): the wire record of polarity-free images on sensors of <= 65 535 pixels"""
+    raw = np.ascontiguousarray(raw, RAW_DTYPE)
+    return (raw["y"].astype(np.uint32) * np.uint32(LW) + raw["x"].astype(np.uint32)).astype(np.uint16)
+
+
 class EvImConverter:
     """EORB_SLAM::EvImConverter (include/Event/EventConversion.h:45-75), static-method style."""
 
@@ -860,11 +866,11 @@ class FrontEndBatch:
     def run_dev(self, d_events, offsets, d_images=None, d_kps=None, d_desc=None, d_nkps=None, d_m12=None, d_nm=None, raw=False):
         """d_* are raw device pointers (ints), e.g. torch tensors' data_ptr(); offsets: int64[B+1] on the host.
         raw=True: d_events holds eorb_raw_event records (sensor pixels; set_undistort_maps first); raw=4: eorb_raw_event4 records
-        (pack_raw_events4)."""
+        (pack_raw_events4); raw=2: eorb_raw_event2 records (pack_raw_events2)."""
         offsets = np.ascontiguousarray(offsets, np.int64)
         B = len(offsets) - 1
         vp = lambda x: C.c_void_p(x) if x else None
-        fn = (self.ctx.L.eorb_fe_run_batch_raw4_dev if raw == 4 else self.ctx.L.eorb_fe_run_batch_raw_dev) if raw else self.ctx.L.eorb_fe_run_batch_dev
+        fn = (self.ctx.L.eorb_fe_run_batch_raw4_dev if raw == 4 else (self.ctx.L.eorb_fe_run_batch_raw2_dev if raw == 2 else self.ctx.L.eorb_fe_run_batch_raw_dev)) if raw else self.ctx.L.eorb_fe_run_batch_dev
         self.ctx.check(fn(self.ctx.h, vp(d_events), _p(offsets), B, vp(d_images), vp(d_kps),
                           vp(d_desc), vp(d_nkps), vp(d_m12), vp(d_nm)))
 

@@ -66,6 +66,9 @@ typedef struct {
  * polarity, src/Event/EventConversion.cc:173-269): x | p << 15 | y << 16, sensor sizes up to 32767 x 65535.  A quarter of the bytes
  * on the host -> HBM link (bench.py --stream). */
 typedef uint32_t eorb_raw_event4;
+/* the 2-byte wire record: the sensor pixel's linear index y * LW + x in the maps of eorb_set_undistort_maps (0xffff = no event); for
+ * polarity-free images on sensors of at most 65 535 pixels, which read nothing else of an event */
+typedef uint16_t eorb_raw_event2;
 
 /* cv::KeyPoint (28 B): what ORBextractor::operator() fills (_keypoints) */
 typedef struct {
@@ -402,6 +405,12 @@ int eorb_fe_run_batch_raw_dev(eorb_ctx* ctx, const eorb_raw_event* d_events, con
 
 /* as eorb_fe_run_batch_raw_dev, for 4-byte sensor records (eorb_raw_event4) resident in HBM */
 int eorb_fe_run_batch_raw4_dev(eorb_ctx* ctx, const eorb_raw_event4* d_events, const int64_t* h_offsets, int B,
+                               uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
+                               int32_t* d_matches12, int32_t* d_nmatches);
+
+/* as eorb_fe_run_batch_raw_dev, for 2-byte sensor records (eorb_raw_event2) resident in HBM: polarity-free images on sensors of at
+ * most 65 535 pixels (a DAVIS 240x180 has 43 200) never read more of an event than its pixel */
+int eorb_fe_run_batch_raw2_dev(eorb_ctx* ctx, const eorb_raw_event2* d_events, const int64_t* h_offsets, int B,
                                uint8_t* d_images, eorb_keypoint* d_kps, uint8_t* d_desc, int32_t* d_nkps,
                                int32_t* d_matches12, int32_t* d_nmatches);
 

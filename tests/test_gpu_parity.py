@@ -1309,19 +1309,19 @@ def test_raw_dense_batch_on_vga_class_sensors(oracle, fe):
 
 
 def test_packed_wire_records_equal_raw_records(oracle, fe):
-    """eorb_raw_event4 (x | p << 15 | y << 16, a quarter of the bytes on the host -> HBM link) through the batch entry point: the
-    images, keypoints and descriptors of the 16-byte records, for a dense batch (slot lists read the 4-byte records directly), a
-    sparse one and a polarity image (both widen the records first)."""
+    """eorb_raw_event4 (x | p << 15 | y << 16, a quarter of the bytes on the host -> HBM link) and eorb_raw_event2 (y * LW + x, an
+    eighth) through the batch entry points: the images, keypoints and descriptors of the 16-byte records, for a dense batch (slot
+    lists read the short records directly), a sparse one and a polarity image (both widen the records first; 4-byte only)."""
     W, H = 240, 180
     mx, my = _maps(W, H)
     for n, B, pol in ((60000, 3, False), (1500, 3, False), (30000, 2, True)):
         raws = [synth.shapes_events(n, W, H, seed=600 + b, motion=0.4, undistort=True, return_raw=True)[1] for b in range(B)]
         outs = []
-        for fmt in (True, 4):
+        for fmt in ((True, 4) if pol else (True, 4, 2)):           # (the 2-byte record carries no polarity)
             fb = fe.FrontEndBatch(W, H, 1.0, pol, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=n)
             c, cap = fb.ctx, fb.cap
             fe.EvImConverter.set_undistort_maps(mx, my, True, ctx=c)
-            blob = np.concatenate(raws) if fmt is True else np.concatenate([fe.pack_raw_events4(r) for r in raws])
+            blob = np.concatenate(raws) if fmt is True else np.concatenate([fe.pack_raw_events4(r) if fmt == 4 else fe.pack_raw_events2(r, W) for r in raws])
             d_ev = c.dev_alloc(blob.nbytes); c.upload(d_ev, blob)
             d_img = c.dev_alloc(B * W * H); d_kp = c.dev_alloc(B * cap * 28); d_desc = c.dev_alloc(B * cap * 32); d_n = c.dev_alloc(B * 4)
             fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * n, d_img, d_kp, d_desc, d_n, raw=fmt)
@@ -1334,12 +1334,13 @@ def test_packed_wire_records_equal_raw_records(oracle, fe):
             for p_ in (d_ev, d_img, d_kp, d_desc, d_n):
                 c.dev_free(p_)
             c.close()
-        a, b = outs
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (n, B, pol)
-        for x, y in zip(a[2] + a[3], b[2] + b[3]):
-            assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        a = outs[0]
+        for b in outs[1:]:
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (n, B, pol)
+            for x, y in zip(a[2] + a[3], b[2] + b[3]):
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
         ev0 = oracle.undistort_events(raws[0], mx, my, W, H, True, 1.0)
-        assert np.array_equal(oracle.ev2im_gauss(ev0, W, H, 1.0, pol, True, fast=True)[1], b[0][0])
+        assert np.array_equal(oracle.ev2im_gauss(ev0, W, H, 1.0, pol, True, fast=True)[1], outs[-1][0][0])
 
 
 def test_raw_gather_four_column_variant(oracle):
