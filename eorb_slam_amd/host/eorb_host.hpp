@@ -9,7 +9,9 @@
 // what a C++ host without OpenCV uses, and what tests/test_host_cpp.py compiles.  Everything runs on the GPU
 // through libeorb_fe.so; there is no CPU path here.
 #pragma once
+#include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -192,6 +194,133 @@ struct EventDataStore {
         out.resize(n);
         return out;
     }
+};
+
+// The data path of EORB_SLAM::EvImBuilder::Track (src/Event/EvImBuilder.cpp:1300-1515) over the one-call seams: per chunk of
+// l1ChunkSize events the event image and its frame -- INIT: detect-only ORBextractor + ELK_Tracker::setRefImage (init :568-592);
+// TRACKING: ELK_Tracker::trackAndMatchCurrImage (KLT_Tracker.cpp:215-234) + refineTrackedPts (:104-151) -- the window-size rule
+// (resolveEvWinSize :209-232) and, on a dispatch, generateMCImage (:1146-1247) + isMcImageGood (:260-267).  The optimisers that hand
+// generateMCImage its poses, step()'s two-view refinement, the IMU and the L2 queue stay with the caller, as in the reference.
+// (Python twin with the same members: eorb_slam_amd/frontend.py::EvImBuilder; tests/test_gpu_chain.py checks that one against the
+// oracle's chain chunk by chunk, tests/test_host_cpp.py checks this one against the separate seams.)
+class EvImBuilder {
+public:
+    enum TrackState { IDLE, INIT, TRACKING };
+    struct Params {            // Event.* of Examples/Event/EvETHZ.yaml:178-208
+        int imWidth = 240, imHeight = 180; unsigned l1ChunkSize = 2000; int l1NumLoop = 3; bool l1FixedWinSz = false, continTracking = true;
+        float maxPixelDisp = 3.f, l1WinOverlap = 0.5f, l1ImSigma = 1.f; double minEvGenRate = 1.0;
+        int maxNumPts = 400, fastTh = 0, imMargin = 9; eorb_klt_params klt{23, 1, 10, 0.03, 1e-4f};
+    };
+    struct MciPoses { const eorb_se3_motion* dp = nullptr; const eorb_se3_motion* ba = nullptr; const float* se2 = nullptr; int nse2 = 3; const eorb_camera* cam = nullptr; };
+    struct ChunkResult {
+        TrackState state = IDLE; bool dispatched = false; int skipped = 0;
+        std::vector<eorb_host::KeyPoint> kps;                          // INIT frame
+        std::vector<float> pts; std::vector<uint8_t> status; std::vector<float> err; std::vector<int> matches12;   // TRACKING frame
+        unsigned nMatches = 0; float medPxDisp = 0.f; unsigned chunkSize = 0;
+        float focus[5] = {-1, -1, -1, -1, -1}; int winner = -1; eorb_host::Mat8 mcImage; std::vector<eorb_host::KeyPoint> l2Kps; bool mcGood = false;
+        size_t window = 0, overlap = 0;                                // events of the dispatched window / handed back to the queue (its tail)
+    };
+    static const int DEF_TH_MIN_KPTS = 100, DEF_TH_MIN_MATCHES = 50;   // include/Event/EventData.h:24-26
+
+    explicit EvImBuilder(const Params& p) : P(p), mL1EvWinSize(p.l1ChunkSize), mInitL1EvWinSize(p.l1ChunkSize) {
+        eorb_orb_params q{p.maxNumPts, 1.0f, 1, p.fastTh, 0, p.imMargin, p.imWidth};       // "FAST = ORB with one level": EvBaseTracker.cpp:150-164
+        l1_.check(eorb_orb_configure(l1_.get(), &q, p.imWidth, p.imHeight));
+        q.nfeatures = 2 * p.maxNumPts;                                  // the L2 tracker's extractor: EvAsynchTracker.cpp:51
+        l2_.check(eorb_orb_configure(l2_.get(), &q, p.imWidth, p.imHeight));
+        cap1_ = eorb_orb_max_keypoints(l1_.get()); cap2_ = eorb_orb_max_keypoints(l2_.get());
+        mnWinOverlap = (unsigned long)(p.l1WinOverlap * (double)(p.l1NumLoop * mL1EvWinSize));      // :40
+        reset();
+    }
+    void resetAll() { mStat = IDLE; mL1EvWinSize = mInitL1EvWinSize; reset(); }                      // :70-93
+    unsigned getL1ChunkSize() const { return mL1EvWinSize; }
+
+    // one pass of the loop body for the chunk l1Evs; `poses` = what the resolve*() calls of generateMCImage deliver (absent = failed)
+    ChunkResult Track(const std::vector<eorb_host::EventData>& l1Evs, const MciPoses* (*mciPoses)(const std::vector<eorb_host::EventData>&, void*) = nullptr, void* user = nullptr) {
+        ChunkResult out;
+        if (mStat == IDLE) mStat = INIT;
+        if (mStat == INIT) reset();
+        if (l1Evs.empty()) return out;
+        const double evTspan = l1Evs.back().ts - l1Evs[0].ts;           // calcEventGenRate, src/Event/EventData.cpp:14-19
+        const double evGenRate = (double)l1Evs.size() / (evTspan * P.imWidth * P.imHeight);
+        out.state = mStat;
+        const int rate = checkEvGenRate(evGenRate);
+        if (rate != 0) {
+            if (rate == -1) mStat = INIT; else mvSharedL2Evs.insert(mvSharedL2Evs.end(), l1Evs.begin(), l1Evs.end());
+            out.skipped = rate;
+            return out;
+        }
+        bool sendMCF = false;
+        if (mStat == INIT) {
+            out.kps.assign(cap1_, eorb_host::KeyPoint{});
+            int n = 0, mono = 0;
+            l1_.check(eorb_ev_slice_extract(l1_.get(), l1Evs.data(), nullptr, l1Evs.size(), P.l1ImSigma, 0, 1000, 0, out.kps.data(), nullptr, nullptr,
+                                            cap1_, &n, &mono, nullptr));
+            out.kps.resize(n);
+            mRefKPoints = out.kps; mvMatchesCnt.assign(n, 1);
+            mLastTrackedPts.resize(2 * (size_t)n);
+            for (int i = 0; i < n; i++) { mLastTrackedPts[2 * i] = out.kps[i].x; mLastTrackedPts[2 * i + 1] = out.kps[i].y; }
+            if (n > DEF_TH_MIN_KPTS || (P.continTracking && P.l1FixedWinSz)) { updateState(l1Evs); mStat = TRACKING; }
+            else mL1EvWinSize = mInitL1EvWinSize;
+        } else {
+            const int nref = (int)mRefKPoints.size();
+            out.status.assign(nref, 0); out.err.assign(nref, 0.f);
+            l1_.check(eorb_ev_slice_track(l1_.get(), l1Evs.data(), nullptr, l1Evs.size(), P.l1ImSigma, &P.klt, mLastTrackedPts.data(), out.status.data(),
+                                          out.err.data(), nref, nullptr));
+            out.pts = mLastTrackedPts;
+            out.matches12.assign(nref, -1);
+            std::vector<float> vPxDisp;
+            for (int i = 0; i < nref; i++) {                            // refineTrackedPts
+                const float x = out.pts[2 * i], y = out.pts[2 * i + 1];
+                if (out.status[i] == 1 && x >= 0 && x < (float)P.imWidth && y >= 0 && y < (float)P.imHeight) {
+                    mvMatchesCnt[i]++; out.matches12[i] = i; out.nMatches++;
+                    const float dx = x - mRefKPoints[i].x, dy = y - mRefKPoints[i].y;
+                    vPxDisp.push_back(std::sqrt(dx * dx + dy * dy));
+                }
+            }
+            std::sort(vPxDisp.begin(), vPxDisp.end());
+            out.medPxDisp = vPxDisp.empty() ? 0.f : vPxDisp[vPxDisp.size() / 2];
+            if (out.nMatches < (unsigned)DEF_TH_MIN_MATCHES && !P.continTracking && mCurrIdx < 3) { mL1EvWinSize = mInitL1EvWinSize; mStat = INIT; out.chunkSize = mL1EvWinSize; return out; }
+            updateState(l1Evs);
+            const bool dispatchMCI = resolveEvWinSize(out.medPxDisp);
+            if (dispatchMCI || out.nMatches < (unsigned)DEF_TH_MIN_MATCHES) { mStat = INIT; sendMCF = true; }
+        }
+        out.chunkSize = mL1EvWinSize;
+        if (sendMCF) {
+            const MciPoses none; const MciPoses* mp = mciPoses ? mciPoses(mvSharedL2Evs, user) : &none;
+            out.mcImage = eorb_host::Mat8(P.imHeight, P.imWidth);
+            out.l2Kps.assign(cap2_, eorb_host::KeyPoint{});
+            int n = 0;
+            l1_.check(eorb_ev_mc_contest(l1_.get(), mvSharedL2Evs.data(), mvSharedL2Evs.size(), mp->cam, mp->dp, mp->ba, mp->se2, mp->nse2, P.imWidth, P.imHeight,
+                                         P.l1ImSigma, out.focus, &out.winner, out.mcImage.ptr(), l2_.get(), 0, 1000, out.l2Kps.data(), cap2_, &n));
+            out.l2Kps.resize(n);
+            out.dispatched = true; out.window = mvSharedL2Evs.size();
+            out.mcGood = n > DEF_TH_MIN_KPTS || P.continTracking;
+            if (P.continTracking) out.overlap = P.l1FixedWinSz ? mnWinOverlap : (size_t)(mvSharedL2Evs.size() * P.l1WinOverlap);     // :1465-1469
+        }
+        return out;
+    }
+    const std::vector<eorb_host::EventData>& accumulatedEvents() const { return mvSharedL2Evs; }
+
+private:
+    void reset() { mCurrIdx = 0; mCntLowEvGenRate = 0; mvSharedL2Evs.clear(); mvMatchesCnt.clear(); }          // :95-139
+    void updateState(const std::vector<eorb_host::EventData>& ev) { mCurrIdx++; mvSharedL2Evs.insert(mvSharedL2Evs.end(), ev.begin(), ev.end()); }      // :427-435
+    int checkEvGenRate(double rate) {                                    // :284-328
+        if (rate > P.minEvGenRate) { mCntLowEvGenRate = 0; return 0; }
+        if (P.continTracking) return (!P.l1FixedWinSz && mStat == INIT) ? -1 : 0;
+        if (mStat == INIT) return -1;
+        return ++mCntLowEvGenRate > 3 ? -1 : 1;
+    }
+    bool resolveEvWinSize(float medPxDisp) {                             // :209-232, calcNewL1ChunkSize :197-201
+        if (!P.l1FixedWinSz && medPxDisp > P.maxPixelDisp) { mL1EvWinSize = (unsigned)floorf(((float)(mCurrIdx + 1) / medPxDisp) * ((float)mL1EvWinSize)); return true; }
+        return P.l1FixedWinSz && (int)mCurrIdx >= P.l1NumLoop;
+    }
+    Params P;
+    eorb_host::Context l1_, l2_;
+    int cap1_ = 0, cap2_ = 0;
+    TrackState mStat = IDLE;
+    unsigned mCurrIdx = 0, mL1EvWinSize, mInitL1EvWinSize; int mCntLowEvGenRate = 0; unsigned long mnWinOverlap = 0;
+    std::vector<eorb_host::EventData> mvSharedL2Evs;
+    std::vector<eorb_host::KeyPoint> mRefKPoints; std::vector<float> mLastTrackedPts; std::vector<int> mvMatchesCnt;
 };
 
 }  // namespace EORB_SLAM

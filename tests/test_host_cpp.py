@@ -57,9 +57,40 @@ int main(int argc, char** argv) {
             for (auto& x : th) x.join();
             for (int v : okv) pool_ok = pool_ok && v;
         }
+        // the L1 builder's chunk loop over the one-call seams: an INIT chunk, then tracking chunks until the window rule dispatches; the
+        // INIT frame and the first tracked frame equal the separate seams (ev2im_gauss + extractor / LK are checked in Python)
+        bool chain_ok = true;
+        {
+            EORB_SLAM::EvImBuilder::Params bp;
+            EORB_SLAM::EvImBuilder b(bp);
+            std::vector<eorb_host::EventData> chunk(2000);
+            int ndisp = 0, ninit = 0, ntrack = 0;
+            for (int k = 0; k < 12; k++) {
+                for (size_t i = 0; i < chunk.size(); i++) {                  // four edges drifting to the right, 2 px per chunk
+                    const unsigned h = (unsigned)(k * 2000 + i) * 2654435761u;
+                    const int e = (h >> 8) % 4, t = (h >> 12) % 120;
+                    chunk[i].ts = 1e-6 * (k * 2000.0 + i); chunk[i].x = (float)(30 + 45 * e + 2 * k + (t % 3)); chunk[i].y = (float)(20 + t); chunk[i].p = (h >> 30) & 1;
+                }
+                auto r = b.Track(chunk);
+                if (k == 0) {
+                    eorb_host::Mat8 i8; eorb_host::Mat32f i32;
+                    EORB_SLAM::EvImConverter::ev2im_gauss(chunk, 240, 180, 1.0f, false, true, i8, i32);
+                    ORB_SLAM3::ORBxParams q; q.nfeatures = 400; q.scaleFactor = 1.0f; q.nlevels = 1; q.iniThFAST = 0; q.minThFAST = 0; q.edgeTh = 9; q.imWidth = 240; q.imHeight = 180;
+                    ORB_SLAM3::ORBextractor ex2(q);
+                    std::vector<eorb_host::KeyPoint> k2;
+                    ex2(i8, k2, std::vector<int>{0, 1000});
+                    chain_ok = chain_ok && r.state == EORB_SLAM::EvImBuilder::INIT && k2.size() == r.kps.size() &&
+                               (k2.empty() || std::memcmp(k2.data(), r.kps.data(), k2.size() * sizeof(eorb_host::KeyPoint)) == 0);
+                }
+                ninit += r.state == EORB_SLAM::EvImBuilder::INIT; ntrack += r.state == EORB_SLAM::EvImBuilder::TRACKING;
+                if (r.dispatched) { ndisp++; chain_ok = chain_ok && r.winner == 2 && r.focus[2] > 0 && r.focus[0] == -1.f && r.window >= 4000 && r.overlap == r.window / 2; }
+            }
+            std::printf("chain: init %d tracking %d dispatches %d ok=%d\n", ninit, ntrack, ndisp, (int)chain_ok);
+            chain_ok = chain_ok && ndisp >= 1 && ntrack >= 2;
+        }
         const size_t made = eorb_host::ContextPool::instance().created();
         std::printf("pool contexts=%zu ok=%d\n", made, (int)pool_ok);
-        return (mono == 0 && m1 == -1 && same && best[0] >= 0 && best[0] < 5 && pool_ok && made <= 5) ? 0 : 1;
+        return (mono == 0 && m1 == -1 && same && best[0] >= 0 && best[0] < 5 && pool_ok && made <= 5 && chain_ok) ? 0 : 1;
     } catch (const eorb_host::Error& e) { std::printf("error %d: %s\n", e.code, e.what()); return 2; }
 }
 '''
