@@ -112,6 +112,12 @@ struct eorb_ctx {
     // float events in bulk: the distinct positions of a call become the rows of a per-call stamp table (ev_accumulate_dev)
     eorb::DevBuf dd_tab, dd_src_info, dd_stamps, dd_ev, dd_cnt, dd_sl_tab, dd_sl_tile, dd_sl_rows;
     int dd_sl_ok = 0, dd_sl_null = 0; size_t dd_sl_info_off = 0;
+    // ... and across calls: once a call's positions are known, the next calls of the context look theirs up in a frozen dictionary
+    // (compact hash -> dense id < 65 536, tables per id) and only fall back to the per-call tabulation when a new position turns up
+    eorb::DevBuf pd_hash, pd_lut, pd_src_info, pd_sl_tab, pd_sl_tile, pd_sl_rows, pd_cnt;
+    int pd_valid = 0, pd_K = 0, pd_W = 0, pd_H = 0, pd_sl_null = 0, pd_cooldown = 0; float pd_sigma = 0.f; size_t pd_sl_info_off = 0;
+    int dd_keep = 0;                             // the per-call position table holds an earlier call's positions and is extended, not cleared
+    long long pd_hits = 0, pd_misses = 0;        // calls served by the dictionary / calls that found a new position (eorb_debug_counter)
     eorb::DevBuf focus_sd;                       // measureImageFocus: per-patch deviations
     int64_t dbg_dd_min = (int64_t)1 << 20;       // events from which the positions are deduplicated (test hook: "dedupe_min_events")
     int lut_w = 0, lut_h = 0, lut_check = 1;
@@ -159,6 +165,7 @@ struct eorb_ctx {
     long long dbg_slot_hot_min = -1;             // slot form: list length from which the register-row kernel takes a list (-1: default / EORB_SLOT_HOT_MIN)
     int dbg_slot_hot_cap = 0;                    // slot form: lists per length bucket of the register-row kernel (0: kHotCap), to force the overflow branch
     int dbg_slot_hot_waves = 0;                  // slot form: wavefronts of the register-row kernel (0: default / EORB_SLOT_HOT_WAVES)
+    int dbg_pd = 1;                              // float events in bulk: 0 = never freeze / use the position dictionary (test hook "position_dict")
     int dbg_slot_halves = -1;                    // slot form: -1 by the batch's shape / EORB_SLOT_HALVES, 0 one part, 1 two halves whatever the shape
 };
 
@@ -194,8 +201,11 @@ int ev_parse_text_dev(eorb_ctx* c, const char* d_text, size_t nbytes, uint64_t* 
 int ev_slots_prepare_launch(eorb_ctx* c, int W, int H, int h, int TX, int TY);
 int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const float* d_stamps /* nullptr: taps from c->lut */, int stamp_stride, int SWP,
                       float two_sig2, float norm);
+struct SlotDict {              // float events looked up in the context's position dictionary by the count pass (ev_slots.hip)
+    const uint4* hash; uint32_t mask; uint32_t* rec; int* miss;
+};
 int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
-                        float* d_f32, uint32_t* d_minmax_enc);
+                        float* d_f32, uint32_t* d_minmax_enc, const SlotDict* dict = nullptr);
 int ev_slots_trace_read(eorb_ctx* c, unsigned long long* out, long long max_records);
 // klt.hip
 int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int W, int H, int stride, const float* d_prev_pts,

@@ -261,7 +261,7 @@ void eorb_destroy(eorb_ctx* c)
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
-                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena, &c->l1_ref_img, &c->l1_ref_pts, &c->ev_info, &c->ev_stamps};
+                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena, &c->l1_ref_img, &c->l1_ref_pts, &c->ev_info, &c->ev_stamps, &c->pd_hash, &c->pd_lut, &c->pd_src_info, &c->pd_sl_tab, &c->pd_sl_tile, &c->pd_sl_rows, &c->pd_cnt};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -309,6 +309,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "slot_hot_min")) { c->dbg_slot_hot_min = value; return EORB_OK; }
     if (!strcmp(name, "slot_hot_cap")) { c->dbg_slot_hot_cap = value; return EORB_OK; }
     if (!strcmp(name, "slot_halves")) { c->dbg_slot_halves = value; return EORB_OK; }
+    if (!strcmp(name, "position_dict")) { c->dbg_pd = value; if (!value) { c->pd_valid = 0; c->dd_keep = 0; } return EORB_OK; }
     if (!strcmp(name, "slot_hot_waves")) { c->dbg_slot_hot_waves = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
@@ -318,6 +319,9 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
     if (!c || !name) return -1;
     if (!strcmp(name, "slot_calls")) return c->sl_calls;
     if (!strcmp(name, "slot_rank_ok")) return c->sl_rank_ok;
+    if (!strcmp(name, "dict_hits")) return c->pd_hits;                    // bulk float calls served by the frozen position dictionary
+    if (!strcmp(name, "dict_misses")) return c->pd_misses;                // ... that found a new position and tabulated afresh
+    if (!strcmp(name, "dict_positions")) return c->pd_valid ? c->pd_K : 0;
     if (!strcmp(name, "slot_scatter_form")) return c->sl_last_rank;       // the scatter of the last slot-form call: 1 rank form, 0 ballot form
     if (!strcmp(name, "slot_chunk")) return c->sl_last_chunk;
     if (!strcmp(name, "slot_parts")) return c->sl_last_parts;              // 2: the last slot-form call ran its batch as two halves

@@ -2112,6 +2112,113 @@ __global__ void ev_unpack2_kernel(const uint16_t* __restrict__ in, int64_t n, in
     }
 }
 
+// ---- float events in bulk, across calls: the position dictionary -----------------------------------------------------------------
+// A loader's maps do not change between calls, so the positions of one call's events are those of the next.  After a call whose
+// positions were tabulated (dd_insert_kernel) and number at most 65 535, they are frozen into a DICTIONARY: a compact open-addressing
+// table { x bits, y bits, dense id } (2^17 entries: L2-resident) and, per dense id, what the maps' tables hold per sensor pixel (position,
+// integer position, slot tables, rows).  The following calls run the slot form straight on the float events: its count pass looks
+// every position up (sl_count_lds_kernel<16, true>) and writes the dense id as the hashed record -- one pass over the events where the
+// per-call tabulation makes two, no table to clear and rebuild.  A position the dictionary does not hold is counted; the call then
+// falls back to the per-call tabulation (whose table becomes the next dictionary).
+constexpr int kPdLog = 17;
+__global__ void pd_build_kernel(const unsigned long long* __restrict__ tab, int nslots, int max_ids, int* __restrict__ cnt, float2* __restrict__ lut,
+                                uint4* __restrict__ hash)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nslots) return;
+    const unsigned long long key = tab[i];
+    if (key == kDdEmpty) return;
+    const int id = atomicAdd(&cnt[0], 1);
+    if (id >= max_ids) return;
+    const uint32_t kx = (uint32_t)key, ky = (uint32_t)(key >> 32);
+    lut[id] = make_float2(__uint_as_float(kx), __uint_as_float(ky));
+    const uint32_t mask = (1u << kPdLog) - 1u;
+    uint32_t h = dd_hash(key) & mask;
+    // claim a free entry through its id word (0xffffffff = free), then fill the key: the table is read only after this kernel
+    for (;;) {
+        if (atomicCAS(&hash[h].z, 0xffffffffu, (uint32_t)id) == 0xffffffffu) { hash[h].x = kx; hash[h].y = ky; break; }
+        h = (h + 1) & mask;
+    }
+}
+
+// the tables of the call's positions (the context's dd_* set, valid right after a per-call tabulation) -> the frozen dictionary
+static int pd_freeze(eorb_ctx* c, int W, int H, int h, float sigma, int TX, int TY, int npos)
+{
+    c->pd_valid = 0;
+    if (npos < 1 || npos > 65535) return EORB_OK;                      // (dense ids travel as hashed records below 65 536 rows: the LDS count pass)
+    const size_t cap = (size_t)1 << kDdLog, hcap = (size_t)1 << kPdLog;
+    int rc;
+    if ((rc = ensure(c, c->pd_hash, sizeof(uint4) * hcap)) || (rc = ensure(c, c->pd_lut, sizeof(float2) * 65536)) || (rc = ensure(c, c->pd_cnt, 64))) return rc;
+    EORB_HIP(c, hipMemsetAsync(c->pd_hash.p, 0xff, sizeof(uint4) * hcap, c->stream));
+    EORB_HIP(c, hipMemsetAsync(c->pd_cnt.p, 0, 64, c->stream));
+    pd_build_kernel<<<(int)((cap + 255) / 256), 256, 0, c->stream>>>((const unsigned long long*)c->dd_tab.p, (int)cap, 65535, (int*)c->pd_cnt.p, (float2*)c->pd_lut.p, (uint4*)c->pd_hash.p);
+    EORB_LAUNCH_CHECK(c, "pd_build_kernel");
+    // the per-id tables: the raw path's own builders on the dictionary's positions as a (K x 1) "sensor"
+    auto swap_tables = [&]() {
+        std::swap(c->lut, c->pd_lut); std::swap(c->src_info, c->pd_src_info);
+        std::swap(c->sl_tab, c->pd_sl_tab); std::swap(c->sl_tile, c->pd_sl_tile); std::swap(c->sl_rows, c->pd_sl_rows);
+        std::swap(c->sl_null, c->pd_sl_null); std::swap(c->sl_info_off, c->pd_sl_info_off);
+    };
+    swap_tables();
+    const int sw = c->lut_w, sh = c->lut_h, sc = c->lut_check, sok = c->sl_ok, sl0 = c->sl_launched;
+    c->lut_w = npos; c->lut_h = 1; c->lut_check = 0; c->sl_launched = 0;
+    rc = ensure(c, c->src_info, sizeof(uint32_t) * (size_t)npos);
+    if (!rc) {
+        ev_src_info_kernel<<<(npos + 255) / 256, 256, 0, c->stream>>>((const float2*)c->lut.p, npos, W, H, 0, 0, (uint32_t*)c->src_info.p);
+        const float sig2 = sigma * sigma;
+        rc = ev_slots_prepare(c, W, H, h, TX, TY, nullptr, 0, 0, 2.0f * sig2, 2.0f * (float)3.1415926535897932384626433832795 * sig2);
+    }
+    const int ok = c->sl_ok;
+    c->lut_w = sw; c->lut_h = sh; c->lut_check = sc; c->sl_ok = sok; c->sl_launched = sl0;
+    swap_tables();
+    if (rc) return rc;
+    // the count pass keeps the dense ids' tile ranges and its per-wavefront counters in LDS (ev_slots.hip, sl_count_lds_kernel)
+    const int NTp = (TX * TY + 1) & ~1;
+    const bool lds_ok = TX <= 127 && TY <= 127 && 4 * (((size_t)npos + 2) / 2) + (size_t)16 * NTp * 2 <= 159 * 1024;
+    if (ok && lds_ok) { c->pd_valid = 1; c->pd_K = npos; c->pd_W = W; c->pd_H = H; c->pd_sigma = sigma; }
+    return EORB_OK;
+}
+
+// a call served by the dictionary; *missed = 1 when a position was not in it (the images are then incomplete: the caller redoes the call)
+static int pd_accumulate(eorb_ctx* c, const eorb_event16* d_src, const int64_t* off, int B, int W, int H, int TX, int TY, float sigma,
+                         float* d_f32, uint8_t* d_u8, int normalized, uint32_t* d_minmax_enc, int64_t n0, int* missed)
+{
+    int rc;
+    if ((rc = ensure(c, c->dd_ev, 4 * (size_t)std::max<int64_t>(n0, 1)))) return rc;
+    EORB_HIP(c, hipMemsetAsync(c->pd_cnt.p, 0, 64, c->stream));
+    auto swap_tables = [&]() {
+        std::swap(c->lut, c->pd_lut); std::swap(c->src_info, c->pd_src_info);
+        std::swap(c->sl_tab, c->pd_sl_tab); std::swap(c->sl_tile, c->pd_sl_tile); std::swap(c->sl_rows, c->pd_sl_rows);
+        std::swap(c->sl_null, c->pd_sl_null); std::swap(c->sl_info_off, c->pd_sl_info_off);
+    };
+    swap_tables();
+    const int sw = c->lut_w, sh = c->lut_h, sok = c->sl_ok;
+    c->lut_w = c->pd_K; c->lut_h = 1; c->sl_ok = 1;
+    {
+        ProfScope ps(c, "ev_minmax_init");
+        ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
+    }
+    SlotDict D{(const uint4*)c->pd_hash.p, (1u << kPdLog) - 1u, (uint32_t*)c->dd_ev.p, (int*)c->pd_cnt.p};
+    rc = ev_slots_accumulate(c, d_src, 16, off, B, W, H, TX, TY, d_f32, d_minmax_enc, &D);
+    c->lut_w = sw; c->lut_h = sh; c->sl_ok = sok;
+    swap_tables();
+    if (rc < 0) return rc;
+    if (rc > 0) { *missed = 1; return EORB_OK; }                        // the batch's shape does not fit the slot form: the per-call path decides
+    if (normalized && d_u8) {
+        ProfScope ps(c, "ev_normalize");
+        dim3 grid((W * H + 255) / 256 > 64 ? 64 : (W * H + 255) / 256, B);
+        ev_normalize_kernel<<<grid, 256, 0, c->stream>>>(d_f32, d_minmax_enc, d_u8, W * H, 0);
+        EORB_LAUNCH_CHECK(c, "ev_normalize_kernel");
+    }
+    // the call's one wait: did every position have its entry?
+    int* rb = readback_buf(c);
+    if (!rb) return set_err(c, EORB_E_HIP, "pinned alloc failed");
+    EORB_HIP(c, hipMemcpyAsync(rb, c->pd_cnt.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    *missed = rb[0] != 0;
+    return EORB_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t* h_offsets, int B, int W, int H,
                       float sigma, int pol, int mode_count, float* d_f32, uint8_t* d_u8, int normalized,
@@ -2148,14 +2255,31 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
         const size_t cap = (size_t)1 << kDdLog;
         const int max_ids = (int)(cap / 2);
         int rc;
+        const bool slot_shape = !pol && !mode_count && (c->dbg_gather_form == 0 || c->dbg_gather_form == 4) && h >= 1 && h <= 4;
+        if (fits && slot_shape && c->pd_valid && c->pd_W == W && c->pd_H == H && c->pd_sigma == sigma && c->pd_cooldown == 0 && c->dbg_pd != 0) {
+            // the positions of an earlier call, frozen: one pass over the events (see pd_accumulate)
+            std::vector<int64_t> off(B + 1);
+            for (int b = 0; b <= B; b++) off[b] = h_offsets[b] - h_offsets[0];
+            int missed = 0;
+            if ((rc = pd_accumulate(c, (const eorb_event16*)d_events + h_offsets[0], off.data(), B, W, H, TX, TY, sigma, d_f32, d_u8, normalized, d_minmax_enc, n0, &missed))) return rc;
+            if (!missed) { c->pd_hits++; return EORB_OK; }
+            c->pd_misses++; c->pd_valid = 0;                            // new positions: tabulate this call's afresh (below), freeze those
+        }
+        if (c->pd_cooldown > 0) c->pd_cooldown--;
         if (fits) {
             if ((rc = ensure(c, c->dd_tab, 8 * cap)) || (rc = ensure(c, c->dd_cnt, 64)) || (rc = ensure(c, c->dd_ev, 4 * (size_t)n0))) return rc;
             const eorb_event16* src = (const eorb_event16*)d_events + h_offsets[0];
             int hc[2] = {0, 0};
             {
                 ProfScope ps(c, "ev_dedupe");
-                EORB_HIP(c, hipMemsetAsync(c->dd_tab.p, 0xff, 8 * cap, c->stream));
-                EORB_HIP(c, hipMemsetAsync(c->dd_cnt.p, 0, 64, c->stream));
+                // the table of an earlier call is kept while the positions seen so far can still become a dictionary (a sparse call does
+                // not see every sensor pixel: the table accumulates them over the calls); otherwise it starts empty
+                const bool keep = c->dd_keep && slot_shape && c->dbg_pd != 0;
+                if (!keep) {
+                    EORB_HIP(c, hipMemsetAsync(c->dd_tab.p, 0xff, 8 * cap, c->stream));
+                    EORB_HIP(c, hipMemsetAsync(c->dd_cnt.p, 0, 64, c->stream));
+                } else EORB_HIP(c, hipMemsetAsync((int*)c->dd_cnt.p + 1, 0, 4, c->stream));      // (the crowding flag is per call)
+                c->dd_keep = 0;
                 dd_insert_kernel<<<4096, 256, 0, c->stream>>>(src, n0, (unsigned long long*)c->dd_tab.p, (int*)c->dd_cnt.p, (uint32_t*)c->dd_ev.p);
                 EORB_LAUNCH_CHECK(c, "dd_insert_kernel");
                 int* rb = readback_buf(c);
@@ -2201,6 +2325,12 @@ int ev_accumulate_dev(eorb_ctx* c, const void* d_events, int raw, const int64_t*
                 rc = ev_accumulate_dev(c, c->dd_ev.p, 2, off.data(), B, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, d_minmax_enc);
                 swap_tables();
                 c->lut_w = sw; c->lut_h = sh; c->lut_check = sc; c->lut_key_W = kW; c->lut_key_H = kH; c->lut_key_mode = kM; c->lut_key_sigma = kS;
+                // these positions serve the next calls (a call that just missed the dictionary with MANY new positions -- events that are not
+                // map-valued -- does not try again for a while)
+                if (!rc && slot_shape && c->dbg_pd != 0) {
+                    if (hc[0] <= 65535) { const int rc3 = pd_freeze(c, W, H, h, sigma, TX, TY, hc[0]); if (rc3) return rc3; c->dd_keep = 1; }
+                    else c->pd_cooldown = 16;
+                }
                 return rc;
             }
         }

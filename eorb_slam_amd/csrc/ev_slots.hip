@@ -238,10 +238,19 @@ __global__ __launch_bounds__(256) void sl_count_kernel(const eorb_raw_event* __r
 // pass ran at 3.2 TB/s, with the lookup computed instead it ran at 5.2 (profiles/r03_ko_table_lookup.txt).  So: one 16-wave
 // workgroup per CU copies the 16-bit ranges of all sensor pixels into LDS once (240x180: 86 KB) and every WAVEFRONT counts whole
 // chunks on its own -- own counters (packed 16-bit, a chunk has <= 2048 events), no workgroup barrier after the table is in.
-template <int stride>
+// KEYED (stride 16 only): the records are float events (eorb_event16) whose positions are looked up in the context's frozen position
+// dictionary -- a compact open-addressing table { x bits, y bits, dense id, - } -- and the dense id goes out as a 4-byte hashed record
+// for the scatter (rec[event index]); a position the dictionary does not hold counts a miss (the caller then tabulates the call's
+// positions afresh).  One pass over the events instead of a hashing pass plus a counting pass.
+__device__ __forceinline__ uint32_t sl_dict_hash(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+template <int stride, bool KEYED = false>
 __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
                                                                        int nchunks, const uint16_t* __restrict__ slot_geo, int LW, int LH,
-                                                                       int TX, int NT, uint16_t* __restrict__ segcnt)
+                                                                       int TX, int NT, uint16_t* __restrict__ segcnt, SlotDict D = SlotDict{nullptr, 0u, nullptr, nullptr})
 {
     extern __shared__ uint32_t smc[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -259,6 +268,27 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
         const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)astride;
         for (int k0 = lane; k0 < cd.n; k0 += 64 * U) {
             uint32_t xy[U], g[U];
+            if (KEYED) {
+                uint2 pos[U]; uint4 ent[U]; uint32_t hh[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { const int k = k0 + u * 64; pos[u] = k < cd.n ? *(const uint2*)(e + (size_t)k * 16) : make_uint2(0x7fc00000u, 0x7fc00000u); }
+#pragma unroll
+                for (int u = 0; u < U; u++) { hh[u] = sl_dict_hash((uint64_t)pos[u].x | ((uint64_t)pos[u].y << 32)) & D.mask; ent[u] = D.hash[hh[u]]; }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int k = k0 + u * 64;
+                    const float fx = __uint_as_float(pos[u].x), fy = __uint_as_float(pos[u].y);
+                    uint32_t id = 0x7fffffffu;                           // dropped (NaN coordinates are never in the image)
+                    if (k < cd.n && fx == fx && fy == fy) {
+                        uint32_t h = hh[u]; uint4 q = ent[u]; int probes = 0;
+                        while (!(q.x == pos[u].x && q.y == pos[u].y) && q.z != 0xffffffffu && ++probes <= 64) { h = (h + 1) & D.mask; q = D.hash[h]; }
+                        if (q.x == pos[u].x && q.y == pos[u].y && q.z != 0xffffffffu) id = q.z;
+                        else atomicAdd(D.miss, 1);
+                    }
+                    if (k < cd.n) D.rec[cd.start + k] = id;
+                    g[u] = id < (uint32_t)LW * (uint32_t)LH ? tab[id] : kNoGeo;
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < U; u++) { const int k = k0 + u * 64; xy[u] = k < cd.n ? sl_load_rec<stride>(e, k) : 0xffffffffu; }
 #pragma unroll
@@ -266,6 +296,7 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
                 const uint32_t x = xy[u] & xmask, y = xy[u] >> 16, row = xy[u] & 0x7fffffffu;      // (hashed records: the row itself)
                 if (stride < 0 || stride == 2) g[u] = row < (uint32_t)LW * (uint32_t)LH ? tab[row] : kNoGeo;
                 else g[u] = (x < (uint32_t)LW && y < (uint32_t)LH) ? tab[y * (uint32_t)LW + x] : kNoGeo;
+            }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -1108,9 +1139,11 @@ static int sl_streams(eorb_ctx* c)
 // count -> scan -> scatter -> plan -> gather for the B slices of one PART of a batch (the whole batch, or one of its halves), on the
 // part's own workspaces.  Streams: binning on the context's stream; the plan on P; the long lists on H; the LDS gather on G when the
 // batch runs in halves (so that the next half's binning, HBM- and LDS-atomic-bound, runs under it), else on the context's stream.
-static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, const void* d_events, int stride, const int64_t* h_offsets, int B,
-                      int W, int H, int TX, int TY, float* d_f32, uint32_t* d_minmax_enc, const SlotScatterChoice& sc)
+static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, const void* d_events, int stride_in, const int64_t* h_offsets, int B,
+                      int W, int H, int TX, int TY, float* d_f32, uint32_t* d_minmax_enc, const SlotScatterChoice& sc, const SlotDict* dict)
 {
+    // with a position dictionary the count pass reads the float events and writes the hashed records every later pass reads
+    const int stride = dict ? -4 : stride_in;
     const int NT = TX * TY;
     const int64_t nev = h_offsets[B] - h_offsets[0];
     const int chunk = sc.chunk;
@@ -1173,7 +1206,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
     uint32_t* d_nslots = (uint32_t*)c->sl_tile.p;
     uint32_t* d_rowbase = d_nslots + NT;
     int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
-    const eorb_raw_event* d_ev = (const eorb_raw_event*)d_events;
+    const eorb_raw_event* d_ev = dict ? (const eorb_raw_event*)dict->rec : (const eorb_raw_event*)d_events;
     const uint2* d_tab = (const uint2*)c->sl_tab.p;
     const int ncu = sl_ncu(c);
     const int NTp = (NT + 1) & ~1;
@@ -1219,7 +1252,14 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
         const size_t nsrc = (size_t)c->lut_w * (size_t)c->lut_h;
         const size_t lds_c = 4 * ((nsrc + 2) / 2) + (size_t)kCountWaves * NTp * 2;
         static const int cl_env = [] { const char* e = getenv("EORB_SLOT_COUNT_LDS"); return e ? atoi(e) : 1; }();
-        if (nchunks && cl_env && TX <= 127 && TY <= 127 && lds_c <= 159 * 1024) {
+        if (dict && !(TX <= 127 && TY <= 127 && lds_c <= 159 * 1024)) return set_err(c, EORB_E_CAPACITY, "slot form: the position dictionary needs the LDS count pass");
+        if (nchunks && dict) {
+            const uint16_t* d_geo = (const uint16_t*)((const char*)c->sl_tab.p + sizeof(uint2) * nsrc);
+            const int g = std::min(ncu, (nchunks + kCountWaves - 1) / kCountWaves);
+            if ((rc = sl_optin(c, 13, (const void*)sl_count_lds_kernel<16, true>, 159 * 1024))) return rc;
+            sl_count_lds_kernel<16, true><<<g, 64 * kCountWaves, lds_c, M>>>((const eorb_raw_event*)d_events, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt, *dict);
+        }
+        else if (nchunks && cl_env && TX <= 127 && TY <= 127 && lds_c <= 159 * 1024) {
             const uint16_t* d_geo = (const uint16_t*)((const char*)c->sl_tab.p + sizeof(uint2) * nsrc);
             const int g = std::min(ncu, (nchunks + kCountWaves - 1) / kCountWaves);
 #define SL_COUNT(ST, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_count_lds_kernel<ST>, 159 * 1024))) return rc; \
@@ -1298,7 +1338,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
 // second (HBM- and LDS-atomic bound).  Returns kSlotDeclined (> 0, nothing launched) when the batch's shape does not
 // fit: the caller goes on with the batch pipeline.
 int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
-                        float* d_f32, uint32_t* d_minmax_enc)
+                        float* d_f32, uint32_t* d_minmax_enc, const SlotDict* dict)
 {
     const int NT = TX * TY;
     const int64_t nev = h_offsets[B] - h_offsets[0];
@@ -1329,7 +1369,7 @@ int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int
     for (int part = 0; part < nparts; part++) {
         const int b0 = part ? B0 : 0, nb_ = part ? B - B0 : B0;
         if ((rc = slots_part(c, c->sl_ws[part], part, nparts, d_events, stride, h_offsets + b0, nb_, W, H, TX, TY,
-                             d_f32 + (size_t)b0 * W * H, d_minmax_enc + 2 * (size_t)b0, sc))) return rc;
+                             d_f32 + (size_t)b0 * W * H, d_minmax_enc + 2 * (size_t)b0, sc, dict))) return rc;
     }
     // whatever the other streams did is done before the images are read (streams are in order: the last part's events cover the first's)
     hipEvent_t* E = c->sl_ev + 5 * (nparts - 1);

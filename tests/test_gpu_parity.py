@@ -78,6 +78,67 @@ def test_float_bulk_form_and_its_fallback(oracle, fe):
     c.close()
 
 
+def test_float_bulk_position_dictionary(oracle, fe):
+    """Float events in bulk across calls: the positions of a call are frozen into the context's dictionary and the next calls look
+    theirs up in the count pass (one pass over the events).  Calls 2-3 are served by the dictionary; a call with a new position falls
+    back to the per-call tabulation and refreezes; a different sigma rebuilds; positions that never repeat (600 000 distinct) are not
+    frozen; with the test hook off nothing is.  Every image against the oracle; also as a batch through the front end."""
+    W, H = 240, 180
+    c = fe.Context()
+    c.debug_option("dedupe_min_events", 1)
+
+    def check(ev, sigma=1.0):
+        of, ou, omm = oracle.ev2im_gauss(ev, W, H, sigma, False, True, fast=True)
+        gf, gu, gmm = fe.EvImConverter.ev2im_gauss(ev, W, H, sigma, False, True, ctx=c, return_all=True)
+        assert _same_bits(of, gf) and np.array_equal(ou, gu) and _same_bits(omm, gmm), (len(ev), sigma)
+    evs = [synth.shapes_events(200000 + 1000 * k, W, H, seed=41 + k, undistort=True) for k in range(6)]
+    # a sparse call does not see every sensor pixel: the positions accumulate over the calls that miss (each extends the table and
+    # refreezes) until the dictionary holds all that fire
+    check(evs[0]); assert c.debug_counter("dict_hits") == 0 and 1000 < c.debug_counter("dict_positions") <= 43200
+    n1 = c.debug_counter("dict_positions")
+    check(evs[5]); assert c.debug_counter("dict_misses") == 1 and n1 < c.debug_counter("dict_positions") <= 43200
+    # a call that visits every pixel completes it
+    mx, my = synth.undistort_lut(W, H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    allpix = np.zeros(W * H, synth.RAW_DTYPE); allpix["x"] = xx.ravel(); allpix["y"] = yy.ravel(); allpix["p"] = 1; allpix["t"] = np.arange(W * H) * 1e-6
+    cover = np.concatenate([oracle.undistort_events(allpix, mx, my, W, H, True, 1.0), evs[0][:180000]])
+    check(cover)
+    m0, h0 = c.debug_counter("dict_misses"), c.debug_counter("dict_hits")
+    check(evs[1]); check(evs[2])
+    assert c.debug_counter("dict_hits") == h0 + 2 and c.debug_counter("dict_misses") == m0
+    odd = evs[3].copy(); odd["x"][777] += np.float32(0.125); odd["y"][12345] = np.float32(-2.5)      # two positions no map produces
+    check(odd); assert c.debug_counter("dict_misses") == m0 + 1 and c.debug_counter("dict_hits") == h0 + 2
+    check(odd); check(evs[4]); assert c.debug_counter("dict_hits") == h0 + 4
+    check(evs[0], 0.7); check(evs[1], 0.7); assert c.debug_counter("dict_hits") == h0 + 5      # another sigma: frozen afresh (the positions are kept), then used
+    nan = evs[2].copy(); nan["x"][5] = np.nan
+    check(nan, 0.7); assert c.debug_counter("dict_hits") == h0 + 6                                 # NaN coordinates are dropped, not looked up
+    hits = c.debug_counter("dict_hits")
+    check(synth.random_events(600000, W, H, seed=42, frac=True))                                   # never repeats: list pipeline, nothing frozen, nothing looked up
+    assert c.debug_counter("dict_hits") == hits
+    check(evs[3], 0.7); assert c.debug_counter("dict_hits") == hits + 1                            # (the sigma 0.7 dictionary is still there)
+    hits += 1
+    c.debug_option("position_dict", 0)
+    check(evs[0]); check(evs[1]); assert c.debug_counter("dict_hits") == hits and c.debug_counter("dict_positions") == 0
+    c.close()
+    # the batched front end: the second batch of a context goes through the dictionary and equals the raw path's result
+    mx, my = _maps(W, H)
+    B, n = 3, 400000
+    pairs = [synth.shapes_events(n, W, H, seed=90 + b, motion=0.4, undistort=True, return_raw=True) for b in range(2 * B)]
+    fb = fe.FrontEndBatch(W, H, 1.0, False, 1000, 1.2, 4, 10, 0, 19, max_batch=B, max_events=n)
+    cc, cap = fb.ctx, fb.cap
+    d_ev = cc.dev_alloc(B * n * 16); d_img = cc.dev_alloc(B * W * H)
+    for half in range(2):
+        blob = np.concatenate([fe.pack_events(p[0]) for p in pairs[half * B:(half + 1) * B]])
+        cc.upload(d_ev, blob)
+        fb.run_dev(d_ev, np.arange(B + 1, dtype=np.int64) * n, d_img, None, None, None, None, None, raw=False)
+        cc.sync()
+        imgs = np.zeros((B, H, W), np.uint8); cc.download(imgs, d_img)
+        for b in range(B):
+            assert np.array_equal(imgs[b], oracle.ev2im_gauss(pairs[half * B + b][0], W, H, 1.0, False, True, fast=True)[1]), (half, b)
+    assert cc.debug_counter("dict_hits") + cc.debug_counter("dict_misses") == 1            # (1.2 M events: the second batch may still meet a new pixel)
+    cc.dev_free(d_ev); cc.dev_free(d_img); cc.close()
+
+
 def test_ev2im_gauss_shapes_lut(oracle, fe, ctx):
     """C1 stand-in: LUT-undistorted shapes events, L1 chunk (2000) and L2 window (6000)."""
     for n in (2000, 6000, 50000):
