@@ -94,7 +94,7 @@ struct eorb_ctx {
     // slot form of the raw accumulation (ev_slots.hip): per sensor pixel its tiles / slot numbers, per tile its rows; valid when sl_ok
     eorb::DevBuf sl_tab, sl_tile, sl_rows, sl_trace; long long sl_trace_n = 0;
     // per-batch workspaces of the slot form, one set per part of a batch (a batch of 64 slices or more runs as two halves)
-    struct SlotWS { eorb::DevBuf chunks, segoff, entries, tile_order, plan, hot; };
+    struct SlotWS { eorb::DevBuf chunks, segoff, entries, tile_order, plan, hot, rec16; };
     SlotWS sl_ws[2];
     // its streams (made together, ev_slots.hip sl_streams): sl_side = the register-row kernel (high priority), sl_pstream = the plan,
     // sl_gstream = the LDS gather of one half while the next half is binned; five events per part

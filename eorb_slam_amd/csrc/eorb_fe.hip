@@ -272,7 +272,7 @@ void eorb_destroy(eorb_ctx* c)
     if (c->sl_side) hipStreamDestroy(c->sl_side);
     if (c->sl_pstream) hipStreamDestroy(c->sl_pstream);
     if (c->sl_gstream) hipStreamDestroy(c->sl_gstream);
-    for (auto& w : c->sl_ws) { free_buf(w.chunks); free_buf(w.segoff); free_buf(w.entries); free_buf(w.tile_order); free_buf(w.plan); free_buf(w.hot); }
+    for (auto& w : c->sl_ws) { free_buf(w.chunks); free_buf(w.segoff); free_buf(w.entries); free_buf(w.tile_order); free_buf(w.plan); free_buf(w.hot); free_buf(w.rec16); }
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
