@@ -32,11 +32,12 @@ int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, c
                          const uint8_t* cur_is_orb, const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
                          const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
                          int dist_th, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
-                         int32_t* nmatches);
+                         int32_t* nmatches, const float* cur_uright = nullptr, const float* q_ur = nullptr);
 int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
                         int M, const uint8_t* in_view, const float4* mp_f4 /* projX, projY, viewCos, levelScale */,
                         const int32_t* level, const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb,
-                        eorb_grid_bounds gb, int32_t* frame_mp, float th, float nnratio, int32_t* nmatches);
+                        eorb_grid_bounds gb, int32_t* frame_mp, float th, float nnratio, int32_t* nmatches,
+                        const float* uright = nullptr, const float* q_ur = nullptr);
 
 int orb_pyramid_blur_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride);
 int orb_tracked_dev(eorb_ctx* c, eorb_keypoint* d_kps, int n, int mode, const uint8_t* d_ref, uint8_t* d_desc, uint8_t* d_oob);
@@ -1167,10 +1168,10 @@ static int proj_last_common(eorb_ctx* c,
         const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
         const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
         const float* level_scale, const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri,
-        int dist_th, int* nmatches)
+        int dist_th, int* nmatches, const float* cur_uright = nullptr, const float* q_ur = nullptr)
 {
     if (!c) return EORB_E_ARG;
-    if (n_cur < 0 || n_last < 0 || !gb || !cur_mp || cur_stride < 32 || !level_scale)
+    if (n_cur < 0 || n_last < 0 || !gb || !cur_mp || cur_stride < 32 || !level_scale || ((cur_uright != nullptr) != (q_ur != nullptr)))
         return set_err(c, EORB_E_ARG, "search_by_projection_last: bad arguments");
     hipSetDevice(c->device);
     if (nmatches) *nmatches = 0;
@@ -1184,6 +1185,7 @@ static int proj_last_common(eorb_ctx* c,
     for (int i = 0; i < n_last; i++) { f3[3 * i] = uv[2 * i]; f3[3 * i + 1] = uv[2 * i + 1]; f3[3 * i + 2] = level_scale[i]; }
     const size_t o_f3 = A.in(f3.data(), sizeof(float) * f3.size());
     const size_t o_va = A.in(valid, n_last), o_ob = A.in(mp_obs, n_last);
+    const size_t o_ur2 = A.in(cur_uright, cur_uright ? sizeof(float) * (size_t)n_cur : 0), o_qur = A.in(q_ur, q_ur ? sizeof(float) * (size_t)n_last : 0);
     // outputs, contiguous: nmatches | slots (in/out)
     const size_t o_nm = A.in(nullptr, 16);
     const size_t o_mp = A.in(cur_mp, sizeof(int32_t) * (size_t)n_cur);
@@ -1192,7 +1194,7 @@ static int proj_last_common(eorb_ctx* c,
                               cur_is_orb ? A.dev<uint8_t>(o_co) : nullptr, A.dev<eorb_keypoint>(o_lk), n_last,
                               last_is_orb ? A.dev<uint8_t>(o_lo) : nullptr, A.dev<uint8_t>(o_va), A.dev<float>(o_f3),
                               A.dev<uint8_t>(o_md), A.dev<uint8_t>(o_ob), dist_th, *gb, A.dev<int32_t>(o_mp), th,
-                              mode, checkOri, A.dev<int32_t>(o_nm));
+                              mode, checkOri, A.dev<int32_t>(o_nm), cur_uright ? A.dev<float>(o_ur2) : nullptr, q_ur ? A.dev<float>(o_qur) : nullptr);
     if (rc) return rc;
     const char* h;
     if ((rc = A.download(o_nm, o_mp + sizeof(int32_t) * (size_t)n_cur - o_nm, &h))) return rc;
@@ -1210,6 +1212,18 @@ int eorb_search_by_projection_last(eorb_ctx* c,
 {
     return proj_last_common(c, cur_kps, n_cur, cur_desc, cur_stride, cur_is_orb, last_kps, n_last, last_is_orb, valid, uv, mp_desc,
                             mp_obs, level_scale, gb, cur_mp, th, mode, checkOri, 100 /* TH_HIGH */, nmatches);
+}
+
+int eorb_search_by_projection_last_stereo(eorb_ctx* c,
+        const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
+        const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
+        const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+        const float* level_scale, const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri,
+        const float* cur_uright, const float* proj_ur, int* nmatches)
+{
+    if (c && (!cur_uright || !proj_ur)) return set_err(c, EORB_E_ARG, "search_by_projection_last_stereo: mvuRight and the projected right coordinates are needed");
+    return proj_last_common(c, cur_kps, n_cur, cur_desc, cur_stride, cur_is_orb, last_kps, n_last, last_is_orb, valid, uv, mp_desc,
+                            mp_obs, level_scale, gb, cur_mp, th, mode, checkOri, 100 /* TH_HIGH */, nmatches, cur_uright, proj_ur);
 }
 
 int eorb_search_by_projection_kf(eorb_ctx* c,
@@ -1234,14 +1248,14 @@ int eorb_search_by_projection_kf(eorb_ctx* c,
     return EORB_OK;
 }
 
-int eorb_search_by_projection_map(eorb_ctx* c,
+static int proj_map_common(eorb_ctx* c,
         const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
         int M, const uint8_t* in_view, const float* proj_xy, const int32_t* level, const float* view_cos,
         const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
-        const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, int* nmatches)
+        const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, int* nmatches, const float* uright, const float* proj_xr)
 {
     if (!c) return EORB_E_ARG;
-    if (n < 0 || M < 0 || !gb || !frame_mp || stride < 32) return set_err(c, EORB_E_ARG, "search_by_projection_map: bad arguments");
+    if (n < 0 || M < 0 || !gb || !frame_mp || stride < 32 || ((uright != nullptr) != (proj_xr != nullptr))) return set_err(c, EORB_E_ARG, "search_by_projection_map: bad arguments");
     hipSetDevice(c->device);
     if (nmatches) *nmatches = 0;
     if (M == 0 || n == 0) return EORB_OK;
@@ -1254,18 +1268,41 @@ int eorb_search_by_projection_map(eorb_ctx* c,
     for (int m = 0; m < M; m++) { f4[4 * m] = proj_xy[2 * m]; f4[4 * m + 1] = proj_xy[2 * m + 1]; f4[4 * m + 2] = view_cos[m]; f4[4 * m + 3] = level_scale[m]; }
     const size_t o_f4 = A.in(f4.data(), sizeof(float) * f4.size()), o_lv = A.in(level, sizeof(int32_t) * (size_t)M);
     const size_t o_iv = A.in(in_view, M), o_ob = A.in(mp_obs, M), o_mo = A.in(mp_is_orb, mp_is_orb ? M : 0);
+    const size_t o_ur2 = A.in(uright, uright ? sizeof(float) * (size_t)n : 0), o_qur = A.in(proj_xr, proj_xr ? sizeof(float) * (size_t)M : 0);
     const size_t o_nm = A.in(nullptr, 16);
     const size_t o_fm = A.in(frame_mp, sizeof(int32_t) * (size_t)n);
     if ((rc = A.upload())) return rc;
     rc = search_proj_map_dev(c, A.dev<eorb_keypoint>(o_k), n, A.dev<uint8_t>(o_d), stride, is_orb ? A.dev<uint8_t>(o_o) : nullptr, M,
                              A.dev<uint8_t>(o_iv), A.dev<float4>(o_f4), A.dev<int32_t>(o_lv), A.dev<uint8_t>(o_md), A.dev<uint8_t>(o_ob),
-                             mp_is_orb ? A.dev<uint8_t>(o_mo) : nullptr, *gb, A.dev<int32_t>(o_fm), th, nnratio, A.dev<int32_t>(o_nm));
+                             mp_is_orb ? A.dev<uint8_t>(o_mo) : nullptr, *gb, A.dev<int32_t>(o_fm), th, nnratio, A.dev<int32_t>(o_nm),
+                             uright ? A.dev<float>(o_ur2) : nullptr, proj_xr ? A.dev<float>(o_qur) : nullptr);
     if (rc) return rc;
     const char* h;
     if ((rc = A.download(o_nm, o_fm + sizeof(int32_t) * (size_t)n - o_nm, &h))) return rc;
     memcpy(frame_mp, h + o_fm, sizeof(int32_t) * (size_t)n);
     if (nmatches) *nmatches = *(const int32_t*)(h + o_nm);
     return EORB_OK;
+}
+
+int eorb_search_by_projection_map(eorb_ctx* c,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
+        int M, const uint8_t* in_view, const float* proj_xy, const int32_t* level, const float* view_cos,
+        const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
+        const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, int* nmatches)
+{
+    return proj_map_common(c, kps, n, desc, stride, is_orb, M, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, mp_is_orb, level_scale, gb,
+                           frame_mp, th, nnratio, nmatches, nullptr, nullptr);
+}
+
+int eorb_search_by_projection_map_stereo(eorb_ctx* c,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
+        int M, const uint8_t* in_view, const float* proj_xy, const int32_t* level, const float* view_cos,
+        const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
+        const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, const float* uright, const float* proj_xr, int* nmatches)
+{
+    if (c && (!uright || !proj_xr)) return set_err(c, EORB_E_ARG, "search_by_projection_map_stereo: mvuRight and mTrackProjXR are needed");
+    return proj_map_common(c, kps, n, desc, stride, is_orb, M, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, mp_is_orb, level_scale, gb,
+                           frame_mp, th, nnratio, nmatches, uright, proj_xr);
 }
 
 static int bow_common(eorb_ctx* c, int kf_kf,

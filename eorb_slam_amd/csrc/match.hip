@@ -201,6 +201,9 @@ struct WinArgs {
     // SearchByProjection: queries = last-frame keypoints / map points
     const eorb_keypoint* qkps; const uint8_t* q_is_orb; const uint8_t* valid; const float* qf; const int32_t* qlevel;
     const uint8_t* mp_desc; const uint8_t* mp_obs; const uint8_t* mp_is_orb; float th; int mode; int dist_th;
+    // stereo gate (src/ORBmatcher.cc:96-104, :2056-2062): uright2 = mvuRight of the searched frame's keypoints (> 0: has a right match),
+    // q_ur = the query's right coordinate (mTrackProjXR, or uv.x - mbf * invzc); both NULL in the mono configurations
+    const float* uright2; const float* q_ur;
     GridB g; float nnratio; int checkOri;
     int dmax;                  // phase 1 keeps candidates with dist < dmax
     int wcap;                  // list capacity of one query
@@ -216,6 +219,7 @@ struct WinQuery {              // wave-uniform description of one query
     int minLevel, maxLevel;
     bool isorb;
     uint64_t d0, d1, d2, d3;
+    float ur; bool has_ur;            // stereo: the query's right coordinate
 };
 
 // searched-frame record: cell (16 bits, 0xFFFF = PosInGrid false) | level (8 bits, signed) << 16 | isORB << 24
@@ -234,6 +238,7 @@ __device__ __forceinline__ WinQuery win_query(const WinArgs& A, int pair, int q)
 {
     WinQuery Q;
     Q.active = true; Q.minLevel = Q.maxLevel = 0; Q.qx = Q.qy = Q.r = 0.f; Q.isorb = true; Q.d0 = Q.d1 = Q.d2 = Q.d3 = 0;
+    Q.ur = 0.f; Q.has_ur = false;
     if (KIND == 0) {
         const eorb_keypoint k1 = A.kps1[(size_t)pair * A.kp1_stride + q];
         Q.isorb = A.is_orb1 ? A.is_orb1[(size_t)pair * A.capq + q] != 0 : true;
@@ -267,6 +272,7 @@ __device__ __forceinline__ WinQuery win_query(const WinArgs& A, int pair, int q)
         }
         const uint64_t* dq = (const uint64_t*)(A.mp_desc + (size_t)q * 32);
         Q.d0 = dq[0]; Q.d1 = dq[1]; Q.d2 = dq[2]; Q.d3 = dq[3];
+        if (A.q_ur && A.uright2) { Q.ur = A.q_ur[q]; Q.has_ur = true; }
     }
     return Q;
 }
@@ -274,7 +280,7 @@ __device__ __forceinline__ WinQuery win_query(const WinArgs& A, int pair, int q)
 // candidate test of Frame::GetFeaturesInArea (Frame.cc:747-777) + the MixedMatcher type gate (MixedMatcher.cpp:65-67, :565-568,
 // :787-790).  Returns the key, or ~0 when i2 is no candidate.  key = dist << 44 | cell << 32 | index << 8 | level + 1
 __device__ __forceinline__ uint64_t win_key(const WinQuery& Q, int cx0, int cx1, int cy0, int cy1, uint32_t info, float x, float y,
-                                            const uint64_t* __restrict__ dp, int i2)
+                                            const uint64_t* __restrict__ dp, int i2, float uright = -1.f)
 {
     const int cell = (int)(info & 0xffffu);
     if (cell == 0xFFFF) return ~0ull;
@@ -288,6 +294,8 @@ __device__ __forceinline__ uint64_t win_key(const WinQuery& Q, int cx0, int cx1,
     const float distx = x - Q.qx, disty = y - Q.qy;
     if (!(fabsf(distx) < Q.r && fabsf(disty) < Q.r)) return ~0ull;
     if ((((info >> 24) & 1u) != 0) != Q.isorb) return ~0ull;
+    // "if(F.mvuRight[idx]>0) { er = fabs(projXR - F.mvuRight[idx]); if(er > radius) continue; }" (:96-104, :2056-2062)
+    if (Q.has_ur && uright > 0.f && fabsf(Q.ur - uright) > Q.r) return ~0ull;
     const int dist = __popcll(Q.d0 ^ dp[0]) + __popcll(Q.d1 ^ dp[1]) + __popcll(Q.d2 ^ dp[2]) + __popcll(Q.d3 ^ dp[3]);
     return ((uint64_t)dist << 44) | ((uint64_t)cell << 32) | ((uint64_t)(uint32_t)i2 << 8) | (uint64_t)((lv + 1) & 0xff);
 }
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
             for (int i0 = 0; i0 < N2; i0 += 64) {
                 const int i2 = i0 + lane;
                 uint64_t key = ~0ull;
-                if (i2 < N2) key = win_key(Q, cx0, cx1, cy0, cy1, info2[i2], x2[i2], y2[i2], &d2[(size_t)i2 * 4], i2);
+                if (i2 < N2) key = win_key(Q, cx0, cx1, cy0, cy1, info2[i2], x2[i2], y2[i2], &d2[(size_t)i2 * 4], i2, Q.has_ur ? A.uright2[i2] : -1.f);
                 const bool ok = key != ~0ull && (int)(key >> 44) < A.dmax;
                 const uint64_t bal = __ballot(ok);
                 if (ok) { const uint32_t pos = n + (uint32_t)__popcll(bal & lt_mask); if (pos < (uint32_t)A.wcap) wl[pos] = key; }
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
                         const bool isorb = O2 ? O2[i2] != 0 : true;
                         uint64_t dd[4];
                         load_desc32(D2 + (size_t)i2 * A.dstride2, dd[0], dd[1], dd[2], dd[3]);
-                        const uint64_t key = win_key(Q, cx0, cx1, cy0, cy1, f2_info(k, isorb, A.g), k.x, k.y, dd, i2);
+                        const uint64_t key = win_key(Q, cx0, cx1, cy0, cy1, f2_info(k, isorb, A.g), k.x, k.y, dd, i2, Q.has_ur ? A.uright2[i2] : -1.f);
                         if (key != ~0ull && passes(key)) { if (key < k0) { k1 = k0; k0 = key; } else if (key < k1) k1 = key; }
                     }
                 }
@@ -781,10 +789,10 @@ int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, c
                          const uint8_t* cur_is_orb, const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
                          const uint8_t* valid, const float* uvs, const uint8_t* mp_desc, const uint8_t* mp_obs,
                          int dist_th, eorb_grid_bounds gb, int32_t* cur_mp, float th, int mode, int checkOri,
-                         int32_t* nmatches)
+                         int32_t* nmatches, const float* cur_uright, const float* q_ur)
 {
     WinArgs A{};
-    A.dist_th = dist_th;
+    A.dist_th = dist_th; A.uright2 = cur_uright; A.q_ur = q_ur;
     A.kps2 = cur_kps; A.n2 = n_cur; A.cap2 = std::max(n_cur, 1); A.desc2 = cur_desc; A.dstride2 = cur_stride; A.is_orb2 = cur_is_orb;
     A.nq = n_last; A.capq = std::max(n_last, 1); A.qkps = last_kps; A.q_is_orb = last_is_orb; A.valid = valid; A.qf = uvs;
     A.mp_desc = mp_desc; A.mp_obs = mp_obs;
@@ -797,9 +805,10 @@ int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, c
 int search_proj_map_dev(eorb_ctx* c, const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
                         int M, const uint8_t* in_view, const float4* mp_f4, const int32_t* level, const uint8_t* mp_desc,
                         const uint8_t* mp_obs, const uint8_t* mp_is_orb, eorb_grid_bounds gb, int32_t* frame_mp, float th,
-                        float nnratio, int32_t* nmatches)
+                        float nnratio, int32_t* nmatches, const float* uright, const float* q_ur)
 {
     WinArgs A{};
+    A.uright2 = uright; A.q_ur = q_ur;
     A.kps2 = kps; A.n2 = n; A.cap2 = std::max(n, 1); A.desc2 = desc; A.dstride2 = stride; A.is_orb2 = is_orb;
     A.nq = M; A.capq = std::max(M, 1); A.valid = in_view; A.qf = (const float*)mp_f4; A.qlevel = level;
     A.mp_desc = mp_desc; A.mp_obs = mp_obs; A.mp_is_orb = mp_is_orb;

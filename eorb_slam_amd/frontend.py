@@ -355,14 +355,25 @@ class ORBmatcher:
                                                    int(self.mbCheckOrientation), C.byref(nm)))
         return nm.value, m12, pm
 
-    def SearchByProjectionLast(self, Cur, Last, valid, uv, mp_desc, mp_obs, cur_mp, th, level_scale, mode=0):
+    def SearchByProjectionLast(self, Cur, Last, valid, uv, mp_desc, mp_obs, cur_mp, th, level_scale, mode=0,
+                               uright=None, proj_ur=None):
         """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) with the projection done
-        by the caller (valid/uv), src/ORBmatcher.cc:1969-2187."""
+        by the caller (valid/uv), src/ORBmatcher.cc:1969-2187.  uright = CurrentFrame.mvuRight and proj_ur = u - mbf*invzc
+        per last-frame point switch the rectified-stereo gate (:2056-2062) on."""
         valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
         mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
         ls = np.ascontiguousarray(level_scale, np.float32)
         cm = np.ascontiguousarray(cur_mp, np.int32).copy(); nm = C.c_int(0)
         c = self.ctx
+        if uright is not None:
+            ur = np.ascontiguousarray(uright, np.float32); pu = np.ascontiguousarray(proj_ur, np.float32)
+            if len(ur) != Cur.N or len(pu) != Last.N:
+                raise ValueError("uright is per current keypoint, proj_ur per last-frame keypoint")
+            c.check(c.L.eorb_search_by_projection_last_stereo(c.h, _p(Cur.kps), Cur.N, _p(Cur.desc), Cur.desc.shape[1], _p(Cur.is_orb),
+                                                              _p(Last.kps), Last.N, _p(Last.is_orb), _p(valid), _p(uv), _p(mp_desc),
+                                                              _p(mp_obs), _p(ls), C.byref(Cur.gb), _p(cm), float(th), int(mode),
+                                                              int(self.mbCheckOrientation), _p(ur), _p(pu), C.byref(nm)))
+            return nm.value, cm
         c.check(c.L.eorb_search_by_projection_last(c.h, _p(Cur.kps), Cur.N, _p(Cur.desc), Cur.desc.shape[1], _p(Cur.is_orb),
                                                    _p(Last.kps), Last.N, _p(Last.is_orb), _p(valid), _p(uv), _p(mp_desc),
                                                    _p(mp_obs), _p(ls), C.byref(Cur.gb), _p(cm), float(th), int(mode),
@@ -386,9 +397,10 @@ class ORBmatcher:
         return nm.value, cm
 
     def SearchByProjectionMap(self, F, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, frame_mp, th, level_scale,
-                              mp_is_orb=None):
+                              mp_is_orb=None, uright=None, proj_xr=None):
         """SearchByProjection(Frame &F, const vector<MapPoint*>&, th) with Frame::isInFrustum's outputs as inputs,
-        src/ORBmatcher.cc:44-219."""
+        src/ORBmatcher.cc:44-219.  uright = F.mvuRight and proj_xr = mTrackProjXR per map point switch the
+        rectified-stereo gate (:96-104) on."""
         in_view = np.ascontiguousarray(in_view, np.uint8); proj_xy = np.ascontiguousarray(proj_xy, np.float32)
         level = np.ascontiguousarray(level, np.int32); view_cos = np.ascontiguousarray(view_cos, np.float32)
         mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
@@ -396,6 +408,15 @@ class ORBmatcher:
         mio = None if mp_is_orb is None else np.ascontiguousarray(mp_is_orb, np.uint8)
         fm = np.ascontiguousarray(frame_mp, np.int32).copy(); nm = C.c_int(0)
         c = self.ctx
+        if uright is not None:
+            ur = np.ascontiguousarray(uright, np.float32); px = np.ascontiguousarray(proj_xr, np.float32)
+            if len(ur) != F.N or len(px) != len(in_view):
+                raise ValueError("uright is per frame keypoint, proj_xr per map point")
+            c.check(c.L.eorb_search_by_projection_map_stereo(c.h, _p(F.kps), F.N, _p(F.desc), F.desc.shape[1], _p(F.is_orb),
+                                                             len(in_view), _p(in_view), _p(proj_xy), _p(level), _p(view_cos),
+                                                             _p(mp_desc), _p(mp_obs), _p(mio), _p(ls), C.byref(F.gb), _p(fm),
+                                                             float(th), self.mfNNratio, _p(ur), _p(px), C.byref(nm)))
+            return nm.value, fm
         c.check(c.L.eorb_search_by_projection_map(c.h, _p(F.kps), F.N, _p(F.desc), F.desc.shape[1], _p(F.is_orb),
                                                   len(in_view), _p(in_view), _p(proj_xy), _p(level), _p(view_cos),
                                                   _p(mp_desc), _p(mp_obs), _p(mio), _p(ls), C.byref(F.gb), _p(fm),

@@ -272,6 +272,23 @@ int eorb_search_by_projection_map(eorb_ctx* ctx,
         const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
         const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, int* nmatches);
 
+/* The rectified-stereo / RGB-D gate of the two matchers above -- "if(F.mvuRight[idx]>0) { er = fabs(projXR - F.mvuRight[idx]);
+ * if(er > radius) continue; }" (src/ORBmatcher.cc:96-104 with pMP->mTrackProjXR and r * getORBScaleFactor(level); :2056-2062 with
+ * ur = uv.x - mbf * invzc and th * getORBScaleFactor(octave)): uright = mvuRight of the searched frame's keypoints (n floats, <= 0: no
+ * right match), proj_xr / proj_ur = the right coordinate of every query, computed by the caller with the projection.  Everything else
+ * as the mono entry points (whose configurations pass no mvuRight: Frame::numKPtsLeft() != -1 or all mvuRight = -1). */
+int eorb_search_by_projection_map_stereo(eorb_ctx* ctx,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const uint8_t* is_orb,
+        int M, const uint8_t* in_view, const float* proj_xy, const int32_t* level, const float* view_cos,
+        const uint8_t* mp_desc, const uint8_t* mp_obs, const uint8_t* mp_is_orb, const float* level_scale,
+        const eorb_grid_bounds* gb, int32_t* frame_mp, float th, float nnratio, const float* uright, const float* proj_xr, int* nmatches);
+int eorb_search_by_projection_last_stereo(eorb_ctx* ctx,
+        const eorb_keypoint* cur_kps, int n_cur, const uint8_t* cur_desc, int cur_stride, const uint8_t* cur_is_orb,
+        const eorb_keypoint* last_kps, int n_last, const uint8_t* last_is_orb,
+        const uint8_t* valid, const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+        const float* level_scale, const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri,
+        const float* cur_uright, const float* proj_ur, int* nmatches);
+
 /* replaces the mono branch of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:276-478;
  * MixedMatcher.cpp:148-356).  DBoW2::FeatureVector as CSR (node ids ascending, offsets, feature indices in vector
  * order).  kf_has_mp[i] = map point present and !isBad().  match_f[n_f] out = KeyFrame feature index or -1. */

@@ -251,6 +251,15 @@ int orc_search_by_projection_map(const orc_frame* F, int M, const uint8_t* in_vi
                                  const int* level, const float* view_cos, const uint8_t* mp_desc,
                                  const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
                                  float th, float nnratio, const float* level_scale);
+/* the rectified-stereo gate of the two projection matchers (src/ORBmatcher.cc:96-104, :2056-2062) */
+int orc_search_by_projection_last_stereo(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
+                                         const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+                                         int* cur_mp, float th, int mode, int checkOri, const float* level_scale,
+                                         const float* uright, const float* proj_ur);
+int orc_search_by_projection_map_stereo(const orc_frame* F, int M, const uint8_t* in_view, const float* proj_xy,
+                                        const int* level, const float* view_cos, const uint8_t* mp_desc,
+                                        const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
+                                        float th, float nnratio, const float* level_scale, const float* uright, const float* proj_xr);
 
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:276-478), mono branch.  The DBoW2 feature vectors
  * are CSR: node ids ascending, node_off[nn+1], idx[] = feature indices in vector order.  kf_has_mp[i] = map point present

@@ -167,6 +167,10 @@ def lib(fast=False):
     L.orc_search_by_projection_last.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp]
     L.orc_search_by_projection_map.restype = ci
     L.orc_search_by_projection_map.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp]
+    L.orc_search_by_projection_last_stereo.restype = ci
+    L.orc_search_by_projection_last_stereo.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, ci, ci, vp, vp, vp]
+    L.orc_search_by_projection_map_stereo.restype = ci
+    L.orc_search_by_projection_map_stereo.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp]
     L.orc_orb_tracked_descriptors.restype = ci; L.orc_orb_tracked_descriptors.argtypes = [vp, vp, ci, ci, ci, vp, ci, vp, vp]
     L.orc_orb_assign_level_by_best_desc.restype = ci
     L.orc_orb_assign_level_by_best_desc.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci]
@@ -396,24 +400,35 @@ def search_for_initialization(F1, F2, prev_matched, windowSize=100, nnratio=0.9,
 
 
 def search_by_projection_last(cur, last, valid, uv, mp_desc, mp_obs, cur_mp, th, level_scale,
-                              mode=0, checkOri=True):
+                              mode=0, checkOri=True, uright=None, proj_ur=None):
     valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
     mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
     cm = np.ascontiguousarray(cur_mp, np.int32).copy()
     ls = np.ascontiguousarray(level_scale, np.float32)
+    if uright is not None:
+        ur = np.ascontiguousarray(uright, np.float32); pu = np.ascontiguousarray(proj_ur, np.float32)
+        n = cur.L.orc_search_by_projection_last_stereo(cur.h, last.h, _p(valid), _p(uv), _p(mp_desc), _p(mp_obs),
+                                                       _p(cm), th, mode, int(checkOri), _p(ls), _p(ur), _p(pu))
+        return n, cm
     n = cur.L.orc_search_by_projection_last(cur.h, last.h, _p(valid), _p(uv), _p(mp_desc), _p(mp_obs),
                                             _p(cm), th, mode, int(checkOri), _p(ls))
     return n, cm
 
 
 def search_by_projection_map(F, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, frame_mp, th,
-                             nnratio, level_scale, mp_is_orb=None):
+                             nnratio, level_scale, mp_is_orb=None, uright=None, proj_xr=None):
     in_view = np.ascontiguousarray(in_view, np.uint8); proj_xy = np.ascontiguousarray(proj_xy, np.float32)
     level = np.ascontiguousarray(level, np.int32); view_cos = np.ascontiguousarray(view_cos, np.float32)
     mp_desc = np.ascontiguousarray(mp_desc, np.uint8); mp_obs = np.ascontiguousarray(mp_obs, np.uint8)
     level_scale = np.ascontiguousarray(level_scale, np.float32)
     mio = None if mp_is_orb is None else np.ascontiguousarray(mp_is_orb, np.uint8)
     fm = np.ascontiguousarray(frame_mp, np.int32).copy()
+    if uright is not None:
+        ur = np.ascontiguousarray(uright, np.float32); px = np.ascontiguousarray(proj_xr, np.float32)
+        n = F.L.orc_search_by_projection_map_stereo(F.h, len(in_view), _p(in_view), _p(proj_xy), _p(level),
+                                                    _p(view_cos), _p(mp_desc), _p(mp_obs), _p(mio), _p(fm),
+                                                    th, nnratio, _p(level_scale), _p(ur), _p(px))
+        return n, fm
     n = F.L.orc_search_by_projection_map(F.h, len(in_view), _p(in_view), _p(proj_xy), _p(level),
                                          _p(view_cos), _p(mp_desc), _p(mp_obs), _p(mio), _p(fm),
                                          th, nnratio, _p(level_scale))

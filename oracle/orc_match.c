@@ -228,9 +228,21 @@ static int holds_observed(const int* slot_mp, int idx, const uint8_t* mp_obs)
 }
 
 /* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono) :1969-2187, mono */
+/* stereo: uright = CurrentFrame.mvuRight (NULL in the mono configurations), proj_ur = uv.x - mbf * invzc per last-frame point (:2056-2062) */
+int orc_search_by_projection_last_stereo(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
+                                         const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+                                         int* cur_mp, float th, int mode, int checkOri, const float* level_scale,
+                                         const float* uright, const float* proj_ur);
 int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
                                   const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
                                   int* cur_mp, float th, int mode, int checkOri, const float* level_scale)
+{
+    return orc_search_by_projection_last_stereo(cur, last, valid, uv, mp_desc, mp_obs, cur_mp, th, mode, checkOri, level_scale, NULL, NULL);
+}
+int orc_search_by_projection_last_stereo(const orc_frame* cur, const orc_frame* last, const uint8_t* valid,
+                                         const float* uv, const uint8_t* mp_desc, const uint8_t* mp_obs,
+                                         int* cur_mp, float th, int mode, int checkOri, const float* level_scale,
+                                         const float* uright, const float* proj_ur)
 {
     int nmatches = 0;
     const int Nc = cur->N;
@@ -253,6 +265,11 @@ int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, c
         for (int c = 0; c < nc; c++) {
             const int i2 = idxs[c];
             if (holds_observed(cur_mp, i2, mp_obs)) continue;
+            if (uright && uright[i2] > 0) {                       /* :2056-2062 */
+                const float ur = proj_ur[i];
+                const float er = fabsf(ur - uright[i2]);
+                if (er > radius) continue;
+            }
             const int isORBPt = !cur->is_orb || cur->is_orb[i2];
             if (isORBMP != isORBPt) continue;                     /* MixedMatcher.cpp:787-790 */
             const int dist = orc_descriptor_distance(dMP, cur->desc + (size_t)i2 * cur->desc_stride);
@@ -283,10 +300,22 @@ int orc_search_by_projection_last(const orc_frame* cur, const orc_frame* last, c
 
 /* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) :44-219 mono branch;
  * MixedMatcher.cpp:500-691 adds the isORB gate (mp_is_orb / frame is_orb). */
+/* stereo: uright = F.mvuRight (NULL in the mono configurations), proj_xr = pMP->mTrackProjXR per map point (:96-104) */
+int orc_search_by_projection_map_stereo(const orc_frame* F, int M, const uint8_t* in_view, const float* proj_xy,
+                                        const int* level, const float* view_cos, const uint8_t* mp_desc,
+                                        const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
+                                        float th, float nnratio, const float* level_scale, const float* uright, const float* proj_xr);
 int orc_search_by_projection_map(const orc_frame* F, int M, const uint8_t* in_view, const float* proj_xy,
                                  const int* level, const float* view_cos, const uint8_t* mp_desc,
                                  const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
                                  float th, float nnratio, const float* level_scale)
+{
+    return orc_search_by_projection_map_stereo(F, M, in_view, proj_xy, level, view_cos, mp_desc, mp_obs, mp_is_orb, frame_mp, th, nnratio, level_scale, NULL, NULL);
+}
+int orc_search_by_projection_map_stereo(const orc_frame* F, int M, const uint8_t* in_view, const float* proj_xy,
+                                        const int* level, const float* view_cos, const uint8_t* mp_desc,
+                                        const uint8_t* mp_obs, const uint8_t* mp_is_orb, int* frame_mp,
+                                        float th, float nnratio, const float* level_scale, const float* uright, const float* proj_xr)
 {
     int nmatches = 0;
     const int bFactor = th != 1.0;
@@ -306,6 +335,10 @@ int orc_search_by_projection_map(const orc_frame* F, int M, const uint8_t* in_vi
         for (int c = 0; c < nc; c++) {
             const int idx = idxs[c];
             if (holds_observed(frame_mp, idx, mp_obs)) continue;
+            if (uright && uright[idx] > 0) {                      /* :96-104: er > r * F.getORBScaleFactor(nPredictedLevel) */
+                const float er = fabsf(proj_xr[m] - uright[idx]);
+                if (er > r * level_scale[m]) continue;
+            }
             const int isORBPt = !F->is_orb || F->is_orb[idx];
             if (isORBMP != isORBPt) continue;
             const int dist = orc_descriptor_distance(dMP, F->desc + (size_t)idx * F->desc_stride);

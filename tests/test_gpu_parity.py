@@ -351,6 +351,61 @@ def test_search_by_projection_map(oracle, fe, ctx):
     assert on > 10
 
 
+def test_search_by_projection_stereo_gate(oracle, fe, ctx):
+    """The rectified-stereo gate of the two projection matchers (src/ORBmatcher.cc:96-104, :2056-2062): a candidate with a right
+    coordinate (mvuRight > 0) must also lie within the radius of the query's predicted right coordinate.  Keypoints without a right
+    match (<= 0) are not gated; with none at all the result is the mono matcher's."""
+    k1, d1, k2, d2 = _two_frames(oracle, seed=23, shift=2)
+    rng = np.random.default_rng(4)
+    n1, n2 = len(k1), len(k2)
+    sf = oracle.OrbExtractor(1000, 1.2, 4).scale_factors
+    ls = sf[np.clip(k1["octave"], 0, 3)]
+    valid = (rng.uniform(size=n1) < 0.85).astype(np.uint8)
+    uv = np.stack([k1["x"] - 2 + rng.normal(0, 1, n1), k1["y"] + 2 + rng.normal(0, 1, n1)], axis=1).astype(np.float32)
+    mp_obs = (rng.uniform(size=n1) < 0.7).astype(np.uint8)
+    cur_mp = np.full(n2, -1, np.int32); cur_mp[::17] = -2
+    disp = rng.uniform(2, 30, n2).astype(np.float32)
+    ur2 = (k2["x"] - disp).astype(np.float32)
+    ur2[rng.uniform(size=n2) < 0.3] = -1.0                        # no right match
+    # the queries' predicted right coordinate: near the true one for most, far off for some (those candidates drop out)
+    q_ur = (uv[:, 0] - rng.uniform(2, 30, n1)).astype(np.float32)
+    F2, F1 = oracle.Frame(k2, d2, 240, 180), oracle.Frame(k1, d1, 240, 180)
+    G2, G1 = fe.FrameView(k2, d2, 240, 180), fe.FrameView(k1, d1, 240, 180)
+    seen = []
+    for mode in (0, 1, 2):
+        for th in (7.0, 15.0):
+            on, ocm = oracle.search_by_projection_last(F2, F1, valid, uv, d1, mp_obs, cur_mp, th, ls, mode, True, uright=ur2, proj_ur=q_ur)
+            gn, gcm = fe.ORBmatcher(0.9, True, ctx).SearchByProjectionLast(G2, G1, valid, uv, d1, mp_obs, cur_mp, th, ls, mode, uright=ur2, proj_ur=q_ur)
+            assert on == gn and np.array_equal(ocm, gcm)
+            mn, mcm = fe.ORBmatcher(0.9, True, ctx).SearchByProjectionLast(G2, G1, valid, uv, d1, mp_obs, cur_mp, th, ls, mode)
+            seen.append((on, mn, not np.array_equal(gcm, mcm)))
+    assert any(d for _, _, d in seen) and all(a > 5 for a, _, _ in seen)          # the gate changed the result, and matches remain
+    none = np.full(n2, -1.0, np.float32)
+    gn, gcm = fe.ORBmatcher(0.9, True, ctx).SearchByProjectionLast(G2, G1, valid, uv, d1, mp_obs, cur_mp, 15.0, ls, 0, uright=none, proj_ur=q_ur)
+    mn, mcm = fe.ORBmatcher(0.9, True, ctx).SearchByProjectionLast(G2, G1, valid, uv, d1, mp_obs, cur_mp, 15.0, ls, 0)
+    assert gn == mn and np.array_equal(gcm, mcm)
+    # the map form: mTrackProjXR per map point
+    M = n1
+    in_view = (rng.uniform(size=M) < 0.9).astype(np.uint8)
+    proj = np.stack([k1["x"] - 2 + rng.normal(0, 0.7, M), k1["y"] + 2 + rng.normal(0, 0.7, M)], axis=1).astype(np.float32)
+    level = k1["octave"].astype(np.int32)
+    vc = rng.uniform(0.99, 1.0, M).astype(np.float32)
+    lsm = sf[np.clip(level, 0, 3)]
+    fm = np.full(n2, -1, np.int32); fm[::19] = -2
+    xr = (proj[:, 0] - rng.uniform(2, 30, M)).astype(np.float32)
+    changed = False
+    for th in (1.0, 3.0):
+        on, ofm = oracle.search_by_projection_map(F2, in_view, proj, level, vc, d1, mp_obs, fm, th, 0.8, lsm, uright=ur2, proj_xr=xr)
+        gn, gfm = fe.ORBmatcher(0.8, True, ctx).SearchByProjectionMap(G2, in_view, proj, level, vc, d1, mp_obs, fm, th, lsm, uright=ur2, proj_xr=xr)
+        assert on == gn and np.array_equal(ofm, gfm)
+        mn, mfm = fe.ORBmatcher(0.8, True, ctx).SearchByProjectionMap(G2, in_view, proj, level, vc, d1, mp_obs, fm, th, lsm)
+        changed |= not np.array_equal(gfm, mfm)
+    assert changed and on > 5
+    gn, gfm = fe.ORBmatcher(0.8, True, ctx).SearchByProjectionMap(G2, in_view, proj, level, vc, d1, mp_obs, fm, 3.0, lsm, uright=none, proj_xr=xr)
+    mn, mfm = fe.ORBmatcher(0.8, True, ctx).SearchByProjectionMap(G2, in_view, proj, level, vc, d1, mp_obs, fm, 3.0, lsm)
+    assert gn == mn and np.array_equal(gfm, mfm)
+
+
 def _mix(k, d, rng, frac=(2, 3)):
     """A MixedFrame stand-in: the first 2/3 of the rows are ORB, the rest "AKAZE" (61-byte rows whose first 32 bytes are
     compared, octaves of their own scale ladder)."""

@@ -346,3 +346,41 @@ def test_kannala_brandt8_known_answers(oracle):
                            np.array([0.0, 0.0, 1.0]).ctypes.data_as(C.c_void_p), np.zeros(3).ctypes.data_as(C.c_void_p),
                            C.c_float(1.0), None, uv.ctypes.data_as(C.c_void_p))
     assert np.abs(uv[:, 0] - ev["x"]).max() < 2e-3 and np.abs(uv[:, 1] - ev["y"]).max() < 2e-3
+
+
+def test_projection_stereo_gate_known_answers(oracle):
+    """src/ORBmatcher.cc:2056-2062 / :96-104 on a hand-built case: one projected point, two candidates in its window; the nearer
+    descriptor has a right coordinate off by more than the radius and drops out, the other (within the radius, or without a right
+    match at all) wins."""
+    e = oracle.OrbExtractor(1000, 1.2, 4, 10, 0, edgeTh=19)
+    _, k, d, _ = e.extract(synth.texture_image(240, 180, seed=5))
+    k = k[:3].copy(); d = d[:3].copy()
+    k["octave"] = 0; k["angle"] = 0.0
+    k["x"] = [100.0, 101.0, 180.0]; k["y"] = [90.0, 90.0, 40.0]
+    q = np.zeros(32, np.uint8)
+    d[0] = q; d[0, 0] = 0x01                                           # distance 1: the mono winner
+    d[1] = q; d[1, 0] = 0x07                                           # distance 3
+    d[2] = 0xFF
+    last = k[:1].copy(); last["x"] = 100.5; last["y"] = 90.0
+    cur_mp = np.full(3, -1, np.int32)
+    args = (oracle.Frame(k, d, 240, 180), oracle.Frame(last, q[None], 240, 180), np.ones(1, np.uint8), np.array([[100.5, 90.0]], np.float32),
+            q[None], np.ones(1, np.uint8), cur_mp, 7.0, np.ones(1, np.float32), 0, False)
+    n, cm = oracle.search_by_projection_last(*args)
+    assert n == 1 and cm.tolist() == [0, -1, -1]
+    # radius = th * scale = 7: candidate 0 at |80 - 90| = 10 > 7 is gated out, candidate 1 at |80 - 85| = 5 stays
+    n, cm = oracle.search_by_projection_last(*args, uright=np.array([90.0, 85.0, -1.0], np.float32), proj_ur=np.array([80.0], np.float32))
+    assert n == 1 and cm.tolist() == [-1, 0, -1]
+    # exactly on the radius is kept (er > radius), no right match (<= 0) is never gated
+    n, cm = oracle.search_by_projection_last(*args, uright=np.array([87.0, 85.0, -1.0], np.float32), proj_ur=np.array([80.0], np.float32))
+    assert cm.tolist() == [0, -1, -1]
+    n, cm = oracle.search_by_projection_last(*args, uright=np.array([0.0, 85.0, -1.0], np.float32), proj_ur=np.array([80.0], np.float32))
+    assert cm.tolist() == [0, -1, -1]
+    # the map form: r = th * RadiusByViewingCos(0.999) = 2.5, gate r * scale
+    margs = (oracle.Frame(k, d, 240, 180), np.ones(1, np.uint8), np.array([[100.5, 90.0]], np.float32), np.zeros(1, np.int32),
+             np.array([0.9995], np.float32), q[None], np.ones(1, np.uint8), cur_mp, 1.0, 0.8, np.ones(1, np.float32))
+    n, fm = oracle.search_by_projection_map(*margs)
+    assert n == 1 and fm.tolist() == [0, -1, -1]
+    n, fm = oracle.search_by_projection_map(*margs, uright=np.array([83.0, 82.0, -1.0], np.float32), proj_xr=np.array([80.0], np.float32))
+    assert n == 1 and fm.tolist() == [-1, 0, -1]
+    n, fm = oracle.search_by_projection_map(*margs, uright=np.array([82.5, 82.0, -1.0], np.float32), proj_xr=np.array([80.0], np.float32))
+    assert fm.tolist() == [0, -1, -1]
