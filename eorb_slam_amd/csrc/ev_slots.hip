@@ -36,6 +36,10 @@
 namespace eorb {
 
 constexpr uint32_t kNoSlot = 0xffu;
+// An entry of a (slice, tile) list: 16 bits, kEntryTag | slot.  The tag is what M0[15:12] must hold in the VGPR index mode of
+// sl_hot_kernel (SRC0 relative), so that kernel moves an entry to M0 with one scalar instruction; sl_gather_kernel reads the slot byte.
+typedef uint16_t slot_entry;
+constexpr uint32_t kEntryTag = 0x1000u;
 constexpr int kSlotScatWaves = 8;
 constexpr uint16_t kNoGeo = 0xffffu;           // (tile 127,127 with a second tile: never a valid range, TX and TY <= 127 there)
 constexpr int kCountWaves = 16;
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
                                                                          const uint2* __restrict__ slot_tab, int stride, int LW, int LH, int TX, int TY,
                                                                          int NT, int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                                          const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
-                                                                         uint8_t* __restrict__ entries)
+                                                                         slot_entry* __restrict__ entries)
 {
     extern __shared__ unsigned char sm2[];
     __shared__ uint32_t s_wsum[kSlotScatWaves];
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
     }
     __syncthreads();
     // ---- D ----
-    uint8_t* out = entries + (size_t)slice_ebase[cd.slice];
+    slot_entry* out = entries + (size_t)slice_ebase[cd.slice];
     const int E = loff[NT];
     for (int p = tid; p < E; p += NTHR) {
         const uint32_t sv = sidx[p];
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(64 * kSlotScatWaves) void sl_scatter_kernel(const e
         const uint32_t r0 = prng[k];
         const int t = ((int)(r0 >> 8) + dy) * TX + (int)(r0 & 0xff) + dx;
         const uint32_t slot = (pay[k] >> (8 * (dy * 2 + dx))) & 0xffu;
-        out[(size_t)gbase[t] + (uint32_t)(p - (int)loff[t])] = (uint8_t)slot;
+        out[(size_t)gbase[t] + (uint32_t)(p - (int)loff[t])] = (slot_entry)(kEntryTag | slot);
     }
 }
 
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
                                                                               const uint2* __restrict__ slot_tab, int LW, int LH, int TX, int NT,
                                                                               int chunk_cap, const int64_t* __restrict__ slice_ebase,
                                                                               const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
-                                                                              uint8_t* __restrict__ entries)
+                                                                              slot_entry* __restrict__ entries)
 {
     extern __shared__ unsigned char sm2[];
     __shared__ uint32_t s_wsum[NW];
@@ -638,9 +642,9 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
     }
     __syncthreads();
     // ---- D: consecutive threads write consecutive entries of a run ----
-    uint8_t* out = entries + (size_t)slice_ebase[cd.slice];
+    slot_entry* out = entries + (size_t)slice_ebase[cd.slice];
     const int E = loff[NT];
-    for (int p = tid; p < E; p += NTHR) out[(size_t)(uint32_t)(gbase[stile[p]] + (uint32_t)p)] = sorted[p];     // (gbase holds base - loff mod 2^32)
+    for (int p = tid; p < E; p += NTHR) out[(size_t)(uint32_t)(gbase[stile[p]] + (uint32_t)p)] = (slot_entry)(kEntryTag | sorted[p]);     // (gbase holds base - loff mod 2^32)
 }
 
 // Are the results of a wave's LDS atomic add handed out in lane order among the lanes that hit the same counter (32-bit words
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
         if (v & 0x80000000u) {
             const uint32_t c = v & 0x7fffffffu, b = hloc[s] >> 16, k = hbase[b] + (hloc[s] & 0xffffu);
             if (k < hot_cap) {
-                const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
+                const uint64_t off = ((uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t]) * sizeof(slot_entry);      // bytes
                 HotDesc d; d.slice = (uint32_t)s; d.tile = (uint32_t)t; d.cnt = c; d.off_lo = (uint32_t)off; d.off_hi = (uint32_t)(off >> 32);
                 d.tx0 = (uint32_t)(t % TX) * 8u; d.ty0 = (uint32_t)(t / TX) * 8u; d.rows_off = rowbase[t] * 256u;
                 hot_items[(size_t)b * kHotCap + k] = d;
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(256) void sl_plan_kernel(const uint32_t* __restrict
         const uint32_t c = pc[s];
         int rank = s;
         if (sorted) { rank = 0; for (int j = 0; j < B; j++) { const uint32_t v = pc[j]; rank += (v > c || (v == c && j < s)) ? 1 : 0; } }
-        const uint64_t off = (uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t];
+        const uint64_t off = ((uint64_t)slice_ebase[s] + tile_base[(size_t)s * NT + t]) * sizeof(slot_entry);          // bytes
         items[(size_t)t * B + rank] = make_uint4((uint32_t)s | (c & 0x80000000u), c & 0x7fffffffu, (uint32_t)off, (uint32_t)(off >> 32));
     }
 #pragma unroll
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(1024) void sl_tasks_kernel(const uint32_t* __restri
 // (Sharing a long list out by pixel quadrant was built and dropped: a 7x7 stamp centred inside an 8x8 tile reaches all four quadrants,
 // so on the tiles that matter a quadrant's wave keeps 95 % of the entries.)
 struct SlotGather {
-    const uint32_t* task_tile; const uint4* items; const uint8_t* entries;
+    const uint32_t* task_tile; const uint4* items; const uint8_t* entries;      /* (byte pointer: the descriptors carry byte offsets) */
     const uint32_t* nslots; const uint32_t* rowbase; const float* rows; const uint32_t* tile_w; uint32_t* ctr;
     float* img; uint32_t* minmax_enc; int* info; int* status;
     int B, W, H, TX, NT, null_slot; uint32_t prio_ref;
@@ -856,12 +860,12 @@ void sl_gather_kernel(SlotGather P)
         if (tid < 16) dst[P.null_slot * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    const uint32_t nullword = (uint32_t)P.null_slot * 0x01010101u;
+    const uint32_t nullword = (uint32_t)P.null_slot * 0x00010001u;
     uint32_t* const ctr = P.ctr + tile;
-    // v_perm_b32 selectors: LDS byte address of entry j's row for this lane = { 0, 0, slot byte j of the entry dword, 4 * lane }
+    // v_perm_b32 selectors: LDS byte address of an entry's row for this lane = { 0, 0, slot byte of the entry (byte 0 / 2 of the dword), 4 * lane }
     const uint32_t lane4 = (uint32_t)lane * 4u;
-    uint32_t sel0 = 0x0c0c0400u, sel1 = 0x0c0c0500u, sel2 = 0x0c0c0600u, sel3 = 0x0c0c0700u;
-    asm volatile("" : "+v"(sel0), "+v"(sel1), "+v"(sel2), "+v"(sel3));
+    uint32_t sel0 = 0x0c0c0400u, sel1 = 0x0c0c0600u;
+    asm volatile("" : "+v"(sel0), "+v"(sel1));
     const int nit = P.B;
     const uint4* const items = P.items + (size_t)tile * P.B;
     auto ticket = [&]() { int t = 0; if (lane == 0) t = (int)atomicAdd(ctr, 1u); return t; };         // lane 0 holds the value
@@ -883,7 +887,7 @@ void sl_gather_kernel(SlotGather P)
         else if (cnt >= P.prio_ref / 16u) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
         float acc = 0.0f;
-        const int nblk = (int)((cnt + 1023u) >> 10);
+        const int nblk = (int)((cnt + 511u) >> 9);           // a block = 64 lanes x 8 entries
         if (!have_first && nblk) En = list[lane];
         have_first = false;
         int tk = 0; int stage_t = 0;                   // 0: no ticket yet, 1: ticket requested, 2: descriptor requested
@@ -898,36 +902,37 @@ void sl_gather_kernel(SlotGather P)
                 En = ((const uint4*)(P.entries + (((uint64_t)uni(dn.w) << 32) | uni(dn.z))))[lane];
                 have_first = true;
             }
-            const int rem = (int)cnt - b * 1024;
-            if (rem < 1024) {
+            const int rem = (int)cnt - b * 512;
+            if (rem < 512) {
                 // entries past the end of the list -> the null slot
                 auto fix = [&](uint32_t w, int dd) {
-                    const int nv = rem - lane * 16 - dd * 4;                  // valid bytes of this dword
-                    const uint32_t keep = nv >= 4 ? 0xffffffffu : (nv <= 0 ? 0u : ((1u << (8 * nv)) - 1u));
+                    const int nv = rem - lane * 8 - dd * 2;                   // valid entries of this dword
+                    const uint32_t keep = nv >= 2 ? 0xffffffffu : (nv <= 0 ? 0u : 0xffffu);
                     return (w & keep) | (nullword & ~keep);
                 };
                 E.x = fix(E.x, 0); E.y = fix(E.y, 1); E.z = fix(E.z, 2); E.w = fix(E.w, 3);
             }
-            const int lane_end = min(64, (rem + 15) >> 4);               // one lane (16 entries) per iteration
+            const int lane_end = (min(64, (rem + 7) >> 3) + 1) & ~1;     // two lanes (8 entries each) per iteration; an odd count takes one lane of null entries along
 #ifdef EORB_SLOT_TRACE
-            tr_kept += (unsigned long long)lane_end * 16;
+            tr_kept += (unsigned long long)lane_end * 8;
 #endif
             {
             float r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-            int sl, se;
-            // one dword = four entries: addresses by v_perm_b32, reads into the address registers, adds of the group read three groups ago
-#define SL_GROUP(EV, RA, RB, RC, RD, AA, AB, AC, AD) \
+            int sl, sl1, se, sf;
+            // two dwords = four entries: addresses by v_perm_b32, reads into the address registers, adds of the group read three groups ago
+#define SL_GROUP(EV, EW, SL, RA, RB, RC, RD, AA, AB, AC, AD) \
             "s_waitcnt lgkmcnt(8)\n" \
-            "v_readlane_b32 %[se], %[" EV "], %[sl]\n" \
+            "v_readlane_b32 %[se], %[" EV "], %[" SL "]\n" \
             "v_add_f32 %[acc], %[acc], %[" AA "]\n" \
+            "v_readlane_b32 %[sf], %[" EW "], %[" SL "]\n" \
             "v_perm_b32 %[" RA "], %[se], %[l4], %[q0]\n" \
             "v_perm_b32 %[" RB "], %[se], %[l4], %[q1]\n" \
             "ds_read_b32 %[" RA "], %[" RA "]\n" \
             "v_add_f32 %[acc], %[acc], %[" AB "]\n" \
-            "v_perm_b32 %[" RC "], %[se], %[l4], %[q2]\n" \
+            "v_perm_b32 %[" RC "], %[sf], %[l4], %[q0]\n" \
             "ds_read_b32 %[" RB "], %[" RB "]\n" \
             "v_add_f32 %[acc], %[acc], %[" AC "]\n" \
-            "v_perm_b32 %[" RD "], %[se], %[l4], %[q3]\n" \
+            "v_perm_b32 %[" RD "], %[sf], %[l4], %[q1]\n" \
             "ds_read_b32 %[" RC "], %[" RC "]\n" \
             "v_add_f32 %[acc], %[acc], %[" AD "]\n" \
             "ds_read_b32 %[" RD "], %[" RD "]\n"
@@ -937,11 +942,12 @@ void sl_gather_kernel(SlotGather P)
                 "v_mov_b32 %[r12], 0\n v_mov_b32 %[r13], 0\n v_mov_b32 %[r14], 0\n v_mov_b32 %[r15], 0\n"
                 "s_mov_b32 %[sl], 0\n"
                 "1:\n"
-                SL_GROUP("e0", "r0", "r1", "r2", "r3", "r4", "r5", "r6", "r7")
-                SL_GROUP("e1", "r4", "r5", "r6", "r7", "r8", "r9", "r10", "r11")
-                SL_GROUP("e2", "r8", "r9", "r10", "r11", "r12", "r13", "r14", "r15")
-                SL_GROUP("e3", "r12", "r13", "r14", "r15", "r0", "r1", "r2", "r3")
-                "s_add_u32 %[sl], %[sl], 1\n"
+                "s_add_u32 %[sl1], %[sl], 1\n"
+                SL_GROUP("e0", "e1", "sl", "r0", "r1", "r2", "r3", "r4", "r5", "r6", "r7")
+                SL_GROUP("e2", "e3", "sl", "r4", "r5", "r6", "r7", "r8", "r9", "r10", "r11")
+                SL_GROUP("e0", "e1", "sl1", "r8", "r9", "r10", "r11", "r12", "r13", "r14", "r15")
+                SL_GROUP("e2", "e3", "sl1", "r12", "r13", "r14", "r15", "r0", "r1", "r2", "r3")
+                "s_add_u32 %[sl], %[sl], 2\n"
                 "s_cmp_lt_u32 %[sl], %[lend]\n"
                 "s_cbranch_scc1 1b\n"
                 "s_waitcnt lgkmcnt(0)\n"
@@ -951,9 +957,9 @@ void sl_gather_kernel(SlotGather P)
                 : [acc] "+v"(acc), [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5),
                   [r6] "=&v"(r6), [r7] "=&v"(r7), [r8] "=&v"(r8), [r9] "=&v"(r9), [r10] "=&v"(r10), [r11] "=&v"(r11),
                   [r12] "=&v"(r12), [r13] "=&v"(r13), [r14] "=&v"(r14), [r15] "=&v"(r15),
-                  [sl] "=&s"(sl), [se] "=&s"(se)
+                  [sl] "=&s"(sl), [sl1] "=&s"(sl1), [se] "=&s"(se), [sf] "=&s"(sf)
                 : [e0] "v"(E.x), [e1] "v"(E.y), [e2] "v"(E.z), [e3] "v"(E.w), [lend] "s"(lane_end), [l4] "v"(lane4),
-                  [q0] "v"(sel0), [q1] "v"(sel1), [q2] "v"(sel2), [q3] "v"(sel3), [ldsp] "v"(lds)
+                  [q0] "v"(sel0), [q1] "v"(sel1), [ldsp] "v"(lds)
                 : "scc", "memory");
 #undef SL_GROUP
             }
@@ -990,7 +996,7 @@ void sl_gather_kernel(SlotGather P)
 // against 29 for the LDS form (tools/mb/gpr_idx.hip), which is what bounds a launch whose longest list holds 200 000 entries.
 // 256 VGPRs: one such wavefront per SIMD, beside four of the gather's (56 VGPRs each).  The body is generated (tools/gen_sl_hot.py).
 __global__ __launch_bounds__(64) void sl_hot_kernel(const uint32_t* __restrict__ hcnt, uint32_t* __restrict__ ticket, const HotDesc* __restrict__ items,
-                                                    int hcap, const float* __restrict__ rows, const uint8_t* __restrict__ entries,
+                                                    int hcap, const float* __restrict__ rows, const slot_entry* __restrict__ entries,
                                                     float* __restrict__ img, uint32_t* __restrict__ mm, int W, int H)
 {
     const uint32_t rows_lo = (uint32_t)(uintptr_t)rows, rows_hi = (uint32_t)((uintptr_t)rows >> 32);
@@ -1187,7 +1193,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
     if ((rc = ensure(c, ws.chunks, cd_bytes + sc_bytes + eb_bytes))) return rc;
     const size_t cnt_bytes = (sizeof(uint16_t) * (size_t)std::max(nchunks, 1) * NT + 15) & ~(size_t)15;
     if ((rc = ensure(c, ws.segoff, cnt_bytes + sizeof(uint32_t) * (size_t)std::max(nchunks, 1) * NT))) return rc;
-    if ((rc = ensure(c, ws.entries, (size_t)eb + 8192))) return rc;      // + slack: the gather requests blocks past a list's end
+    if ((rc = ensure(c, ws.entries, sizeof(slot_entry) * (size_t)eb + 8192))) return rc;      // + slack: the gather requests blocks past a list's end
     if ((rc = ensure(c, ws.tile_order, sizeof(uint32_t) * 2 * (size_t)nb))) return rc;
     if (on_dev) {
         SliceOffsets so;
@@ -1308,14 +1314,14 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
         if (nchunks && sc.rank) {
 #define SL_SCAT(ST, NW, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_scatter_rank_kernel<ST, NW>, 159 * 1024))) return rc; \
                 sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, sc.lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
-                                                                                   d_slice_eb, d_segbase, d_tile_base, (uint8_t*)ws.entries.p); } while (0)
+                                                                                   d_slice_eb, d_segbase, d_tile_base, (slot_entry*)ws.entries.p); } while (0)
             if (sc.waves == 16) { if (stride == 16) SL_SCAT(16, 16, 3); else if (stride == 4) SL_SCAT(4, 16, 4); else if (stride == 2) SL_SCAT(2, 16, 11); else SL_SCAT(-4, 16, 5); }
             else { if (stride == 16) SL_SCAT(16, 8, 6); else if (stride == 4) SL_SCAT(4, 8, 7); else if (stride == 2) SL_SCAT(2, 8, 12); else SL_SCAT(-4, 8, 8); }
 #undef SL_SCAT
         }
         else if (nchunks)
             sl_scatter_kernel<<<nchunks, 64 * kSlotScatWaves, sc.lds, M>>>(d_ev, d_chunks, d_tab, stride, c->lut_w, c->lut_h, TX, TY, NT, chunk,
-                                                                                 d_slice_eb, d_segbase, d_tile_base, (uint8_t*)ws.entries.p);
+                                                                                 d_slice_eb, d_segbase, d_tile_base, (slot_entry*)ws.entries.p);
         EORB_LAUNCH_CHECK(c, "ev_bin (slot) kernels");
     }
     EORB_HIP(c, hipEventRecord(E[2], M));                                // the part's entries are in place
@@ -1335,7 +1341,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
             const int hw = c->dbg_slot_hot_waves > 0 ? c->dbg_slot_hot_waves : (hw_env > 0 ? hw_env : 8 * ncu);     // two per SIMD: all of its registers
             EORB_HIP(c, hipStreamWaitEvent(Hs, E[2], 0));
             EORB_HIP(c, hipStreamWaitEvent(Hs, E[1], 0));
-            sl_hot_kernel<<<hw, 64, 0, Hs>>>(d_hot_cnt, d_hot_cnt + 32, d_hot_items, kHotCap, (const float*)c->sl_rows.p, (const uint8_t*)ws.entries.p,
+            sl_hot_kernel<<<hw, 64, 0, Hs>>>(d_hot_cnt, d_hot_cnt + 32, d_hot_items, kHotCap, (const float*)c->sl_rows.p, (const slot_entry*)ws.entries.p,
                                              d_f32, d_minmax_enc, W, H);
         }
         EORB_HIP(c, hipEventRecord(E[3], Hs));

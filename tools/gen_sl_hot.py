@@ -2,25 +2,31 @@
 """Generates eorb_slam_amd/csrc/sl_hot_asm.h: the body of sl_hot_kernel (ev_slots.hip) as one inline-asm string plus its clobber list.
 
 The kernel keeps a tile position's rows IN REGISTERS (row r = VGPR r, lane = pixel; 240 rows + a zero row) and walks a long
-(slice, tile) list with the VGPR index mode of gfx9-class ISAs: per entry one s_set_gpr_idx_idx (M0[7:0] <- the entry byte) and one
-v_add_f32 acc, v[0 + M0], acc -- no LDS read, no address arithmetic.  Entries come through scalar loads, 64 per s_load_dwordx16, three
-buffers in rotation so that the only load outstanding at a wait is one phase old.  python3 tools/gen_sl_hot.py > eorb_slam_amd/csrc/sl_hot_asm.h
+(slice, tile) list with the VGPR index mode of gfx9-class ISAs.  An entry is 16 bits, 0x1000 | slot: exactly the low half of M0 in
+that mode (M0[7:0] = index, M0[15:12] = which operands are relative: SRC0), so an entry costs ONE scalar instruction (s_mov_b32 m0 /
+s_lshr_b32 m0, .., 16 -- M0[31:16] is not looked at) and one v_add_f32 acc, v[0 + M0], acc: no LDS read, no address arithmetic, no
+byte extraction (the one-byte entries of round 3 cost 1.75 scalar instructions each, and the scalar ALU, one per CU, was the binding
+pipe).  Entries come through scalar loads, 32 per s_load_dwordx16, three buffers in rotation so that the only load outstanding at a
+wait is one phase old.  python3 tools/gen_sl_hot.py > eorb_slam_amd/csrc/sl_hot_asm.h
 """
 NROWS = 240            # rows held in v0..v239; v240 = 0.0 (the null row); v241 acc; v242 4*lane; v243 px; v244 py; v245.. temps
 L = []
 def a(s): L.append(s)
 
-def process(buf0, lab=None):
-    """64 entries held in s[buf0 .. buf0+15]; fixed 44 bytes of code per dword (the tail jumps into this sequence)"""
+PF_AHEAD = 3968        # bytes the L2 prefetch runs ahead of the scalar loads (immediate offset: < 4096)
+DW_BYTES = 16          # code bytes per entry dword below (the tail jumps into the sequence)
+def process(buf0):
+    """32 entries held in s[buf0 .. buf0+15]"""
     for d in range(16):
         s = "s%d" % (buf0 + d)
-        a("s_set_gpr_idx_idx %s" % s); a("v_add_f32 v241, v0, v241")
-        for sh in (8, 16, 24):
-            a("s_lshr_b32 s33, %s, %d" % (s, sh)); a("s_set_gpr_idx_idx s33"); a("v_add_f32 v241, v0, v241")
+        a("s_mov_b32 m0, %s" % s); a("v_add_f32 v241, v0, v241")
+        a("s_lshr_b32 m0, %s, 16" % s); a("v_add_f32 v241, v0, v241")
 
 # ---- prologue ----
 a("s_setprio 3")                                                           # a long list is a serial chain: its wave goes first at the issue arbiter
 a("v_mbcnt_lo_u32_b32 v242, -1, 0"); a("v_mbcnt_hi_u32_b32 v242, -1, v242")
+a("v_and_b32 v249, 1, v242"); a("v_lshlrev_b32 v249, 7, v249")           # prefetch pattern of the loop: two 128-byte lines
+a("v_lshlrev_b32 v252, 6, v242")                                           # ... and of a list's start: 64 x 64 bytes
 a("v_and_b32 v243, 7, v242"); a("v_lshrrev_b32 v244, 3, v242"); a("v_lshlrev_b32 v242, 2, v242")
 a("v_mov_b32 v246, v243"); a("v_mov_b32 v247, v244")                      # lx, ly
 a("s_load_dwordx16 s[48:63], %[hcnt], 0x0")                                # items per bucket (16 buckets, heaviest first)
@@ -51,39 +57,40 @@ for blk in range(NROWS // 16):
     a("s_add_u32 s44, s44, 0x1000"); a("s_addc_u32 s45, s45, 0")
 a("v_mov_b32 v240, 0"); a("v_mov_b32 v241, 0")
 a("s_add_u32 s44, %[ent_lo], s39"); a("s_addc_u32 s45, %[ent_hi], s40")   # the list
-a("s_lshr_b32 s46, s38, 6")                                                # full 64-entry phases
+a("global_load_dword v250, v252, s[44:45]")                                # the list's first 4 KB towards the L2: scalar loads cannot run
+                                                                           # far enough ahead of their use to hide HBM (v250 is never read)
+a("s_lshr_b32 s46, s38, 5")                                                # full 32-entry phases
 a("s_load_dwordx16 s[64:79], s[44:45], 0x0"); a("s_load_dwordx16 s[80:95], s[44:45], 0x40")
-a("s_add_u32 s34, s44, 0x80"); a("s_addc_u32 s35, s45, 0")                 # next block to request
+a("s_mov_b32 s34, 0x80")                                                   # byte offset of the next block to request
 a("s_mov_b32 s47, 0")
 a("s_waitcnt vmcnt(0)")
 a("s_set_gpr_idx_on s47, gpr_idx(SRC0)")
-# ---- phases: buffers s[64:79], s[80:95], s[96:101]+...: keep to three buffers at s64, s80 and s48 (the bucket counts are reloaded per item) ----
+# ---- phases: three buffers at s64, s80 and s48 (the bucket counts are reloaded per item) ----
 bufs = [64, 80, 48]
 a("SLH_LOOP:")
+a("v_add_u32 v251, s34, v249"); a("global_load_dword v250, v251, s[44:45] offset:%d" % PF_AHEAD)      # the 256 bytes PF_AHEAD + 128 past the next request
 for k in range(3):
-    a("s_cmp_eq_u32 s46, 0"); a("s_cbranch_scc1 SLH_TAIL")
+    a("s_sub_u32 s46, s46, 1"); a("s_cbranch_scc1 SLH_TAIL")              # (borrow: no full phase left)
     a("s_waitcnt lgkmcnt(0)")
     nb = bufs[(k + 2) % 3]
-    a("s_load_dwordx16 s[%d:%d], s[34:35], 0x0" % (nb, nb + 15)); a("s_add_u32 s34, s34, 0x40"); a("s_addc_u32 s35, s35, 0")
+    a("s_load_dwordx16 s[%d:%d], s[44:45], s34" % (nb, nb + 15)); a("s_add_u32 s34, s34, 0x40")
     process(bufs[k])
-    a("s_sub_u32 s46, s46, 1")
 a("s_branch SLH_LOOP")
-# ---- tail: the last (cnt mod 64) entries = the last bytes of the 64-byte block that ends at the list's (4-byte rounded) end ----
+# ---- tail: the last (cnt mod 32) entries = the last halves of the 64-byte block that ends at the list's (4-byte rounded) end ----
 a("SLH_TAIL:")
 a("s_waitcnt lgkmcnt(0)")
-a("s_and_b32 s46, s38, 63"); a("s_cmp_eq_u32 s46, 0"); a("s_cbranch_scc1 SLH_STORE")
-a("s_add_u32 s47, s38, 3"); a("s_and_b32 s47, s47, -4")                    # cnt rounded up to a dword
+a("s_and_b32 s46, s38, 31"); a("s_cmp_eq_u32 s46, 0"); a("s_cbranch_scc1 SLH_STORE")
+a("s_add_u32 s47, s38, 1"); a("s_and_b32 s47, s47, -2"); a("s_lshl_b32 s47, s47, 1")     # bytes of the list, rounded up to a dword
 a("s_add_u32 s34, s44, s47"); a("s_addc_u32 s35, s45, 0"); a("s_sub_u32 s34, s34, 0x40"); a("s_subb_u32 s35, s35, 0")
 a("s_load_dwordx16 s[64:79], s[34:35], 0x0")
 a("s_waitcnt lgkmcnt(0)")
-# bytes of the last dword past the end of the list -> the null row (240 = 0xf0)
-a("s_and_b32 s33, s38, 3"); a("s_cmp_eq_u32 s33, 0"); a("s_cbranch_scc1 SLH_TAILGO")
-a("s_lshl_b32 s33, s33, 3"); a("s_lshl_b32 s98, -1, s33")                  # mask of the invalid bytes
-a("s_andn2_b32 s79, s79, s98"); a("s_and_b32 s98, s98, 0xf0f0f0f0"); a("s_or_b32 s79, s79, s98")
+# an odd count: the upper half of the last dword is past the end of the list -> the null row (0x1000 | 240)
+a("s_bitcmp1_b32 s38, 0"); a("s_cbranch_scc0 SLH_TAILGO")
+a("s_and_b32 s79, s79, 0xffff"); a("s_or_b32 s79, s79, 0x10f00000")
 a("SLH_TAILGO:")
-# jump to dword (16 - ndw) of the sequence below, ndw = dwords that hold tail entries; 44 bytes of code per dword
-a("s_and_b32 s33, s47, 63"); a("s_cmp_eq_u32 s33, 0"); a("s_cselect_b32 s33, 64, s33"); a("s_lshr_b32 s33, s33, 2")   # ndw in 1..16
-a("s_sub_u32 s33, 16, s33"); a("s_mul_i32 s33, s33, 44")
+# jump to dword (16 - ndw) of the sequence below, ndw = dwords that hold tail entries
+a("s_add_u32 s33, s46, 1"); a("s_lshr_b32 s33, s33, 1")                   # ndw in 1..16
+a("s_sub_u32 s33, 16, s33"); a("s_mul_i32 s33, s33, %d" % DW_BYTES)
 a("s_getpc_b64 s[34:35]")
 a("s_add_u32 s34, s34, s33"); a("s_addc_u32 s35, s35, 0")
 a("s_add_u32 s34, s34, 20"); a("s_addc_u32 s35, s35, 0")                   # the five 4-byte instructions between s_getpc's return value and the sequence
