@@ -72,7 +72,7 @@ def test_slot_gather_has_no_static_lds_and_no_scratch():
 
 
 def test_hot_kernel_jump_arithmetic(tmp_path):
-    """sl_hot_kernel enters its 32-entry sequence in the middle for the tail of a list: s_getpc + 20 bytes + 16 bytes per entry dword
+    """sl_hot_kernel enters its 64-entry sequence in the middle for the tail of a list: s_getpc + 20 bytes + 16 bytes per entry dword
     (tools/gen_sl_hot.py).  Both constants are encoding sizes: checked here against the assembled code object."""
     llvm = "/opt/rocm/lib/llvm/bin"
     if not (os.path.exists("/opt/rocm/bin/hipcc") and os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/clang-offload-bundler")):
@@ -88,12 +88,12 @@ def test_hot_kernel_jump_arithmetic(tmp_path):
     i = gp[0]
     sp = next(j for j in range(i, i + 12) if ins[j][1].startswith("s_setpc_b64"))
     first = ins[sp + 1]
-    assert first[1].startswith("s_mov_b32 m0, s64") and first[0] - ins[i + 1][0] == 20, (ins[i + 1], first)
-    starts = [a for a, t in ins[sp + 1:sp + 1 + 16 * 4] if re.fullmatch(r"s_mov_b32 m0, s(6[4-9]|7[0-9])", t)]
-    assert len(starts) == 16 and all(b - a == 16 for a, b in zip(starts, starts[1:])), starts
-    seq = [t for _, t in ins[sp + 1:sp + 1 + 16 * 4]]
+    assert first[1].startswith("s_mov_b32 m0, s36") and first[0] - ins[i + 1][0] == 20, (ins[i + 1], first)
+    starts = [a for a, t in ins[sp + 1:sp + 1 + 32 * 4] if re.fullmatch(r"s_mov_b32 m0, s(3[6-9]|[45][0-9]|6[0-7])", t)]
+    assert len(starts) == 32 and all(b - a == 16 for a, b in zip(starts, starts[1:])), starts
+    seq = [t for _, t in ins[sp + 1:sp + 1 + 32 * 4]]
     assert all(seq[4 * d + 1].startswith("v_add_f32") and seq[4 * d + 3].startswith("v_add_f32")
-               and re.fullmatch(r"s_lshr_b32 m0, s%d, 16" % (64 + d), seq[4 * d + 2]) for d in range(16)), seq[:8]
+               and re.fullmatch(r"s_lshr_b32 m0, s%d, 16" % (36 + d), seq[4 * d + 2]) for d in range(32)), seq[:8]
     # the kernel owns the whole architectural VGPR file of a wave: 256 registers, no scratch
     text = _device_asm("ev_slots.hip")
     body = re.findall(r"\.amdhsa_kernel (\S*sl_hot_kernel\S*)(.*?)\.end_amdhsa_kernel", text, re.S)[0][1]
