@@ -363,15 +363,20 @@ N_CU = 256
 def issue_floor(entries, hot_entries, measured_gather_ms):
     """What the two gather kernels' binding pipes allow for the entries they walked: the LDS-row gather reads one 256-byte
     row per entry = 2 LDS-array cycles per entry and CU (ds_read_b32 of 64 lanes at 128 B/clk; tools/mb/slot_loop.hip measures 2.05);
-    the register-row kernel issues 1.75 scalar instructions per entry on the CU's scalar ALU (s_set_gpr_idx_idx per entry + 3 shifts per 4)."""
+    the register-row kernel issues per 16-bit entry one scalar instruction (s_mov_b32 / s_lshr_b32 to M0; + 6 per 64 entries of loop) on the
+    CU's one scalar ALU and one 64-lane v_add_f32 = 4 cycles of one of the CU's four vector ALUs: both floors are 1 cycle per entry and CU."""
     lds_entries = max(entries - hot_entries, 0)
     f_lds = lds_entries * 2.0 / (N_CU * GPU_CLOCK_HZ) * 1e3
-    f_salu = hot_entries * 1.75 / (N_CU * GPU_CLOCK_HZ) * 1e3
+    salu_per_entry = 1.0 + 6.0 / 64.0
+    f_salu = hot_entries * salu_per_entry / (N_CU * GPU_CLOCK_HZ) * 1e3
+    f_valu = hot_entries * 4.0 / (4 * N_CU * GPU_CLOCK_HZ) * 1e3
     return {"entries_per_step": int(entries), "register_row_entries": int(hot_entries), "lds_row_entries": int(lds_entries),
             "sl_gather_kernel": {"lds_cycles_per_entry": 2, "floor_ms": f_lds},
-            "sl_hot_kernel": {"salu_instructions_per_entry": 1.75, "floor_ms": f_salu},
-            "floor_ms": max(f_lds, f_salu), "measured_ms": measured_gather_ms,
-            "note": "the two kernels run side by side (LDS array / scalar ALU): the stage cannot beat the larger floor; measured = the live launch time of sl_gather_kernel, which the register-row kernel overlaps"}
+            "sl_hot_kernel": {"salu_instructions_per_entry": salu_per_entry, "salu_floor_ms": f_salu, "valu_cycles_per_entry_and_simd": 4, "valu_floor_ms": f_valu,
+                              "floor_ms": max(f_salu, f_valu)},
+            "floor_ms": max(f_lds, f_salu, f_valu), "measured_ms": measured_gather_ms, "clock_hz": GPU_CLOCK_HZ,
+            "note": "the two kernels run side by side (LDS array / scalar + vector ALU): the stage cannot beat the larger floor; measured = the live launch time of sl_gather_kernel, "
+                    "which the register-row kernel overlaps; floors at the peak engine clock (the counters' GRBM_GUI_ACTIVE puts the sustained clock near 1.9 GHz: x 1.26)"}
 
 
 def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, inputs_key=None):

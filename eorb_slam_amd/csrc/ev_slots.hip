@@ -11,7 +11,7 @@
 //   K1a sl_count_lds_kernel    entries of every (chunk, tile): the sensor pixels' tile ranges as a 16-bit table in LDS, one wavefront per
 //                              chunk (sl_count_kernel where that table does not fit)
 //   K1b sl_scan_kernel         one contiguous event-ordered list per (slice, tile); per-tile weights
-//   K1c sl_scatter_rank_kernel order-preserving scatter of ONE-BYTE entries (the slot number): stable ranks from the return values of the
+//   K1c sl_scatter_rank_kernel order-preserving scatter of TWO-BYTE entries (0x1000 | slot number): stable ranks from the return values of the
 //                              counting LDS atomics, the chunk tile-sorted in LDS, runs streamed out (sl_scatter_kernel: the ballot form,
 //                              kept as the fallback when the device check of the atomics' lane order fails)
 //       sl_plan_kernel / sl_tasks_kernel   per tile position its lists sorted longest first, long lists to the buckets of K2h, workgroup
@@ -20,9 +20,11 @@
 //                              (slice, tile) lists by ticket: lane = pixel, per entry v_readlane (1/4) + v_perm_b32 (row address
 //                              { slot, 4 * lane }) + ds_read_b32 + v_add_f32, in list order = event order (newVal = image + val,
 //                              :251-254).  x + 0.0f == x bit for bit, so lanes the stamp does not reach keep their value.
-//   K2h sl_hot_kernel          long lists, beside K2p on the side stream: the rows in 240 VGPRs, per entry s_set_gpr_idx_idx + v_add_f32
+//   K2h sl_hot_kernel          long lists, beside K2p on the side stream: the rows in 240 VGPRs, per entry ONE scalar instruction (the
+//                              16-bit entry IS the low half of M0 in the VGPR index mode) + one v_add_f32
 // Versus the batch pipeline of ev_accum.hip (64-entry batches through value waves and an add wave, ~6.4 wave-instructions and 8
-// bytes per entry) an entry costs ~3 issue slots and 1 byte; K2p sits on the LDS array (2 cycles per entry and CU), K2h on the scalar ALU.
+// bytes per entry) an entry costs 2-3 issue slots and 2 bytes; K2p sits on the LDS array (2 cycles per entry and CU), K2h on the
+// scalar AND the vector ALU at once (1 cycle per entry and CU each: 78 % / 75 % busy, profiles/r04_*).
 #include "eorb_ctx.h"
 #include "ev_common.h"
 #include "dev_math.h"
@@ -991,10 +993,11 @@ void sl_gather_kernel(SlotGather P)
 }
 
 // ---- K2h: the long lists.  One wavefront per item at a time (tickets over the 16 length buckets, longest first): the tile
-// position's rows are loaded into VGPRs v0..v239 (lane = pixel, exactly one register per row), and every entry is one
-// s_set_gpr_idx_idx (M0[7:0] <- entry byte: the VGPR index mode of this ISA) + one v_add_f32 acc, v[M0], acc: 13 cycles per entry
-// against 29 for the LDS form (tools/mb/gpr_idx.hip), which is what bounds a launch whose longest list holds 200 000 entries.
-// 256 VGPRs: one such wavefront per SIMD, beside four of the gather's (56 VGPRs each).  The body is generated (tools/gen_sl_hot.py).
+// position's rows are loaded into VGPRs v0..v239 (lane = pixel, exactly one register per row), and every 16-bit entry is one scalar
+// move to M0 (0x1000 | slot = "SRC0 relative, index slot" in the VGPR index mode of this ISA) + one v_add_f32 acc, v[M0], acc:
+// 8-9 cycles per entry and wavefront against 29 for the LDS form (tools/mb/gpr_idx.hip), two wavefronts per SIMD = all of its
+// registers.  Entries arrive by scalar loads, two 32-SGPR buffers, behind a vector-load prefetch into the L2 (tools/gen_sl_hot.py,
+// which generates the body and explains the schedule).
 __global__ __launch_bounds__(64) void sl_hot_kernel(const uint32_t* __restrict__ hcnt, uint32_t* __restrict__ ticket, const HotDesc* __restrict__ items,
                                                     int hcap, const float* __restrict__ rows, const slot_entry* __restrict__ entries,
                                                     float* __restrict__ img, uint32_t* __restrict__ mm, int W, int H)

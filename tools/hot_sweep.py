@@ -20,8 +20,8 @@ def main():
     run = lambda: fb.run_dev(d_ev, off, d_img, d_kp, d_desc, d_n, d_m, d_nm, raw=True)
     ref = None
     print("hot_min hot_waves  ms/step  hot lists", flush=True)
-    for hw in (1024, 1536, 2048):
-        for hm in (8000, 12000, 16000, 24000, 32000, 48000):
+    for hw in (1536, 2048, 3072):
+        for hm in (1000, 2000, 4000, 6000, 8000, 12000, 16000, 24000):
             c.debug_option("slot_hot_min", hm); c.debug_option("slot_hot_waves", hw)
             for _ in range(3): run()
             c.sync()
