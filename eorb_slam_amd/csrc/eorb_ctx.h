@@ -69,6 +69,7 @@ struct OrbState {
     int kp_total = 0;        // per slice: sum of kp_cap  (= eorb_orb_max_keypoints)
     int max_out = 0;
     int oct_lds[2] = {0, 0};       // dynamic LDS bytes of the octree kernel, per placement (single frames / many workgroups)
+    int oct_all_lds[2] = {0, 0};   // every item of that placement is in LDS: the kernel variant with LDS-typed pointers
     int oct_scratch[2] = {0, 0};   // per (slice, level) global scratch bytes
     DevBuf tabs;             // resize tables (short/int), level geometry, pattern, umax
     DevBuf geom;

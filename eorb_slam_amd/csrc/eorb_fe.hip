@@ -336,6 +336,9 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
         }
         return n;
     }
+    if (!strcmp(name, "oct_lds_only")) return c->orb.oct_all_lds[0] | (c->orb.oct_all_lds[1] << 1);      // octree working set entirely in LDS: single frames | batches
+    if (!strcmp(name, "oct_lds_bytes")) return c->orb.oct_lds[0];
+    if (!strcmp(name, "oct_scratch_bytes")) return c->orb.oct_scratch[0];
     if (!strcmp(name, "slot_hot_items")) {              // lists the last slot-form call handed to the register-row kernel (synchronises)
         long long n = 0;
         for (int part = 0; part < std::max(c->sl_last_parts, 1); part++) {

@@ -276,6 +276,11 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
         const ChunkDesc cd = chunks[ch];
         for (int i = lane; i < (NTp >> 1); i += 64) cnt[i] = 0u;
         const unsigned char* e = (const unsigned char*)ev + (size_t)cd.start * (size_t)astride;
+        uint32_t xyn[U];                                               // (the next trip's records, requested before this trip's are counted)
+        if (!KEYED) {
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int k = lane + u * 64; xyn[u] = k < cd.n ? sl_load_rec<stride>(e, k) : 0xffffffffu; }
+        }
         for (int k0 = lane; k0 < cd.n; k0 += 64 * U) {
             uint32_t xy[U], g[U];
             if (KEYED) {
@@ -300,7 +305,11 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
                 }
             } else {
 #pragma unroll
-            for (int u = 0; u < U; u++) { const int k = k0 + u * 64; xy[u] = k < cd.n ? sl_load_rec<stride>(e, k) : 0xffffffffu; }
+            for (int u = 0; u < U; u++) xy[u] = xyn[u];
+            if (k0 + 64 * U < cd.n) {
+#pragma unroll
+                for (int u = 0; u < U; u++) { const int k = k0 + 64 * U + u * 64; xyn[u] = k < cd.n ? sl_load_rec<stride>(e, k) : 0xffffffffu; }
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t x = xy[u] & xmask, y = xy[u] >> 16, row = xy[u] & 0x7fffffffu;      // (hashed records: the row itself)

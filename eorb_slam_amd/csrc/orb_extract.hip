@@ -288,6 +288,28 @@ __device__ int oct_block_scan(int* a, int n, int* ws)
     return carry;
 }
 
+// two exclusive prefix sums at once (the same barriers): a[0..na) and the 16-bit b[0..nb); returns a's total
+__device__ int oct_block_scan2(int* a, int na, uint16_t* b, int nb, int* ws, int* ws2)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    int carry = 0, carryb = 0;
+    const int n = max(na, nb);
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + tid;
+        const int v = i < na ? a[i] : 0, vb = i < nb ? (int)b[i] : 0;
+        const int incl = oct_wave_incl_scan(v), inclb = oct_wave_incl_scan(vb);
+        if (lane == 63) { ws[wave] = incl; ws2[wave] = inclb; }
+        __syncthreads();
+        int before = carry, beforeb = carryb, tot = 0, totb = 0;
+        for (int w = 0; w < nw; w++) { const int x = ws[w], y = ws2[w]; if (w < wave) { before += x; beforeb += y; } tot += x; totb += y; }
+        if (i < na) a[i] = before + incl - v;
+        if (i < nb) b[i] = (uint16_t)(beforeb + inclb - vb);
+        carry += tot; carryb += totb;
+        __syncthreads();
+    }
+    return carry;
+}
+
 // bitonic sort (ascending) of n u64 items by the whole workgroup; padded with ~0 up to the next power of two.  Thread t keeps
 // items t, t + 512, ... in registers: partners less than 64 apart are exchanged by lane shuffles, partners a multiple of 512 apart
 // are the thread's own registers, and only the distances 64, 128, 256 go through the array and two barriers (6 of the 45 steps of a
@@ -376,13 +398,17 @@ __device__ void oct_block_sort_u64(uint64_t* a, int n)
     }
 }
 
+// LDS_ONLY: every item of the working set sits in LDS (single frames, small levels).  The pointers are then known to be LDS
+// pointers and the compiler emits ds_read / ds_write; with the mixed placement they are generic and every access is a FLAT
+// instruction, whose round trip to the LDS is several times longer -- and a round is a chain of ~20 dependent accesses.
+template <bool LDS_ONLY>
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __restrict__ G, const int32_t* __restrict__ cell_cnt,
                                                              const uint32_t* __restrict__ cell_cand, unsigned char* __restrict__ scratch_g,
                                                              uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_cnt,
                                                              int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky, int placement)
 {
     extern __shared__ unsigned char smem[];
-    __shared__ int s_ws[kOctThreads / 64 + 2];
+    __shared__ int s_ws[kOctThreads / 64 + 2], s_ws2[kOctThreads / 64];
     __shared__ int s_m, s_flag, s_nbig;
     __shared__ uint16_t s_big[kOctBigMax];
     __shared__ int s_wc[kOctThreads / 64][4];
@@ -393,15 +419,22 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     // every item in LDS when the 160 KB hold it, otherwise in this (slice, level)'s block of the global scratch buffer: the
     // workgroup sits on one CU, whose own stores are visible to its later loads after __syncthreads()
     unsigned char* gblk = scratch_g + (size_t)blockIdx.x * G->oct_gblock_bytes[placement];
-    auto item = [&](int k) -> unsigned char* { return (G->oct_in_lds[placement][k] ? smem : gblk) + G->oct_off[placement][k]; };
-    ONode* nodes[2] = {(ONode*)item(0), (ONode*)item(0) + pc};
-    uint64_t* vsp[2] = {(uint64_t*)item(1), (uint64_t*)item(2)};
-    uint16_t* keys[2] = {(uint16_t*)item(3), (uint16_t*)item(4)};
-    uint32_t* pts = (uint32_t*)item(5);
-    int* aux = (int*)item(6);                       // pc ints: scan array (ne | n2 << 16 per processed node / survivor flags)
-    uint16_t* P = (uint16_t*)(aux + pc);            // pc: nodes to divide, in processing order
-    uint8_t* dv = (uint8_t*)(P + pc);               // pc: node is divided in this round
-    uint64_t* cc = (uint64_t*)(((uintptr_t)(dv + pc) + 7) & ~(uintptr_t)7);       // pc: child counts of the processed nodes, 4 x 16 bits
+    // (byte offsets, not pointers, are what is kept and selected between: under LDS_ONLY every pointer is then visibly smem + offset)
+    auto item = [&](int k, int extra) -> unsigned char* {
+        if (LDS_ONLY) return smem + (G->oct_off[placement][k] + extra);
+        return (G->oct_in_lds[placement][k] ? smem : gblk) + (G->oct_off[placement][k] + extra);
+    };
+    auto NODES = [&](int w) -> ONode* { return (ONode*)item(0, w * pc * (int)sizeof(ONode)); };
+    auto VSP = [&](int w) -> uint64_t* { return (uint64_t*)item(1 + w, 0); };
+    auto KEYS = [&](int w) -> uint16_t* { return (uint16_t*)item(3 + w, 0); };
+    uint32_t* pts = (uint32_t*)item(5, 0);
+    int* aux = (int*)item(6, 0);                    // pc ints: scan array (ne | n2 << 16 per processed node / survivor flags)
+    auto PB = [&](int w) -> uint16_t* { return (uint16_t*)item(6, (4 + 2 * w) * pc); };      // 2 x pc: nodes to divide, in processing order (this pass | the next one)
+    uint16_t* sv = (uint16_t*)item(6, 8 * pc);      // pc: full passes: the undivided nodes' ranks
+    uint8_t* dv = (uint8_t*)item(6, 10 * pc);       // pc: cut-off passes: node is divided in this round
+    uint64_t* cc = (uint64_t*)item(6, (11 * pc + 7) & ~7);      // pc: child counts of the processed nodes, 4 x 16 bits (item offsets are multiples of 16)
+    int pb = 0;
+    if (tid == 0) s_nbig = 0;
     uint32_t* lkp = lvl_kp + (size_t)slice * G->kp_total + L.kp_off;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     auto raise = [&](int bit) { if (tid == 0) { atomicOr(err_flag, bit); if (sticky) atomicOr(sticky, bit); } };
@@ -421,14 +454,14 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 const int o = aux[cidx], ccnt = (cidx + 1 < nc ? aux[cidx + 1] : n) - o;
                 const uint32_t* src = cell_cand + ((size_t)slice * G->ncells + L.cell_off + cidx) * G->cell_cap;
                 for (int i = lane; i < ccnt; i += 64)
-                    if (o + i < ncap) { pts[o + i] = src[i]; keys[0][o + i] = (uint16_t)(o + i); }
+                    if (o + i < ncap) { pts[o + i] = src[i]; KEYS(0)[o + i] = (uint16_t)(o + i); }
             }
         } else {
             for (int cidx = 0; cidx < nc; cidx++) {
                 const int ccnt = ccnt_g[cidx];
                 const uint32_t* src = cell_cand + ((size_t)slice * G->ncells + L.cell_off + cidx) * G->cell_cap;
                 for (int i = tid; i < ccnt; i += kOctThreads)
-                    if (n + i < ncap) { pts[n + i] = src[i]; keys[0][n + i] = (uint16_t)(n + i); }
+                    if (n + i < ncap) { pts[n + i] = src[i]; KEYS(0)[n + i] = (uint16_t)(n + i); }
                 n += ccnt;
             }
         }
@@ -441,7 +474,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     const int width = L.maxBX - L.minBX, height = L.maxBY - L.minBY;
     const int nIni = (int)roundf((float)width / (float)height);
     const float hX = (float)width / (float)nIni;
-    int cur = 0, lsize = 0, seqctr = 0;
+    int cur = 0, lsize = 0, seqctr = 0, nPnext = 0;
     // ---- root nodes :562-603: stable partition of the keys by root index (wave 0), empty roots erased, singletons bNoMore ----
     {
         int off = 0;
@@ -452,14 +485,14 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                     const int i = k0 + lane;
                     bool mine = false; uint16_t key = 0;
                     if (i < n) {
-                        key = keys[0][i];
+                        key = KEYS(0)[i];
                         const float kx = (float)(pts[key] & 0xfff);
                         int b = (int)(kx / hX);
                         b = min(max(b, 0), nIni - 1);
                         mine = (b == r);
                     }
                     const uint64_t bal = __ballot(mine);
-                    if (mine) keys[1][off + c + __popcll(bal & lt_mask)] = key;
+                    if (mine) KEYS(1)[off + c + __popcll(bal & lt_mask)] = key;
                     c += __popcll(bal);
                 }
                 if (lane == 0) s_m = c;
@@ -473,8 +506,10 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                     nd.y0 = 0; nd.y1 = (uint16_t)height;
                     nd.start = (uint16_t)off; nd.cnt = (uint16_t)c; nd.seq = (uint16_t)seqctr;
                     nd.flags = (uint8_t)((c == 1 ? 1 : 0) | 2); nd.pad = 0;
-                    nodes[0][lsize] = nd;                           // push_back
+                    NODES(0)[lsize] = nd;                           // push_back
+                    if (c > 1) PB(0)[nPnext] = (uint16_t)lsize;     // (the first pass walks the roots in list order)
                 }
+                if (c > 1) nPnext++;
                 lsize++; seqctr++;
             }
             off += c;
@@ -483,25 +518,31 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     }
 
     // One round: divide the nodes P[0..nP) (processing order).  cut: stop after the division that brings the list to N nodes
-    // (:741-757).  Returns through the references; vsp[vw] receives the children with more than one key, in creation order.
+    // (:741-757).  Returns through the references; VSP(vw) receives the children with more than one key, in creation order.
     bool overflow = false;
     int nvsp = 0, vw = 0;
     auto round = [&](int nP, bool cut, int& nToExpand) {
-        const ONode* src = nodes[cur];
-        ONode* dst = nodes[cur ^ 1];
+        const ONode* src = NODES(cur);
+        ONode* dst = NODES(cur ^ 1);
+        const uint16_t* P = PB(pb);
+        uint16_t* Pn = PB(pb ^ 1);
         // 2a. nodes with many keys (the first passes: one or two roots hold every candidate): the whole workgroup partitions one
         //     node, wave w its w-th contiguous share of the keys; the shares' class counts meet in LDS
-        if (tid == 0) s_nbig = 0;
-        __syncthreads();
-        for (int j = tid; j < nP; j += kOctThreads)
-            if (src[P[j]].cnt >= kOctBigNode) { const int k = atomicAdd(&s_nbig, 1); if (k < kOctBigMax) s_big[k] = (uint16_t)j; }
-        __syncthreads();
-        const int nbig = min(s_nbig, kOctBigMax);                   // (at most ncap / kOctBigNode <= 64 such nodes exist)
+        //     (no node can be that large on a level with fewer candidates: the two barriers are skipped, s_nbig stays 0)
+        int nbig = 0;
+        if (n >= kOctBigNode) {
+            if (tid == 0) s_nbig = 0;
+            __syncthreads();
+            for (int j = tid; j < nP; j += kOctThreads)
+                if (src[P[j]].cnt >= kOctBigNode) { const int k = atomicAdd(&s_nbig, 1); if (k < kOctBigMax) s_big[k] = (uint16_t)j; }
+            __syncthreads();
+            nbig = min(s_nbig, kOctBigMax);                         // (at most ncap / kOctBigNode <= 64 such nodes exist)
+        }
         for (int b = 0; b < nbig; b++) {
             const int j = s_big[b];
             const ONode nd = src[P[j]];
             const int sb = (nd.flags >> 1) & 1;
-            const uint16_t* ks = keys[sb]; uint16_t* kd = keys[sb ^ 1];
+            const uint16_t* ks = KEYS(sb); uint16_t* kd = KEYS(sb ^ 1);
             const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
             const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
             const int start = nd.start, cnt = nd.cnt;
@@ -564,7 +605,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
                 int cls = -1; uint16_t key = 0;
                 if (small && gl < nd.cnt) {
-                    key = keys[sb][nd.start + gl];
+                    key = KEYS(sb)[nd.start + gl];
                     const uint32_t p = pts[key];
                     cls = ((int)(p & 0xfff) < midx ? 0 : 1) + ((int)((p >> 12) & 0xfff) < midy ? 0 : 2);
                 }
@@ -575,7 +616,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 if (cls >= 0) {
                     const uint32_t mb = cls == 0 ? b0 : (cls == 1 ? b1 : (cls == 2 ? b2 : b3));
                     const int base = nd.start + (cls > 0 ? c0 : 0) + (cls > 1 ? c1 : 0) + (cls > 2 ? c2 : 0);
-                    keys[sb ^ 1][base + __popc(mb & ((1u << gl) - 1u))] = key;
+                    KEYS(sb ^ 1)[base + __popc(mb & ((1u << gl) - 1u))] = key;
                 }
                 if (small && gl == 0) {
                     cc[jg] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
@@ -596,7 +637,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
                 int cls = -1; uint16_t key = 0;
                 if (lane < nd.cnt) {
-                    key = keys[sb][nd.start + lane];
+                    key = KEYS(sb)[nd.start + lane];
                     const uint32_t p = pts[key];
                     cls = ((int)(p & 0xfff) < midx ? 0 : 1) + ((int)((p >> 12) & 0xfff) < midy ? 0 : 2);
                 }
@@ -605,7 +646,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 if (cls >= 0) {
                     const uint64_t mb = cls == 0 ? b0 : (cls == 1 ? b1 : (cls == 2 ? b2 : b3));
                     const int base = nd.start + (cls > 0 ? c0 : 0) + (cls > 1 ? c1 : 0) + (cls > 2 ? c2 : 0);
-                    keys[sb ^ 1][base + __popcll(mb & lt_mask)] = key;
+                    KEYS(sb ^ 1)[base + __popcll(mb & lt_mask)] = key;
                 }
                 if (lane == 0) {
                     cc[j] = (uint64_t)c0 | ((uint64_t)c1 << 16) | ((uint64_t)c2 << 32) | ((uint64_t)c3 << 48);
@@ -614,7 +655,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 continue;
             }
             const int sb = (nd.flags >> 1) & 1;
-            const uint16_t* ks = keys[sb]; uint16_t* kd = keys[sb ^ 1];
+            const uint16_t* ks = KEYS(sb); uint16_t* kd = KEYS(sb ^ 1);
             const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
             const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
             const int start = nd.start, cnt = nd.cnt;
@@ -654,6 +695,49 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
             }
           }
         }
+        if (!cut) {
+            // ---- a full pass divides every node of P = every node with more than one key: the survivors are the bNoMore nodes.  Both
+            //      prefix sums (children over the processing order, survivors over the list) share their barriers, the next pass's
+            //      processing order falls out of the children's placement: four barriers per pass ----
+            for (int i = tid; i < lsize; i += kOctThreads) sv[i] = (uint16_t)(src[i].flags & 1);
+            __syncthreads();
+            const int tot = oct_block_scan2(aux, nP, sv, lsize, s_ws, s_ws2);
+            const int C = tot & 0xffff, n2tot = tot >> 16, nsurv = lsize - nP;
+            if (C + nsurv > pool || n2tot > vcap) { overflow = true; nToExpand = 0; return; }   // uniform: every thread sees the same numbers
+            uint64_t* vout = VSP(vw);
+            for (int j = tid; j < nP; j += kOctThreads) {
+                const ONode nd = src[P[j]];
+                const uint64_t cj = cc[j];
+                const int c[4] = {(int)(cj & 0xffff), (int)((cj >> 16) & 0xffff), (int)((cj >> 32) & 0xffff), (int)(cj >> 48)};
+                const int halfX = (int)ceilf((float)(nd.x1 - nd.x0) / 2), halfY = (int)ceilf((float)(nd.y1 - nd.y0) / 2);
+                const int midx = nd.x0 + halfX, midy = nd.y0 + halfY;
+                const int sb = (nd.flags >> 1) & 1;
+                int k = aux[j] & 0xffff, k2 = aux[j] >> 16, sb0 = nd.start;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {                       // n1..n4: x-low/y-low, x-high/y-low, x-low/y-high, x-high/y-high
+                    if (c[q] > 0) {
+                        ONode ch;
+                        ch.x0 = (uint16_t)((q & 1) ? midx : nd.x0); ch.x1 = (uint16_t)((q & 1) ? nd.x1 : midx);
+                        ch.y0 = (uint16_t)((q & 2) ? midy : nd.y0); ch.y1 = (uint16_t)((q & 2) ? nd.y1 : midy);
+                        ch.start = (uint16_t)sb0; ch.cnt = (uint16_t)c[q]; ch.seq = (uint16_t)(seqctr + k);
+                        ch.flags = (uint8_t)((c[q] == 1 ? 1 : 0) | ((sb ^ 1) << 1)); ch.pad = 0;
+                        const int pos = C - 1 - k;                  // push_front in creation order
+                        dst[pos] = ch;
+                        if (c[q] > 1) {
+                            vout[k2] = ((uint64_t)c[q] << 32) | ((uint64_t)(uint16_t)(seqctr + k) << 16) | (uint64_t)pos;
+                            Pn[n2tot - 1 - k2] = (uint16_t)pos;     // list order of the next pass = the reverse of the creation order
+                            k2++;
+                        }
+                        k++;
+                    }
+                    sb0 += c[q];
+                }
+            }
+            for (int i = tid; i < lsize; i += kOctThreads) if (src[i].flags & 1) dst[C + sv[i]] = src[i];
+            __syncthreads();
+            seqctr += C; lsize = C + nsurv; cur ^= 1; nvsp = n2tot; nToExpand = n2tot; nPnext = n2tot; pb ^= 1;
+            return;
+        }
         if (tid == 0) s_m = nP;
         __syncthreads();
         // 3. prefix sums over the processing order: aux[j] = children (low half) / children with > 1 key (high half) before j
@@ -679,7 +763,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
         const int nsurv = lsize - m;
         if (C + nsurv > pool || n2tot > vcap) { overflow = true; nToExpand = 0; return; }   // uniform: every thread sees the same numbers
         // children first (they only need aux / cc / src), then the survivors' scan reuses aux
-        uint64_t* vout = vsp[vw];
+        uint64_t* vout = VSP(vw);
         for (int j = tid; j < m; j += kOctThreads) {
             const ONode nd = src[P[j]];
             const uint64_t cj = cc[j];
@@ -717,12 +801,8 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     int guard = 0;
     while (!finish && !overflow && guard++ < 64) {
         const int prevSize = lsize;
-        // processing order of a full pass = list order of the expandable nodes (:618-686)
-        for (int i = tid; i < lsize; i += kOctThreads) aux[i] = (nodes[cur][i].flags & 1) ? 0 : 1;
-        __syncthreads();
-        const int nP = oct_block_scan(aux, lsize, s_ws);
-        for (int i = tid; i < lsize; i += kOctThreads) if (!(nodes[cur][i].flags & 1)) P[aux[i]] = (uint16_t)i;
-        __syncthreads();
+        // processing order of a full pass = list order of the expandable nodes (:618-686): left in PB(pb) by the roots / the previous pass
+        const int nP = nPnext;
         int nToExpand = 0;
         if (nP > 0) round(nP, false, nToExpand);
         if (overflow) break;
@@ -734,8 +814,8 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 const int prevSize2 = lsize;
                 const int nprev = nvsp;
                 // largest first: ascending sort of (size, creation order), walked from the back (:703-712)
-                oct_block_sort_u64(vsp[vw], nprev);
-                for (int j = tid; j < nprev; j += kOctThreads) P[j] = (uint16_t)(vsp[vw][nprev - 1 - j] & 0xffff);
+                oct_block_sort_u64(VSP(vw), nprev);
+                for (int j = tid; j < nprev; j += kOctThreads) PB(pb)[j] = (uint16_t)(VSP(vw)[nprev - 1 - j] & 0xffff);
                 vw ^= 1;
                 __syncthreads();
                 int dummy = 0;
@@ -748,11 +828,11 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
 
     // ---- retain the best point of each node, in list order (:760-780) ----
     {
-        const ONode* nd = nodes[cur];
+        const ONode* nd = NODES(cur);
         const int nout = min(lsize, L.kp_cap);
         if (lsize > L.kp_cap) raise(4);
         for (int i = tid; i < nout; i += kOctThreads) {
-            const uint16_t* ks = keys[(nd[i].flags >> 1) & 1] + nd[i].start;
+            const uint16_t* ks = KEYS((nd[i].flags >> 1) & 1) + nd[i].start;
             const int cnt = nd[i].cnt;
             uint32_t best = pts[ks[0]];
             for (int q = 1; q < cnt; q++) {
@@ -1167,11 +1247,11 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
                                   sizeof(uint64_t) * (size_t)vsp_pow2, sizeof(uint64_t) * (size_t)vsp_pow2,
                                   (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15, (sizeof(uint16_t) * (size_t)ncap_max + 15) & ~(size_t)15,
                                   (sizeof(uint32_t) * (size_t)ncap_max + 15) & ~(size_t)15,
-                                  ((size_t)node_cap_max * (4 + 2 + 1 + 8) + 8 + 15) & ~(size_t)15};
+                                  ((size_t)node_cap_max * (4 + 2 + 2 + 2 + 1 + 8) + 8 + 15) & ~(size_t)15};
     int oct_in_lds[2][7], oct_off[2][7];
     // placement order: the per-round arrays and the node arrays first (touched by every step), then the size lists, keys, points
     const int order[7] = {6, 0, 1, 2, 3, 4, 5};
-    static const int budget_kb = [] { const char* e = getenv("EORB_OCT_BUDGET_KB"); return e ? atoi(e) : 150; }();      // (A/B runs)
+    static const int budget_kb = [] { const char* e = getenv("EORB_OCT_BUDGET_KB"); return e ? atoi(e) : 156; }();      // (A/B runs)
     for (int v = 0; v < 2; v++) {
         // measured on 1 024 frames of 240x180 / 400 features: 344 us with 150 KB per workgroup, 211 us with 76 KB, 253 us with the
         // whole working set in global memory; a single frame per call is 5 % faster with everything in LDS
@@ -1202,7 +1282,9 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
     EORB_HIP(c, hipMemcpy(o.geom.p, &g, sizeof(g), hipMemcpyHostToDevice));
     if (!tabs.empty()) EORB_HIP(c, hipMemcpy(o.tabs.p, tabs.data(), tabs.size() * sizeof(short), hipMemcpyHostToDevice));
     EORB_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), k_orb_pattern_31, 1024));
-    EORB_HIP(c, hipFuncSetAttribute((const void*)octree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    EORB_HIP(c, hipFuncSetAttribute((const void*)octree_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    EORB_HIP(c, hipFuncSetAttribute((const void*)octree_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    for (int v = 0; v < 2; v++) { o.oct_all_lds[v] = 1; for (int k = 0; k < 7; k++) o.oct_all_lds[v] &= oct_in_lds[v][k]; }
     o.configured = true;
     return EORB_OK;
 }
@@ -1247,12 +1329,15 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     }
     {
         ProfScope ps(c, "orb_octree");
-        octree_kernel<<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
-                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p,
-                                                                    (int32_t*)c->lvl_cnt.p, err_flag,
-                                                                    // a call that hands its own flag back (the host entry point) stays out of the sticky word
-                                                                    // of the *_dev calls: eorb_sync still reports an earlier batch's overflow
-                                                                    d_flag_out ? nullptr : (int32_t*)c->status.p, placement);
+        // a call that hands its own flag back (the host entry point) stays out of the sticky word of the *_dev calls: eorb_sync still
+        // reports an earlier batch's overflow
+        int32_t* sticky = d_flag_out ? nullptr : (int32_t*)c->status.p;
+        if (o.oct_all_lds[placement])
+            octree_kernel<true><<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
+                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement);
+        else
+            octree_kernel<false><<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
+                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement);
         EORB_LAUNCH_CHECK(c, "octree_kernel");
     }
     {
