@@ -69,6 +69,7 @@ struct OrbState {
     int kp_total = 0;        // per slice: sum of kp_cap  (= eorb_orb_max_keypoints)
     int max_out = 0;
     int oct_lds[2] = {0, 0};       // dynamic LDS bytes of the octree kernel, per placement (single frames / many workgroups)
+    int oct_direct_cap[2] = {0, 0};
     int oct_all_lds[2] = {0, 0};   // every item of that placement is in LDS: the kernel variant with LDS-typed pointers
     int oct_scratch[2] = {0, 0};   // per (slice, level) global scratch bytes
     DevBuf tabs;             // resize tables (short/int), level geometry, pattern, umax
@@ -159,7 +160,7 @@ struct eorb_ctx {
     // read back by eorb_sync / eorb_fe_status
     eorb::DevBuf status;
     // test hooks (eorb_debug_option): shrink the octree node pool to force an overflow; force the octree's global-memory layout
-    int dbg_pool_shrink = 0, dbg_force_global = 0;
+    int dbg_pool_shrink = 0, dbg_force_global = 0, dbg_oct_list = 0;      // (dbg_oct_list: the octree's list algorithm for every pass; applies at the next eorb_orb_configure)
     int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices), 4 slot lists (K2p)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
     int dbg_slot_rank = -1;                      // slot form: -1 by the device check / EORB_SLOT_RANK, 0 ballot scatter, 1 rank scatter (if the check passed)

@@ -302,6 +302,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!c || !name) return EORB_E_ARG;
     if (!strcmp(name, "octree_pool_shrink")) { c->dbg_pool_shrink = value; return EORB_OK; }
     if (!strcmp(name, "octree_force_global")) { c->dbg_force_global = value; return EORB_OK; }
+    if (!strcmp(name, "octree_list_algorithm")) { c->dbg_oct_list = value; return EORB_OK; }
     if (!strcmp(name, "win_list_cap")) { c->dbg_win_wcap = value; return EORB_OK; }
     if (!strcmp(name, "win_pool_cap")) { c->dbg_win_ecap = value; return EORB_OK; }
     if (!strcmp(name, "gather_form")) { c->dbg_gather_form = value; return EORB_OK; }
@@ -338,6 +339,7 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
     }
     if (!strcmp(name, "oct_lds_only")) return c->orb.oct_all_lds[0] | (c->orb.oct_all_lds[1] << 1);      // octree working set entirely in LDS: single frames | batches
     if (!strcmp(name, "oct_lds_bytes")) return c->orb.oct_lds[0];
+    if (!strcmp(name, "oct_direct_cap")) return c->orb.oct_direct_cap[0] | ((long long)c->orb.oct_direct_cap[1] << 16);
     if (!strcmp(name, "oct_scratch_bytes")) return c->orb.oct_scratch[0];
     if (!strcmp(name, "slot_hot_items")) {              // lists the last slot-form call handed to the register-row kernel (synchronises)
         long long n = 0;

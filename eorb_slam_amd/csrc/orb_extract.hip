@@ -40,6 +40,7 @@ struct DevGeom {
     // it (two workgroups per CU: launches with more workgroups than CUs)
     int oct_in_lds[2][7], oct_off[2][7];
     int oct_lds_bytes[2], oct_gblock_bytes[2];
+    int oct_direct_cap[2];       // most candidates of a level whose full passes are computed directly (0: never): the sort's buffer = the two size lists
     int node_cap_max, vsp_cap_max, ncap_max;
 };
 
@@ -398,6 +399,35 @@ __device__ void oct_block_sort_u64(uint64_t* a, int n)
     }
 }
 
+// The cell path of a candidate: root index (bits 31..24), then twelve quadrant digits n1..n4 = 0..3 (bits 23..0, first division in the
+// top two).  The boxes of DivideNode (:494-556) depend on the geometry only -- halfX = ceil((x1 - x0) / 2) -- so the path is a function
+// of the position; the arithmetic is the list algorithm's own (float ceil of the integer extents, the roots' (int)(hX * r)).
+__device__ __forceinline__ uint32_t oct_path_code(int px, int py, int nIni, float hX, int height)
+{
+    int r = (int)((float)px / hX);
+    r = min(max(r, 0), nIni - 1);
+    int x0 = (int)(uint16_t)(int)(hX * (float)r), x1 = (int)(uint16_t)(int)(hX * (float)(r + 1)), y0 = 0, y1 = height;
+    uint32_t code = (uint32_t)r << 24;
+#pragma unroll
+    for (int d = 0; d < 12; d++) {
+        const int halfX = (int)ceilf((float)(x1 - x0) / 2), halfY = (int)ceilf((float)(y1 - y0) / 2);
+        const int midx = x0 + halfX, midy = y0 + halfY;
+        const int q = (px < midx ? 0 : 1) + (py < midy ? 0 : 2);
+        code |= (uint32_t)q << (22 - 2 * d);
+        if (q & 1) x0 = midx; else x1 = midx;
+        if (q & 2) y0 = midy; else y1 = midy;
+    }
+    return code;
+}
+// leading path levels two codes share: 0 = different roots, 1 = the root only, ..., 13 = all of it
+__device__ __forceinline__ int oct_share(uint32_t a, uint32_t b)
+{
+    const uint32_t x = a ^ b;
+    if (x >> 24) return 0;
+    if (x == 0u) return 13;
+    return 1 + ((__clz((int)x) - 8) >> 1);
+}
+
 // LDS_ONLY: every item of the working set sits in LDS (single frames, small levels).  The pointers are then known to be LDS
 // pointers and the compiler emits ds_read / ds_write; with the mixed placement they are generic and every access is a FLAT
 // instruction, whose round trip to the LDS is several times longer -- and a round is a chain of ~20 dependent accesses.
@@ -408,6 +438,14 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                                                              int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky, int placement)
 {
     extern __shared__ unsigned char smem[];
+#ifdef EORB_OCT_TIMING      // (experiment builds only: where a call's cycles go, printed by workgroup 0)
+    __shared__ long long s_tm[8]; __shared__ int s_tn[8];
+    long long t_last = clock64();
+    if (threadIdx.x < 8) { s_tm[threadIdx.x] = 0; s_tn[threadIdx.x] = 0; }
+#define OCT_T(k) do { if (threadIdx.x == 0) { const long long t_now = clock64(); s_tm[k] += t_now - t_last; s_tn[k]++; t_last = t_now; } } while (0)
+#else
+#define OCT_T(k) do { } while (0)
+#endif
     __shared__ int s_ws[kOctThreads / 64 + 2], s_ws2[kOctThreads / 64];
     __shared__ int s_m, s_flag, s_nbig;
     __shared__ uint16_t s_big[kOctBigMax];
@@ -469,14 +507,149 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     }
     __syncthreads();
     if (n == 0) { if (tid == 0) lvl_cnt[slice * G->nlevels + level] = 0; return; }
+    OCT_T(0);
 
     const int N = L.nfeat;
     const int width = L.maxBX - L.minBX, height = L.maxBY - L.minBY;
     const int nIni = (int)roundf((float)width / (float)height);
     const float hX = (float)width / (float)nIni;
     int cur = 0, lsize = 0, seqctr = 0, nPnext = 0;
+    bool overflow = false;
+    int nvsp = 0, vw = 0;
+    // ---- The full passes, computed instead of executed.  While no pass is cut short, EVERY node with more than one key is divided,
+    // so after p passes a key sits in the cell of depth min(p, s) of its path, s = the depth at which it is alone.  Sorting the
+    // path codes puts the keys of a cell side by side: the levels a key shares with its neighbours give s, the list size and the
+    // number of divisible nodes after every pass (hence the pass that ends the loop or starts the cut-off stage :688-757) come from
+    // two 13-bin histograms.  The LIST ORDER follows from push_front: after pass p the list is the pass's children in reverse
+    // creation order, then the undivided (single-key) nodes in the order they had; creation order = the parents' list order, n1..n4
+    // -- unrolled: a lexicographic order of the path digits whose directions alternate with the depth (below).  A second sort by
+    // (that order, original key index) leaves the keys grouped by node, in list order, each node's keys in vToDistributeKeys order,
+    // which is all the cut-off stage and the selection need.  A pass of the list algorithm is ~20 dependent LDS round trips; this is
+    // two sorts in registers.  Levels whose keys do not fit the two size lists (the sort's buffer) keep the list algorithm. ----
+    bool direct_done = false; int direct_cut = 0;
+    __shared__ int s_hist[3][16];
+    if (LDS_ONLY && n <= G->oct_direct_cap[placement] && nIni <= 255) {
+        uint64_t* S = VSP(0);                       // (VSP(1) follows VSP(0): oct_direct_cap is 0 otherwise)
+        uint16_t* sh = KEYS(1);
+        if (tid < 48) s_hist[tid >> 4][tid & 15] = 0;
+        for (int i = tid; i < n; i += kOctThreads) {
+            const uint32_t p = pts[i];
+            S[i] = ((uint64_t)oct_path_code((int)(p & 0xfff), (int)((p >> 12) & 0xfff), nIni, hX, height) << 16) | (uint64_t)i;
+        }
+        __syncthreads();
+        oct_block_sort_u64(S, n);
+        for (int i = tid; i < n; i += kOctThreads) sh[i] = (uint16_t)(i > 0 ? oct_share((uint32_t)(S[i] >> 16), (uint32_t)(S[i - 1] >> 16)) : 0);
+        __syncthreads();
+        for (int i = tid; i < n; i += kOctThreads) {
+            const int a = sh[i], b = i > 0 ? (int)sh[i - 1] : 0, nx = i + 1 < n ? (int)sh[i + 1] : 0;
+            if (i > 0) {
+                atomicAdd(&s_hist[0][a], 1);                              // pairs by shared levels
+                if (a > b) { atomicAdd(&s_hist[1][b + 1], 1); atomicAdd(&s_hist[1][min(a + 1, 15)], -1); }     // a run of pairs sharing >= d levels starts here, for b < d <= a
+            }
+            atomicAdd(&s_hist[2][min(max(a, nx), 15)], 1);                // keys by the depth at which they are alone
+        }
+        __syncthreads();
+        // L(p) = nodes after p passes, X(p) = those with more than one key, created(p) = nodes pass p made
+        int cntge[16], runs[16], alone_lt[16];
+        { int acc = 0; for (int d = 15; d >= 0; d--) { acc += s_hist[0][d]; cntge[d] = acc; } }
+        { int acc = 0; for (int d = 0; d < 16; d++) { acc += s_hist[1][d]; runs[d] = acc; } }
+        { int acc = 0; for (int d = 0; d < 16; d++) { alone_lt[d] = acc; acc += s_hist[2][d]; } }
+        bool ok = s_hist[0][13] == 0 && s_hist[0][14] == 0 && s_hist[0][15] == 0;      // (two keys on one pixel: not a FAST output)
+        int Pf = 0, ls = n - cntge[1], nx = runs[1], seqbase = 0, created = ls;
+        if (ls > pool || nx > vcap) ok = false;
+        bool fin = false;
+        while (ok && !fin && !direct_cut) {
+            const int prev = ls;
+            if (nx == 0 || Pf >= 12) { fin = true; break; }                // nothing left to divide: the size does not change (:690)
+            Pf++;
+            seqbase += created;
+            ls = n - cntge[Pf + 1]; nx = runs[Pf + 1]; created = ls - alone_lt[Pf];
+            if (ls > pool || nx > vcap) { ok = false; break; }
+            if (ls >= N || ls == prev) fin = true;
+            else if (ls + nx * 3 > N) direct_cut = 1;
+        }
+        if (ok) {
+            // the list-order key of every key's node
+            uint64_t item[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int i = tid + kOctThreads * m;
+                item[m] = ~0ull;
+                if (i < n) {
+                    const uint32_t code = (uint32_t)(S[i] >> 16);
+                    const int a = sh[i], nxs = i + 1 < n ? (int)sh[i + 1] : 0;
+                    const int e = min(Pf, max(a, nxs));
+                    const int r = (int)(code >> 24);
+                    uint32_t rk, qk = 0u;
+                    if (e == 0) rk = (uint32_t)r;                                   // the roots were push_back'ed: ascending
+                    else {
+                        rk = ((e - 1) & 1) ? (uint32_t)r : (uint32_t)(nIni - 1 - r);
+                        for (int k = 1; k <= e; k++) {
+                            const uint32_t dgt = (code >> (24 - 2 * k)) & 3u;
+                            qk |= (((e - k) & 1) ? dgt : 3u - dgt) << (24 - 2 * k);
+                        }
+                    }
+                    item[m] = ((((uint64_t)(Pf - e) << 32) | ((uint64_t)rk << 24) | (uint64_t)qk) << 16) | (S[i] & 0xffffull);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 8; m++) { const int i = tid + kOctThreads * m; if (i < n) S[i] = item[m]; }
+            __syncthreads();
+            oct_block_sort_u64(S, n);
+            // node boundaries -> list positions
+            for (int i = tid; i < n; i += kOctThreads) sh[i] = (uint16_t)((i > 0 && (S[i] >> 16) != (S[i - 1] >> 16)) ? 1 : 0);
+            __syncthreads();
+            oct_block_scan2(aux, 0, sh, n, s_ws, s_ws2);                  // (exclusive: sh[i] = boundaries before i; + the boundary at i itself below)
+            uint16_t* nstart = PB(0);
+            for (int i = tid; i < n; i += kOctThreads) {
+                const bool bnd = i == 0 || (S[i] >> 16) != (S[i - 1] >> 16);
+                const int pos = (int)sh[i] + ((i > 0 && bnd) ? 1 : 0);
+                KEYS(0)[i] = (uint16_t)(S[i] & 0xffffull);
+                if (bnd) nstart[pos] = (uint16_t)i;
+            }
+            __syncthreads();
+            // the nodes, in list order; the divisible ones also go to the size list of the cut-off stage
+            for (int pos = tid; pos < ls; pos += kOctThreads) aux[pos] = 0;
+            __syncthreads();
+            for (int pos = tid; pos < ls; pos += kOctThreads) {
+                const int st = nstart[pos], cnt = (pos + 1 < ls ? (int)nstart[pos + 1] : n) - st;
+                const uint64_t it = S[st];
+                const int e = Pf - (int)((it >> 48) & 0xf);
+                const uint32_t p = pts[it & 0xffffull];
+                const int px = (int)(p & 0xfff), py = (int)((p >> 12) & 0xfff);
+                int r = (int)((float)px / hX);
+                r = min(max(r, 0), nIni - 1);
+                int x0 = (int)(uint16_t)(int)(hX * (float)r), x1 = (int)(uint16_t)(int)(hX * (float)(r + 1)), y0 = 0, y1 = height;
+                for (int d = 0; d < e; d++) {
+                    const int halfX = (int)ceilf((float)(x1 - x0) / 2), halfY = (int)ceilf((float)(y1 - y0) / 2);
+                    const int midx = x0 + halfX, midy = y0 + halfY;
+                    if (px < midx) x1 = midx; else x0 = midx;
+                    if (py < midy) y1 = midy; else y0 = midy;
+                }
+                ONode nd;
+                nd.x0 = (uint16_t)x0; nd.x1 = (uint16_t)x1; nd.y0 = (uint16_t)y0; nd.y1 = (uint16_t)y1;
+                nd.start = (uint16_t)st; nd.cnt = (uint16_t)cnt;
+                const int seq = e == Pf ? (Pf == 0 ? pos : seqbase + created - 1 - pos) : 0;
+                nd.seq = (uint16_t)seq; nd.flags = (uint8_t)(cnt == 1 ? 1 : 0); nd.pad = 0;
+                NODES(0)[pos] = nd;
+                if (cnt > 1) aux[pos] = 1;
+            }
+            __syncthreads();
+            // (S = VSP(0..1) is free now: the size list is written over it)
+            oct_block_scan(aux, ls, s_ws);
+            for (int pos = tid; pos < ls; pos += kOctThreads) {
+                const ONode nd = NODES(0)[pos];
+                if (nd.cnt > 1) VSP(0)[aux[pos]] = ((uint64_t)nd.cnt << 32) | ((uint64_t)nd.seq << 16) | (uint64_t)pos;
+            }
+            __syncthreads();
+            cur = 0; lsize = ls; seqctr = seqbase + created; nvsp = nx; vw = 0; pb = 0;
+            direct_done = true;
+        } else direct_cut = 0;
+    }
+    OCT_T(6);
     // ---- root nodes :562-603: stable partition of the keys by root index (wave 0), empty roots erased, singletons bNoMore ----
-    {
+    if (!direct_done) {
         int off = 0;
         for (int r = 0; r < nIni; r++) {
             int c = 0;
@@ -517,10 +690,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
         }
     }
 
+    OCT_T(1);
     // One round: divide the nodes P[0..nP) (processing order).  cut: stop after the division that brings the list to N nodes
     // (:741-757).  Returns through the references; VSP(vw) receives the children with more than one key, in creation order.
-    bool overflow = false;
-    int nvsp = 0, vw = 0;
     auto round = [&](int nP, bool cut, int& nToExpand) {
         const ONode* src = NODES(cur);
         ONode* dst = NODES(cur ^ 1);
@@ -798,30 +970,38 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     };
 
     bool finish = false;
-    int guard = 0;
-    while (!finish && !overflow && guard++ < 64) {
-        const int prevSize = lsize;
-        // processing order of a full pass = list order of the expandable nodes (:618-686): left in PB(pb) by the roots / the previous pass
-        const int nP = nPnext;
-        int nToExpand = 0;
-        if (nP > 0) round(nP, false, nToExpand);
-        if (overflow) break;
-        if (lsize >= N || lsize == prevSize) {
-            finish = true;
-        } else if (lsize + nToExpand * 3 > N) {
-            int guard2 = 0;
-            while (!finish && !overflow && guard2++ < 4096) {
-                const int prevSize2 = lsize;
-                const int nprev = nvsp;
-                // largest first: ascending sort of (size, creation order), walked from the back (:703-712)
-                oct_block_sort_u64(VSP(vw), nprev);
-                for (int j = tid; j < nprev; j += kOctThreads) PB(pb)[j] = (uint16_t)(VSP(vw)[nprev - 1 - j] & 0xffff);
-                vw ^= 1;
-                __syncthreads();
-                int dummy = 0;
-                if (nprev > 0) round(nprev, true, dummy);
-                if (lsize >= N || lsize == prevSize2) finish = true;
-            }
+    // the cut-off stage :688-757: the divisible nodes largest first (ascending sort of (size, creation order), walked from the back
+    // :703-712), one at a time until the list holds N nodes; repeated on the children while that changes anything
+    auto cut_stage = [&]() {
+        int guard2 = 0;
+        while (!finish && !overflow && guard2++ < 4096) {
+            const int prevSize2 = lsize;
+            const int nprev = nvsp;
+            oct_block_sort_u64(VSP(vw), nprev);
+            OCT_T(3);
+            for (int j = tid; j < nprev; j += kOctThreads) PB(pb)[j] = (uint16_t)(VSP(vw)[nprev - 1 - j] & 0xffff);
+            vw ^= 1;
+            __syncthreads();
+            int dummy = 0;
+            if (nprev > 0) round(nprev, true, dummy);
+            OCT_T(4);
+            if (lsize >= N || lsize == prevSize2) finish = true;
+        }
+    };
+    if (direct_done) {
+        if (direct_cut) cut_stage();
+    } else {
+        int guard = 0;
+        while (!finish && !overflow && guard++ < 64) {
+            const int prevSize = lsize;
+            // processing order of a full pass = list order of the expandable nodes (:618-686): left in PB(pb) by the roots / the previous pass
+            const int nP = nPnext;
+            int nToExpand = 0;
+            if (nP > 0) round(nP, false, nToExpand);
+            OCT_T(2);
+            if (overflow) break;
+            if (lsize >= N || lsize == prevSize) finish = true;
+            else if (lsize + nToExpand * 3 > N) cut_stage();
         }
     }
     if (overflow) raise(2);
@@ -843,6 +1023,12 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
         }
         if (tid == 0) lvl_cnt[slice * G->nlevels + level] = nout;
     }
+    OCT_T(5);
+#ifdef EORB_OCT_TIMING
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        printf("octree n=%d N=%d lsize=%d direct %d (cap %d) %lld: gather %lld | roots %lld | full passes %d x %lld | cut sorts %d x %lld | cut rounds %d x %lld | select %lld cycles\n", n, N, lsize, (int)direct_done, G->oct_direct_cap[placement], s_tm[6],
+               s_tm[0], s_tm[1], s_tn[2], s_tn[2] ? s_tm[2] / s_tn[2] : 0, s_tn[3], s_tn[3] ? s_tm[3] / s_tn[3] : 0, s_tn[4], s_tn[4] ? s_tm[4] / s_tn[4] : 0, s_tm[5]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1274,7 +1460,12 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
     g.minTh = std::min(std::max(p->minThFAST, 0), 255);
     memcpy(g.umax, o.umax, sizeof(o.umax)); memcpy(g.sf, o.sf, sizeof(o.sf));
     memcpy(g.oct_in_lds, oct_in_lds, sizeof(oct_in_lds)); memcpy(g.oct_off, oct_off, sizeof(oct_off));
-    for (int v = 0; v < 2; v++) { g.oct_lds_bytes[v] = o.oct_lds[v]; g.oct_gblock_bytes[v] = o.oct_scratch[v]; }
+    for (int v = 0; v < 2; v++) {
+        g.oct_lds_bytes[v] = o.oct_lds[v]; g.oct_gblock_bytes[v] = o.oct_scratch[v];
+        bool all = true; for (int k = 0; k < 7; k++) all = all && oct_in_lds[v][k];
+        static const int direct_on = [] { const char* e = getenv("EORB_OCT_DIRECT"); return e ? atoi(e) : 1; }();       // (A/B runs, parity tests of the list algorithm)
+        o.oct_direct_cap[v] = g.oct_direct_cap[v] = (direct_on && !c->dbg_oct_list && all && oct_off[v][2] == oct_off[v][1] + (int)(sizeof(uint64_t) * vsp_pow2)) ? std::min(4096, 2 * vsp_pow2) : 0;
+    }
     g.node_cap_max = node_cap_max; g.vsp_cap_max = vsp_cap_max; g.ncap_max = ncap_max;
     int rc;
     if ((rc = ensure(c, o.geom, sizeof(DevGeom)))) return rc;

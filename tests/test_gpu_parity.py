@@ -1799,6 +1799,40 @@ def test_octree_working_set_in_global_memory(oracle, fe, cfg):
     c.close()
 
 
+@pytest.mark.parametrize("list_algorithm", [0, 1])
+def test_octree_direct_passes_equal_list_algorithm(oracle, fe, list_algorithm):
+    """The octree's full passes are computed (two sorts of the candidates' cell paths) where a level's candidates fit the sort buffer,
+    and executed pass by pass (the reference's list algorithm, restated) elsewhere: both against the oracle, over frames that leave the
+    pass loop by every door -- the cut-off stage (:688-757), `size >= N` straight after a pass, nothing left to divide (fewer
+    candidates than N), a single candidate, a wide frame with several root nodes, a square one with a single root."""
+    cases = [
+        (synth.texture_image(240, 180, seed=3), dict(nfeatures=1000, scaleFactor=1.2, nlevels=4, iniThFAST=10, minThFAST=0, edgeTh=19)),
+        (synth.texture_image(240, 180, seed=5), dict(nfeatures=60, scaleFactor=1.2, nlevels=2, iniThFAST=10, minThFAST=0, edgeTh=19)),        # N far below the candidates
+        (synth.texture_image(240, 180, seed=6), dict(nfeatures=17, scaleFactor=1.0, nlevels=1, iniThFAST=10, minThFAST=0, edgeTh=9)),
+        (_event_image(oracle, n=6000, seed=7), dict(nfeatures=400, scaleFactor=1.0, nlevels=1, iniThFAST=0, minThFAST=0, edgeTh=9)),         # fewer candidates than N
+        (_event_image(oracle, n=900, seed=8), dict(nfeatures=400, scaleFactor=1.0, nlevels=1, iniThFAST=0, minThFAST=0, edgeTh=9)),
+        (synth.texture_image(640, 120, seed=9), dict(nfeatures=500, scaleFactor=1.2, nlevels=3, iniThFAST=10, minThFAST=0, edgeTh=19)),       # five roots
+        (synth.texture_image(200, 200, seed=10), dict(nfeatures=300, scaleFactor=1.2, nlevels=3, iniThFAST=10, minThFAST=0, edgeTh=19)),
+    ]
+    one = np.zeros((180, 240), np.uint8); one[60:64, 100:104] = 255                        # a lone blob: a handful of corners
+    cases.append((one, dict(nfeatures=400, scaleFactor=1.0, nlevels=1, iniThFAST=0, minThFAST=0, edgeTh=9)))
+    seen_direct = 0
+    for img, p in cases:
+        H, W = img.shape
+        c = fe.Context()
+        c.debug_option("octree_list_algorithm", list_algorithm)
+        oe = oracle.OrbExtractor(imWidth=W, **p)
+        ge = fe.ORBextractor(imSize=(W, H), ctx=c, **p)
+        seen_direct += 1 if (c.debug_counter("oct_direct_cap") & 0xffff) else 0
+        for lap in ((0, 1000), (60, 120)):
+            omono, okp, odesc, ooob = oe.extract(img, lap, True)
+            gmono, gkp, gdesc, goob = ge(img, lap, True)
+            assert omono == gmono and len(okp) == len(gkp), (p, len(okp), len(gkp))
+            assert np.array_equal(okp.view(np.uint8), gkp.view(np.uint8)) and np.array_equal(odesc, gdesc), p
+        c.close()
+    assert (seen_direct == 0) if list_algorithm else (seen_direct == len(cases))
+
+
 def test_error_paths_return_codes(fe, ctx):
     ev = synth.random_events(10, seed=1)
     L = ctx.L
