@@ -375,8 +375,44 @@ __device__ void oct_block_sort_regs(uint64_t* a, int np2)
     for (int m = 0; m < M; m++) { const int i = tid + kOctThreads * m; if (i < np2) a[i] = v[m]; }
     __syncthreads();
 }
+// Up to one item per thread: sorted by RANK -- every thread counts the items below its own (all lanes read the same LDS word: a
+// broadcast, no conflicts) and writes its item to that place.  n reads and compares per thread, no exchange network: 45 dependent
+// shuffle / LDS steps of the bitonic sort against one pass.  The items must be distinct.  SH32: the items differ in bits [SH32 + 31 :
+// SH32] already (cell paths; (size, creation order)), which makes the compare a 32-bit one; SH32 < 0: the whole 64 bits.
+template <int SH32>
+__device__ void oct_rank_sort_u64(uint64_t* a, int n)
+{
+    const int tid = threadIdx.x;
+    const uint64_t v = tid < n ? a[tid] : ~0ull;
+    int rank = 0;
+    if (SH32 >= 0) {
+        // the 32-bit keys packed at the front of the array (the items wait in registers): four keys per broadcast read
+        const uint32_t mine = (uint32_t)(v >> SH32);
+        const int n4 = (n + 3) & ~3;
+        __syncthreads();
+        if (tid < n4) ((uint32_t*)a)[tid] = tid < n ? mine : 0xffffffffu;     // (padding: never below anything)
+        __syncthreads();
+        const uint4* k4 = (const uint4*)a;
+#pragma unroll 4
+        for (int j = 0; j < (n4 >> 2); j++) {
+            const uint4 q = k4[j];
+            rank += (q.x < mine ? 1 : 0) + (q.y < mine ? 1 : 0) + (q.z < mine ? 1 : 0) + (q.w < mine ? 1 : 0);
+        }
+    } else {
+        const ulonglong2* k2 = (const ulonglong2*)a;
+        const int n2 = n >> 1;
+#pragma unroll 4
+        for (int j = 0; j < n2; j++) { const ulonglong2 q = k2[j]; rank += (q.x < v ? 1 : 0) + (q.y < v ? 1 : 0); }
+        if (n & 1) rank += (a[n - 1] < v) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < n) a[rank] = v;
+    __syncthreads();
+}
+template <int SH32 = -1>
 __device__ void oct_block_sort_u64(uint64_t* a, int n)
 {
+    if (n <= kOctThreads) { oct_rank_sort_u64<SH32>(a, n); return; }
     int np2 = 1; while (np2 < n) np2 <<= 1;
     for (int i = n + threadIdx.x; i < np2; i += blockDim.x) a[i] = ~0ull;
     __syncthreads();
@@ -439,9 +475,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
 {
     extern __shared__ unsigned char smem[];
 #ifdef EORB_OCT_TIMING      // (experiment builds only: where a call's cycles go, printed by workgroup 0)
-    __shared__ long long s_tm[8]; __shared__ int s_tn[8];
+    __shared__ long long s_tm[24]; __shared__ int s_tn[24];
     long long t_last = clock64();
-    if (threadIdx.x < 8) { s_tm[threadIdx.x] = 0; s_tn[threadIdx.x] = 0; }
+    if (threadIdx.x < 24) { s_tm[threadIdx.x] = 0; s_tn[threadIdx.x] = 0; }
 #define OCT_T(k) do { if (threadIdx.x == 0) { const long long t_now = clock64(); s_tm[k] += t_now - t_last; s_tn[k]++; t_last = t_now; } } while (0)
 #else
 #define OCT_T(k) do { } while (0)
@@ -537,7 +573,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
             S[i] = ((uint64_t)oct_path_code((int)(p & 0xfff), (int)((p >> 12) & 0xfff), nIni, hX, height) << 16) | (uint64_t)i;
         }
         __syncthreads();
-        oct_block_sort_u64(S, n);
+        OCT_T(8);
+        oct_block_sort_u64<16>(S, n);                // (the cell paths of distinct pixels differ)
+        OCT_T(9);
         for (int i = tid; i < n; i += kOctThreads) sh[i] = (uint16_t)(i > 0 ? oct_share((uint32_t)(S[i] >> 16), (uint32_t)(S[i - 1] >> 16)) : 0);
         __syncthreads();
         for (int i = tid; i < n; i += kOctThreads) {
@@ -549,6 +587,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
             atomicAdd(&s_hist[2][min(max(a, nx), 15)], 1);                // keys by the depth at which they are alone
         }
         __syncthreads();
+        OCT_T(10);
         // L(p) = nodes after p passes, X(p) = those with more than one key, created(p) = nodes pass p made
         int cntge[16], runs[16], alone_lt[16];
         { int acc = 0; for (int d = 15; d >= 0; d--) { acc += s_hist[0][d]; cntge[d] = acc; } }
@@ -568,6 +607,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
             if (ls >= N || ls == prev) fin = true;
             else if (ls + nx * 3 > N) direct_cut = 1;
         }
+        OCT_T(11);
         if (ok) {
             // the list-order key of every key's node
             uint64_t item[8];
@@ -596,7 +636,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
 #pragma unroll
             for (int m = 0; m < 8; m++) { const int i = tid + kOctThreads * m; if (i < n) S[i] = item[m]; }
             __syncthreads();
+            OCT_T(12);
             oct_block_sort_u64(S, n);
+            OCT_T(13);
             // node boundaries -> list positions
             for (int i = tid; i < n; i += kOctThreads) sh[i] = (uint16_t)((i > 0 && (S[i] >> 16) != (S[i - 1] >> 16)) ? 1 : 0);
             __syncthreads();
@@ -609,6 +651,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 if (bnd) nstart[pos] = (uint16_t)i;
             }
             __syncthreads();
+            OCT_T(14);
             // the nodes, in list order; the divisible ones also go to the size list of the cut-off stage
             for (int pos = tid; pos < ls; pos += kOctThreads) aux[pos] = 0;
             __syncthreads();
@@ -636,6 +679,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
                 if (cnt > 1) aux[pos] = 1;
             }
             __syncthreads();
+            OCT_T(15);
             // (S = VSP(0..1) is free now: the size list is written over it)
             oct_block_scan(aux, ls, s_ws);
             for (int pos = tid; pos < ls; pos += kOctThreads) {
@@ -977,7 +1021,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
         while (!finish && !overflow && guard2++ < 4096) {
             const int prevSize2 = lsize;
             const int nprev = nvsp;
-            oct_block_sort_u64(VSP(vw), nprev);
+            oct_block_sort_u64<16>(VSP(vw), nprev);     // (size << 16 | creation order: distinct, 32 bits)
             OCT_T(3);
             for (int j = tid; j < nprev; j += kOctThreads) PB(pb)[j] = (uint16_t)(VSP(vw)[nprev - 1 - j] & 0xffff);
             vw ^= 1;
@@ -1025,8 +1069,10 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     }
     OCT_T(5);
 #ifdef EORB_OCT_TIMING
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        printf("octree n=%d N=%d lsize=%d direct %d (cap %d) %lld: gather %lld | roots %lld | full passes %d x %lld | cut sorts %d x %lld | cut rounds %d x %lld | select %lld cycles\n", n, N, lsize, (int)direct_done, G->oct_direct_cap[placement], s_tm[6],
+    if (threadIdx.x == 0 && slice == 0)
+        printf("   direct: codes %lld sort1 %lld shares+hist %lld sim %lld items %lld sort2 %lld bounds %lld nodes %lld vsp %lld\n", s_tm[8], s_tm[9], s_tm[10], s_tm[11], s_tm[12], s_tm[13], s_tm[14], s_tm[15], s_tm[6]);
+    if (threadIdx.x == 0 && slice == 0)
+        printf("octree L%d n=%d N=%d lsize=%d direct %d (cap %d) %lld: gather %lld | roots %lld | full passes %d x %lld | cut sorts %d x %lld | cut rounds %d x %lld | select %lld cycles\n", level, n, N, lsize, (int)direct_done, G->oct_direct_cap[placement], s_tm[6],
                s_tm[0], s_tm[1], s_tn[2], s_tn[2] ? s_tm[2] / s_tn[2] : 0, s_tn[3], s_tn[3] ? s_tm[3] / s_tn[3] : 0, s_tn[4], s_tn[4] ? s_tm[4] / s_tn[4] : 0, s_tm[5]);
 #endif
 }
