@@ -205,6 +205,7 @@ int ev_slots_prepare(eorb_ctx* c, int W, int H, int h, int TX, int TY, const flo
                       float two_sig2, float norm);
 struct SlotDict {              // float events looked up in the context's position dictionary by the count pass (ev_slots.hip)
     const uint4* hash; uint32_t mask; uint32_t* rec; int* miss;
+    int rec2;                  // the dictionary holds fewer than 65 535 positions: rec is written as 2-byte records (0xffff = none), else 4-byte
 };
 int ev_slots_accumulate(eorb_ctx* c, const void* d_events, int stride, const int64_t* h_offsets, int B, int W, int H, int TX, int TY,
                         float* d_f32, uint32_t* d_minmax_enc, const SlotDict* dict = nullptr);

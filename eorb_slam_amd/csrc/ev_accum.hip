@@ -2198,7 +2198,7 @@ static int pd_accumulate(eorb_ctx* c, const eorb_event16* d_src, const int64_t* 
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
     }
-    SlotDict D{(const uint4*)c->pd_hash.p, (1u << kPdLog) - 1u, (uint32_t*)c->dd_ev.p, (int*)c->pd_cnt.p};
+    SlotDict D{(const uint4*)c->pd_hash.p, (1u << kPdLog) - 1u, (uint32_t*)c->dd_ev.p, (int*)c->pd_cnt.p, c->pd_K < 65535 ? 1 : 0};
     rc = ev_slots_accumulate(c, d_src, 16, off, B, W, H, TX, TY, d_f32, d_minmax_enc, &D);
     c->lut_w = sw; c->lut_h = sh; c->sl_ok = sok;
     swap_tables();

@@ -259,7 +259,7 @@ __device__ __forceinline__ uint32_t sl_dict_hash(uint64_t k)
 template <int stride, bool KEYED = false>
 __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
                                                                        int nchunks, const uint16_t* __restrict__ slot_geo, int LW, int LH,
-                                                                       int TX, int NT, uint16_t* __restrict__ segcnt, SlotDict D = SlotDict{nullptr, 0u, nullptr, nullptr},
+                                                                       int TX, int NT, uint16_t* __restrict__ segcnt, SlotDict D = SlotDict{nullptr, 0u, nullptr, nullptr, 0},
                                                                        uint16_t* __restrict__ rec16 = nullptr)
 {
     extern __shared__ uint32_t smc[];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
 #pragma unroll
                 for (int u = 0; u < U; u++) { const int k = k0 + u * 64; pos[u] = k < cd.n ? *(const uint2*)(e + (size_t)k * 16) : make_uint2(0x7fc00000u, 0x7fc00000u); }
 #pragma unroll
-                for (int u = 0; u < U; u++) { hh[u] = sl_dict_hash((uint64_t)pos[u].x | ((uint64_t)pos[u].y << 32)) & D.mask; ent[u] = D.hash[hh[u]]; }
+                for (int u = 0; u < U; u++) { hh[u] = sl_dict_hash((uint64_t)pos[u].x | ((uint64_t)pos[u].y << 32)) & D.mask; ent[u] = D.hash[hh[u]]; }      // (a non-temporal load here: 1.89 -> 3.09 ms; the L1 does serve part of the probes)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int k = k0 + u * 64;
@@ -300,7 +300,10 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
                         if (q.x == pos[u].x && q.y == pos[u].y && q.z != 0xffffffffu) id = q.z;
                         else atomicAdd(D.miss, 1);
                     }
-                    if (k < cd.n) D.rec[cd.start + k] = id;
+                    if (k < cd.n) {
+                        if (D.rec2) ((uint16_t*)D.rec)[cd.start + k] = id == 0x7fffffffu ? (uint16_t)0xffffu : (uint16_t)id;
+                        else D.rec[cd.start + k] = id;
+                    }
                     g[u] = id < (uint32_t)LW * (uint32_t)LH ? tab[id] : kNoGeo;
                 }
             } else {
@@ -1169,7 +1172,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
                       int W, int H, int TX, int TY, float* d_f32, uint32_t* d_minmax_enc, const SlotScatterChoice& sc, const SlotDict* dict)
 {
     // with a position dictionary the count pass reads the float events and writes the hashed records every later pass reads
-    const int stride = dict ? -4 : stride_in;
+    const int stride = dict ? (dict->rec2 ? 2 : -4) : stride_in;
     const int NT = TX * TY;
     const int64_t nev = h_offsets[B] - h_offsets[0];
     const int chunk = sc.chunk;
