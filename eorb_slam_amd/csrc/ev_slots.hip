@@ -607,6 +607,9 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
         }
     }
     __syncthreads();
+#if defined(EORB_KO_SCAT) && EORB_KO_SCAT == 1          // (experiment builds: the kernel cut short after a phase)
+    if (rk[0] == 0x12345678u) entries[0] = 0; return;
+#endif
     // ---- B: per tile the exclusive prefix over the waves; exclusive scan of the totals over the tiles ----
     {
         const int per = (NT + NTHR - 1) / NTHR;
@@ -632,6 +635,9 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
         if (tid == NTHR - 1) loff[NT] = (uint16_t)before;
     }
     __syncthreads();
+#if defined(EORB_KO_SCAT) && EORB_KO_SCAT == 2
+    if (rk[0] == 0x12345678u) entries[0] = 0; return;
+#endif
     // ---- C: every entry to its place in the tile-sorted order ----
     const uint16_t* cw = cntw + wave * NTp;
 #pragma unroll
@@ -655,6 +661,9 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
         }
     }
     __syncthreads();
+#if defined(EORB_KO_SCAT) && EORB_KO_SCAT == 3
+    if (rk[0] == 0x12345678u) entries[0] = 0; return;
+#endif
     // ---- D: consecutive threads write consecutive entries of a run ----
     slot_entry* out = entries + (size_t)slice_ebase[cd.slice];
     const int E = loff[NT];
