@@ -216,6 +216,8 @@ int klt_track_dev(eorb_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, int
                   uint8_t* d_status, float* d_err, unsigned long long ref_key = 0);
 // ref_key != 0: d_prev is the reference frame `ref_key` -- its pyramid and derivatives are built once and reused while the key stays
 // orb_extract.hip
+int stereo_match_dev(eorb_ctx* c, const eorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
+                     float* d_uright, float* d_depth, int32_t* d_sad, int32_t* d_nmatch);
 int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t img_slice_bytes, int B, int lap0, int lap1,
                     int want_desc, eorb_keypoint* d_kps, uint8_t* d_desc, uint8_t* d_oob, int32_t* d_n, int32_t* d_mono,
                     int32_t* d_flag_out = nullptr);      // d_flag_out: receives the overflow flag of this extraction (host entry point)

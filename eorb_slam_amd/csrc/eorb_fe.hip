@@ -1074,6 +1074,54 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     return EORB_OK;
 }
 
+// Frame::Frame(imLeft, imRight, ...) (src/Frame.cc:97-152): both images through the extractor (two slices of one batch: the
+// reference's two extractors have equal parameters, :122-125 with vLappingArea {0, 0}), then ComputeStereoMatches (:869-1048)
+int eorb_frame_stereo(eorb_ctx* c, const uint8_t* imLeft, const uint8_t* imRight, int W, int H, int stride, float mb, float mbf,
+                      eorb_keypoint* kpsL, uint8_t* descL, int* nL, eorb_keypoint* kpsR, uint8_t* descR, int* nR, int cap,
+                      float* uRight, float* depth, int* nmatches)
+{
+    if (!c) return EORB_E_ARG;
+    if (nL) *nL = 0; if (nR) *nR = 0; if (nmatches) *nmatches = 0;
+    if (!imLeft || !imRight || W <= 0 || H <= 0) return EORB_E_EMPTY;
+    OrbState& o = c->orb;
+    if (!o.configured) return set_err(c, EORB_E_NOTCONF, "eorb_frame_stereo: not configured");
+    if (W != o.W || H != o.H || stride < W) return set_err(c, EORB_E_ARG, "eorb_frame_stereo: the images do not match the configured %dx%d", o.W, o.H);
+    if (!(mb > 0.f) || !(mbf > 0.f)) return set_err(c, EORB_E_ARG, "eorb_frame_stereo: baseline %.4f, bf %.4f", mb, mbf);
+    hipSetDevice(c->device);
+    int rc;
+    const size_t mo = (size_t)o.max_out;
+    Arena A(c);
+    const size_t o_imL = A.in2d(imLeft, H, (size_t)W, (size_t)stride), o_imR = A.in2d(imRight, H, (size_t)W, (size_t)stride);
+    // outputs, contiguous: {n[2], mono[2], flag, matches, pad} | keypoints [2] | descriptors [2] | uRight | depth | (norms)
+    const size_t o_n = A.reserve(32), o_kp = A.reserve(sizeof(eorb_keypoint) * mo * 2), o_desc = A.reserve(32 * mo * 2);
+    const size_t o_ur = A.reserve(sizeof(float) * mo), o_dp = A.reserve(sizeof(float) * mo), o_sad = A.reserve(sizeof(int32_t) * mo);
+    if ((rc = A.upload())) return rc;
+    int32_t* dn = A.dev<int32_t>(o_n);
+    rc = orb_extract_dev(c, A.dev<uint8_t>(o_imL), W, o_imR - o_imL, 2, 0, 0, 1, A.dev<eorb_keypoint>(o_kp), A.dev<uint8_t>(o_desc), nullptr, dn, dn + 2, dn + 4);
+    if (rc) return rc;
+    if ((rc = stereo_match_dev(c, A.dev<eorb_keypoint>(o_kp), A.dev<uint8_t>(o_desc), dn, mb, mbf, A.dev<float>(o_ur), A.dev<float>(o_dp),
+                               A.dev<int32_t>(o_sad), dn + 5))) return rc;
+    const char* h;
+    if ((rc = A.download(o_n, o_sad - o_n, &h))) return rc;
+    const int32_t* hn = (const int32_t*)(h + o_n);
+    if (hn[4]) return set_err(c, EORB_E_CAPACITY, "eorb_frame_stereo: internal capacity exceeded (flag %d)", hn[4]);
+    if (hn[0] > cap || hn[1] > cap) return set_err(c, EORB_E_CAPACITY, "eorb_frame_stereo: %d / %d keypoints > caller capacity %d", hn[0], hn[1], cap);
+    if (hn[0] > 0) {
+        if (kpsL) memcpy(kpsL, h + o_kp, sizeof(eorb_keypoint) * (size_t)hn[0]);
+        if (descL) memcpy(descL, h + o_desc, 32 * (size_t)hn[0]);
+        if (uRight) memcpy(uRight, h + o_ur, sizeof(float) * (size_t)hn[0]);
+        if (depth) memcpy(depth, h + o_dp, sizeof(float) * (size_t)hn[0]);
+    }
+    if (hn[1] > 0) {
+        if (kpsR) memcpy(kpsR, h + o_kp + sizeof(eorb_keypoint) * mo, sizeof(eorb_keypoint) * (size_t)hn[1]);
+        if (descR) memcpy(descR, h + o_desc + 32 * mo, 32 * (size_t)hn[1]);
+    }
+    if (nL) *nL = hn[0];
+    if (nR) *nR = hn[1];
+    if (nmatches) *nmatches = hn[5];
+    return EORB_OK;
+}
+
 static int tracked_common(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, eorb_keypoint* kps_io, const eorb_keypoint* kps_in,
                           int n, int mode, const uint8_t* ref, uint8_t* desc, uint8_t* oob)
 {

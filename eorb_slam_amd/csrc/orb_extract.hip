@@ -1645,6 +1645,153 @@ int orb_tracked_dev(eorb_ctx* c, eorb_keypoint* d_kps, int n, int mode, const ui
     return EORB_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (src/Frame.cc:869-1048) on the last extraction of a (left, right) pair = slices 0 and 1 of one batch
+// (the reference runs two extractors of equal parameters, :122-125).  One wavefront per left keypoint:
+//   candidates (:909-959): every right keypoint whose row band [floor(y - r), ceil(y + r)], r = 2 * scale(octave), holds the row
+//   (int)vL, octave within +-1, uR in [uL - mbf / mb, uL]; the smallest descriptor distance, the first in iR order among equals =
+//   the wave minimum of (distance << 16 | iR); kept below (TH_HIGH + TH_LOW) / 2 (a best distance in [75, 100) is dropped by :962);
+//   correlation (:962-1033): L1 norm of the 11 x 11 patches of the keypoint's level image (mvImagePyramid: the un-blurred level)
+//   over the shifts -5..5, lanes = pixels, integer sums; first smallest shift, parabola, re-scaling and disparity in the
+//   reference's float operations.  sad[iL] = the norm of an accepted match, -1 otherwise.
+// stereo_median_kernel (:1036-1047): the matches ordered by (norm, iL); everything at or above 1.5 * 1.4 * the norm of rank size / 2
+// is taken back -- ranks by counting, one workgroup.
+__global__ __launch_bounds__(256) void stereo_match_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr, const eorb_keypoint* __restrict__ kps,
+                                                           const uint8_t* __restrict__ desc, const int32_t* __restrict__ n, int cap, float mb, float mbf,
+                                                           float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ sad)
+{
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int N = min(n[0], cap), Nr = min(n[1], cap);
+    if (iL >= N) return;
+    const eorb_keypoint kL = kps[iL];
+    const eorb_keypoint* kR = kps + cap;
+    const uint64_t* dR = (const uint64_t*)(desc + (size_t)cap * 32);
+    const uint64_t* dl = (const uint64_t*)(desc + (size_t)iL * 32);
+    const uint64_t d0 = dl[0], d1 = dl[1], d2 = dl[2], d3 = dl[3];
+    if (lane == 0) { uRight[iL] = -1.0f; depth[iL] = -1.0f; sad[iL] = -1; }
+    const int levelL = kL.octave;
+    const float vL = kL.y, uL = kL.x;
+    const int row = (int)vL;
+    const float minD = 0.f, maxD = mbf / mb;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) return;
+    uint32_t best = 0xffffffffu;
+    for (int i0 = 0; i0 < Nr; i0 += 64) {
+        const int iR = i0 + lane;
+        uint32_t key = 0xffffffffu;
+        if (iR < Nr) {
+            const eorb_keypoint k = kR[iR];
+            const float r = 2.0f * G->sf[k.octave];
+            const int maxr = (int)ceilf(k.y + r), minr = (int)floorf(k.y - r);
+            if (row >= minr && row <= maxr && k.octave >= levelL - 1 && k.octave <= levelL + 1 && k.x >= minU && k.x <= maxU) {
+                const uint64_t* q = dR + (size_t)iR * 4;
+                const int dist = __popcll(d0 ^ q[0]) + __popcll(d1 ^ q[1]) + __popcll(d2 ^ q[2]) + __popcll(d3 ^ q[3]);
+                key = ((uint32_t)dist << 16) | (uint32_t)iR;
+            }
+        }
+        best = min(best, key);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, d, 64));
+    if (best == 0xffffffffu || (int)(best >> 16) >= (100 + 50) / 2) return;              // TH_HIGH, TH_LOW: src/ORBmatcher.cc:36-37
+    const int bestIdxR = (int)(best & 0xffffu);
+    const float uR0 = kR[bestIdxR].x;
+    const float scaleFactor = 1.0f / G->sf[levelL];                                     // mvInvScaleFactor (src/ORBextractor.cc:436)
+    const float scaleduL = roundf(uL * scaleFactor), scaledvL = roundf(vL * scaleFactor), scaleduR0 = roundf(uR0 * scaleFactor);
+    const int w = 5, Lw = 5;
+    const LevelGeom& LG = G->lv[levelL];
+    const float iniu = scaleduR0 + Lw - w, endu = scaleduR0 + Lw + w + 1;
+    if (iniu < 0 || endu >= (float)LG.w) return;
+    const int r0 = (int)(scaledvL - w), cL0 = (int)(scaleduL - w);
+    // (patches inside the level images: true for every keypoint of the extractor, 16 pixels inside its level; OpenCV would throw)
+    if (r0 < 0 || r0 + 2 * w + 1 > LG.h || cL0 < 0 || cL0 + 2 * w + 1 > LG.w) return;
+    if ((int)(scaleduR0 - Lw - w) < 0 || (int)(scaleduR0 + Lw + w + 1) > LG.w) return;
+    const int E = G->edge;
+    const uint8_t* bufL = pyr + LG.buf_off;
+    const uint8_t* bufR = pyr + (size_t)G->pyr_bytes + LG.buf_off;
+    // lanes = pixels of the 11 x 11 patch (two per lane)
+    int pl[2], po[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int p = lane + 64 * t;
+        const int y = p / 11, x = p - y * 11;
+        pl[t] = p < 121 ? (int)bufL[(size_t)(r0 + y + E) * LG.bw + (cL0 + x + E)] : 0;
+        po[t] = p < 121 ? (r0 + y + E) * LG.bw + (x + E) : -1;
+    }
+    int bestD = 0x7fffffff, bestincR = 0;
+    float vd[11];
+#pragma unroll
+    for (int inc = -5; inc <= 5; inc++) {
+        const int cR0 = (int)(scaleduR0 + (float)inc - w);
+        int s = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) if (po[t] >= 0) s += abs(pl[t] - (int)bufR[(size_t)po[t] + cR0]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float dist = (float)s;
+        if (dist < (float)bestD) { bestD = (int)dist; bestincR = inc; }
+        vd[inc + 5] = dist;
+    }
+    if (bestincR == -5 || bestincR == 5) return;
+    float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
+#pragma unroll
+    for (int k = 1; k <= 9; k++) if (k == bestincR + 5) { dist1 = vd[k - 1]; dist2 = vd[k]; dist3 = vd[k + 1]; }
+    const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+    if (deltaR < -1 || deltaR > 1) return;
+    float bestuR = G->sf[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+    float disparity = uL - bestuR;
+    if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01; bestuR = (float)((double)uL - 0.01); }      // (double literals: :1021-1022)
+        if (lane == 0) { depth[iL] = mbf / disparity; uRight[iL] = bestuR; sad[iL] = bestD; }
+    }
+}
+
+__global__ __launch_bounds__(1024) void stereo_median_kernel(const int32_t* __restrict__ n, int cap, const int32_t* __restrict__ sad,
+                                                             float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ nmatch)
+{
+    __shared__ int s_cnt, s_med;
+    const int N = min(n[0], cap), tid = threadIdx.x;
+    if (tid == 0) { s_cnt = 0; s_med = -1; }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < N; i += 1024) mine += sad[i] >= 0 ? 1 : 0;
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    const int M = s_cnt;
+    if (tid == 0) *nmatch = M;
+    if (M == 0) return;                                  // (the reference reads vDistIdx[0] of an empty vector here)
+    // the entry of rank M / 2 in the order (norm, iL)
+    for (int i = tid; i < N; i += 1024) {
+        const int si = sad[i];
+        if (si < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < N; j++) { const int sj = sad[j]; rank += (sj >= 0 && (sj < si || (sj == si && j < i))) ? 1 : 0; }
+        if (rank == M / 2) s_med = si;
+    }
+    __syncthreads();
+    const float median = (float)s_med;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = tid; i < N; i += 1024) {
+        const int si = sad[i];
+        if (si >= 0 && !((float)si < thDist)) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    }
+}
+
+int stereo_match_dev(eorb_ctx* c, const eorb_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_n, float mb, float mbf,
+                     float* d_uright, float* d_depth, int32_t* d_sad, int32_t* d_nmatch)
+{
+    OrbState& o = c->orb;
+    if (!o.configured) return set_err(c, EORB_E_NOTCONF, "stereo matches: eorb_orb_configure not called");
+    ProfScope ps(c, "stereo_match");
+    const int cap = o.max_out;
+    stereo_match_kernel<<<(cap + 3) / 4, 256, 0, c->stream>>>((const DevGeom*)o.geom.p, (const uint8_t*)c->pyr.p, d_kps, d_desc, d_n, cap, mb, mbf,
+                                                              d_uright, d_depth, d_sad);
+    stereo_median_kernel<<<1, 1024, 0, c->stream>>>(d_n, cap, d_sad, d_uright, d_depth, d_nmatch);
+    EORB_LAUNCH_CHECK(c, "stereo match kernels");
+    return EORB_OK;
+}
+
 // the flag of the last extraction of B slices, copied device-to-device next to the call's other outputs
 int orb_err_flag_to(eorb_ctx* c, int B, int32_t* d_dst)
 {

@@ -281,6 +281,22 @@ class ORBextractor:
         self.ctx.check(self.ctx.L.eorb_orb_get_tables(self.ctx.h, _p(sf), _p(inv), _p(nf), C.byref(e)))
         self.mvScaleFactor, self.mvInvScaleFactor, self.mnFeaturesPerLevel, self.edge = sf, inv, nf, e.value
 
+    def stereo(self, imLeft, imRight, mb, mbf):
+        """Frame::Frame(imLeft, imRight, ...) (src/Frame.cc:97-152): both extractions and Frame::ComputeStereoMatches (:869-1048) in one
+        call.  Returns dict(kpsL, descL, kpsR, descR, uRight (mvuRight), depth (mvDepth), nmatches (before the median cut))."""
+        imL = np.ascontiguousarray(imLeft, np.uint8); imR = np.ascontiguousarray(imRight, np.uint8)
+        H, W = imL.shape
+        if imR.shape != imL.shape:
+            raise ValueError("left and right image differ in size")
+        cap = self.cap
+        kL = np.zeros(cap, KP_DTYPE); kR = np.zeros(cap, KP_DTYPE); dL = np.zeros((cap, 32), np.uint8); dR = np.zeros((cap, 32), np.uint8)
+        ur = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
+        nL, nR, nm = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.check(self.ctx.L.eorb_frame_stereo(self.ctx.h, _p(imL), _p(imR), W, H, imL.strides[0], float(mb), float(mbf), _p(kL), _p(dL), C.byref(nL),
+                                                    _p(kR), _p(dR), C.byref(nR), cap, _p(ur), _p(dp), C.byref(nm)))
+        a, b = nL.value, nR.value
+        return dict(kpsL=kL[:a].copy(), descL=dL[:a].copy(), kpsR=kR[:b].copy(), descR=dR[:b].copy(), uRight=ur[:a].copy(), depth=dp[:a].copy(), nmatches=nm.value)
+
     def GetLevels(self):
         return self.nlevels
 

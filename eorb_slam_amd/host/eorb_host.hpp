@@ -365,6 +365,25 @@ public:
         keypoints.resize(n);
         return mono;
     }
+    // Frame::Frame(imLeft, imRight, ...) (src/Frame.cc:97-152): ExtractORB on both images (:122-125) + ComputeStereoMatches (:869-1048)
+    // in one call; mb = baseline (mbf / fx).  Fills what the constructor fills: mvKeys, mDescriptors, mvKeysRight, mDescriptorsRight,
+    // mvuRight, mvDepth.  Returns the number of correlated matches before the median cut.
+    int ExtractStereo(const eorb_host::Mat8& imLeft, const eorb_host::Mat8& imRight, float mb, float mbf,
+                      std::vector<eorb_host::KeyPoint>& mvKeys, eorb_host::Mat8& mDescriptors,
+                      std::vector<eorb_host::KeyPoint>& mvKeysRight, eorb_host::Mat8& mDescriptorsRight,
+                      std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+        mvKeys.assign(cap_, eorb_host::KeyPoint{}); mvKeysRight.assign(cap_, eorb_host::KeyPoint{});
+        eorb_host::Mat8 dl(cap_, 32), dr(cap_, 32);
+        mvuRight.assign(cap_, -1.0f); mvDepth.assign(cap_, -1.0f);
+        int nl = 0, nr = 0, nm = 0;
+        ctx_.check(eorb_frame_stereo(ctx_.get(), imLeft.ptr(), imRight.ptr(), imLeft.cols, imLeft.rows, imLeft.cols, mb, mbf, mvKeys.data(), dl.ptr(), &nl,
+                                     mvKeysRight.data(), dr.ptr(), &nr, cap_, mvuRight.data(), mvDepth.data(), &nm));
+        mvKeys.resize(nl); mvKeysRight.resize(nr); mvuRight.resize(nl); mvDepth.resize(nl);
+        mDescriptors = eorb_host::Mat8(nl, 32); mDescriptorsRight = eorb_host::Mat8(nr, 32);
+        if (nl) std::memcpy(mDescriptors.ptr(), dl.ptr(), (size_t)nl * 32);
+        if (nr) std::memcpy(mDescriptorsRight.ptr(), dr.ptr(), (size_t)nr * 32);
+        return nm;
+    }
     int GetLevels() const { return p_.nlevels; }
     float GetScaleFactor() const { return p_.scaleFactor; }
     std::vector<float> GetScaleFactors() const { return mvScaleFactor; }

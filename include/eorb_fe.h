@@ -289,6 +289,17 @@ int eorb_search_by_projection_last_stereo(eorb_ctx* ctx,
         const float* level_scale, const eorb_grid_bounds* gb, int32_t* cur_mp, float th, int mode, int checkOri,
         const float* cur_uright, const float* proj_ur, int* nmatches);
 
+/* replaces the stereo constructor's hot path, Frame::Frame(imLeft, imRight, ...) (src/Frame.cc:97-152): ExtractORB on both images
+ * (:122-125, two extractors of equal parameters, vLappingArea {0, 0}) and Frame::ComputeStereoMatches (:869-1048: row-band candidates,
+ * best descriptor distance below (TH_HIGH + TH_LOW) / 2, 11 x 11 L1 correlation over the shifts -5..5 on the keypoint's level image,
+ * parabola, median cut).  mb = baseline in metres (mbf / fx), mbf = baseline x fx.  Out: the keypoints and descriptors of both images
+ * (mvKeys / mvKeysRight order), uRight / depth [nL] = mvuRight / mvDepth (-1: none), nmatches = correlated matches before the median
+ * cut.  One upload, one wait, one download.  The rectified images are what the caller passes (the reference assumes undistorted
+ * images here, :136-141). */
+int eorb_frame_stereo(eorb_ctx* ctx, const uint8_t* imLeft, const uint8_t* imRight, int W, int H, int stride, float mb, float mbf,
+                      eorb_keypoint* kpsL, uint8_t* descL, int* nL, eorb_keypoint* kpsR, uint8_t* descR, int* nR, int cap,
+                      float* uRight, float* depth, int* nmatches);
+
 /* replaces the mono branch of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:276-478;
  * MixedMatcher.cpp:148-356).  DBoW2::FeatureVector as CSR (node ids ascending, offsets, feature indices in vector
  * order).  kf_has_mp[i] = map point present and !isBad().  match_f[n_f] out = KeyFrame feature index or -1. */

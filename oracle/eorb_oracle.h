@@ -357,6 +357,11 @@ void orc_resolve_num_mixed(int nDetectedORB, int nDetectedAK, int nDesired, int 
  * ascending; ties -> lowest train index.  idx2/dist2: nq*2 (-1 / INT_MAX when nt < k). */
 void orc_bf_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx2, int32_t* dist2);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:869-1048): eL / eR = the extractors that produced the left / right keypoints (their level
+ * images are read); uRight / depth [N] out (-1: no match); returns the number of correlated matches before the median cut. */
+int orc_compute_stereo_matches(const orc_orb* eL, const orc_orb* eR, const orc_keypoint* kL, int N, const uint8_t* dL,
+                               const orc_keypoint* kR, int Nr, const uint8_t* dR, float mb, float mbf, float* uRight, float* depth);
+
 #ifdef __cplusplus
 }
 #endif

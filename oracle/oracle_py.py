@@ -287,6 +287,18 @@ class OrbExtractor:
         assert rc == 0, rc
         return kps
 
+    def compute_stereo_matches(self, right, kL, dL, kR, dR, mb, mbf):
+        """Frame::ComputeStereoMatches (src/Frame.cc:869-1048): self / right = the extractors of the left / right image (after their
+        extract() calls); returns (mvuRight, mvDepth, matches before the median cut)."""
+        kL = np.ascontiguousarray(kL, KP_DTYPE); kR = np.ascontiguousarray(kR, KP_DTYPE)
+        dL = np.ascontiguousarray(dL, np.uint8); dR = np.ascontiguousarray(dR, np.uint8)
+        ur = np.zeros(len(kL), np.float32); dp = np.zeros(len(kL), np.float32)
+        self.L.orc_compute_stereo_matches.restype = C.c_int
+        self.L.orc_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        n = self.L.orc_compute_stereo_matches(self.h, right.h, _p(kL), len(kL), _p(dL), _p(kR), len(kR), _p(dR), mb, mbf, _p(ur), _p(dp))
+        return ur, dp, n
+
     def level_size(self, l):
         w, h = C.c_int(), C.c_int()
         self.L.orc_orb_level_size(self.h, l, C.byref(w), C.byref(h))

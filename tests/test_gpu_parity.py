@@ -1833,6 +1833,50 @@ def test_octree_direct_passes_equal_list_algorithm(oracle, fe, list_algorithm):
     assert (seen_direct == 0) if list_algorithm else (seen_direct == len(cases))
 
 
+def _stereo_pair(seed, W=346, H=260, dmax=14):
+    """A rectified pair: the right image is the left one warped by a smooth, row-wise varying disparity in [2, dmax] pixels
+    (bilinear in x, nothing vertical), plus a little independent noise."""
+    rng = np.random.default_rng(seed)
+    left = synth.texture_image(W + 32, H, seed=seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    disp = 2.0 + (dmax - 2.0) * (0.5 + 0.5 * np.sin(yy / 37.0 + xx / 91.0))
+    xs = xx + disp                                                         # right(x) = left(x + d)
+    x0 = np.floor(xs).astype(np.int64); fr = xs - x0
+    rows = yy.astype(np.int64)
+    right = (1 - fr) * left[rows, x0] + fr * left[rows, np.minimum(x0 + 1, W + 31)]
+    right = np.clip(np.rint(right + rng.normal(0, 1.0, right.shape)), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(left[:, :W]), right
+
+
+@pytest.mark.parametrize("cfg", [dict(W=346, H=260, nf=1000, nl=8, th=(20, 7), mb=0.11, mbf=40.0, seed=31),
+                                 dict(W=346, H=260, nf=2000, nl=8, th=(10, 1), mb=0.11, mbf=25.0, seed=32),     # many candidates per row band
+                                 dict(W=240, H=180, nf=1000, nl=4, th=(10, 0), mb=0.11, mbf=3.0, seed=33),      # maxD = 27: most matches fall outside
+                                 dict(W=752, H=480, nf=1200, nl=8, th=(20, 7), mb=0.11, mbf=47.9, seed=34)])    # EuRoC: Examples/Stereo/EuRoC.yaml
+def test_frame_stereo_matches(oracle, fe, cfg):
+    """Frame::Frame(imLeft, imRight) + ComputeStereoMatches (src/Frame.cc:97-152, :869-1048): keypoints / descriptors of both images,
+    mvuRight and mvDepth as bit patterns, the number of correlated matches, against the oracle's restatement."""
+    W, H = cfg["W"], cfg["H"]
+    left, right = _stereo_pair(cfg["seed"], W, H)
+    oL = oracle.OrbExtractor(cfg["nf"], 1.2, cfg["nl"], cfg["th"][0], cfg["th"][1], edgeTh=19, imWidth=W)
+    oR = oracle.OrbExtractor(cfg["nf"], 1.2, cfg["nl"], cfg["th"][0], cfg["th"][1], edgeTh=19, imWidth=W)
+    _, kL, dL, _ = oL.extract(left, (0, 0)); _, kR, dR, _ = oR.extract(right, (0, 0))
+    our, odp, on = oL.compute_stereo_matches(oR, kL, dL, kR, dR, cfg["mb"], cfg["mbf"])
+    ge = fe.ORBextractor(cfg["nf"], 1.2, cfg["nl"], cfg["th"][0], cfg["th"][1], 19, (W, H))
+    for _ in range(2):                                                    # (the second call reuses the arena and the pyramids' buffers)
+        g = ge.stereo(left, right, cfg["mb"], cfg["mbf"])
+        assert len(g["kpsL"]) == len(kL) and len(g["kpsR"]) == len(kR)
+        assert np.array_equal(g["kpsL"].view(np.uint8), kL.view(np.uint8)) and np.array_equal(g["kpsR"].view(np.uint8), kR.view(np.uint8))
+        assert np.array_equal(g["descL"], dL) and np.array_equal(g["descR"], dR)
+        assert g["nmatches"] == on
+        assert np.array_equal(g["uRight"].view(np.uint32), our.view(np.uint32)) and np.array_equal(g["depth"].view(np.uint32), odp.view(np.uint32))
+    matched = our > 0
+    assert matched.sum() > (20 if cfg["mbf"] < 5 else 150), matched.sum()
+    # the recovered disparities are the planted ones (sub-pixel): a sanity check of the test itself, not of parity
+    d = (kL["x"] - our)[matched]
+    assert np.median(np.abs(d - (2.0 + 12.0 * (0.5 + 0.5 * np.sin(kL["y"][matched] / 37.0 + kL["x"][matched] / 91.0))))) < 0.6
+    ge.ctx.close()
+
+
 def test_error_paths_return_codes(fe, ctx):
     ev = synth.random_events(10, seed=1)
     L = ctx.L

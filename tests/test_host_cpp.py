@@ -88,9 +88,25 @@ int main(int argc, char** argv) {
             std::printf("chain: init %d tracking %d dispatches %d ok=%d\n", ninit, ntrack, ndisp, (int)chain_ok);
             chain_ok = chain_ok && ndisp >= 1 && ntrack >= 2;
         }
+        // the stereo constructor's path: a textured image and the same image moved by 5 pixels -> disparities of 5
+        bool stereo_ok = true;
+        {
+            const int W = 240, H = 180;
+            eorb_host::Mat8 L(H, W), R(H, W);
+            auto tex = [](int x, int y) { unsigned h = (unsigned)(x / 3) * 73856093u ^ (unsigned)(y / 3) * 19349663u; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15; return (unsigned char)(h & 0xff); };
+            for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { L.ptr()[y * W + x] = tex(x, y); R.ptr()[y * W + x] = tex(x + 5, y); }
+            ORB_SLAM3::ORBxParams q; q.nfeatures = 1000; q.scaleFactor = 1.2f; q.nlevels = 4; q.iniThFAST = 20; q.minThFAST = 7; q.edgeTh = 19; q.imWidth = W; q.imHeight = H;
+            ORB_SLAM3::ORBextractor exs(q);
+            std::vector<eorb_host::KeyPoint> kl, kr; eorb_host::Mat8 dl, dr; std::vector<float> ur, dp;
+            const int nm = exs.ExtractStereo(L, R, 0.11f, 40.0f, kl, dl, kr, dr, ur, dp);
+            int good = 0, matched = 0;
+            for (size_t i = 0; i < kl.size(); i++) if (ur[i] > 0) { matched++; good += std::fabs(kl[i].x - ur[i] - 5.0f) < 1.5f && dp[i] == 40.0f / (kl[i].x - ur[i]); }
+            std::printf("stereo: %zu / %zu keypoints, %d correlated, %d kept, %d at the planted disparity\n", kl.size(), kr.size(), nm, matched, good);
+            stereo_ok = kl.size() > 100 && matched > 50 && good * 10 >= matched * 9 && nm >= matched;
+        }
         const size_t made = eorb_host::ContextPool::instance().created();
         std::printf("pool contexts=%zu ok=%d\n", made, (int)pool_ok);
-        return (mono == 0 && m1 == -1 && same && best[0] >= 0 && best[0] < 5 && pool_ok && made <= 5 && chain_ok) ? 0 : 1;
+        return (mono == 0 && m1 == -1 && same && best[0] >= 0 && best[0] < 5 && pool_ok && made <= 6 && chain_ok && stereo_ok) ? 0 : 1;
     } catch (const eorb_host::Error& e) { std::printf("error %d: %s\n", e.code, e.what()); return 2; }
 }
 '''

@@ -384,3 +384,27 @@ def test_projection_stereo_gate_known_answers(oracle):
     assert n == 1 and fm.tolist() == [-1, 0, -1]
     n, fm = oracle.search_by_projection_map(*margs, uright=np.array([82.5, 82.0, -1.0], np.float32), proj_xr=np.array([80.0], np.float32))
     assert fm.tolist() == [0, -1, -1]
+
+
+def test_compute_stereo_matches_known_answers(oracle):
+    """Frame::ComputeStereoMatches (src/Frame.cc:869-1048) on a pair whose answer is known: the right image is the left one moved by
+    exactly 6 pixels, so every accepted match has its best shift at the keypoint itself (a zero L1 norm, a symmetric parabola unless
+    the neighbours differ) and a disparity within a pixel of 6; the median cut keeps the zero norms; no right keypoints -> no match;
+    a baseline that forbids the disparity (maxD = mbf / mb < 6) -> no match."""
+    left = synth.texture_image(346 + 16, 260, seed=4)
+    right = np.ascontiguousarray(left[:, 6:6 + 346]); left = np.ascontiguousarray(left[:, :346])
+    eL = oracle.OrbExtractor(1000, 1.2, 8, 20, 7, edgeTh=19, imWidth=346); eR = oracle.OrbExtractor(1000, 1.2, 8, 20, 7, edgeTh=19, imWidth=346)
+    _, kL, dL, _ = eL.extract(left, (0, 0)); _, kR, dR, _ = eR.extract(right, (0, 0))
+    ur, dp, n = eL.compute_stereo_matches(eR, kL, dL, kR, dR, 0.11, 40.0)
+    m = ur > 0
+    assert n > 300 and m.sum() > 200
+    d = kL["x"][m] - ur[m]
+    assert np.all(np.abs(d - 6.0) < 1.0 * eL.scale_factors[kL["octave"][m]] + 1e-3)
+    lvl0 = m & (kL["octave"] == 0)
+    assert lvl0.sum() > 20 and np.all(np.abs(kL["x"][lvl0] - ur[lvl0] - 6.0) <= 0.5)          # level 0: the pixels are identical, the parabola stays within half a pixel
+    assert np.array_equal(dp[m].view(np.uint32), (np.float32(40.0) / (kL["x"][m] - ur[m]).astype(np.float32)).view(np.uint32))
+    assert np.all(ur[~m] == -1) and np.all(dp[~m] == -1)
+    ur0, dp0, n0 = eL.compute_stereo_matches(eR, kL, dL, kR[:0], dR[:0], 0.11, 40.0)
+    assert n0 == 0 and np.all(ur0 == -1)
+    ur1, dp1, n1 = eL.compute_stereo_matches(eR, kL, dL, kR, dR, 0.11, 0.5)                    # maxD = 4.5 pixels
+    assert (ur1 > 0).sum() < 0.1 * m.sum()
