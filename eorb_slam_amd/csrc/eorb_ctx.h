@@ -70,6 +70,7 @@ struct OrbState {
     int max_out = 0;
     int oct_lds[2] = {0, 0};       // dynamic LDS bytes of the octree kernel, per placement (single frames / many workgroups)
     int oct_direct_cap[2] = {0, 0};
+    int oct_dyn[2] = {0, 0}, oct_dyn_lds[2] = {0, 0};   // dynamic placement in use (its direct-pass cap, -1: none), its LDS bytes
     int oct_all_lds[2] = {0, 0};   // every item of that placement is in LDS: the kernel variant with LDS-typed pointers
     int oct_scratch[2] = {0, 0};   // per (slice, level) global scratch bytes
     DevBuf tabs;             // resize tables (short/int), level geometry, pattern, umax

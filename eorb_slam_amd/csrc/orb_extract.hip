@@ -40,6 +40,9 @@ struct DevGeom {
     // it (two workgroups per CU: launches with more workgroups than CUs)
     int oct_in_lds[2][7], oct_off[2][7];
     int oct_lds_bytes[2], oct_gblock_bytes[2];
+    // dynamic placement (levels whose CAPACITY does not fit the LDS but whose candidates of this frame do): the fixed items (6, 0, 1, 2)
+    // at oct_off_dyn, the key buffers and the points behind them (from oct_dyn_base) sized by the level's candidates; 0: not in use
+    int oct_dyn[2], oct_off_dyn[2][7], oct_dyn_base[2], oct_dyn_lds[2];
     int oct_direct_cap[2];       // most candidates of a level whose full passes are computed directly (0: never): the sort's buffer = the two size lists
     int node_cap_max, vsp_cap_max, ncap_max;
 };
@@ -471,7 +474,8 @@ template <bool LDS_ONLY>
 __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __restrict__ G, const int32_t* __restrict__ cell_cnt,
                                                              const uint32_t* __restrict__ cell_cand, unsigned char* __restrict__ scratch_g,
                                                              uint32_t* __restrict__ lvl_kp, int32_t* __restrict__ lvl_cnt,
-                                                             int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky, int placement)
+                                                             int32_t* __restrict__ err_flag, int32_t* __restrict__ sticky, int placement,
+                                                             int32_t* __restrict__ redo /* LDS_ONLY with the dynamic placement: out, 1 = this level did not fit; else: in, only those levels run (null: all) */)
 {
     extern __shared__ unsigned char smem[];
 #ifdef EORB_OCT_TIMING      // (experiment builds only: where a call's cycles go, printed by workgroup 0)
@@ -493,9 +497,34 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     // every item in LDS when the 160 KB hold it, otherwise in this (slice, level)'s block of the global scratch buffer: the
     // workgroup sits on one CU, whose own stores are visible to its later loads after __syncthreads()
     unsigned char* gblk = scratch_g + (size_t)blockIdx.x * G->oct_gblock_bytes[placement];
+    if (!LDS_ONLY && redo && !redo[blockIdx.x]) return;             // (the LDS kernel did this level)
+    // dynamic placement: the level's candidates are counted first, the key buffers and the points sized by them
+    const bool dynp = LDS_ONLY && G->oct_dyn[placement];
+    int o3 = 0, o4 = 0, o5 = 0;
+    if (dynp) {
+        const int nc0 = L.nCols * L.nRows;
+        const int32_t* cc0 = cell_cnt + (size_t)slice * G->ncells + L.cell_off;
+        int part = 0;
+        for (int i = tid; i < nc0; i += kOctThreads) part += cc0[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_ws[wave] = part;
+        __syncthreads();
+        int ntot = 0;
+        for (int w = 0; w < nwaves; w++) ntot += s_ws[w];
+        __syncthreads();
+        const int ncl = min(ntot, ncap), kb = (2 * ncl + 15) & ~15;
+        o3 = G->oct_dyn_base[placement]; o4 = o3 + kb; o5 = o4 + kb;
+        const bool fits = o5 + 4 * ncl <= G->oct_dyn_lds[placement];
+        if (tid == 0 && redo) redo[blockIdx.x] = fits ? 0 : 1;
+        if (!fits) return;
+    }
     // (byte offsets, not pointers, are what is kept and selected between: under LDS_ONLY every pointer is then visibly smem + offset)
     auto item = [&](int k, int extra) -> unsigned char* {
-        if (LDS_ONLY) return smem + (G->oct_off[placement][k] + extra);
+        if (LDS_ONLY) {
+            const int base = !dynp ? G->oct_off[placement][k] : (k == 3 ? o3 : (k == 4 ? o4 : (k == 5 ? o5 : G->oct_off_dyn[placement][k])));
+            return smem + (base + extra);
+        }
         return (G->oct_in_lds[placement][k] ? smem : gblk) + (G->oct_off[placement][k] + extra);
     };
     auto NODES = [&](int w) -> ONode* { return (ONode*)item(0, w * pc * (int)sizeof(ONode)); };
@@ -564,7 +593,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     // two sorts in registers.  Levels whose keys do not fit the two size lists (the sort's buffer) keep the list algorithm. ----
     bool direct_done = false; int direct_cut = 0;
     __shared__ int s_hist[3][16];
-    if (LDS_ONLY && n <= G->oct_direct_cap[placement] && nIni <= 255) {
+    if (LDS_ONLY && n <= (dynp ? G->oct_dyn[placement] : G->oct_direct_cap[placement]) && nIni <= 255) {
         uint64_t* S = VSP(0);                       // (VSP(1) follows VSP(0): oct_direct_cap is 0 otherwise)
         uint16_t* sh = KEYS(1);
         if (tid < 48) s_hist[tid >> 4][tid & 15] = 0;
@@ -1072,7 +1101,7 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     if (threadIdx.x == 0 && slice == 0)
         printf("   direct: codes %lld sort1 %lld shares+hist %lld sim %lld items %lld sort2 %lld bounds %lld nodes %lld vsp %lld\n", s_tm[8], s_tm[9], s_tm[10], s_tm[11], s_tm[12], s_tm[13], s_tm[14], s_tm[15], s_tm[6]);
     if (threadIdx.x == 0 && slice == 0)
-        printf("octree L%d n=%d N=%d lsize=%d direct %d (cap %d) %lld: gather %lld | roots %lld | full passes %d x %lld | cut sorts %d x %lld | cut rounds %d x %lld | select %lld cycles\n", level, n, N, lsize, (int)direct_done, G->oct_direct_cap[placement], s_tm[6],
+        printf("octree L%d n=%d N=%d lsize=%d direct %d (cap %d) %lld: gather %lld | roots %lld | full passes %d x %lld | cut sorts %d x %lld | cut rounds %d x %lld | select %lld cycles\n", level, n, N, lsize, (int)direct_done + 10 * (int)dynp + 100 * (int)LDS_ONLY, G->oct_direct_cap[placement], s_tm[6],
                s_tm[0], s_tm[1], s_tn[2], s_tn[2] ? s_tm[2] / s_tn[2] : 0, s_tn[3], s_tn[3] ? s_tm[3] / s_tn[3] : 0, s_tn[4], s_tn[4] ? s_tm[4] / s_tn[4] : 0, s_tm[5]);
 #endif
 }
@@ -1510,6 +1539,20 @@ int orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
         g.oct_lds_bytes[v] = o.oct_lds[v]; g.oct_gblock_bytes[v] = o.oct_scratch[v];
         bool all = true; for (int k = 0; k < 7; k++) all = all && oct_in_lds[v][k];
         static const int direct_on = [] { const char* e = getenv("EORB_OCT_DIRECT"); return e ? atoi(e) : 1; }();       // (A/B runs, parity tests of the list algorithm)
+        // the dynamic placement: the items sized by the features (6, 0, 1, 2) at fixed LDS offsets, the rest behind them
+        {
+            const size_t lds_budget = c->dbg_force_global ? 0 : (v == 0 ? (size_t)budget_kb * 1024 : std::min<size_t>((size_t)budget_kb, 76) * 1024);
+            size_t lds = 0;
+            const int fixed[4] = {6, 0, 1, 2};
+            for (int k = 0; k < 7; k++) g.oct_off_dyn[v][k] = 0;
+            for (int fi = 0; fi < 4; fi++) { g.oct_off_dyn[v][fixed[fi]] = (int)lds; lds += item_bytes[fixed[fi]]; }
+            g.oct_dyn_base[v] = (int)lds; g.oct_dyn_lds[v] = (int)lds_budget;
+            static const int dyn_on = [] { const char* e = getenv("EORB_OCT_DYNAMIC"); return e ? atoi(e) : 1; }();
+            // (in use when the static placement leaves something in global memory and the fixed items leave room for 1 024 candidates)
+            g.oct_dyn[v] = (dyn_on && !all && lds + 8 * 1024 <= lds_budget) ? ((direct_on && !c->dbg_oct_list) ? std::min(4096, 2 * vsp_pow2) : 1) : 0;
+            if (g.oct_dyn[v] && !(direct_on && !c->dbg_oct_list)) g.oct_dyn[v] = -1;     // (dynamic, no direct passes: the cap test `n <= -1` fails)
+            o.oct_dyn[v] = g.oct_dyn[v]; o.oct_dyn_lds[v] = g.oct_dyn_lds[v];
+        }
         o.oct_direct_cap[v] = g.oct_direct_cap[v] = (direct_on && !c->dbg_oct_list && all && oct_off[v][2] == oct_off[v][1] + (int)(sizeof(uint64_t) * vsp_pow2)) ? std::min(4096, 2 * vsp_pow2) : 0;
     }
     g.node_cap_max = node_cap_max; g.vsp_cap_max = vsp_cap_max; g.ncap_max = ncap_max;
@@ -1542,7 +1585,7 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     const int placement = B * o.nlevels > 256 ? 1 : 0;                                         // more workgroups than CUs: two per CU
     if ((rc = ensure(c, c->oct_scratch, nb * o.nlevels * (size_t)o.oct_scratch[placement]))) return rc;   // octree items that do not fit the LDS
     if ((rc = ensure(c, c->lvl_kp, nb * o.kp_total * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(c, c->lvl_cnt, nb * o.nlevels * sizeof(int32_t) + 64))) return rc;
+    if ((rc = ensure(c, c->lvl_cnt, 2 * nb * o.nlevels * sizeof(int32_t) + 64))) return rc;     // counts | error flag (16 ints) | the octree's redo flags
     if ((rc = ensure(c, c->kp_angle, nb * o.kp_total * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->out_desc, nb * o.kp_total * 32))) return rc;                        // per-level descriptors
     if ((rc = ensure(c, c->out_oob, nb * o.kp_total))) return rc;
@@ -1569,12 +1612,19 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
         // a call that hands its own flag back (the host entry point) stays out of the sticky word of the *_dev calls: eorb_sync still
         // reports an earlier batch's overflow
         int32_t* sticky = d_flag_out ? nullptr : (int32_t*)c->status.p;
+        int32_t* redo = err_flag + 16;                               // one flag per (slice, level), behind the error flag
         if (o.oct_all_lds[placement])
             octree_kernel<true><<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
-                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement);
-        else
+                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement, nullptr);
+        else if (o.oct_dyn[placement]) {
+            // levels whose candidates fit the LDS this time run there; the others are left to the mixed placement
+            octree_kernel<true><<<B * o.nlevels, kOctThreads, o.oct_dyn_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
+                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement, redo);
             octree_kernel<false><<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
-                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement);
+                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement, redo);
+        } else
+            octree_kernel<false><<<B * o.nlevels, kOctThreads, o.oct_lds[placement], c->stream>>>(G, (const int32_t*)c->cell_cnt.p, (const uint32_t*)c->cell_cand.p,
+                                                                    (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement, nullptr);
         EORB_LAUNCH_CHECK(c, "octree_kernel");
     }
     {
@@ -1655,7 +1705,7 @@ int orb_tracked_dev(eorb_ctx* c, eorb_keypoint* d_kps, int n, int mode, const ui
 //   over the shifts -5..5, lanes = pixels, integer sums; first smallest shift, parabola, re-scaling and disparity in the
 //   reference's float operations.  sad[iL] = the norm of an accepted match, -1 otherwise.
 // stereo_median_kernel (:1036-1047): the matches ordered by (norm, iL); everything at or above 1.5 * 1.4 * the norm of rank size / 2
-// is taken back -- ranks by counting, one workgroup.
+// is taken back -- that norm by a two-level counting select, one workgroup.
 __global__ __launch_bounds__(256) void stereo_match_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr, const eorb_keypoint* __restrict__ kps,
                                                            const uint8_t* __restrict__ desc, const int32_t* __restrict__ n, int cap, float mb, float mbf,
                                                            float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ sad)
@@ -1750,27 +1800,39 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const DevGeom* __rest
 __global__ __launch_bounds__(1024) void stereo_median_kernel(const int32_t* __restrict__ n, int cap, const int32_t* __restrict__ sad,
                                                              float* __restrict__ uRight, float* __restrict__ depth, int32_t* __restrict__ nmatch)
 {
-    __shared__ int s_cnt, s_med;
+    // the norm of rank M / 2 among the M accepted matches ordered by (norm, iL) -- its VALUE does not depend on how equal norms are
+    // ordered --: a two-level counting select over the norms' 15 bits (an 11 x 11 patch: <= 30 855)
+    __shared__ int s_hist[256];
+    __shared__ int s_sel[3];                             // M | chosen high byte, rank inside it | the median
     const int N = min(n[0], cap), tid = threadIdx.x;
-    if (tid == 0) { s_cnt = 0; s_med = -1; }
+    if (tid < 256) s_hist[tid] = 0;
     __syncthreads();
-    int mine = 0;
-    for (int i = tid; i < N; i += 1024) mine += sad[i] >= 0 ? 1 : 0;
-    if (mine) atomicAdd(&s_cnt, mine);
+    for (int i = tid; i < N; i += 1024) { const int v = sad[i]; if (v >= 0) atomicAdd(&s_hist[min(v >> 7, 255)], 1); }
     __syncthreads();
-    const int M = s_cnt;
-    if (tid == 0) *nmatch = M;
-    if (M == 0) return;                                  // (the reference reads vDistIdx[0] of an empty vector here)
-    // the entry of rank M / 2 in the order (norm, iL)
-    for (int i = tid; i < N; i += 1024) {
-        const int si = sad[i];
-        if (si < 0) continue;
-        int rank = 0;
-        for (int j = 0; j < N; j++) { const int sj = sad[j]; rank += (sj >= 0 && (sj < si || (sj == si && j < i))) ? 1 : 0; }
-        if (rank == M / 2) s_med = si;
+    if (tid == 0) {
+        int M = 0;
+        for (int b = 0; b < 256; b++) M += s_hist[b];
+        s_sel[0] = M;
+        int k = M / 2, hb = 0;
+        while (hb < 255 && k >= s_hist[hb]) { k -= s_hist[hb]; hb++; }
+        s_sel[1] = hb; s_sel[2] = k;
+        *nmatch = M;
     }
     __syncthreads();
-    const float median = (float)s_med;
+    const int M = s_sel[0], hb = s_sel[1], k = s_sel[2];
+    if (M == 0) return;                                  // (the reference reads vDistIdx[0] of an empty vector here)
+    __syncthreads();
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024) { const int v = sad[i]; if (v >= 0 && min(v >> 7, 255) == hb) atomicAdd(&s_hist[hb == 255 ? min(v - (255 << 7), 255) : (v & 127)], 1); }
+    __syncthreads();
+    if (tid == 0) {
+        int kk = k, lb = 0;
+        while (lb < 255 && kk >= s_hist[lb]) { kk -= s_hist[lb]; lb++; }
+        s_sel[2] = (hb << 7) + lb;
+    }
+    __syncthreads();
+    const float median = (float)s_sel[2];
     const float thDist = 1.5f * 1.4f * median;
     for (int i = tid; i < N; i += 1024) {
         const int si = sad[i];

@@ -104,6 +104,23 @@ def main():
     bf = fe.BFMatcher(ctx)
     g = gpu(ctx, lambda: bf.knnMatch2(q, tdesc)); c = timed(lambda: orc.bf_knn2(q, tdesc), 1)
     rows["a15 BFMatcher knn2 %d x %d" % (len(q), len(tdesc))] = {"gpu_kernels_ms": sum(g.values()), "cpu_oracle_ms": c}
+    # ---- f5: a stereo frame (EuRoC shape: 752x480, 1 200 features, 8 levels): both extractions + ComputeStereoMatches ----
+    SW, SH = 752, 480
+    left = synth.texture_image(SW + 32, SH, seed=9)
+    right = np.ascontiguousarray(left[:, 9:9 + SW]); left = np.ascontiguousarray(left[:, :SW])
+    ge = fe.ORBextractor(1200, 1.2, 8, 20, 7, 19, (SW, SH))
+    oL = orc.OrbExtractor(1200, 1.2, 8, 20, 7, edgeTh=19, imWidth=SW); oR = orc.OrbExtractor(1200, 1.2, 8, 20, 7, edgeTh=19, imWidth=SW)
+
+    def cpu_stereo():
+        _, kl, dl, _ = oL.extract(left, (0, 0)); _, kr, dr, _ = oR.extract(right, (0, 0))
+        return oL.compute_stereo_matches(oR, kl, dl, kr, dr, 0.11, 47.9)
+    g = gpu(ge.ctx, lambda: ge.stereo(left, right, 0.11, 47.9)); c = timed(cpu_stereo, 1)
+    t_call = timed(lambda: ge.stereo(left, right, 0.11, 47.9), 20)
+    _, kl, dl, _ = oL.extract(left, (0, 0)); _, kr, dr, _ = oR.extract(right, (0, 0))
+    c_match = timed(lambda: oL.compute_stereo_matches(oR, kl, dl, kr, dr, 0.11, 47.9), 3)
+    rows["f5 stereo frame 752x480: 2 x extract + ComputeStereoMatches"] = {"gpu_kernels_ms": sum(g.values()), "cpu_oracle_ms": c, "detail": g, "call_ms_through_ctypes": t_call,
+                                                                             "cpu_oracle_ms_stereo_matches_alone": c_match}
+    ge.ctx.close()
     for k, v in rows.items():
         v["speedup"] = v["cpu_oracle_ms"] / max(v["gpu_kernels_ms"], 1e-9)
     print(json.dumps(rows, indent=1))
