@@ -339,6 +339,16 @@ long long eorb_debug_counter(eorb_ctx* c, const char* name)
     }
     if (!strcmp(name, "oct_lds_only")) return c->orb.oct_all_lds[0] | (c->orb.oct_all_lds[1] << 1);      // octree working set entirely in LDS: single frames | batches
     if (!strcmp(name, "oct_lds_bytes")) return c->orb.oct_lds[0];
+    if (!strcmp(name, "oct_dynamic")) return c->orb.oct_dyn[0] != 0 ? 1 : 0;          // single frames use the dynamic LDS placement
+    if (!strcmp(name, "oct_redo_levels")) {                                            // levels of the last single-frame extraction that did not fit it (synchronises)
+        const int nl = c->orb.nlevels;
+        if (!c->orb.oct_dyn[0] || !c->lvl_cnt.p || nl <= 0) return 0;
+        std::vector<int32_t> f((size_t)nl);
+        if (hipMemcpyAsync(f.data(), (const char*)c->lvl_cnt.p + (size_t)nl * sizeof(int32_t) + 64, sizeof(int32_t) * (size_t)nl, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+        long long r = 0; for (int v : f) r += v ? 1 : 0;
+        return r;
+    }
     if (!strcmp(name, "oct_direct_cap")) return c->orb.oct_direct_cap[0] | ((long long)c->orb.oct_direct_cap[1] << 16);
     if (!strcmp(name, "oct_scratch_bytes")) return c->orb.oct_scratch[0];
     if (!strcmp(name, "slot_hot_items")) {              // lists the last slot-form call handed to the register-row kernel (synchronises)

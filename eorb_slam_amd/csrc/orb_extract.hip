@@ -536,8 +536,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
     uint16_t* sv = (uint16_t*)item(6, 8 * pc);      // pc: full passes: the undivided nodes' ranks
     uint8_t* dv = (uint8_t*)item(6, 10 * pc);       // pc: cut-off passes: node is divided in this round
     uint64_t* cc = (uint64_t*)item(6, (11 * pc + 7) & ~7);      // pc: child counts of the processed nodes, 4 x 16 bits (item offsets are multiples of 16)
-    int pb = 0;
+    int pb = 0, cut_stamp = 0;
     if (tid == 0) s_nbig = 0;
+    for (int i = tid; i < pc; i += kOctThreads) dv[i] = 0;              // (the cut-off rounds' stamps; barriers follow before any use)
     uint32_t* lkp = lvl_kp + (size_t)slice * G->kp_total + L.kp_off;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     auto raise = [&](int bit) { if (tid == 0) { atomicOr(err_flag, bit); if (sticky) atomicOr(sticky, bit); } };
@@ -1000,14 +1001,18 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
         int C, n2tot;
         if (m == nP) { C = tot & 0xffff; n2tot = tot >> 16; }
         else { C = aux[m] & 0xffff; n2tot = aux[m] >> 16; }
-        // 4a. survivors: old nodes that are not divided keep their relative order behind the children
-        for (int i = tid; i < lsize; i += kOctThreads) dv[i] = 0;
-        __syncthreads();
-        for (int j = tid; j < m; j += kOctThreads) dv[P[j]] = 1;
-        __syncthreads();
+        // 4a. survivors: old nodes that are not divided keep their relative order behind the children.  dv[i] == this round's stamp marks
+        //     a divided node (no clearing between rounds; the array is cleared when the 8-bit stamp wraps)
+        if (++cut_stamp == 256) {
+            for (int i = tid; i < pc; i += kOctThreads) dv[i] = 0;
+            cut_stamp = 1;
+            __syncthreads();
+        }
+        const uint8_t stamp = (uint8_t)cut_stamp;
         const int nsurv = lsize - m;
         if (C + nsurv > pool || n2tot > vcap) { overflow = true; nToExpand = 0; return; }   // uniform: every thread sees the same numbers
-        // children first (they only need aux / cc / src), then the survivors' scan reuses aux
+        for (int j = tid; j < m; j += kOctThreads) dv[P[j]] = stamp;
+        // the children in the same phase (they only need aux / cc / src)
         uint64_t* vout = VSP(vw);
         for (int j = tid; j < m; j += kOctThreads) {
             const ONode nd = src[P[j]];
@@ -1034,10 +1039,9 @@ __global__ __launch_bounds__(kOctThreads) void octree_kernel(const DevGeom* __re
             }
         }
         __syncthreads();
-        for (int i = tid; i < lsize; i += kOctThreads) aux[i] = dv[i] ? 0 : 1;
-        __syncthreads();
-        oct_block_scan(aux, lsize, s_ws);
-        for (int i = tid; i < lsize; i += kOctThreads) if (!dv[i]) dst[C + aux[i]] = src[i];
+        for (int i = tid; i < lsize; i += kOctThreads) sv[i] = dv[i] == stamp ? 0 : 1;       // (read back by the same thread in the scan)
+        oct_block_scan2(aux, 0, sv, lsize, s_ws, s_ws2);
+        for (int i = tid; i < lsize; i += kOctThreads) if (dv[i] != stamp) dst[C + sv[i]] = src[i];
         __syncthreads();
         seqctr += C; lsize = C + nsurv; cur ^= 1; nvsp = n2tot; nToExpand = n2tot;
     };

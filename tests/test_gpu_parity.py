@@ -1799,6 +1799,29 @@ def test_octree_working_set_in_global_memory(oracle, fe, cfg):
     c.close()
 
 
+def test_octree_dynamic_placement_and_its_fallback(oracle, fe):
+    """Levels whose CAPACITY-sized working set does not fit the LDS get the key buffers and the points sized by the frame's candidates
+    (the LDS kernel), and only levels whose candidates do not fit either are redone by the mixed-placement kernel: a sparse frame (every
+    level fits), a frame crowded with corners at thresholds 1 / 1 (the fine levels do not), both against the oracle."""
+    W, H = 752, 480
+    rng = np.random.default_rng(71)
+    sparse = synth.texture_image(W, H, seed=71)
+    crowded = rng.integers(0, 256, (H, W)).astype(np.uint8)                # white noise: a corner on every other pixel
+    seen = []
+    for img, th in ((sparse, (20, 7)), (crowded, (1, 1))):
+        c = fe.Context()
+        oe = oracle.OrbExtractor(1200, 1.2, 8, th[0], th[1], edgeTh=19, imWidth=W)
+        ge = fe.ORBextractor(1200, 1.2, 8, th[0], th[1], 19, (W, H), ctx=c)
+        assert c.debug_counter("oct_dynamic") == 1
+        omono, okp, odesc, _ = oe.extract(img)
+        gmono, gkp, gdesc, _ = ge(img)
+        seen.append(c.debug_counter("oct_redo_levels"))
+        assert omono == gmono and len(okp) == len(gkp)
+        assert np.array_equal(okp.view(np.uint8), gkp.view(np.uint8)) and np.array_equal(odesc, gdesc)
+        c.close()
+    assert seen[0] == 0 and seen[1] >= 1, seen
+
+
 @pytest.mark.parametrize("list_algorithm", [0, 1])
 def test_octree_direct_passes_equal_list_algorithm(oracle, fe, list_algorithm):
     """The octree's full passes are computed (two sorts of the candidates' cell paths) where a level's candidates fit the sort buffer,
