@@ -395,6 +395,8 @@ def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, inputs_key=
         r["traffic_source"] = src
         sc = e["scopes"].get(dom) if e else None
         if sc:
+            if sc.get("kernels"):                   # (the scope's longest kernel in the rocprofv3 trace of the same sources: the name the profile files use)
+                r["kernel"] = max(sc["kernels"].items(), key=lambda kv: kv[1].get("avg_ms", 0.0))[0]
             r["traffic"] = sc["traffic_bytes"]
             r["rocprof_avg_launch_ms"] = sc["rocprof_ms"]
             if "issue" in sc:
