@@ -161,6 +161,9 @@ struct eorb_ctx {
     // read back by eorb_sync / eorb_fe_status
     eorb::DevBuf status;
     // test hooks (eorb_debug_option): shrink the octree node pool to force an overflow; force the octree's global-memory layout
+    // set by a caller whose float event images (and running extremes) are still to be normalised: orb_extract_dev's first kernel does
+    // it while it builds level 0 (and writes the u8 images to its d_img argument); cleared by that call
+    const float* pyr0_f32 = nullptr; const uint32_t* pyr0_mm = nullptr;
     int dbg_pool_shrink = 0, dbg_force_global = 0, dbg_oct_list = 0;      // (dbg_oct_list: the octree's list algorithm for every pass; applies at the next eorb_orb_configure)
     int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices), 4 slot lists (K2p)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)

@@ -800,9 +800,11 @@ int eorb_ev_slice_extract(eorb_ctx* c, const eorb_event* ev, const eorb_raw_even
     uint8_t* d_u8 = A.dev<uint8_t>(o_u8);
     int32_t* dn = A.dev<int32_t>(o_n);
     // EvImConverter::ev2im_gauss(l1Evs, W, H, sigma) :1345 (pol = false, normalized = true)
+    // (the normalisation to u8 is left to the extraction's first kernel: one launch less)
     c->mm_preset = true;
-    if ((rc = ev_accumulate_dev(c, A.dev<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 1, A.dev<uint32_t>(o_mm)))) return rc;
+    if ((rc = ev_accumulate_dev(c, A.dev<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 0, A.dev<uint32_t>(o_mm)))) return rc;
     // makeFrame :1348 -> EvFrame ctor -> ORBextractor::operator() (EventFrame.cpp:220)
+    c->pyr0_f32 = A.dev<float>(o_f32); c->pyr0_mm = A.dev<uint32_t>(o_mm);
     if ((rc = orb_extract_dev(c, d_u8, W, npix, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp), A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob),
                               dn, dn + 1, dn + 2))) return rc;
     if ((rc = ensure(c, c->l1_ref_img, npix)) || (rc = ensure(c, c->l1_ref_pts, sizeof(float) * 2 * mo))) return rc;
@@ -1842,9 +1844,11 @@ static int fe_run_batch_common(eorb_ctx* c, const void* d_events, int raw, const
     eorb_keypoint* wk = (eorb_keypoint*)c->fe_prev_kp.p;
     uint8_t* wd = (uint8_t*)c->fe_prev_desc.p;
     int32_t* wn = (int32_t*)c->fe_prev_n.p;             // [0] prev, [1..B] this batch, then mono index
-    int rc = from_images ? EORB_OK : ev_accumulate_dev(c, d_events, raw, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 1,
+    // (the images' normalisation to u8 is left to the extraction's first kernel, which builds level 0 from the float images)
+    int rc = from_images ? EORB_OK : ev_accumulate_dev(c, d_events, raw, h_offsets, B, f.W, f.H, f.sigma, f.pol, 0, (float*)c->img_f32.p, img, 0,
                                                        (uint32_t*)c->minmax.p);
     if (rc) return rc;
+    if (!from_images) { c->pyr0_f32 = (const float*)c->img_f32.p; c->pyr0_mm = (const uint32_t*)c->minmax.p; }
     rc = orb_extract_dev(c, img, f.W, npix, B, f.lap0, f.lap1, f.want_desc, wk + cap, wd + 32 * cap, nullptr, wn + 1,
                          wn + 1 + f.max_batch + 1);
     if (rc) return rc;

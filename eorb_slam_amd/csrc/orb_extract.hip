@@ -75,6 +75,42 @@ __global__ void pyr_level0_kernel(const uint8_t* __restrict__ img, int stride, s
     }
 }
 
+// The same with cv::normalize(MINMAX, 0..255, CV_8U) of the float event image folded in (EventConversion.cc:207-212; the
+// arithmetic of ev_normalize_kernel): level 0 is built straight from the accumulated float image and its running extremes, the u8
+// image -- an output of its own -- is written by the threads that hold its pixels.  One launch less on the event path.
+__device__ __forceinline__ unsigned dec_mm_f32(unsigned e) { return (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e; }
+__global__ void pyr_level0_f32_kernel(const float* __restrict__ f32, const uint32_t* __restrict__ mm, uint8_t* __restrict__ img_out, int stride,
+                                      size_t slice_bytes, const DevGeom* __restrict__ G, uint8_t* __restrict__ pyr, int32_t* __restrict__ err_flag)
+{
+    if (err_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *err_flag = 0;
+    const LevelGeom& L = G->lv[0];
+    const int slice = blockIdx.y;
+    const int n = L.bw * L.bh;
+    uint8_t* dst = pyr + (size_t)slice * G->pyr_bytes + L.buf_off;
+    const float* src = f32 + (size_t)slice * L.w * L.h;
+    uint8_t* out = img_out + (size_t)slice * slice_bytes;
+    const float mn = __uint_as_float(dec_mm_f32(mm[2 * slice])), mx = __uint_as_float(dec_mm_f32(mm[2 * slice + 1]));
+    const float alpha = 255.f / (mx - mn);
+    const float beta = -mn * alpha;
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 * 4 < n; i4 += gridDim.x * blockDim.x) {
+        int y = (i4 * 4) / L.bw, x = i4 * 4 - y * L.bw;
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int yy = min(y, L.bh - 1) - G->edge, xx = x - G->edge;
+            const int sy = reflect101(yy, L.h), sx = reflect101(xx, L.w);
+            const float m = src[(size_t)sy * L.w + sx] * alpha;
+            const float v = m + beta;
+            int iv = __float2int_rn(v);
+            iv = min(max(iv, 0), 255);
+            w |= (uint32_t)iv << (8 * k);
+            if (sy == yy && sx == xx && y < L.bh) out[(size_t)sy * stride + sx] = (uint8_t)iv;
+            if (++x == L.bw) { x = 0; y++; }
+        }
+        ((uint32_t*)dst)[i4] = w;
+    }
+}
+
 // xtab: per destination column {int16 sx, int16 a0, int16 a1, pad}; ytab: per row {sy0, sy1, b0, b1}
 __global__ void pyr_resize_kernel(int level, const DevGeom* __restrict__ G, const short4* __restrict__ tabs,
                                   uint8_t* __restrict__ pyr)
@@ -1599,6 +1635,11 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
     {
         ProfScope ps(c, "orb_pyr");
         const int n0 = o.lv[0].bw * o.lv[0].bh;
+        if (c->pyr0_f32) {
+            // (the caller left the normalisation of its float images to this kernel; d_img is where the u8 images go)
+            pyr_level0_f32_kernel<<<dim3((n0 / 4 + 256) / 256, B), 256, 0, c->stream>>>(c->pyr0_f32, c->pyr0_mm, const_cast<uint8_t*>(d_img), img_stride, img_slice_bytes, G, pyr, err_flag);
+            c->pyr0_f32 = nullptr; c->pyr0_mm = nullptr;
+        } else
         pyr_level0_kernel<<<dim3((n0 / 4 + 256) / 256, B), 256, 0, c->stream>>>(d_img, img_stride, img_slice_bytes, G, pyr, err_flag);
         for (int l = 1; l < o.nlevels; l++) {
             const int n = o.lv[l].bw * o.lv[l].bh;
@@ -1851,6 +1892,7 @@ int stereo_match_dev(eorb_ctx* c, const eorb_keypoint* d_kps, const uint8_t* d_d
     if (!o.configured) return set_err(c, EORB_E_NOTCONF, "stereo matches: eorb_orb_configure not called");
     ProfScope ps(c, "stereo_match");
     const int cap = o.max_out;
+    if (cap > 65535) return set_err(c, EORB_E_CAPACITY, "stereo matches: %d keypoints per image exceed the 16-bit candidate index", cap);
     stereo_match_kernel<<<(cap + 3) / 4, 256, 0, c->stream>>>((const DevGeom*)o.geom.p, (const uint8_t*)c->pyr.p, d_kps, d_desc, d_n, cap, mb, mbf,
                                                               d_uright, d_depth, d_sad);
     stereo_median_kernel<<<1, 1024, 0, c->stream>>>(d_n, cap, d_sad, d_uright, d_depth, d_nmatch);
