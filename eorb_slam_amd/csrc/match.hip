@@ -754,7 +754,10 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     EORB_HIP(c, hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     EORB_HIP(c, hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     ProfScope ps(c, name);
-    const int qpb = npairs >= 8 ? 32 : 8;  // queries per phase-1 workgroup (a lone pair is spread over more workgroups)
+    // queries per phase-1 workgroup: a lone pair is spread over as many workgroups as it has queries per wavefront (one each: 0.091 ->
+    // 0.085 ms per SearchForInitialization call against two each; every workgroup stages the searched frame, 57 KB, from the L2)
+    static const int qpb_env = [] { const char* e = getenv("EORB_WIN_QPB"); return e ? atoi(e) : 0; }();      // (A/B runs)
+    const int qpb = qpb_env > 0 ? qpb_env : (npairs >= 8 ? 32 : 4);
     win_cand_kernel<KIND><<<dim3((nq_max + qpb - 1) / qpb, npairs), 256, lds1, c->stream>>>(A, qpb);
     // (SearchByProjection(cur, last): its fixed-point sweeps settle a window of blockDim queries at a time: the widest block)
     win_resolve_kernel<KIND><<<npairs, KIND == 1 ? 1024 : 256, lds2, c->stream>>>(A);
