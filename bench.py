@@ -485,6 +485,45 @@ def _compact(o):
     return c
 
 
+def run_stereo(env):
+    """A stereo frame per call (the stereo constructor's hot path, src/Frame.cc:97-152 + :869-1048): both extractions and
+    ComputeStereoMatches through eorb_frame_stereo, host buffers in and out, on a synthetic rectified pair of the EuRoC shape (752x480, 1 200
+    features, 8 levels, FAST 20 / 7: Examples/Stereo/EuRoC.yaml); verified against the oracle; the oracle timed on one core beside it."""
+    from eorb_slam_amd import frontend as fe, synth
+    from oracle import oracle_py as orc
+    a = env["a"]
+    W, H, NF, NL, TH, MB, MBF = 752, 480, 1200, 8, (20, 7), 0.11, 47.9
+    pairs = [synth.stereo_pair(200 + k, W, H) for k in range(4)]
+    ge = fe.ORBextractor(NF, 1.2, NL, TH[0], TH[1], 19, (W, H))
+    for k in range(max(a.warmup, 1) * 2):
+        ge.stereo(pairs[k % 4][0], pairs[k % 4][1], MB, MBF)
+    calls = max(a.steps, 1) * 8
+    ts = []
+    for k in range(calls):
+        t0 = time.perf_counter(); ge.stereo(pairs[k % 4][0], pairs[k % 4][1], MB, MBF); ts.append(time.perf_counter() - t0)
+    ts = np.array(ts)
+    # verification + the CPU sample: every pair once through the oracle
+    oL = orc.OrbExtractor(NF, 1.2, NL, TH[0], TH[1], edgeTh=19, imWidth=W); oR = orc.OrbExtractor(NF, 1.2, NL, TH[0], TH[1], edgeTh=19, imWidth=W)
+    bad = 0; cpu = []; matched = 0
+    for L, R in pairs:
+        t0 = time.perf_counter()
+        _, kl, dl, _ = oL.extract(L, (0, 0)); _, kr, dr, _ = oR.extract(R, (0, 0))
+        ur, dp, nm = oL.compute_stereo_matches(oR, kl, dl, kr, dr, MB, MBF)
+        cpu.append(time.perf_counter() - t0)
+        g = ge.stereo(L, R, MB, MBF)
+        same = (len(g["kpsL"]) == len(kl) and len(g["kpsR"]) == len(kr) and g["nmatches"] == nm and _bits_equal(g["kpsL"], kl) and _bits_equal(g["kpsR"], kr)
+                and _bits_equal(g["descL"], dl) and _bits_equal(g["descR"], dr) and _bits_equal(g["uRight"], ur) and _bits_equal(g["depth"], dp))
+        bad += 0 if same else 1
+        matched += int((ur > 0).sum())
+    ge.ctx.close()
+    return {"value": float(1.0 / ts.mean()), "unit": "stereo frames/s", "calls": int(calls), "p50_ms": float(np.median(ts) * 1e3), "p95_ms": float(np.percentile(ts, 95) * 1e3),
+            "workload": "stereo: %dx%d pair -> ORB-%d x 2 (%d levels) -> ComputeStereoMatches, one frame per call through ctypes (eorb_frame_stereo)" % (W, H, NF, NL),
+            "mean_stereo_matches": matched / len(pairs),
+            "cpu_baseline": {"value": float(1.0 / np.mean(cpu)), "unit": "stereo frames/s", "cores": 1, "kind": "port", "p50_ms": float(np.median(cpu) * 1e3),
+                             "sample": "%d pairs through the oracle (2 x extract + compute_stereo_matches)" % len(pairs)},
+            "verified": {"units": len(pairs), "mismatches": int(bad), "compared": ["keypoint records of both images", "descriptors of both images", "mvuRight bits", "mvDepth bits", "matches before the median cut"]}}
+
+
 def side_runs(env, main_out):
     """Short runs of the other BASELINE configs and input forms inside the default command, each with its own CPU sample and its own
     verification against the oracle, so that ONE recorded line carries a number for configs[0]..[3] (w1, w2, w3, w4), for the
@@ -507,6 +546,14 @@ def side_runs(env, main_out):
             side[name]["wall_s"] = time.perf_counter() - t0
         except Exception as e:                                   # a side run must not cost the main line
             side[name] = {"error": "%s: %s" % (type(e).__name__, e), "verified": {"mismatches": 1, "what": "the side run failed"}}
+    t0 = time.perf_counter()
+    try:
+        v = dict(vars(a)); v.update(steps=6, warmup=1)
+        env2 = dict(env); env2["a"] = argparse.Namespace(**v)
+        side["stereo"] = run_stereo(env2)
+        side["stereo"]["wall_s"] = time.perf_counter() - t0
+    except Exception as e:
+        side["stereo"] = {"error": "%s: %s" % (type(e).__name__, e), "verified": {"mismatches": 1, "what": "the side run failed"}}
     if "streaming" in main_out:
         side["streaming"] = main_out["streaming"]
     return side

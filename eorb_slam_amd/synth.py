@@ -219,3 +219,18 @@ def l1_mci_poses(window):
     return dict(dp=dict(angle=0.010 * s, axis=(0.1, -0.2, 0.97), t=(0.004 * s, -0.003 * s, 0.001), medDepth=1.0),
                 ba=dict(angle=0.016 * s, axis=(-0.3, 0.1, 0.95), t=(-0.002 * s, 0.005 * s, 0.0), medDepth=1.3),
                 se2=np.array([0.012 * s, 1.5 * s, -0.8 * s], np.float32))
+
+
+def stereo_pair(seed, W=346, H=260, dmax=14):
+    """A rectified stereo pair: the right image is the left one warped by a smooth disparity field in [2, dmax] pixels -- d(x, y) = 2 +
+    (dmax - 2) (0.5 + 0.5 sin(y / 37 + x / 91)), bilinear in x, nothing vertical -- plus a little independent noise.  Returns (left, right) u8."""
+    rng = np.random.default_rng(seed)
+    left = texture_image(W + 32, H, seed=seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    disp = 2.0 + (dmax - 2.0) * (0.5 + 0.5 * np.sin(yy / 37.0 + xx / 91.0))
+    xs = xx + disp                                                         # right(x) = left(x + d)
+    x0 = np.floor(xs).astype(np.int64); fr = xs - x0
+    rows = yy.astype(np.int64)
+    right = (1 - fr) * left[rows, x0] + fr * left[rows, np.minimum(x0 + 1, W + 31)]
+    right = np.clip(np.rint(right + rng.normal(0, 1.0, right.shape)), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(left[:, :W]), right

@@ -1857,18 +1857,7 @@ def test_octree_direct_passes_equal_list_algorithm(oracle, fe, list_algorithm):
 
 
 def _stereo_pair(seed, W=346, H=260, dmax=14):
-    """A rectified pair: the right image is the left one warped by a smooth, row-wise varying disparity in [2, dmax] pixels
-    (bilinear in x, nothing vertical), plus a little independent noise."""
-    rng = np.random.default_rng(seed)
-    left = synth.texture_image(W + 32, H, seed=seed)
-    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
-    disp = 2.0 + (dmax - 2.0) * (0.5 + 0.5 * np.sin(yy / 37.0 + xx / 91.0))
-    xs = xx + disp                                                         # right(x) = left(x + d)
-    x0 = np.floor(xs).astype(np.int64); fr = xs - x0
-    rows = yy.astype(np.int64)
-    right = (1 - fr) * left[rows, x0] + fr * left[rows, np.minimum(x0 + 1, W + 31)]
-    right = np.clip(np.rint(right + rng.normal(0, 1.0, right.shape)), 0, 255).astype(np.uint8)
-    return np.ascontiguousarray(left[:, :W]), right
+    return synth.stereo_pair(seed, W, H, dmax)
 
 
 @pytest.mark.parametrize("cfg", [dict(W=346, H=260, nf=1000, nl=8, th=(20, 7), mb=0.11, mbf=40.0, seed=31),
