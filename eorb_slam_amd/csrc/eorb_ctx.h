@@ -171,6 +171,7 @@ struct eorb_ctx {
     long long dbg_slot_hot_min = -1;             // slot form: list length from which the register-row kernel takes a list (-1: default / EORB_SLOT_HOT_MIN)
     int dbg_slot_hot_cap = 0;                    // slot form: lists per length bucket of the register-row kernel (0: kHotCap), to force the overflow branch
     int dbg_slot_hot_waves = 0;                  // slot form: wavefronts of the register-row kernel (0: default / EORB_SLOT_HOT_WAVES)
+    int dbg_slot_prerank = -1;                   // slot form: ranks kept by the count pass, sl_scatter_pre_kernel (-1: default / EORB_SLOT_PRERANK, 0 / 1: test hook)
     int dbg_pd = 1;                              // float events in bulk: 0 = never freeze / use the position dictionary (test hook "position_dict")
     int dbg_slot_halves = -1;                    // slot form: -1 by the batch's shape / EORB_SLOT_HALVES, 0 one part, 1 two halves whatever the shape
 };

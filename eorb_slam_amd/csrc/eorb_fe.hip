@@ -313,6 +313,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "slot_halves")) { c->dbg_slot_halves = value; return EORB_OK; }
     if (!strcmp(name, "position_dict")) { c->dbg_pd = value; if (!value) { c->pd_valid = 0; c->dd_keep = 0; } return EORB_OK; }
     if (!strcmp(name, "slot_hot_waves")) { c->dbg_slot_hot_waves = value; return EORB_OK; }
+    if (!strcmp(name, "slot_prerank")) { c->dbg_slot_prerank = value; return EORB_OK; }
     return set_err(c, EORB_E_ARG, "debug option '%s' unknown", name);
 }
 

@@ -256,7 +256,12 @@ __device__ __forceinline__ uint32_t sl_dict_hash(uint64_t k)
 // rec16 (stride 16 / 4 on sensors of at most 65 535 pixels): the pass also writes every event's linear sensor index y * LW + x as a
 // 2-byte record (0xffff: none), which is all the scatter needs: it then reads 2 bytes per event instead of a dword out of every 16-byte
 // record (2.05 GB of the step's HBM traffic for 0.26 + 0.26).
-template <int stride, bool KEYED = false>
+// RANKS: the pass keeps what its counting atomics return.  One wavefront counts a chunk, its LDS instructions execute in order and the
+// lanes of one ds_add_rtn that hit the same counter are served in lane order (the property sl_rankcheck_kernel verifies, see
+// sl_scatter_rank_kernel) -- so, with an event's tiles visited by parity class like there, the returned value IS the entry's rank in
+// the chunk's (tile) run.  It goes out with the sensor index as one 8-byte record { index : 16, rank of the event's tile of class j :
+// 12 bits each }: the scatter (sl_scatter_pre_kernel) then neither counts nor ranks again -- its two most expensive phases.
+template <int stride, bool KEYED = false, bool RANKS = false>
 __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eorb_raw_event* __restrict__ ev, const ChunkDesc* __restrict__ chunks,
                                                                        int nchunks, const uint16_t* __restrict__ slot_geo, int LW, int LH,
                                                                        int TX, int NT, uint16_t* __restrict__ segcnt, SlotDict D = SlotDict{nullptr, 0u, nullptr, nullptr, 0},
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
         }
         for (int k0 = lane; k0 < cd.n; k0 += 64 * U) {
             uint32_t xy[U], g[U];
+            uint32_t r16[U];                                           // (RANKS: the events' sensor indices)
             if (KEYED) {
                 uint2 pos[U]; uint4 ent[U]; uint32_t hh[U];
 #pragma unroll
@@ -318,11 +324,36 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
                 const uint32_t x = xy[u] & xmask, y = xy[u] >> 16, row = xy[u] & 0x7fffffffu;      // (hashed records: the row itself)
                 if (stride < 0 || stride == 2) g[u] = row < (uint32_t)LW * (uint32_t)LH ? tab[row] : kNoGeo;
                 else g[u] = (x < (uint32_t)LW && y < (uint32_t)LH) ? tab[y * (uint32_t)LW + x] : kNoGeo;
-                if ((stride == 16 || stride == 4) && rec16) {
+                if (RANKS) {
+                    if (stride < 0 || stride == 2) r16[u] = row < (uint32_t)LW * (uint32_t)LH ? row : 0xffffu;
+                    else r16[u] = (x < (uint32_t)LW && y < (uint32_t)LH) ? y * (uint32_t)LW + x : 0xffffu;
+                } else if ((stride == 16 || stride == 4) && rec16) {
                     const int k = k0 + u * 64;
                     if (k < cd.n) rec16[cd.start + k] = (x < (uint32_t)LW && y < (uint32_t)LH) ? (uint16_t)(y * (uint32_t)LW + x) : (uint16_t)0xffffu;
                 }
             }
+            }
+            if (RANKS) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    uint64_t rk = 0ull;
+                    if (g[u] != kNoGeo) {
+                        const int tx0 = (int)(g[u] & 0x7f), ty0 = (int)((g[u] >> 7) & 0x7f);
+                        const int nx = 1 + (int)((g[u] >> 14) & 1), ny = 1 + (int)((g[u] >> 15) & 1);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int dx = ((j & 1) - tx0) & 1, dy = ((j >> 1) - ty0) & 1;       // the event's tile of class j, if it has one
+                            if (dx < nx && dy < ny) {
+                                const int t = (ty0 + dy) * TX + tx0 + dx;
+                                const uint32_t o = atomicAdd(&cnt[t >> 1], 1u << (16 * (t & 1)));
+                                rk |= (uint64_t)((o >> (16 * (t & 1))) & 0xfffu) << (12 * j);
+                            }
+                        }
+                    }
+                    const int k = k0 + u * 64;
+                    if (k < cd.n) ((uint64_t*)rec16)[cd.start + k] = (uint64_t)(r16[u] & 0xffffu) | (rk << 16);
+                }
+                continue;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -663,6 +694,94 @@ __global__ __launch_bounds__(64 * NW) void sl_scatter_rank_kernel(const eorb_raw
     __syncthreads();
 #if defined(EORB_KO_SCAT) && EORB_KO_SCAT == 3
     if (rk[0] == 0x12345678u) entries[0] = 0; return;
+#endif
+    // ---- D: consecutive threads write consecutive entries of a run ----
+    slot_entry* out = entries + (size_t)slice_ebase[cd.slice];
+    const int E = loff[NT];
+    for (int p = tid; p < E; p += NTHR) out[(size_t)(uint32_t)(gbase[stile[p]] + (uint32_t)p)] = (slot_entry)(kEntryTag | sorted[p]);     // (gbase holds base - loff mod 2^32)
+}
+
+// ---- K1c, with the ranks of the count pass (sl_count_lds_kernel<.., RANKS>): an 8-byte record per event { sensor index : 16, rank in the
+// chunk's run of the event's tile of class j : 12 bits each }.  Nothing is counted here: the chunk's tile offsets are the prefix of
+// the count pass's own counts (segcnt), an entry's place in the chunk's tile-sorted order is offset + rank.  Phases C and D as above.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void sl_scatter_pre_kernel(const uint64_t* __restrict__ rec, const ChunkDesc* __restrict__ chunks,
+                                                                 const uint2* __restrict__ slot_tab, int nsrc, int TX, int NT, int chunk_cap,
+                                                                 const int64_t* __restrict__ slice_ebase, const uint16_t* __restrict__ segcnt,
+                                                                 const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ tile_base,
+                                                                 slot_entry* __restrict__ entries)
+{
+    extern __shared__ unsigned char sm2[];
+    __shared__ uint32_t s_wsum[NW];
+    constexpr int NTHR = 64 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x;
+    const ChunkDesc cd = chunks[chunk];
+    const int NTp = (NT + 1) & ~1;
+    uint32_t* gbase = (uint32_t*)sm2;                                 // NT: first entry of the tile's run in the global lists, minus loff
+    uint16_t* stile = (uint16_t*)(gbase + NT);                        // chunk_cap * 4: tile of every slot of the sorted order
+    uint16_t* loff = stile + (size_t)chunk_cap * 4;                   // NT + 1 (+ 1 pad)
+    uint8_t* sorted = (uint8_t*)(loff + NTp + 2);                     // chunk_cap * 4: the entry bytes in tile-sorted order (tile and byte in ONE 32-bit word: 0.75 ms against 0.70)
+    const int Q = (((cd.n + NW - 1) / NW) + 63) & ~63;
+    const int S = Q >> 6;
+    constexpr int SMAX = 4;
+    // ---- A': the records and the slot table rows (all requests before the first use) ----
+    uint64_t rr[SMAX]; uint2 rst[SMAX];
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        const int k = wave * Q + s * 64 + lane;
+        rr[s] = (s < S && k < cd.n) ? rec[cd.start + k] : 0xffffull;
+    }
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        const uint32_t row = (uint32_t)(rr[s] & 0xffffull);
+        rst[s] = (row != 0xffffu && row < (uint32_t)nsrc) ? slot_tab[row] : make_uint2(0u, 0xffffffffu);
+    }
+    // ---- B': the chunk's tile offsets = exclusive scan of the count pass's counts over the tiles ----
+    {
+        const int per = (NT + NTHR - 1) / NTHR;
+        const int t0 = tid * per, t1 = min(t0 + per, NT);
+        const uint16_t* sc = segcnt + (size_t)chunk * NT;
+        uint32_t mine = 0;
+        for (int t = t0; t < t1; t++) mine += sc[t];
+        uint32_t incl = (uint32_t)wave_incl_scan((int)mine);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+        for (int w = 0; w < wave; w++) before += s_wsum[w];
+        for (int t = t0; t < t1; t++) {
+            const uint32_t v = sc[t];
+            loff[t] = (uint16_t)before;
+            gbase[t] = tile_base[(size_t)cd.slice * NT + t] + segbase[(size_t)chunk * NT + t] - before;
+            before += v;
+        }
+        if (tid == NTHR - 1) loff[NT] = (uint16_t)before;
+    }
+    __syncthreads();
+#if defined(EORB_KO_SCAT) && EORB_KO_SCAT == 2
+    if (rst[0].x == 0x12345678u) entries[0] = 0; return;
+#endif
+    // ---- C: every entry to its place in the tile-sorted order ----
+#pragma unroll
+    for (int s = 0; s < SMAX; s++) {
+        const uint32_t rg = rst[s].x, sb = rst[s].y;
+        const int nx = (rg >> 16) & 3, ny = (rg >> 18) & 3;
+        const int tx0 = rg & 0xff, ty0 = (rg >> 8) & 0xff;
+        const uint64_t rk = rr[s] >> 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dx = ((j & 1) - tx0) & 1, dy = ((j >> 1) - ty0) & 1;
+            if (nx && ny && dx < nx && dy < ny) {
+                const int t = (ty0 + dy) * TX + tx0 + dx;
+                const uint32_t pos = (uint32_t)loff[t] + (uint32_t)((rk >> (12 * j)) & 0xfffull);
+                sorted[pos] = (uint8_t)((sb >> (8 * (dy * 2 + dx))) & 0xffu);
+                stile[pos] = (uint16_t)t;
+            }
+        }
+    }
+    __syncthreads();
+#if defined(EORB_KO_SCAT) && EORB_KO_SCAT == 3
+    if (rst[0].x == 0x12345678u) entries[0] = 0; return;
 #endif
     // ---- D: consecutive threads write consecutive entries of a run ----
     slot_entry* out = entries + (size_t)slice_ebase[cd.slice];
@@ -1123,6 +1242,7 @@ constexpr int kSlotDeclined = 1;       // ev_slots_accumulate: the batch's shape
 // the batch pipeline, whose first scatter form needs 4 bytes of LDS per tile only.
 struct SlotScatterChoice { int chunk, waves; bool rank; size_t lds; };
 static size_t sl_lds_rank(int NT, int chunk, int waves) { const int NTp = (NT + 1) & ~1; return ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)waves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15; }
+static size_t sl_lds_pre(int NT, int chunk) { const int NTp = (NT + 1) & ~1; return ((size_t)NT * 4 + (size_t)chunk * 4 * 2 + (size_t)(NTp + 2) * 2 + (size_t)chunk * 4 + 15) & ~(size_t)15; }
 static size_t sl_lds_ballot(int NT, int chunk) { const int NTp = (NT + 1) & ~1; return ((size_t)chunk * 4 + (size_t)chunk * 2 + (size_t)chunk * 4 * 2 + (size_t)kSlotScatWaves * NTp * 2 + (size_t)(NTp + 2) * 2 + (size_t)NT * 4 + 15) & ~(size_t)15; }
 static bool sl_choose_scatter(const eorb_ctx* c, int NT, int64_t per_slice, bool rank_allowed, SlotScatterChoice* out)
 {
@@ -1246,6 +1366,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
     int* d_info = (int*)(d_nslots + 5 * (size_t)NT);
     const eorb_raw_event* d_ev = dict ? (const eorb_raw_event*)dict->rec : (const eorb_raw_event*)d_events;
     int scat_stride = stride;
+    bool prerank = false;                             // the count pass left ranked 8-byte records: sl_scatter_pre_kernel
     const uint2* d_tab = (const uint2*)c->sl_tab.p;
     const int ncu = sl_ncu(c);
     const int NTp = (NT + 1) & ~1;
@@ -1304,6 +1425,20 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
             // 16-byte records on a sensor of at most 65 535 pixels: the pass leaves a 2-byte record per event for the scatter
             static const int tc_env = [] { const char* e = getenv("EORB_SLOT_TRANSCODE"); return e ? atoi(e) : 1; }();
             uint16_t* d_rec16 = nullptr;
+            // ... or, where the rank scatter would run: an 8-byte record that also carries the ranks of the event's entries in the
+            // chunk's runs (the values the counting atomics return), so that the scatter neither counts nor ranks (sl_scatter_pre_kernel)
+            static const int pre_env = [] { const char* e = getenv("EORB_SLOT_PRERANK"); return e ? atoi(e) : 1; }();
+            const int pre_on = c->dbg_slot_prerank >= 0 ? c->dbg_slot_prerank : pre_env;
+            if (pre_on && (stride == 16 || stride == 4 || stride == 2) && nsrc <= 65535 && sc.rank && sl_lds_pre(NT, chunk) <= 158 * 1024) {
+                if ((rc = ensure(c, ws.rec16, sizeof(uint64_t) * (size_t)std::max<int64_t>(h_offsets[B], 1)))) return rc;
+                d_rec16 = (uint16_t*)ws.rec16.p;
+                prerank = true;
+#define SL_COUNTR(ST, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_count_lds_kernel<ST, false, true>, 159 * 1024))) return rc; \
+                sl_count_lds_kernel<ST, false, true><<<g, 64 * kCountWaves, lds_c, M>>>(d_ev, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt, SlotDict{nullptr, 0u, nullptr, nullptr, 0}, d_rec16); } while (0)
+                if (stride == 16) SL_COUNTR(16, 13); else if (stride == 4) SL_COUNTR(4, 14); else SL_COUNTR(2, 15);
+#undef SL_COUNTR
+            }
+            else {
             if (tc_env && stride == 16 && nsrc <= 65535 && sc.rank) {
                 if ((rc = ensure(c, ws.rec16, sizeof(uint16_t) * (size_t)std::max<int64_t>(h_offsets[B], 1)))) return rc;
                 d_rec16 = (uint16_t*)ws.rec16.p;
@@ -1313,6 +1448,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
             if (stride == 16) SL_COUNT(16, 0); else if (stride == 4) SL_COUNT(4, 1); else if (stride == 2) SL_COUNT(2, 10); else SL_COUNT(-4, 2);
 #undef SL_COUNT
             if (d_rec16) { d_ev = (const eorb_raw_event*)d_rec16; scat_stride = 2; }
+            }
         }
         else if (nchunks) {
             if (stride == 16) sl_count_kernel<16><<<nchunks, 256, lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, d_segcnt);
@@ -1335,7 +1471,18 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
         // ---- the scatter (form and chunk size chosen up front: sl_choose_scatter) ----
         ProfScope ps2(c, "ev_scatter");
         const int stride = scat_stride;                                   // (what the count pass left for the scatter)
-        if (nchunks && sc.rank) {
+        if (nchunks && prerank) {
+            const size_t lds_p = sl_lds_pre(NT, chunk);
+            const uint16_t* d_segcnt_c = d_segcnt;
+            if (sc.waves == 16) {
+                if ((rc = sl_optin(c, 16, (const void*)sl_scatter_pre_kernel<16>, 159 * 1024))) return rc;
+                sl_scatter_pre_kernel<16><<<nchunks, 64 * 16, lds_p, M>>>((const uint64_t*)ws.rec16.p, d_chunks, d_tab, c->lut_w * c->lut_h, TX, NT, chunk, d_slice_eb, d_segcnt_c, d_segbase, d_tile_base, (slot_entry*)ws.entries.p);
+            } else {
+                if ((rc = sl_optin(c, 17, (const void*)sl_scatter_pre_kernel<8>, 159 * 1024))) return rc;
+                sl_scatter_pre_kernel<8><<<nchunks, 64 * 8, lds_p, M>>>((const uint64_t*)ws.rec16.p, d_chunks, d_tab, c->lut_w * c->lut_h, TX, NT, chunk, d_slice_eb, d_segcnt_c, d_segbase, d_tile_base, (slot_entry*)ws.entries.p);
+            }
+        }
+        else if (nchunks && sc.rank) {
 #define SL_SCAT(ST, NW, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_scatter_rank_kernel<ST, NW>, 159 * 1024))) return rc; \
                 sl_scatter_rank_kernel<ST, NW><<<nchunks, 64 * NW, sc.lds, M>>>(d_ev, d_chunks, d_tab, c->lut_w, c->lut_h, TX, NT, chunk, \
                                                                                    d_slice_eb, d_segbase, d_tile_base, (slot_entry*)ws.entries.p); } while (0)
