@@ -306,7 +306,8 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
                         if (q.x == pos[u].x && q.y == pos[u].y && q.z != 0xffffffffu) id = q.z;
                         else atomicAdd(D.miss, 1);
                     }
-                    if (k < cd.n) {
+                    if (RANKS) r16[u] = id < (uint32_t)LW * (uint32_t)LH ? id : 0xffffu;      // (the ranked record below carries the id)
+                    else if (k < cd.n) {
                         if (D.rec2) ((uint16_t*)D.rec)[cd.start + k] = id == 0x7fffffffu ? (uint16_t)0xffffu : (uint16_t)id;
                         else D.rec[cd.start + k] = id;
                     }
@@ -1416,8 +1417,18 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
         if (nchunks && dict) {
             const uint16_t* d_geo = (const uint16_t*)((const char*)c->sl_tab.p + sizeof(uint2) * nsrc);
             const int g = std::min(ncu, (nchunks + kCountWaves - 1) / kCountWaves);
+            static const int pre_env_d = [] { const char* e = getenv("EORB_SLOT_PRERANK"); return e ? atoi(e) : 1; }();
+            const int pre_on_d = c->dbg_slot_prerank >= 0 ? c->dbg_slot_prerank : pre_env_d;
+            if (pre_on_d && dict->rec2 && sc.rank && sl_lds_pre(NT, chunk) <= 158 * 1024) {
+                // (the dense ids are 16-bit: the ranked 8-byte record serves the dictionary path too)
+                if ((rc = ensure(c, ws.rec16, sizeof(uint64_t) * (size_t)std::max<int64_t>(h_offsets[B], 1)))) return rc;
+                prerank = true;
+                if ((rc = sl_optin(c, 21, (const void*)sl_count_lds_kernel<16, true, true>, 159 * 1024))) return rc;
+                sl_count_lds_kernel<16, true, true><<<g, 64 * kCountWaves, lds_c, M>>>((const eorb_raw_event*)d_events, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt, *dict, (uint16_t*)ws.rec16.p);
+            } else {
             if ((rc = sl_optin(c, 13, (const void*)sl_count_lds_kernel<16, true>, 159 * 1024))) return rc;
             sl_count_lds_kernel<16, true><<<g, 64 * kCountWaves, lds_c, M>>>((const eorb_raw_event*)d_events, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt, *dict);
+            }
         }
         else if (nchunks && cl_env && TX <= 127 && TY <= 127 && lds_c <= 159 * 1024) {
             const uint16_t* d_geo = (const uint16_t*)((const char*)c->sl_tab.p + sizeof(uint2) * nsrc);
@@ -1435,7 +1446,7 @@ static int slots_part(eorb_ctx* c, eorb_ctx::SlotWS& ws, int part, int nparts, c
                 prerank = true;
 #define SL_COUNTR(ST, BIT) do { if ((rc = sl_optin(c, BIT, (const void*)sl_count_lds_kernel<ST, false, true>, 159 * 1024))) return rc; \
                 sl_count_lds_kernel<ST, false, true><<<g, 64 * kCountWaves, lds_c, M>>>(d_ev, d_chunks, nchunks, d_geo, c->lut_w, c->lut_h, TX, NT, d_segcnt, SlotDict{nullptr, 0u, nullptr, nullptr, 0}, d_rec16); } while (0)
-                if (stride == 16) SL_COUNTR(16, 13); else if (stride == 4) SL_COUNTR(4, 14); else SL_COUNTR(2, 15);
+                if (stride == 16) SL_COUNTR(16, 18); else if (stride == 4) SL_COUNTR(4, 19); else SL_COUNTR(2, 20);
 #undef SL_COUNTR
             }
             else {

@@ -1392,15 +1392,17 @@ def test_slot_scatter_ballot_form_equals_rank_form(oracle, fe):
         "ragged": [synth.random_raw_events(max(int(sz), 1), W, H, seed=820 + b)[:int(sz)] for b, sz in enumerate([40000, 0, 25000, 7, 65536, 0, 1])],
         "hot tiles": _hot_slices(12, 20000, W, H, seed=32),
     }
+    # (form 1 twice: with the ranks the count pass keeps -- sl_scatter_pre_kernel, the default -- and with the scatter ranking by itself,
+    #  sl_scatter_rank_kernel, which sensors of more than 65 535 pixels still take)
     for name, raws in batches.items():
-        for form in (1, 0):
-            got = _raw_batch(fe, raws, W, H, mx, my, (("gather_form", 4), ("slot_rank", form)))
+        for form, pre in ((1, 1), (1, 0), (0, 0)):
+            got = _raw_batch(fe, raws, W, H, mx, my, (("gather_form", 4), ("slot_rank", form), ("slot_prerank", pre)))
             cnt = got[3]
             assert cnt["slot_calls"] == 1 and cnt["slot_flags"] == 0 and cnt["slot_rank_ok"] == 1, (name, form, cnt)
             assert cnt["slot_scatter_form"] == form, (name, form, cnt)
             if name == "2 x 300k":
                 assert cnt["slot_chunk"] == (4096 if form else 2048), cnt
-            _check_raw_batch(oracle, raws, W, H, mx, my, got, (name, form))
+            _check_raw_batch(oracle, raws, W, H, mx, my, got, (name, form, pre))
 
 
 def test_raw_dense_batch_on_vga_class_sensors(oracle, fe):
