@@ -11,6 +11,9 @@
 //   K1a sl_count_lds_kernel    entries of every (chunk, tile): the sensor pixels' tile ranges as a 16-bit table in LDS, one wavefront per
 //                              chunk (sl_count_kernel where that table does not fit)
 //   K1b sl_scan_kernel         one contiguous event-ordered list per (slice, tile); per-tile weights
+//       (RANKS form, the default for sensors of <= 65 535 pixels: the values the counting atomics return are the entries' ranks in the
+//                              chunk's runs; they go out with the sensor index as an 8-byte record per event, and the scatter below
+//                              -- sl_scatter_pre_kernel -- neither counts nor ranks again)
 //   K1c sl_scatter_rank_kernel order-preserving scatter of TWO-BYTE entries (0x1000 | slot number): stable ranks from the return values of the
 //                              counting LDS atomics, the chunk tile-sorted in LDS, runs streamed out (sl_scatter_kernel: the ballot form,
 //                              kept as the fallback when the device check of the atomics' lane order fails)
