@@ -409,6 +409,8 @@ def roofline_of(prof, steps, unit_bytes_by_kernel, units_per_launch, inputs_key=
             alg = unit_bytes_by_kernel("ev_") * units_per_launch
             if stage > 0 and dom.startswith("ev_"):
               r["stage"] = {"what": "all accumulation kernels (ev_*) of a step", "traffic": stage, "algorithmic": alg, "ratio": stage / alg,
+                          "note": "of this, ~1.5 GB per 128 Mev are the count pass's ranked records (8 B per event written once, read once by the scatter, which then neither "
+                                  "counts nor ranks: 3 % more frames/s); EORB_SLOT_PRERANK=0 trades them back: 2.33 x algorithmic, the scatter ranking by itself",
                           "scopes": {k: {"live_ms": prof[k][0] / max(prof[k][1], 1), "rocprof_ms": v["rocprof_ms"], "traffic": v["traffic_bytes"],
                                          "algorithmic_GBps": alg / (prof[k][0] / max(prof[k][1], 1) * 1e-3) / 1e9,
                                          **({"issue_by_kernel": v["issue_by_kernel"]} if "issue_by_kernel" in v else {}),
