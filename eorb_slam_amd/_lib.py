@@ -16,7 +16,7 @@ EXPORTS = [
     "eorb_ev2im", "eorb_ev2im_gauss", "eorb_set_undistort_maps", "eorb_undistort_events", "eorb_parse_events_text", "eorb_ev2im_gauss_raw", "eorb_ev2im_raw", "eorb_fe_run_batch_raw_dev", "eorb_fe_run_batch_raw4_dev", "eorb_fe_run_batch_raw2_dev", "eorb_fe_run_batch_images_dev", "eorb_ev2mci_se3", "eorb_ev2mci_se2", "eorb_ev2mci_se3_cam", "eorb_ev2mci_se2_cam", "eorb_measure_image_focus", "eorb_measure_image_focus_n", "eorb_normalize_minmax_u8",
     "eorb_orb_configure", "eorb_orb_max_keypoints", "eorb_orb_get_tables", "eorb_orb_extract",
     "eorb_search_for_initialization", "eorb_search_by_projection_last", "eorb_search_by_projection_map", "eorb_search_by_projection_kf", "eorb_search_by_projection_last_stereo", "eorb_search_by_projection_map_stereo", "eorb_frame_stereo",
-    "eorb_hamming_bf_knn2", "eorb_search_by_bow", "eorb_search_by_bow_kf", "eorb_distinctive_descriptors", "eorb_hamming_window_match", "eorb_calc_optical_flow_pyr_lk", "eorb_bow_set_vocabulary", "eorb_bow_transform", "eorb_search_for_triangulation", "eorb_kf_radius_match", "eorb_sort_by_response", "eorb_resolve_num_mixed",
+    "eorb_hamming_bf_knn2", "eorb_search_by_bow", "eorb_search_by_bow_kf", "eorb_distinctive_descriptors", "eorb_hamming_window_match", "eorb_calc_optical_flow_pyr_lk", "eorb_bow_set_vocabulary", "eorb_bow_transform", "eorb_search_for_triangulation", "eorb_kf_radius_match", "eorb_kf_radius_match_stereo", "eorb_sort_by_response", "eorb_resolve_num_mixed",
     "eorb_orb_tracked_descriptors", "eorb_orb_assign_level_by_best_desc",
     "eorb_fe_configure", "eorb_fe_run_batch_dev", "eorb_fe_last_f32_dev",
     "eorb_ev_slice_extract", "eorb_ev_slice_track", "eorb_ev_slice_image", "eorb_ev_mc_contest",
@@ -185,6 +185,8 @@ def lib():
                                                 vp, vp, vp, vp, ci, ci, ci, vp, pi]
     L.eorb_kf_radius_match.restype = ci
     L.eorb_kf_radius_match.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, cf, vp, vp]
+    L.eorb_kf_radius_match_stereo.restype = ci
+    L.eorb_kf_radius_match_stereo.argtypes = [vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]
     L.eorb_calc_optical_flow_pyr_lk.restype = ci
     L.eorb_calc_optical_flow_pyr_lk.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, ci, ci, ci, ci, C.c_double, ci, cf, vp, vp]
     L.eorb_bow_set_vocabulary.restype = ci; L.eorb_bow_set_vocabulary.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]

@@ -1522,12 +1522,14 @@ int eorb_search_for_triangulation(eorb_ctx* c,
     return EORB_OK;
 }
 
-int eorb_kf_radius_match(eorb_ctx* c,
+static int kf_radius_common(eorb_ctx* c,
         const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const eorb_grid_bounds* gb,
         int M, const uint8_t* valid, const float* uv, const float* radius, const int32_t* level, const uint8_t* q_desc,
-        const float* inv_sigma2, int nlevels, uint8_t* taken, float accept_thr, int32_t* best_idx, int32_t* best_dist)
+        const float* inv_sigma2, int nlevels, uint8_t* taken, float accept_thr, int32_t* best_idx, int32_t* best_dist,
+        const float* uright, const float* q_ur)
 {
     if (!c) return EORB_E_ARG;
+    if ((uright != nullptr) != (q_ur != nullptr) || (uright && !inv_sigma2)) return set_err(c, EORB_E_ARG, "kf_radius_match: the stereo gate needs uright, q_ur and inv_sigma2");
     if (n < 0 || M < 0 || stride < 32 || !gb || (M > 0 && (!valid || !uv || !radius || !level || !q_desc || !best_idx || !best_dist)) ||
         (inv_sigma2 && (nlevels <= 0 || nlevels > 64)))
         return set_err(c, EORB_E_ARG, "kf_radius_match: bad arguments");
@@ -1547,6 +1549,11 @@ int eorb_kf_radius_match(eorb_ctx* c,
     if ((rc = up(c, c->m_e, fl.data(), fl.size()))) return rc;
     if ((rc = up(c, c->m_f, q_desc, 32 * (size_t)M))) return rc;
     if (inv_sigma2 && (rc = up(c, c->m_i, inv_sigma2, sizeof(float) * nlevels))) return rc;
+    if (uright) {                                    // uright[n] | q_ur[M]
+        std::vector<float> st((size_t)n + M);
+        memcpy(st.data(), uright, sizeof(float) * n); memcpy(st.data() + n, q_ur, sizeof(float) * M);
+        if ((rc = up(c, c->m_j, st.data(), sizeof(float) * st.size()))) return rc;
+    }
     if ((rc = ensure(c, c->m_h, sizeof(int32_t) * 2 * (size_t)M))) return rc;
     if ((rc = ensure(c, c->m_g, sizeof(uint16_t) * (size_t)n))) return rc;
     EORB_HIP(c, hipStreamSynchronize(c->stream));
@@ -1557,6 +1564,7 @@ int eorb_kf_radius_match(eorb_ctx* c,
     A.M = M; A.valid = (const uint8_t*)c->m_e.p; A.uv = (const float*)c->m_c.p;
     A.radius = (const float*)c->m_d.p; A.level = (const int32_t*)c->m_d.p + M; A.q_desc = (const uint8_t*)c->m_f.p;
     A.inv_sigma2 = inv_sigma2 ? (const float*)c->m_i.p : nullptr; A.nlevels = nlevels;
+    A.uright = uright ? (const float*)c->m_j.p : nullptr; A.q_ur = uright ? (const float*)c->m_j.p + n : nullptr;
     A.taken = taken ? (uint8_t*)c->m_e.p + M : nullptr; A.accept_thr = accept_thr;
     A.best_idx = (int32_t*)c->m_h.p; A.best_dist = (int32_t*)c->m_h.p + M;
     if ((rc = kf_radius_dev(c, A, (uint16_t*)c->m_g.p))) return rc;
@@ -1565,6 +1573,22 @@ int eorb_kf_radius_match(eorb_ctx* c,
     if (taken) EORB_HIP(c, hipMemcpyAsync(taken, (uint8_t*)c->m_e.p + M, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     EORB_HIP(c, hipStreamSynchronize(c->stream));
     return EORB_OK;
+}
+
+int eorb_kf_radius_match(eorb_ctx* c,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const eorb_grid_bounds* gb,
+        int M, const uint8_t* valid, const float* uv, const float* radius, const int32_t* level, const uint8_t* q_desc,
+        const float* inv_sigma2, int nlevels, uint8_t* taken, float accept_thr, int32_t* best_idx, int32_t* best_dist)
+{
+    return kf_radius_common(c, kps, n, desc, stride, gb, M, valid, uv, radius, level, q_desc, inv_sigma2, nlevels, taken, accept_thr, best_idx, best_dist, nullptr, nullptr);
+}
+
+int eorb_kf_radius_match_stereo(eorb_ctx* c,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const eorb_grid_bounds* gb,
+        int M, const uint8_t* valid, const float* uv, const float* radius, const int32_t* level, const uint8_t* q_desc,
+        const float* inv_sigma2, int nlevels, const float* uright, const float* q_ur, int32_t* best_idx, int32_t* best_dist)
+{
+    return kf_radius_common(c, kps, n, desc, stride, gb, M, valid, uv, radius, level, q_desc, inv_sigma2, nlevels, nullptr, 0.f, best_idx, best_dist, uright, q_ur);
 }
 
 int eorb_bow_set_vocabulary(eorb_ctx* c, int nnodes, int L, const int32_t* child_off, const int32_t* child_ids,

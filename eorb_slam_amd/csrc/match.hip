@@ -1036,7 +1036,8 @@ __global__ __launch_bounds__(256) void search_tri_kernel(TriArgs A)
     const int total = A.off1[A.nn1];
     for (int p = gw; p < total; p += nw) {
         const int id1 = A.idx1[p];
-        if (!A.elig1[id1]) continue;
+        const uint8_t e1 = A.elig1[id1];                // bit 0: eligible; bit 1: rectified-stereo keypoint (mvuRight >= 0, bStereo1 :1051)
+        if (!(e1 & 1)) continue;
         int lo = 0, hi = A.nn1;                         // node a with off1[a] <= p < off1[a+1]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.off1[mid] <= p) lo = mid; else hi = mid; }
         const uint32_t node = A.nodes1[lo];
@@ -1049,15 +1050,18 @@ __global__ __launch_bounds__(256) void search_tri_kernel(TriArgs A)
         uint64_t k0 = ~0ull;
         for (int i2 = A.off2[l2] + lane; i2 < A.off2[l2 + 1]; i2 += 64) {
             const int id2 = A.idx2[i2];
-            if (!A.elig2[id2]) continue;
+            const uint8_t e2 = A.elig2[id2];
+            if (!(e2 & 1)) continue;
             uint64_t t0, t1, t2, t3;
             load_desc32(A.desc2 + (size_t)id2 * A.stride2, t0, t1, t2, t3);
             const int dist = __popcll(q0 ^ t0) + __popcll(q1 ^ t1) + __popcll(q2 ^ t2) + __popcll(q3 ^ t3);
             if (dist > TH_LOW) continue;
             const eorb_keypoint kp2 = A.kps2[id2];
             if (kp2.octave < 0 || kp2.octave >= A.nlevels) continue;            // rejected on the host already
-            const float distex = A.epx - kp2.x, distey = A.epy - kp2.y;
-            if (distex * distex + distey * distey < 100 * A.scale2[kp2.octave]) continue;
+            if (!((e1 | e2) & 2)) {                                            // "if(!bStereo1 && !bStereo2 && !pKF1->mpCamera2)" :1093
+                const float distex = A.epx - kp2.x, distey = A.epy - kp2.y;
+                if (distex * distex + distey * distey < 100 * A.scale2[kp2.octave]) continue;
+            }
             if (!(A.bCoarse || epipolar_ok(kp1.x, kp1.y, kp2.x, kp2.y, A.F, A.sigma2_2[kp2.octave]))) continue;
             const uint64_t key = ((uint64_t)dist << 32) | (uint32_t)(~(uint32_t)i2);
             if (key < k0) k0 = key;
@@ -1129,8 +1133,15 @@ __device__ __forceinline__ uint64_t radius_scan(const RadArgs& A, int m, int fir
         if (A.inv_sigma2) {
             if (k.octave < 0 || k.octave >= A.nlevels) continue;
             const float ex = u - k.x, ey = v - k.y;
-            const float e2 = ex * ex + ey * ey;
-            if ((double)(e2 * A.inv_sigma2[k.octave]) > 5.99) continue;
+            const float kpr = A.uright ? A.uright[i] : -1.f;
+            if (kpr >= 0.f) {                                                  // "Check reprojection error in stereo" :1541-1553
+                const float er = A.q_ur[m] - kpr;
+                const float e2 = ex * ex + ey * ey + er * er;
+                if ((double)(e2 * A.inv_sigma2[k.octave]) > 7.8) continue;
+            } else {
+                const float e2 = ex * ex + ey * ey;
+                if ((double)(e2 * A.inv_sigma2[k.octave]) > 5.99) continue;
+            }
         }
         uint64_t t0, t1, t2, t3;
         load_desc32(A.desc + (size_t)i * A.stride, t0, t1, t2, t3);

@@ -22,6 +22,7 @@ struct RadArgs {
     const uint16_t* cell;                           // n: ix*48+iy or 0xFFFF (Frame::PosInGrid), from kf_cells_kernel
     int M; const uint8_t* valid; const float* uv; const float* radius; const int32_t* level; const uint8_t* q_desc;
     const float* inv_sigma2; int nlevels;
+    const float* uright; const float* q_ur;       // Fuse, rectified stereo: mvuRight per keypoint (>= 0: has one), the map points' predicted right coordinates
     uint8_t* taken; float accept_thr;
     int32_t* best_idx; int32_t* best_dist;
 };

@@ -490,7 +490,8 @@ def SearchForTriangulation(kps1, desc1, elig1, fv1, kps2, desc2, elig2, fv2, ep,
     return nm.value, np.stack([k, m[k]], axis=1).astype(np.int32)
 
 
-def KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, level, q_desc, inv_sigma2=None, taken=None, accept_thr=0.0, ctx=None):
+def KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, level, q_desc, inv_sigma2=None, taken=None, accept_thr=0.0, ctx=None,
+                        uright=None, q_ur=None):
     """Search core of Fuse / SearchBySim3 / SearchByProjection(KeyFrame*, Scw, ...) (src/ORBmatcher.cc:1512-1578, :1829-1860,
     :548-588). Returns (best_idx, best_dist) or (best_idx, best_dist, taken) when `taken` is given."""
     c = ctx or default_context()
@@ -502,19 +503,29 @@ def KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, level, q_desc, inv_sig
     bi = np.zeros(M, np.int32); bd = np.zeros(M, np.int32)
     isg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
     tk = None if taken is None else np.array(taken, np.uint8)
+    if uright is not None:
+        if isg is None or q_ur is None or tk is not None:
+            raise ValueError("the stereo gate takes uright, q_ur and inv_sigma2, and no taken flags")
+        ur = np.ascontiguousarray(uright, np.float32); qr = np.ascontiguousarray(q_ur, np.float32)
+        if len(ur) != len(kps) or len(qr) != M:
+            raise ValueError("uright is per keypoint, q_ur per map point")
+        c.check(c.L.eorb_kf_radius_match_stereo(c.h, _p(kps), len(kps), _p(desc), desc.shape[1], C.byref(gb), M, _p(valid), _p(uv), _p(radius),
+                                                _p(level), _p(q_desc), _p(isg), len(isg), _p(ur), _p(qr), _p(bi), _p(bd)))
+        return bi, bd
     c.check(c.L.eorb_kf_radius_match(c.h, _p(kps), len(kps), _p(desc), desc.shape[1], C.byref(gb), M, _p(valid), _p(uv), _p(radius),
                                      _p(level), _p(q_desc), None if isg is None else _p(isg), 0 if isg is None else len(isg),
                                      None if tk is None else _p(tk), float(accept_thr), _p(bi), _p(bd)))
     return (bi, bd) if tk is None else (bi, bd, tk)
 
 
-def Fuse(kps, desc, gb, valid, uv, level, scale_factors, inv_sigma2, q_desc, th=3.0, ctx=None):
+def Fuse(kps, desc, gb, valid, uv, level, scale_factors, inv_sigma2, q_desc, th=3.0, ctx=None, uright=None, q_ur=None):
     """Search part of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:1407-1617): returns best_idx per map point
-    with bestDist <= TH_LOW (-1 otherwise); the caller performs Replace / AddObservation (:1581-1600) in order."""
+    with bestDist <= TH_LOW (-1 otherwise); the caller performs Replace / AddObservation (:1581-1600) in order.
+    uright (pKF->mvuRight) and q_ur (u - bf*invz per map point) select the stereo reprojection gate (:1541-1553)."""
     sf = np.asarray(scale_factors, np.float32)
     lv = np.ascontiguousarray(level, np.int32)
     radius = (np.float32(th) * sf[np.clip(lv, 0, len(sf) - 1)]).astype(np.float32)
-    bi, bd = KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, lv, q_desc, inv_sigma2=inv_sigma2, ctx=ctx)
+    bi, bd = KeyFrameRadiusMatch(kps, desc, gb, valid, uv, radius, lv, q_desc, inv_sigma2=inv_sigma2, ctx=ctx, uright=uright, q_ur=q_ur)
     return np.where(bd <= 50, bi, -1).astype(np.int32)
 
 

@@ -324,7 +324,9 @@ int eorb_search_by_bow_kf(eorb_ctx* ctx,
  * isORBDescValid(i), elig2 likewise (vbMatched2 is never written by the reference).  ep[2] = the epipole
  * pKF2->mpCamera->project(R2w*Cw+t2w) (:982-987); F12[9] row-major = K1.t().inv()*t12x*R12*K2.inv(), the matrix
  * Pinhole::epipolarConstrain rebuilds for every candidate (Pinhole.cpp:137-140).  scale2[l] = pKF2->getORBScaleFactor(l),
- * sigma2_2[l] = pKF2->getORBLevelSigma2(l).  match12[n1] out = vMatches12 (the caller forms vMatchedPairs, :1203-1211). */
+ * sigma2_2[l] = pKF2->getORBLevelSigma2(l).  match12[n1] out = vMatches12 (the caller forms vMatchedPairs, :1203-1211).
+ * Rectified stereo: bit 1 of elig1[i] / elig2[i] set = the keypoint has a right coordinate (bStereo1 / bStereo2: mvuRight >= 0, :1051,
+ * :1079): the epipole-distance test (:1093-1100) is skipped for a pair with such a keypoint; bOnlyStereo = clear bit 0 of the others. */
 int eorb_search_for_triangulation(eorb_ctx* ctx,
         const eorb_keypoint* kps1, int n1, const uint8_t* desc1, int stride1, const uint8_t* elig1,
         const uint32_t* nodes1, const int32_t* node_off1, const int32_t* idx1, int nn1,
@@ -346,6 +348,13 @@ int eorb_kf_radius_match(eorb_ctx* ctx,
         const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const eorb_grid_bounds* gb,
         int M, const uint8_t* valid, const float* uv, const float* radius, const int32_t* level, const uint8_t* q_desc,
         const float* inv_sigma2, int nlevels, uint8_t* taken, float accept_thr, int32_t* best_idx, int32_t* best_dist);
+/* Fuse on a rectified-stereo KeyFrame (src/ORBmatcher.cc:1541-1553; the same in the Sim3 overload :1683-): a keypoint with a right
+ * coordinate (uright[i] = pKF->mvuRight[i] >= 0) is gated by the three-term error ex^2 + ey^2 + (q_ur[m] - uright[i])^2 against 7.8
+ * instead of the two-term one against 5.99; q_ur[m] = u - bf * invz of map point m.  inv_sigma2 must be given. */
+int eorb_kf_radius_match_stereo(eorb_ctx* ctx,
+        const eorb_keypoint* kps, int n, const uint8_t* desc, int stride, const eorb_grid_bounds* gb,
+        int M, const uint8_t* valid, const float* uv, const float* radius, const int32_t* level, const uint8_t* q_desc,
+        const float* inv_sigma2, int nlevels, const float* uright, const float* q_ur, int32_t* best_idx, int32_t* best_dist);
 
 /* replaces MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423; f3), batched over M map points: the
  * descriptors observed for map point m are rows offsets[m] .. offsets[m+1]-1 of desc (n x 32); best[m] = the row (relative

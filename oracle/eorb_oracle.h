@@ -308,6 +308,9 @@ int orc_search_for_triangulation(const orc_keypoint* kps1, int n1, const uint8_t
 void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
                          const int32_t* level, const uint8_t* q_desc, const float* inv_sigma2, uint8_t* taken,
                          float accept_thr, int32_t* best_idx, int32_t* best_dist);
+void orc_kf_radius_match_stereo(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
+                         const int32_t* level, const uint8_t* q_desc, const float* inv_sigma2,
+                         const float* uright, const float* q_ur, int32_t* best_idx, int32_t* best_dist);
 
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:349-423) for M map points: descriptors of map point m are rows
  * offsets[m]..offsets[m+1]-1 of desc (n x 32); best[m] = row (relative to offsets[m]) with the least median distance to

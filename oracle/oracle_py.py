@@ -185,6 +185,8 @@ def lib(fast=False):
     L.orc_search_by_projection_kf.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, ci, ci]
     L.orc_kf_radius_match.restype = None
     L.orc_kf_radius_match.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, cf, vp, vp]
+    L.orc_kf_radius_match_stereo.restype = None
+    L.orc_kf_radius_match_stereo.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.orc_distinctive_descriptors.restype = None; L.orc_distinctive_descriptors.argtypes = [vp, vp, ci, vp]
     L.orc_sort_by_response.restype = None; L.orc_sort_by_response.argtypes = [vp, ci, vp]
     L.orc_resolve_num_mixed.restype = None
@@ -548,8 +550,8 @@ def search_for_triangulation(kps1, desc1, elig1, fv1, kps2, desc2, elig2, fv2, e
     return n, m
 
 
-def kf_radius_match(frame, valid, uv, radius, level, q_desc, inv_sigma2=None, taken=None, accept_thr=0.0):
-    """frame: oracle Frame (KeyFrame grid).  Returns (best_idx, best_dist[, taken])."""
+def kf_radius_match(frame, valid, uv, radius, level, q_desc, inv_sigma2=None, taken=None, accept_thr=0.0, uright=None, q_ur=None):
+    """frame: oracle Frame (KeyFrame grid).  Returns (best_idx, best_dist[, taken]).  uright / q_ur: Fuse's stereo gate."""
     valid = np.ascontiguousarray(valid, np.uint8); uv = np.ascontiguousarray(uv, np.float32)
     radius = np.ascontiguousarray(radius, np.float32); level = np.ascontiguousarray(level, np.int32)
     q_desc = np.ascontiguousarray(q_desc, np.uint8)
@@ -557,6 +559,10 @@ def kf_radius_match(frame, valid, uv, radius, level, q_desc, inv_sigma2=None, ta
     bi = np.zeros(M, np.int32); bd = np.zeros(M, np.int32)
     isg = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
     tk = None if taken is None else np.array(taken, np.uint8)
+    if uright is not None:
+        ur = np.ascontiguousarray(uright, np.float32); qr = np.ascontiguousarray(q_ur, np.float32)
+        lib().orc_kf_radius_match_stereo(frame.h, M, _p(valid), _p(uv), _p(radius), _p(level), _p(q_desc), _p(isg), _p(ur), _p(qr), _p(bi), _p(bd))
+        return bi, bd
     lib().orc_kf_radius_match(frame.h, M, _p(valid), _p(uv), _p(radius), _p(level), _p(q_desc),
                               None if isg is None else _p(isg), None if tk is None else _p(tk), float(accept_thr), _p(bi), _p(bd))
     return (bi, bd) if tk is None else (bi, bd, tk)

@@ -571,18 +571,20 @@ int orc_search_for_triangulation(const orc_keypoint* kps1, int n1, const uint8_t
         if (nodes1[a] == nodes2[b]) {
             for (int i1 = off1[a]; i1 < off1[a + 1]; i1++) {
                 const int id1 = idx1[i1];
-                if (!elig1[id1]) continue;                                   /* pMP1 (:1046) / !isORBDescValid */
+                if (!(elig1[id1] & 1)) continue;                             /* pMP1 (:1046) / !isORBDescValid; bit 1: bStereo1 (:1051) */
                 const orc_keypoint* kp1 = &kps1[id1];
                 const uint8_t* d1 = desc1 + (size_t)stride1 * id1;
                 int bestDist = TH_LOW, bestIdx2 = -1;
                 for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
                     const int id2 = idx2[i2];
-                    if (!elig2[id2]) continue;                               /* vbMatched2 is never set in this function */
+                    if (!(elig2[id2] & 1)) continue;                         /* vbMatched2 is never set in this function */
                     const int dist = orc_descriptor_distance(d1, desc2 + (size_t)stride2 * id2);
                     if (dist > TH_LOW || dist > bestDist) continue;
                     const orc_keypoint* kp2 = &kps2[id2];
-                    const float distex = ep[0] - kp2->x, distey = ep[1] - kp2->y;
-                    if (distex * distex + distey * distey < 100 * scale2[kp2->octave]) continue;
+                    if (!((elig1[id1] | elig2[id2]) & 2)) {                  /* if(!bStereo1 && !bStereo2 && !pKF1->mpCamera2) :1093 */
+                        const float distex = ep[0] - kp2->x, distey = ep[1] - kp2->y;
+                        if (distex * distex + distey * distey < 100 * scale2[kp2->octave]) continue;
+                    }
                     if (epipolar_ok(kp1, kp2, F12, sigma2_2[kp2->octave]) || bCoarse) { bestIdx2 = id2; bestDist = dist; }
                 }
                 if (bestIdx2 >= 0) {
@@ -614,9 +616,9 @@ int orc_search_for_triangulation(const orc_keypoint* kps1, int n1, const uint8_t
 }
 
 /* Fuse :1512-1578 / Fuse(Scw) :1619-1741 / SearchBySim3 :1829-1860 / SearchByProjection(KF,Scw) :548-588 search core */
-void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
+static void kf_radius_core(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
                          const int32_t* level, const uint8_t* q_desc, const float* inv_sigma2, uint8_t* taken,
-                         float accept_thr, int32_t* best_idx, int32_t* best_dist)
+                         float accept_thr, int32_t* best_idx, int32_t* best_dist, const float* uright, const float* q_ur)
 {
     int* cand = (int*)malloc(sizeof(int) * (kf->N ? kf->N : 1));
     for (int m = 0; m < M; m++) {
@@ -633,8 +635,14 @@ void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const
             if (kpLevel < L - 1 || kpLevel > L) continue;
             if (inv_sigma2) {
                 const float ex = u - kf->kps[idx].x, ey = v - kf->kps[idx].y;
-                const float e2 = ex * ex + ey * ey;
-                if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+                if (uright && uright[idx] >= 0) {                            /* "Check reprojection error in stereo" :1541-1553 */
+                    const float er = q_ur[m] - uright[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+                }
             }
             const int dist = orc_descriptor_distance(q_desc + 32 * (size_t)m, kf->desc + (size_t)kf->desc_stride * idx);
             if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
@@ -643,6 +651,21 @@ void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const
         if (taken && bestIdx >= 0 && (float)bestDist <= accept_thr) taken[bestIdx] = 1;
     }
     free(cand);
+}
+
+void orc_kf_radius_match(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
+                         const int32_t* level, const uint8_t* q_desc, const float* inv_sigma2, uint8_t* taken,
+                         float accept_thr, int32_t* best_idx, int32_t* best_dist)
+{
+    kf_radius_core(kf, M, valid, uv, radius, level, q_desc, inv_sigma2, taken, accept_thr, best_idx, best_dist, NULL, NULL);
+}
+
+/* Fuse on a rectified-stereo KeyFrame: uright = pKF->mvuRight, q_ur[m] = u - bf*invz (:1506, :1541-1553) */
+void orc_kf_radius_match_stereo(const orc_frame* kf, int M, const uint8_t* valid, const float* uv, const float* radius,
+                         const int32_t* level, const uint8_t* q_desc, const float* inv_sigma2,
+                         const float* uright, const float* q_ur, int32_t* best_idx, int32_t* best_dist)
+{
+    kf_radius_core(kf, M, valid, uv, radius, level, q_desc, inv_sigma2, NULL, 0.f, best_idx, best_dist, uright, q_ur);
 }
 
 /* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) :2189-2312 / MixedMatcher.cpp:928-1063 */

@@ -719,6 +719,19 @@ def test_search_for_triangulation(oracle, fe, ctx, ori, coarse):
         assert np.all(e1[pairs[:, 0]] == 1) and np.all(e2[pairs[:, 1]] == 1)
         total += on
     assert total > 40
+    # rectified stereo (:1051, :1079, :1093): keypoints with a right coordinate carry bit 1; a pair with one skips the epipole-distance
+    # test.  The epipole is put among the keypoints so that the test bites: with the bits the result differs from the mono one.
+    s1 = (rng.uniform(size=len(k1)) < 0.5).astype(np.uint8); s2 = (rng.uniform(size=len(k2)) < 0.5).astype(np.uint8)
+    e1s = (e1 | (s1 << 1)).astype(np.uint8); e2s = (e2 | (s2 << 1)).astype(np.uint8)
+    ep = (float(np.median(k2["x"])), float(np.median(k2["y"])))
+    F = (Fd + rng.normal(0, 1e-5, (3, 3))).astype(np.float32)
+    scale_big = (12.0 * scale).astype(np.float32)                           # (a wide exclusion disc around the epipole)
+    on, om = oracle.search_for_triangulation(k1, d1, e1s, fv1, k2, d2, e2s, fv2, ep, F, scale_big, sigma2, coarse, ori)
+    gn, pairs = fe.SearchForTriangulation(k1, d1, e1s, fv1, k2, d2, e2s, fv2, ep, F, scale_big, sigma2, coarse, ori, ctx=ctx)
+    ok = np.nonzero(om >= 0)[0]
+    assert on == gn and np.array_equal(pairs, np.stack([ok, om[ok]], axis=1))
+    mn, mpairs = fe.SearchForTriangulation(k1, d1, e1, fv1, k2, d2, e2, fv2, ep, F, scale_big, sigma2, coarse, ori, ctx=ctx)
+    assert gn > mn, (gn, mn)                                                # pairs inside the disc survive when one side is a stereo keypoint
     # octave outside the level tables is an argument error, not a fault
     bad = k2.copy(); bad["octave"][np.nonzero(e2)[0][0]] = 9
     with pytest.raises(fe.EorbError):
@@ -758,6 +771,20 @@ def test_kf_radius_match_fuse_sim3(oracle, fe, ctx):
     assert np.array_equal(obi, gbi) and np.array_equal(obd, gbd)
     fused = fe.Fuse(k1, d1, gb, valid, uv, level, scale, inv_sigma2, qd, th=3.0, ctx=ctx)
     assert np.array_equal(fused, np.where(obd <= 50, obi, -1)) and (fused >= 0).sum() > 100
+    # Fuse on a rectified-stereo KeyFrame: three-term error against 7.8 where the keypoint has a right coordinate (:1541-1553)
+    uright = np.where(rng.uniform(size=len(k1)) < 0.6, k1["x"] - rng.uniform(2, 30, len(k1)), -1).astype(np.float32)
+    q_ur = np.full(len(valid), -5, np.float32)
+    hit = obi >= 0
+    q_ur[hit] = np.where(uright[obi[hit]] >= 0, uright[obi[hit]], 0) + rng.normal(0, 1.5, hit.sum()).astype(np.float32)
+    sbi, sbd = oracle.kf_radius_match(F1, valid, uv, radius, level, qd, inv_sigma2=inv_sigma2, uright=uright, q_ur=q_ur)
+    gsi, gsd = fe.KeyFrameRadiusMatch(k1, d1, gb, valid, uv, radius, level, qd, inv_sigma2=inv_sigma2, uright=uright, q_ur=q_ur, ctx=ctx)
+    assert np.array_equal(sbi, gsi) and np.array_equal(sbd, gsd)
+    assert not np.array_equal(sbi, obi) and (sbi >= 0).sum() > 200             # the gate bites, both ways of it are taken
+    assert (uright[sbi[sbi >= 0]] >= 0).sum() > 50 and (uright[sbi[sbi >= 0]] < 0).sum() > 50
+    fs = fe.Fuse(k1, d1, gb, valid, uv, level, scale, inv_sigma2, qd, th=3.0, ctx=ctx, uright=uright, q_ur=q_ur)
+    assert np.array_equal(fs, np.where(sbd <= 50, sbi, -1))
+    with pytest.raises(ValueError):
+        fe.KeyFrameRadiusMatch(k1, d1, gb, valid, uv, radius, level, qd, uright=uright, q_ur=q_ur, ctx=ctx)
     # SearchByProjection(KeyFrame, Scw, vpPoints, vpMatched, th, ratioHamming): in-order with vpMatched
     taken0 = (rng.uniform(size=len(k1)) < 0.2).astype(np.uint8)
     for ratio in (1.0, 0.8):
