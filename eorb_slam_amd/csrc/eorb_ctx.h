@@ -132,6 +132,8 @@ struct eorb_ctx {
     // matcher workspaces
     eorb::DevBuf m_a, m_b, m_c, m_d, m_e, m_f, m_g, m_h, m_i, m_j;
     eorb::DevBuf win_ws;                 // candidate lists of the two-phase window matchers
+    eorb::DevBuf win_total;              // their per-pair entry counters: zero between calls (phase 2 puts its pair's back), win_total_n of them known to be
+    size_t win_total_n = 0;
     eorb::DevBuf arena;                  // host-buffer entry points: all inputs / outputs of one call, one H2D and one D2H copy
     void* dl_pinned = nullptr; size_t dl_cap = 0;      // pinned landing buffer of the D2H copy (the call synchronises before reading it)
     hipEvent_t dl_event = nullptr;                     // recorded behind that copy: what the call waits for
@@ -166,6 +168,7 @@ struct eorb_ctx {
     const float* pyr0_f32 = nullptr; const uint32_t* pyr0_mm = nullptr;
     int dbg_pool_shrink = 0, dbg_force_global = 0, dbg_oct_list = 0;      // (dbg_oct_list: the octree's list algorithm for every pass; applies at the next eorb_orb_configure)
     int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices), 4 slot lists (K2p)
+    int dbg_win_lds_ents = 0;                    // window matchers: entries phase 2 stages in LDS (to force its reads from global memory)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
     int dbg_slot_rank = -1;                      // slot form: -1 by the device check / EORB_SLOT_RANK, 0 ballot scatter, 1 rank scatter (if the check passed)
     long long dbg_slot_hot_min = -1;             // slot form: list length from which the register-row kernel takes a list (-1: default / EORB_SLOT_HOT_MIN)

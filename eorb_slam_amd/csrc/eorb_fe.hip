@@ -262,7 +262,7 @@ void eorb_destroy(eorb_ctx* c)
                       &c->blur, &c->cell_cnt, &c->cell_cand, &c->lvl_cnt, &c->lvl_kp, &c->kp_angle, &c->out_kp, &c->out_desc,
                       &c->out_oob, &c->out_n, &c->oct_scratch, &c->in_img, &c->m_a, &c->m_b, &c->m_c, &c->m_d, &c->m_e, &c->m_f,
                       &c->m_g, &c->m_h, &c->m_i, &c->m_j, &c->fe_prev_kp, &c->fe_prev_desc, &c->fe_prev_n, &c->fe_pm,
-                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->arena, &c->l1_ref_img, &c->l1_ref_pts, &c->ev_info, &c->ev_stamps, &c->pd_hash, &c->pd_lut, &c->pd_src_info, &c->pd_sl_tab, &c->pd_sl_tile, &c->pd_sl_rows, &c->pd_cnt};
+                      &c->orb.tabs, &c->orb.geom, &c->status, &c->win_ws, &c->win_total, &c->arena, &c->l1_ref_img, &c->l1_ref_pts, &c->ev_info, &c->ev_stamps, &c->pd_hash, &c->pd_lut, &c->pd_src_info, &c->pd_sl_tab, &c->pd_sl_tile, &c->pd_sl_rows, &c->pd_cnt};
     for (DevBuf* b : bufs) free_buf(*b);
     for (auto& s : c->pinned) { if (s.ev) hipEventDestroy(s.ev); if (s.p) hipHostFree(s.p); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -305,6 +305,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "octree_list_algorithm")) { c->dbg_oct_list = value; return EORB_OK; }
     if (!strcmp(name, "win_list_cap")) { c->dbg_win_wcap = value; return EORB_OK; }
     if (!strcmp(name, "win_pool_cap")) { c->dbg_win_ecap = value; return EORB_OK; }
+    if (!strcmp(name, "win_lds_entries")) { c->dbg_win_lds_ents = value; return EORB_OK; }
     if (!strcmp(name, "gather_form")) { c->dbg_gather_form = value; return EORB_OK; }
     if (!strcmp(name, "dedupe_min_events")) { c->dbg_dd_min = value; return EORB_OK; }
     if (!strcmp(name, "slot_rank")) { c->dbg_slot_rank = value; return EORB_OK; }

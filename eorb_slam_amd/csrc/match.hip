@@ -152,18 +152,21 @@ __device__ __forceinline__ void block_top2(uint64_t& k0, uint64_t& k1, uint64_t*
 }
 
 // ComputeThreeMaxima (ORBmatcher.cc:2314-2355)
+// (selects on locals: the if / else-if ladder over reference arguments was compiled to 150 scratch accesses per thread)
 __device__ __forceinline__ void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3)
 {
     int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
+    int a = -1, b = -1, c = -1;
     for (int i = 0; i < L; i++) {
         const int s = histo[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
+        const bool g1 = s > max1, g2 = s > max2, g3 = s > max3;      // (max1 >= max2 >= max3: g1 implies g2 implies g3)
+        c = g2 ? b : (g3 ? i : c); max3 = g2 ? max2 : (g3 ? s : max3);
+        b = g1 ? a : (g2 ? i : b); max2 = g1 ? max1 : (g2 ? s : max2);
+        a = g1 ? i : a;            max1 = g1 ? s : max1;
     }
-    if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+    if ((float)max2 < 0.1f * (float)max1) { b = -1; c = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { c = -1; }
+    ind1 = a; ind2 = b; ind3 = c;
 }
 
 __device__ __forceinline__ int kp_level(const eorb_keypoint& k, bool isorb)
@@ -207,6 +210,7 @@ struct WinArgs {
     GridB g; float nnratio; int checkOri;
     int dmax;                  // phase 1 keeps candidates with dist < dmax
     int wcap;                  // list capacity of one query
+    int lds_ents;              // entries of a pair that phase 2 holds in LDS
     // phase-1 products (per pair)
     uint64_t* ent; int ecap; uint32_t* off; uint32_t* cnt; uint32_t* total;
     // results
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
         uint32_t off = 0, cnt = n;
         if (n > (uint32_t)A.wcap) cnt = kWinOver;
         else if (n > 0) {
-            if (lane == 0) off = atomicAdd(&A.total[pair], n);
+            if (lane == 0) off = atomicAdd(&A.total[pair], n) & 0x7FFFFFFFu;
             off = (uint32_t)__shfl((int)off, 0, 64);
             if (off + n > (uint32_t)A.ecap) cnt = kWinOver;           // the pair's pool is full
             else {
@@ -360,7 +364,10 @@ __global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
                 }
             }
         }
-        if (lane == 0) { A.cnt[(size_t)pair * A.capq + q] = cnt; A.off[(size_t)pair * A.capq + q] = off; }
+        if (lane == 0) {
+            A.cnt[(size_t)pair * A.capq + q] = cnt; A.off[(size_t)pair * A.capq + q] = off;
+            if (cnt == kWinOver) atomicOr(&A.total[pair], 0x80000000u);          // (bit 31 of the pair's counter: some list overflowed; phase 2 reads it there)
+        }
     }
 }
 
@@ -392,7 +399,32 @@ __device__ __forceinline__ void wave_top2(uint64_t& k0, uint64_t& k1)
     k0 = b0; k1 = b1;
 }
 
-constexpr int kWinLdsEntries = 6144;      // entries of a pair staged in LDS by phase 2 (the rest is read from global memory)
+constexpr int kWinLdsEntries = 6144;      // least number of a pair's entries that phase 2 stages in LDS (WinArgs::lds_ents: as many as fit; the rest is read from global memory)
+
+__device__ __forceinline__ int wave_sum_i32(int v) { for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+
+// histo[b] += 1 for every lane with b >= 0: one LDS atomic per distinct bin of the wavefront (matches of one frame pair share two or
+// three rotation bins: lane-wise atomics on them serialise, 540 of them cost 2 us)
+__device__ __forceinline__ void wave_histo_add(int* histo, int b, int lane)
+{
+    uint64_t todo = __ballot(b >= 0);
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        const int bb = __shfl(b, l, 64);
+        const uint64_t same = __ballot(b == bb);
+        if (lane == l) atomicAdd(&histo[bb], (int)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+// entry e of a pair: from LDS, or from the pool in global memory beyond what LDS holds.  (Written as "cond ? ents[e] : gent[e]" the
+// compiler selects between the two POINTERS and emits one flat load: every walk step then goes through the flat path.)
+__device__ __forceinline__ uint64_t win_entry(const uint64_t* ents, const uint64_t* __restrict__ gent, uint32_t e, uint32_t nlds)
+{
+    uint64_t k = ents[min(e, nlds - 1u)];
+    if (e >= nlds) k = *(const volatile uint64_t*)(gent + e);        // (volatile: not to be merged with the LDS read into one flat load either)
+    return k;
+}
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
@@ -403,47 +435,92 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
     const int N2 = A.n2p ? A.n2p[pair] : A.n2;
     const int NQ = A.nqp ? A.nqp[pair] : A.nq;
     const int c2 = A.cap2, cq = A.capq;
+#ifdef EORB_WIN_TIMING       // (experiment builds only: where the kernel's time goes, printed by pair 0)
+    __shared__ long long s_wt[8]; __shared__ int s_wn[8];
+    long long wt_last = clock64();
+    if (threadIdx.x < 8) { s_wt[threadIdx.x] = 0; s_wn[threadIdx.x] = 0; }
+#define WIN_T(k) do { if (threadIdx.x == 0) { const long long t_now = clock64(); s_wt[k] += t_now - wt_last; s_wn[k]++; wt_last = t_now; } } while (0)
+#else
+#define WIN_T(k) do { } while (0)
+#endif
     // LDS carve-up
-    uint64_t* ents = (uint64_t*)smem;                                 // kWinLdsEntries
-    uint32_t* offs = (uint32_t*)(ents + kWinLdsEntries);              // cq
+    const uint32_t nlds = (uint32_t)A.lds_ents;
+    uint64_t* ents = (uint64_t*)smem;                                 // lds_ents
+    uint32_t* offs = (uint32_t*)(ents + nlds);                        // cq
     uint32_t* cnts = offs + cq;                                       // cq
     int* histo = (int*)(cnts + cq);                                   // 32
-    int* sh_nm = histo + 32;                                          // 4
+    int* sh_nm = histo + 32;                                          // 4: matches, -, the fixed points' "somebody changed" words (2)
+    unsigned int* sflag = (unsigned int*)(sh_nm + 2);
     int* st_a = sh_nm + 4;                                            // c2: KIND 0 vMatchedDistance, else the slot -> map point table
     int* match_at = st_a + c2;                                        // cq: candidate matched by query q when it was processed (-1: none)
     int16_t* m21 = (int16_t*)(match_at + cq);                         // c2: KIND 0 vnMatches21 (-1: none)  [cap1 < 32768]
     uint8_t* obs = (uint8_t*)(m21 + c2);                              // c2: KIND 1/2 "slot holds an observed map point"
     uint8_t* qobs = obs + c2;                                         // cq: KIND 1/2 mp_obs of the query's map point
-    unsigned int* claim = (unsigned int*)(((uintptr_t)(qobs + cq) + 3) & ~(uintptr_t)3);   // c2: earliest query of the round matching the candidate
-    int* fx = (int*)(claim + c2);                                     // KIND 0 fixed point: 4 x cq (match / distance of the next sweep, chain links, distances)
+    unsigned int* claim = (unsigned int*)(smem + (((size_t)((unsigned char*)(qobs + cq) - smem) + 3) & ~(size_t)3));   // 2 x c2 (an offset from smem, not a cast through an integer: the accesses stay LDS instructions): earliest query of the round / sweep matching the candidate
+    float* ang2 = (float*)(claim + 2 * (c2 + 1));                     // c2: the searched keypoints' angles (rotation histogram)
+    int* fx = (int*)(ang2 + c2);                                      // KIND 0 fixed point: 4 x cq (match / distance of the next sweep, chain links, distances)
     int32_t* M12 = A.matches12 ? A.matches12 + (size_t)pair * cq : nullptr;
     const uint64_t* gent = A.ent + (size_t)pair * A.ecap;
-    const uint32_t total = min(A.total[pair], (uint32_t)A.ecap);
-    for (uint32_t i = tid; i < min(total, (uint32_t)kWinLdsEntries); i += blockDim.x) ents[i] = gent[i];
-    for (int i = tid; i < NQ; i += blockDim.x) {
+    const eorb_keypoint* K2s = A.kps2 + (size_t)pair * A.kp2_stride;
+    // set-up: every global load that depends on nothing is issued before the first wait (a load is ~ 1 500 cycles here and the
+    // loops below would take them one after the other: 11 000 cycles of 1 024 threads waiting)
+    const int bd = (int)blockDim.x;
+    uint32_t r_off[2], r_cnt[2]; uint8_t r_qo[2]; int r_slot[2]; float r_ang[2], r_qang[2];
+    const eorb_keypoint* KQ = KIND == 0 ? A.kps1 + (size_t)pair * A.kp1_stride : A.qkps;       // the queries' keypoints (rotation histogram)
+    const uint32_t total_raw = A.total[pair];
+    const uint32_t total = min(total_raw & 0x7FFFFFFFu, (uint32_t)A.ecap);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = tid + u * bd;
+        r_off[u] = 0; r_cnt[u] = 0; r_qo[u] = 0; r_slot[u] = -1; r_ang[u] = 0.f; r_qang[u] = 0.f;
+        if (i < NQ && KIND != 2 && A.checkOri) r_qang[u] = KQ[i].angle;
+        if (i < NQ) { r_off[u] = A.off[(size_t)pair * cq + i]; r_cnt[u] = A.cnt[(size_t)pair * cq + i]; if (KIND != 0) r_qo[u] = A.mp_obs[i]; }
+        if (i < N2) { if (KIND != 0) r_slot[u] = A.slot_mp[i]; if (A.checkOri) r_ang[u] = K2s[i].angle; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = tid + u * bd;
+        if (i < NQ) { offs[i] = r_off[u]; cnts[i] = r_cnt[u]; match_at[i] = -1; if (KIND != 0) qobs[i] = r_qo[u] != 0; }
+    }
+    for (int i = tid + 2 * bd; i < NQ; i += bd) {
         offs[i] = A.off[(size_t)pair * cq + i]; cnts[i] = A.cnt[(size_t)pair * cq + i];
         match_at[i] = -1;
         if (KIND != 0) qobs[i] = A.mp_obs[i] != 0;
     }
-    for (int i = tid; i < N2; i += blockDim.x) {
-        claim[i] = 0xFFFFFFFFu;
-        if (KIND == 0) { st_a[i] = 0x7fffffff; m21[i] = -1; }
-        else {
-            // "if(F.getMapPoint(idx)) if(F.getMapPoint(idx)->Observations()>0) continue;" (:91-93, :2045-2047): slot values
-            // -1 / -3 = empty or unobserved, -2 = holds an observed map point, v >= 0 = map point v
-            const int v = A.slot_mp[i];
-            st_a[i] = v;
-            obs[i] = (v == -2) ? 1 : ((v >= 0) ? (A.mp_obs[v] != 0) : 0);
+    {   // eight loads in flight per thread
+        const uint32_t nst = min(total, nlds);
+        for (uint32_t i0 = 0; i0 < nst; i0 += 8u * (uint32_t)bd) {
+            uint64_t t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)(u * bd + tid); t8[u] = i < nst ? gent[i] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = i0 + (uint32_t)(u * bd + tid); if (i < nst) ents[i] = t8[u]; }
         }
     }
-    if (KIND == 0 && M12) for (int i = tid; i < NQ; i += blockDim.x) M12[i] = -1;
+    // slot values of KIND 1 / 2: "if(F.getMapPoint(idx)) if(F.getMapPoint(idx)->Observations()>0) continue;" (:91-93, :2045-2047):
+    // -1 / -3 = empty or unobserved, -2 = holds an observed map point, v >= 0 = map point v
+    auto slot_in = [&](int i, int v, float ang) {
+        if (KIND == 0) { st_a[i] = 0x7fffffff; m21[i] = -1; }
+        else { st_a[i] = v; obs[i] = (v == -2) ? 1 : ((v >= 0) ? (A.mp_obs[v] != 0) : 0); }
+        if (A.checkOri) ang2[i] = ang;
+    };
+#pragma unroll
+    for (int u = 0; u < 2; u++) { const int i = tid + u * bd; if (i < N2) slot_in(i, r_slot[u], r_ang[u]); }
+    for (int i = tid + 2 * bd; i < N2; i += bd) slot_in(i, KIND != 0 ? A.slot_mp[i] : -1, A.checkOri ? K2s[i].angle : 0.f);
     if (tid < 32) histo[tid] = 0;
-    if (tid == 0) sh_nm[0] = 0;
-    int over_any = 0;
-    if (KIND != 2) for (int i = tid; i < NQ; i += blockDim.x) over_any |= (A.cnt[(size_t)pair * cq + i] == kWinOver) ? 1 : 0;
-    const bool no_over = KIND != 2 && !__syncthreads_or(over_any);         // (also the barrier behind the LDS set-up)
+    if (tid < 4) sh_nm[tid] = 0;
+    const bool no_over = KIND != 2 && (total_raw >> 31) == 0u;          // (no list of the pair overflowed: phase 1 says so in the counter)
+    __syncthreads();
     const bool fixpoint = KIND == 1 && no_over, fixpoint0 = KIND == 0 && no_over;
-    if (KIND == 2) __syncthreads();
+    // claims: the walk's are "earliest lane of the round" (empty = ~0); the fixed point's are tagged by their sweep (empty = 0), in two
+    // buffers of c2 + 1 words: ~0 = closed for good (an observed map point in the slot; word c2 stands for "no entry")
+    for (int i = tid; i < 2 * (c2 + 1); i += bd) {
+        const int ii = i > c2 ? i - (c2 + 1) : i;
+        claim[i] = !fixpoint || ii == c2 || (ii < N2 && obs[ii] != 0) ? 0xFFFFFFFFu : 0u;
+    }
+    if (KIND == 0 && !fixpoint0) for (int i = tid; i < NQ; i += bd) M12[i] = -1;      // (the walk keeps vnMatches12 in global memory)
+    __syncthreads();
+    WIN_T(0);
 
     if (fixpoint) {
         // SearchByProjection(cur, last / KeyFrame): a query takes the FIRST entry of its sorted list whose candidate is free (no
@@ -453,38 +530,68 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
         // with an observed map point has taken", iterated from "nobody has taken anything": query 0 is final after one sweep, and
         // each sweep finalises at least the first query that still changed -- in practice three to five sweeps settle a window of
         // 1 024 queries (dependency chains are short), where the walk below spends a round per conflict.
+        // One barrier per sweep: the claims of sweep s go to buffer s & 1 tagged with s (atomicMax of s << 16 | 0xFFFF - tid: a newer
+        // sweep beats what the buffer still holds, the earliest query wins inside a sweep), sweep s reads buffer (s - 1) & 1 and takes
+        // only tags s - 1, nobody clears anything; "somebody changed" is the word sflag[s & 1] == s.
         int nm = 0;
+        uint32_t s = 1;
         for (int base = 0; base < NQ; base += (int)blockDim.x) {
             const int q = base + tid;
             const uint32_t c = q < NQ ? cnts[q] : 0u;
             const uint32_t o = q < NQ ? offs[q] : 0u;
             const bool blocks = q < NQ && qobs[q] != 0;
             int pick = -1;
-            for (;;) {
-                int np = -1;
-                for (uint32_t j = 0; j < c; j++) {
-                    const uint32_t e = o + j;
-                    const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
-                    const int idx = (int)((key >> 8) & 0xffffffu), dist = (int)(key >> 44);
-                    if (obs[idx] == 0 && dist < 256 && !(claim[idx] < (unsigned int)tid)) { if (dist <= A.dist_th) np = idx; break; }
+            // A sweep lasts as long as its slowest wavefront, and sixteen of them share the four SIMDs of one CU: what counts is the
+            // instructions of a sweep.  Per entry one LDS word and one compare: a candidate is free for query tid in sweep s iff its
+            // word is <= T = (s - 1) << 16 | 0xFFFF - tid (older tags are smaller, a claimant after tid has a smaller low half, ~0 is
+            // a closed slot); the tests on the distance are vacuous here (phase 1 listed dist < dmax <= min(dist_th + 1, 256)).  The
+            // candidates of the first eight entries (the longest walks of a crowded frame are about that long) stay in registers.
+            auto cand4 = [&](uint32_t j0, uint32_t* a4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    a4[u] = (uint32_t)c2;
+                    if (j0 + (uint32_t)u < c) a4[u] = (uint32_t)((win_entry(ents, gent, o + j0 + (uint32_t)u, nlds) >> 8) & 0xffffffu);
                 }
-                const int changed = np != pick;
-                __syncthreads();                                        // every thread has read the claims of this sweep
-                if (changed && pick >= 0 && blocks) claim[pick] = 0xFFFFFFFFu;
-                __syncthreads();
-                // (a claim cleared above may belong to a candidate other threads still hold: they put it back)
+            };
+            uint32_t f4[4], g4[4];
+            cand4(0, f4); cand4(4, g4);
+            for (;; s++) {
+                unsigned int* wr = claim + ((s & 1u) ? (uint32_t)(c2 + 1) : 0u);            // buffer s & 1
+                const unsigned int* rd = claim + ((s & 1u) ? 0u : (uint32_t)(c2 + 1));      // buffer (s - 1) & 1
+                const unsigned int T = ((s - 1u) << 16) | (0xFFFFu - (unsigned int)tid);
+                int np = -1;
+                {
+                    const unsigned int v0 = rd[f4[0]], v1 = rd[f4[1]], v2 = rd[f4[2]], v3 = rd[f4[3]];
+                    np = v0 <= T ? (int)f4[0] : v1 <= T ? (int)f4[1] : v2 <= T ? (int)f4[2] : v3 <= T ? (int)f4[3] : -1;
+                }
+                if (np < 0 && c > 4u) {
+                    const unsigned int v0 = rd[g4[0]], v1 = rd[g4[1]], v2 = rd[g4[2]], v3 = rd[g4[3]];
+                    np = v0 <= T ? (int)g4[0] : v1 <= T ? (int)g4[1] : v2 <= T ? (int)g4[2] : v3 <= T ? (int)g4[3] : -1;
+                }
+                for (uint32_t j0 = 8; np < 0 && j0 < c; j0 += 4) {
+                    uint32_t a4[4];
+                    cand4(j0, a4);
+                    const unsigned int v0 = rd[a4[0]], v1 = rd[a4[1]], v2 = rd[a4[2]], v3 = rd[a4[3]];
+                    np = v0 <= T ? (int)a4[0] : v1 <= T ? (int)a4[1] : v2 <= T ? (int)a4[2] : v3 <= T ? (int)a4[3] : -1;
+                }
+                if (np >= 0 && blocks) atomicMax(&wr[np], (s << 16) | (0xFFFFu - (unsigned int)tid));
+                if (np != pick) sflag[s & 1u] = s;
                 pick = np;
-                if (pick >= 0 && blocks) atomicMin(&claim[pick], (unsigned int)tid);
-                if (!__syncthreads_or(changed)) break;
+                __syncthreads();
+                WIN_T(1);
+                if (sflag[s & 1u] != s) break;
             }
+            s += 2;                                                     // (the next window must not meet this one's last claims)
             // the window's commits: the LAST query that took a candidate owns its slot; an observed map point closes it
             if (pick >= 0) { match_at[q] = pick; st_a[pick] = -1; nm++; }      // (the slot's old content -- empty or an unobserved map point -- goes)
             __syncthreads();
             if (pick >= 0) atomicMax(&st_a[pick], q);
-            if (pick >= 0 && blocks) { obs[pick] = 1; claim[pick] = 0xFFFFFFFFu; }
+            if (pick >= 0 && blocks) { claim[pick] = 0xFFFFFFFFu; claim[c2 + 1 + pick] = 0xFFFFFFFFu; }
             __syncthreads();
+            WIN_T(2);
         }
-        if (nm) atomicAdd(&sh_nm[0], nm);
+        nm = wave_sum_i32(nm);
+        if (lane == 0 && nm) atomicAdd(&sh_nm[0], nm);
     } else if (fixpoint0) {
         // SearchForInitialization (:714-831): query q skips a candidate whose vMatchedDistance is <= its distance (:755), i.e. a candidate
         // that an EARLIER query matched at a distance <= its own; among the rest its best / second best decide whether it matches its
@@ -506,7 +613,7 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
                 int found = 0;
                 for (uint32_t j = 0; j < c && found < 2; j++) {
                     const uint32_t e = o + j;
-                    const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
+                    const uint64_t key = win_entry(ents, gent, e, nlds);
                     const int idx = (int)((key >> 8) & 0xffffffu), dist = (int)(key >> 44);
                     int D = 0x7fffffff;                                       // vMatchedDistance[idx] as query q finds it
                     for (int p2 = st_a[idx]; p2 >= 0; p2 = nxt[p2]) if (p2 < q) D = min(D, dcur[p2]);
@@ -520,7 +627,10 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
                 mnew[q] = m; dnew[q] = d;
                 changed |= (m != mcur[q]) ? 1 : 0;
             }
-            if (!__syncthreads_or(changed)) break;                            // (mnew == mcur: the chains already describe the final matches)
+            if (changed) sflag[sweep & 1] = (unsigned int)sweep + 1u;         // ("somebody changed" as a tagged word: one plain barrier)
+            __syncthreads();
+            WIN_T(1);
+            if (sflag[sweep & 1] != (unsigned int)sweep + 1u) break;          // (mnew == mcur: the chains already describe the final matches)
             { int* t = mcur; mcur = mnew; mnew = t; t = dcur; dcur = dnew; dnew = t; }
             for (int i = tid; i < N2; i += blockDim.x) st_a[i] = -1;
             __syncthreads();
@@ -531,13 +641,16 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
         // its matchers (each later one came with a strictly smaller distance and took it over, :774-781)
         if (mcur != match_at) { for (int q = tid; q < NQ; q += blockDim.x) match_at[q] = mcur[q]; }
         __syncthreads();
+        for (int q = tid; q < NQ; q += blockDim.x) fx[q] = -1;                // vnMatches12 while the kernel still works on it
+        __syncthreads();
         int nm = 0;
         for (int i = tid; i < N2; i += blockDim.x) {
             int owner = -1;
             for (int p2 = st_a[i]; p2 >= 0; p2 = nxt[p2]) owner = max(owner, p2);
-            if (owner >= 0) { M12[owner] = i; nm++; }
+            if (owner >= 0) { fx[owner] = i; nm++; }
         }
-        if (nm) atomicAdd(&sh_nm[0], nm);
+        nm = wave_sum_i32(nm);
+        if (lane == 0 && nm) atomicAdd(&sh_nm[0], nm);
     } else if (wave == 0) {
         // The queries are walked in order, 64 at a time (lane = query).  Every lane evaluates its query against the committed
         // state; a query commits in this round only if no EARLIER query of the round changes a candidate it depends on.  The state
@@ -628,14 +741,14 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
                 // passing entries are almost always among them), the rest of the list one by one
                 uint64_t e4[4]; bool p4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const uint32_t e = o + (uint32_t)u; e4[u] = (uint32_t)u < c ? (e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e]) : ~0ull; }
+                for (int u = 0; u < 4; u++) { const uint32_t e = o + (uint32_t)u; e4[u] = (uint32_t)u < c ? win_entry(ents, gent, e, nlds) : ~0ull; }
 #pragma unroll
                 for (int u = 0; u < 4; u++) p4[u] = e4[u] != ~0ull && passes(e4[u]);
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (p4[u] && found < need) { if (found == 0) k0 = e4[u]; else k1 = e4[u]; found++; }
                 for (uint32_t j = 4; j < c && found < need; j++) {
                     const uint32_t e = o + j;
-                    const uint64_t key = e < (uint32_t)kWinLdsEntries ? ents[e] : gent[e];
+                    const uint64_t key = win_entry(ents, gent, e, nlds);
                     if (passes(key)) { if (found == 0) k0 = key; else k1 = key; found++; }
                 }
             }
@@ -657,50 +770,56 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
         if (lane == 0) sh_nm[0] = nm;
     }
     __syncthreads();
+    WIN_T(3);
     if (KIND == 0) {
-        const eorb_keypoint* K1 = A.kps1 + (size_t)pair * A.kp1_stride;
-        const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
         int8_t* bin1 = (int8_t*)qobs;                                  // free in this kind: the bin of query q's push
+        int* m12s = fx;                                                // vnMatches12 in LDS until the last loop
+        if (!fixpoint0) { for (int i = tid; i < NQ; i += bd) m12s[i] = M12[i]; __syncthreads(); }
         if (A.checkOri) {
             // rotHist[bin].push_back(i1) happened for every match when it was made (:785-797), stolen ones included
-            for (int i = tid; i < NQ; i += blockDim.x) {
-                const int m = match_at[i];
+            auto push = [&](int i, float qang, bool have) {                // (called by whole wavefronts)
                 int b = -1;
-                if (m >= 0) { b = rot_bin(K1[i].angle, K2[m].angle); atomicAdd(&histo[b], 1); }
-                bin1[i] = (int8_t)b;
-            }
+                if (i < NQ) { const int m = match_at[i]; if (m >= 0) b = rot_bin(have ? qang : KQ[i].angle, ang2[m]); bin1[i] = (int8_t)b; }
+                wave_histo_add(histo, b, lane);
+            };
+            push(tid, r_qang[0], true);
+            if (bd < NQ) push(tid + bd, r_qang[1], true);
+            for (int i0 = 2 * bd; i0 < NQ; i0 += bd) push(i0 + tid, 0.f, false);
             __syncthreads();
             int ind1, ind2, ind3;
             three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
             int dec = 0;
-            for (int i = tid; i < NQ; i += blockDim.x) {
+            for (int i = tid; i < NQ; i += bd) {
                 const int b = bin1[i];
-                if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && M12[i] >= 0) { M12[i] = -1; dec++; }
+                if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && m12s[i] >= 0) { m12s[i] = -1; dec++; }
             }
-            if (dec) atomicSub(&sh_nm[0], dec);
-            __threadfence_block();
+            dec = wave_sum_i32(dec);
+            if (lane == 0 && dec) atomicSub(&sh_nm[0], dec);
             __syncthreads();
         }
-        if (A.prev_matched) {
-            float* PM = A.prev_matched + (size_t)pair * cq * 2;
-            for (int i = tid; i < NQ; i += blockDim.x) {
-                const int m = M12[i];
-                if (m >= 0) { const eorb_keypoint k = K2[m]; PM[2 * i] = k.x; PM[2 * i + 1] = k.y; }
-            }
+        float* PM = A.prev_matched ? A.prev_matched + (size_t)pair * cq * 2 : nullptr;
+        for (int i = tid; i < NQ; i += bd) {
+            const int m = m12s[i];
+            M12[i] = m;
+            if (PM && m >= 0) { const eorb_keypoint k = K2s[m]; PM[2 * i] = k.x; PM[2 * i + 1] = k.y; }
         }
     } else {
         if (KIND == 1 && A.checkOri) {
             // rotHist[bin].push_back(bestIdx2) per match (:2146-2160); losing bins: setMapPoint(idx, NULL), nmatches-- per push
-            unsigned int* hbin = (unsigned int*)ents;                  // the entry buffer is free now: c2 words (c2 <= 2 * kWinLdsEntries)
-            for (int i = tid; i < N2; i += blockDim.x) hbin[i] = 0u;
+            unsigned int* hbin = (unsigned int*)ents;                  // the entry buffer is free now: c2 words (c2 <= 2 * kWinLdsEntries <= 2 * lds_ents)
+            for (int i = tid; i < N2; i += bd) hbin[i] = 0u;
             __syncthreads();
-            for (int i = tid; i < NQ; i += blockDim.x) {
-                const int m = match_at[i];
-                if (m >= 0) {
-                    const int b = rot_bin(A.qkps[i].angle, A.kps2[m].angle);
-                    atomicAdd(&histo[b], 1); atomicOr(&hbin[m], 1u << b);
+            auto push = [&](int i, float qang, bool have) {                // (called by whole wavefronts)
+                int b = -1;
+                if (i < NQ) {
+                    const int m = match_at[i];
+                    if (m >= 0) { b = rot_bin(have ? qang : KQ[i].angle, ang2[m]); atomicOr(&hbin[m], 1u << b); }
                 }
-            }
+                wave_histo_add(histo, b, lane);
+            };
+            push(tid, r_qang[0], true);
+            if (bd < NQ) push(tid + bd, r_qang[1], true);
+            for (int i0 = 2 * bd; i0 < NQ; i0 += bd) push(i0 + tid, 0.f, false);
             __syncthreads();
             int ind1, ind2, ind3;
             three_maxima(histo, HISTO_LENGTH, ind1, ind2, ind3);
@@ -708,24 +827,30 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
             if (ind1 >= 0) keep |= 1u << ind1;
             if (ind2 >= 0) keep |= 1u << ind2;
             if (ind3 >= 0) keep |= 1u << ind3;
-            for (int i = tid; i < N2; i += blockDim.x)
+            for (int i = tid; i < N2; i += bd)
                 if (hbin[i] & ~keep) st_a[i] = -1;
-            if (tid == 0) {
-                int dec = 0;
-                for (int b = 0; b < HISTO_LENGTH; b++) if (!(keep & (1u << b))) dec += histo[b];
-                sh_nm[0] -= dec;
+            if (wave == 0) {
+                const int dec = wave_sum_i32((lane < HISTO_LENGTH && !(keep & (1u << lane))) ? histo[lane] : 0);
+                if (lane == 0) sh_nm[0] -= dec;
             }
             __syncthreads();
         }
-        for (int i = tid; i < N2; i += blockDim.x) A.slot_mp[i] = st_a[i];
+        for (int i = tid; i < N2; i += bd) A.slot_mp[i] = st_a[i];
     }
-    if (tid == 0) A.nmatches[pair] = sh_nm[0];
+    if (tid == 0) { A.nmatches[pair] = sh_nm[0]; A.total[pair] = 0u; }        // (the counter goes back to zero for the next call's phase 1)
+#ifdef EORB_WIN_TIMING
+    WIN_T(4);
+    if (tid == 0 && pair == 0)
+        printf("win_resolve<%d> NQ %d N2 %d entries %u: set-up %lld | sweeps %d x %lld | commits %d x %lld | tail of the walk %lld | histogram + outputs %lld (clock64 ticks)\n", KIND, NQ, N2, total,
+               s_wt[0], s_wn[1], s_wn[1] ? s_wt[1] / s_wn[1] : 0, s_wn[2], s_wn[2] ? s_wt[2] / s_wn[2] : 0, s_wt[3], s_wt[4]);
+#endif
 }
 
 static size_t win_cand_lds(int cap2, int wcap) { return ((size_t)cap2 * (32 + 4 + 4 + 4) + (size_t)4 * wcap * 8 + 15) & ~(size_t)15; }
-static size_t win_resolve_lds(int cap2, int capq)
+// phase 2's LDS without the entries: offs, cnts, match_at, qobs, fx per query; st_a, m21, obs, two claim buffers, angle per searched keypoint
+static size_t win_resolve_lds_rest(int cap2, int capq)
 {
-    return ((size_t)kWinLdsEntries * 8 + (size_t)capq * (4 + 4 + 4 + 1 + 16) + (32 + 4) * 4 + (size_t)cap2 * (4 + 2 + 1 + 4) + 8 + 15) & ~(size_t)15;
+    return ((size_t)capq * (4 + 4 + 4 + 1 + 16) + (32 + 4) * 4 + (size_t)cap2 * (4 + 2 + 1 + 8 + 4) + 16 + 15) & ~(size_t)15;
 }
 
 // smallest d in [lo, 256] for which pred(d) holds, else 257 (= keep every candidate)
@@ -738,18 +863,31 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     if (A.cap2 > 2 * kWinLdsEntries) return set_err(c, EORB_E_CAPACITY, "%s: %d keypoints in the searched frame (limit %d)", name, A.cap2, 2 * kWinLdsEntries);
     A.wcap = c->dbg_win_wcap > 0 ? c->dbg_win_wcap : 512;
     A.ecap = c->dbg_win_ecap > 0 ? c->dbg_win_ecap : std::max(4096, 16 * A.capq);
-    const size_t lds1 = win_cand_lds(A.cap2, A.wcap), lds2 = win_resolve_lds(A.cap2, A.capq);
-    if (lds1 > 159 * 1024 || lds2 > 159 * 1024)        // (the kernels own a few words of static LDS besides)
+    // phase 2 keeps as many of a pair's entries in LDS as fit beside its tables (one read from global memory inside a sweep is what the
+    // whole workgroup then waits for at the sweep's barrier), at least kWinLdsEntries
+    const size_t lds1 = win_cand_lds(A.cap2, A.wcap), rest2 = win_resolve_lds_rest(A.cap2, A.capq);
+    A.lds_ents = (int)std::min<size_t>((size_t)A.ecap, rest2 < 159 * 1024 ? (159 * 1024 - rest2) / 8 : 0);
+    const bool fits = A.lds_ents >= std::min(A.ecap, kWinLdsEntries);
+    if (c->dbg_win_lds_ents > 0) A.lds_ents = std::min(A.lds_ents, std::max(c->dbg_win_lds_ents, (A.cap2 + 1) / 2));      // (the rotation histogram's bin masks reuse the buffer)
+    const size_t lds2 = (size_t)A.lds_ents * 8 + rest2;
+    if (lds1 > 159 * 1024 || !fits)        // (the kernels own a few words of static LDS besides)
         return set_err(c, EORB_E_CAPACITY, "%s: %zu / %zu B of LDS needed (searched frame %d, queries %d)", name, lds1, lds2, A.cap2, A.capq);
     int rc;
     // phase-1 products: entries | off | cnt | total
     const size_t ent_b = sizeof(uint64_t) * (size_t)npairs * A.ecap, oc_b = sizeof(uint32_t) * (size_t)npairs * A.capq;
-    if ((rc = ensure(c, c->win_ws, ent_b + 2 * oc_b + sizeof(uint32_t) * (size_t)npairs + 64))) return rc;
+    if ((rc = ensure(c, c->win_ws, ent_b + 2 * oc_b + 64))) return rc;
     A.ent = (uint64_t*)c->win_ws.p;
     A.off = (uint32_t*)((char*)c->win_ws.p + ent_b);
     A.cnt = A.off + (size_t)npairs * A.capq;
-    A.total = A.cnt + (size_t)npairs * A.capq;
-    EORB_HIP(c, hipMemsetAsync(A.total, 0, sizeof(uint32_t) * (size_t)npairs, c->stream));
+    // the pairs' entry counters start at zero: phase 2 leaves them so (a fill per call is a dependent launch of its own: 4 + 3 us)
+    if (c->win_total_n < (size_t)npairs) {
+        if ((rc = ensure(c, c->win_total, sizeof(uint32_t) * (size_t)npairs))) return rc;
+        EORB_HIP(c, hipMemsetAsync(c->win_total.p, 0, c->win_total.cap, c->stream));
+        c->win_total_n = c->win_total.cap / sizeof(uint32_t);
+    }
+    A.total = (uint32_t*)c->win_total.p;
+    const size_t total_n = c->win_total_n;
+    c->win_total_n = 0;                                 // (until both phases are known to have been launched)
     // per device, not per process: a second context on another GPU needs the opt-in too (the call is cheap)
     EORB_HIP(c, hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
     EORB_HIP(c, hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
@@ -759,9 +897,10 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     static const int qpb_env = [] { const char* e = getenv("EORB_WIN_QPB"); return e ? atoi(e) : 0; }();      // (A/B runs)
     const int qpb = qpb_env > 0 ? qpb_env : (npairs >= 8 ? 32 : 4);
     win_cand_kernel<KIND><<<dim3((nq_max + qpb - 1) / qpb, npairs), 256, lds1, c->stream>>>(A, qpb);
-    // (SearchByProjection(cur, last): its fixed-point sweeps settle a window of blockDim queries at a time: the widest block)
-    win_resolve_kernel<KIND><<<npairs, KIND == 1 ? 1024 : 256, lds2, c->stream>>>(A);
+    // (the fixed points of SearchForInitialization and SearchByProjection(cur, last) settle a window of blockDim queries at a time: the widest block)
+    win_resolve_kernel<KIND><<<npairs, KIND == 2 ? 256 : 1024, lds2, c->stream>>>(A);
     EORB_LAUNCH_CHECK(c, name);
+    c->win_total_n = total_n;
     return EORB_OK;
 }
 
@@ -801,7 +940,8 @@ int search_proj_last_dev(eorb_ctx* c, const eorb_keypoint* cur_kps, int n_cur, c
     A.mp_desc = mp_desc; A.mp_obs = mp_obs;
     A.g = GridB{gb.minX, gb.minY, gb.invW, gb.invH};
     A.slot_mp = cur_mp; A.th = th; A.mode = mode; A.checkOri = checkOri; A.nmatches = nmatches;
-    A.dmax = std::min(std::max(dist_th, 0) + 1, 256);               // best only: "if(bestDist<=TH_HIGH)" (:2140), bestDist starts at 256
+    A.dmax = dist_th < 0 ? 0 : std::min(dist_th + 1, 256);          // best only: "if(bestDist<=TH_HIGH)" (:2140), bestDist starts at 256: every listed candidate
+                                                                    // passes both tests, which phase 2's fixed point relies on
     return launch_win<1>(c, A, 1, n_last, "search_proj_last");
 }
 

@@ -477,11 +477,14 @@ def test_search_by_projection_map_mixed_gate(oracle, fe, ctx):
     assert on > 10 and on_plain != on
 
 
-@pytest.mark.parametrize("wcap,ecap", [(2, 0), (0, 40), (1, 3)])
-def test_window_matchers_full_scan_path(oracle, fe, wcap, ecap):
+@pytest.mark.parametrize("wcap,ecap,lds", [(2, 0, 0), (0, 40, 0), (1, 3, 0), (0, 0, 1)])
+def test_window_matchers_full_scan_path(oracle, fe, wcap, ecap, lds):
     """The two-phase window matchers keep a short candidate list per query; a query whose list (or whose frame pair's pool) overflows
-    is resolved by a full scan inside the sequential phase.  Tiny capacities force that path for all three matchers."""
+    is resolved by a full scan inside the sequential phase.  Tiny capacities force that path for all three matchers; the last case keeps
+    the lists but leaves most of them in global memory (phase 2 stages as many entries in LDS as fit: all of them at these sizes)."""
     c = fe.Context()
+    if lds:
+        c.debug_option("win_lds_entries", lds)
     if wcap:
         c.debug_option("win_list_cap", wcap)
     if ecap:

@@ -12,7 +12,7 @@ python3 - /tmp/ko_$tag $R/gpurun_out/ko_$tag.txt <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
 out = open(sys.argv[2], "w")
-for r in list(csv.DictReader(open(f)))[:8]:
+for r in list(csv.DictReader(open(f)))[:16]:
     line = "%-60s %4s %10.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3)
     print(line); out.write(line + "\n")
 PY
