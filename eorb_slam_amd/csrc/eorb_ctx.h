@@ -168,6 +168,7 @@ struct eorb_ctx {
     const float* pyr0_f32 = nullptr; const uint32_t* pyr0_mm = nullptr;
     int dbg_pool_shrink = 0, dbg_force_global = 0, dbg_oct_list = 0;      // (dbg_oct_list: the octree's list algorithm for every pass; applies at the next eorb_orb_configure)
     int dbg_gather_form = 0;                     // raw Gaussian accumulation: 0 by batch shape, 1 K2r, 2 K2s, 3 K2d (<= 4 slices), 4 slot lists (K2p)
+    int dbg_orb_three_launches = 0;              // extraction: orientation, descriptors and output order as three kernels (the path of a lapping area) for every call
     int dbg_win_lds_ents = 0;                    // window matchers: entries phase 2 stages in LDS (to force its reads from global memory)
     int dbg_win_wcap = 0, dbg_win_ecap = 0;      // window matchers: list capacity per query / pool per pair (to force the full-scan path)
     int dbg_slot_rank = -1;                      // slot form: -1 by the device check / EORB_SLOT_RANK, 0 ballot scatter, 1 rank scatter (if the check passed)

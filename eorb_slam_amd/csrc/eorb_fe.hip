@@ -305,6 +305,7 @@ int eorb_debug_option(eorb_ctx* c, const char* name, int value)
     if (!strcmp(name, "octree_list_algorithm")) { c->dbg_oct_list = value; return EORB_OK; }
     if (!strcmp(name, "win_list_cap")) { c->dbg_win_wcap = value; return EORB_OK; }
     if (!strcmp(name, "win_pool_cap")) { c->dbg_win_ecap = value; return EORB_OK; }
+    if (!strcmp(name, "orb_three_launches")) { c->dbg_orb_three_launches = value; return EORB_OK; }
     if (!strcmp(name, "win_lds_entries")) { c->dbg_win_lds_ents = value; return EORB_OK; }
     if (!strcmp(name, "gather_form")) { c->dbg_gather_form = value; return EORB_OK; }
     if (!strcmp(name, "dedupe_min_events")) { c->dbg_dd_min = value; return EORB_OK; }

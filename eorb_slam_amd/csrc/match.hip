@@ -305,7 +305,7 @@ __device__ __forceinline__ uint64_t win_key(const WinQuery& Q, int cx0, int cx1,
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
+__global__ __launch_bounds__(1024) void win_cand_kernel(WinArgs A, int qpb)
 {
     extern __shared__ unsigned char smem[];
     const int pair = blockIdx.y;
@@ -316,24 +316,38 @@ __global__ __launch_bounds__(256) void win_cand_kernel(WinArgs A, int qpb)
     if (q_lo >= NQ) return;
     const int c2 = A.cap2;
     uint64_t* d2 = (uint64_t*)smem;                                   // c2 * 4
-    uint64_t* wl = d2 + (size_t)c2 * 4 + (size_t)wave * A.wcap;       // 4 * wcap: the waves' candidate lists
-    float* x2 = (float*)(d2 + (size_t)c2 * 4 + (size_t)4 * A.wcap);
+    uint64_t* wl = d2 + (size_t)c2 * 4 + (size_t)wave * A.wcap;       // nwaves * wcap: the waves' candidate lists
+    const int nwaves = (int)blockDim.x >> 6;
+    float* x2 = (float*)(d2 + (size_t)c2 * 4 + (size_t)nwaves * A.wcap);
     float* y2 = x2 + c2;
     uint32_t* info2 = (uint32_t*)(y2 + c2);
     const eorb_keypoint* K2 = A.kps2 + (size_t)pair * A.kp2_stride;
     const uint8_t* D2 = A.desc2 + (size_t)pair * A.desc2_slice;
     const uint8_t* O2 = A.is_orb2 ? A.is_orb2 + (size_t)pair * A.cap2 : nullptr;
-    for (int i = tid; i < N2; i += blockDim.x) {
-        const eorb_keypoint k = K2[i];
-        const bool isorb = O2 ? O2[i] != 0 : true;
-        x2[i] = k.x; y2[i] = k.y; info2[i] = f2_info(k, isorb, A.g);
-        load_desc32(D2 + (size_t)i * A.dstride2, d2[(size_t)i * 4 + 0], d2[(size_t)i * 4 + 1], d2[(size_t)i * 4 + 2], d2[(size_t)i * 4 + 3]);
+    // (the wavefront's first query is loaded with the staging loads, not behind the barrier: one global round trip less on the call's path)
+    WinQuery Q0; Q0.active = false;
+    if (q_lo + wave < q_hi) Q0 = win_query<KIND>(A, pair, q_lo + wave);
+    for (int i0 = 0; i0 < N2; i0 += 2 * (int)blockDim.x) {            // two keypoints' loads in flight per thread
+        eorb_keypoint k[2]; bool isorb[2]; uint64_t dd[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = i0 + u * (int)blockDim.x + tid;
+            if (i < N2) { k[u] = K2[i]; isorb[u] = O2 ? O2[i] != 0 : true; load_desc32(D2 + (size_t)i * A.dstride2, dd[u][0], dd[u][1], dd[u][2], dd[u][3]); }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int i = i0 + u * (int)blockDim.x + tid;
+            if (i < N2) {
+                x2[i] = k[u].x; y2[i] = k[u].y; info2[i] = f2_info(k[u], isorb[u], A.g);
+                d2[(size_t)i * 4 + 0] = dd[u][0]; d2[(size_t)i * 4 + 1] = dd[u][1]; d2[(size_t)i * 4 + 2] = dd[u][2]; d2[(size_t)i * 4 + 3] = dd[u][3];
+            }
+        }
     }
     __syncthreads();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint64_t* ent = A.ent + (size_t)pair * A.ecap;
-    for (int q = q_lo + wave; q < q_hi; q += 4) {
-        const WinQuery Q = win_query<KIND>(A, pair, q);
+    for (int q = q_lo + wave; q < q_hi; q += nwaves) {
+        const WinQuery Q = q == q_lo + wave ? Q0 : win_query<KIND>(A, pair, q);
         uint32_t n = 0;
         int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
         if (Q.active && cell_range(A.g, Q.qx, Q.qy, Q.r, cx0, cx1, cy0, cy1)) {
@@ -846,7 +860,7 @@ __global__ __launch_bounds__(1024) void win_resolve_kernel(WinArgs A)
 #endif
 }
 
-static size_t win_cand_lds(int cap2, int wcap) { return ((size_t)cap2 * (32 + 4 + 4 + 4) + (size_t)4 * wcap * 8 + 15) & ~(size_t)15; }
+static size_t win_cand_lds(int cap2, int wcap, int nwaves) { return ((size_t)cap2 * (32 + 4 + 4 + 4) + (size_t)nwaves * wcap * 8 + 15) & ~(size_t)15; }
 // phase 2's LDS without the entries: offs, cnts, match_at, qobs, fx per query; st_a, m21, obs, two claim buffers, angle per searched keypoint
 static size_t win_resolve_lds_rest(int cap2, int capq)
 {
@@ -865,7 +879,13 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     A.ecap = c->dbg_win_ecap > 0 ? c->dbg_win_ecap : std::max(4096, 16 * A.capq);
     // phase 2 keeps as many of a pair's entries in LDS as fit beside its tables (one read from global memory inside a sweep is what the
     // whole workgroup then waits for at the sweep's barrier), at least kWinLdsEntries
-    const size_t lds1 = win_cand_lds(A.cap2, A.wcap), rest2 = win_resolve_lds_rest(A.cap2, A.capq);
+    // phase 1: every workgroup stages the searched frame (44 B per keypoint) from the L2 before its wavefronts take a query each.  A lone
+    // pair (one frame per call) is latency: 16 wavefronts per workgroup stage it in two loads per thread and 4 x fewer workgroups do so
+    // (SearchByProjection 24 -> ... us); a batch of pairs fills the chip either way and keeps the small workgroups.
+    static const int cand_env = [] { const char* e = getenv("EORB_WIN_CAND_WAVES"); return e ? atoi(e) : 0; }();      // (A/B runs)
+    int cw = cand_env > 0 ? cand_env : (npairs >= 8 ? 4 : 16);
+    while (cw > 4 && win_cand_lds(A.cap2, A.wcap, cw) > 159 * 1024) cw >>= 1;
+    const size_t lds1 = win_cand_lds(A.cap2, A.wcap, cw), rest2 = win_resolve_lds_rest(A.cap2, A.capq);
     A.lds_ents = (int)std::min<size_t>((size_t)A.ecap, rest2 < 159 * 1024 ? (159 * 1024 - rest2) / 8 : 0);
     const bool fits = A.lds_ents >= std::min(A.ecap, kWinLdsEntries);
     if (c->dbg_win_lds_ents > 0) A.lds_ents = std::min(A.lds_ents, std::max(c->dbg_win_lds_ents, (A.cap2 + 1) / 2));      // (the rotation histogram's bin masks reuse the buffer)
@@ -895,8 +915,8 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     // queries per phase-1 workgroup: a lone pair is spread over as many workgroups as it has queries per wavefront (one each: 0.091 ->
     // 0.085 ms per SearchForInitialization call against two each; every workgroup stages the searched frame, 57 KB, from the L2)
     static const int qpb_env = [] { const char* e = getenv("EORB_WIN_QPB"); return e ? atoi(e) : 0; }();      // (A/B runs)
-    const int qpb = qpb_env > 0 ? qpb_env : (npairs >= 8 ? 32 : 4);
-    win_cand_kernel<KIND><<<dim3((nq_max + qpb - 1) / qpb, npairs), 256, lds1, c->stream>>>(A, qpb);
+    const int qpb = qpb_env > 0 ? qpb_env : (npairs >= 8 ? 32 : cw);
+    win_cand_kernel<KIND><<<dim3((nq_max + qpb - 1) / qpb, npairs), 64 * cw, lds1, c->stream>>>(A, qpb);
     // (the fixed points of SearchForInitialization and SearchByProjection(cur, last) settle a window of blockDim queries at a time: the widest block)
     win_resolve_kernel<KIND><<<npairs, KIND == 2 ? 256 : 1024, lds2, c->stream>>>(A);
     EORB_LAUNCH_CHECK(c, name);

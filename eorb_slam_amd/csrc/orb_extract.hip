@@ -1414,6 +1414,83 @@ __global__ __launch_bounds__(256) void assemble_kernel(const DevGeom* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// orientation, descriptor and output record of a keypoint by its 32 lanes in ONE launch: orient_kernel + brief_kernel + assemble_kernel for
+// the calls whose lapping area holds no keypoint (all "mono": they leave level by level in the octree's order, slot i of level l goes to
+// e = sum(cnt[l' < l]) + i, :1150-1173) or every keypoint (all_stereo, the monocular pipeline's (0, 1000): filled from the back, n - 1 - e,
+// monoIndex 0).  Three dependent launches cost a one-frame call 3 us each and their own ramps; the arithmetic is the
+// kernels' own (IC_Angle :77-104 as integer moments, computeOrbDescriptor :108-157 through brief_byte).
+template <bool DESC>
+__global__ __launch_bounds__(256) void describe_kernel(const DevGeom* __restrict__ G, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                       const uint32_t* __restrict__ lvl_kp, const int32_t* __restrict__ lvl_cnt, int all_stereo, int out_cap,
+                                                       eorb_keypoint* __restrict__ out_kp, uint8_t* __restrict__ out_desc, uint8_t* __restrict__ out_oob,
+                                                       int32_t* __restrict__ out_n, int32_t* __restrict__ out_mono, const int32_t* __restrict__ err_flag,
+                                                       int32_t* __restrict__ out_flag)
+{
+    const int slice = blockIdx.y;
+    const int gid = blockIdx.x * 8 + (threadIdx.x >> 5);       // keypoint slot in the slice's level arrays
+    const int l32 = (int)(threadIdx.x & 31);
+    const int32_t* cnt = lvl_cnt + slice * G->nlevels;
+    int nk = 0;
+    for (int l = 0; l < G->nlevels; l++) nk += cnt[l];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out_n[slice] = nk;
+        if (out_mono) out_mono[slice] = all_stereo ? 0 : nk;
+        if (out_flag && slice == 0) *out_flag = *err_flag;      // (host entry point: the flag travels with the counters)
+    }
+    if (gid >= G->kp_total) return;
+    int level = 0, before = 0;
+    while (level + 1 < G->nlevels && gid >= G->lv[level + 1].kp_off) { before += cnt[level]; level++; }
+    const LevelGeom& L = G->lv[level];
+    const int i = gid - L.kp_off;
+    if (i >= cnt[level]) return;                               // whole 32-lane group exits together
+    const uint32_t p = lvl_kp[(size_t)slice * G->kp_total + gid];
+    const int cx = (int)(p & 0xfff) + L.minBX, cy = (int)((p >> 12) & 0xfff) + L.minBY;
+    // ---- IC_Angle: lane = column u of the disc (-15 .. 15, one lane idle) ----
+    const uint8_t* center = pyr + (size_t)slice * G->pyr_bytes + L.buf_off + (size_t)(cy + G->edge) * L.bw + (cx + G->edge);
+    const int step = L.bw;
+    const int u = l32 - 15;
+    const int au = u < 0 ? -u : u;
+    int m_01 = 0, m_10 = 0;
+    if (au <= 15) m_10 = u * (int)center[u];
+#pragma unroll
+    for (int v = 1; v <= 15; ++v) {
+        if (au <= G->umax[v]) {
+            const int val_plus = center[u + v * step], val_minus = center[u - v * step];
+            m_01 += v * (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+        m_01 += __shfl_xor(m_01, d, 64);
+        m_10 += __shfl_xor(m_10, d, 64);
+    }
+    const float angle = dev_fast_atan2((float)m_01, (float)m_10);          // (every lane of the group holds both sums)
+    const int dst = all_stereo ? nk - 1 - (before + i) : before + i;
+    int val = 0, oob = 0;
+    if (DESC) val = brief_byte(blur + (size_t)slice * G->roi_bytes + L.roi_off, L.w, L.h, cx, cy, angle, l32, oob);
+    const uint64_t anyoob = __ballot(oob != 0);
+    if (dst < 0 || dst >= out_cap) return;
+    if (DESC && out_desc) out_desc[((size_t)slice * out_cap + dst) * 32 + l32] = (uint8_t)val;
+    if (l32 == 0) {
+        eorb_keypoint kp{};
+        kp.x = (float)(int)(p & 0xfff) + (float)L.minBX;
+        kp.y = (float)(int)((p >> 12) & 0xfff) + (float)L.minBY;
+        const float scale = G->sf[level];
+        if (level != 0) { kp.x = kp.x * scale; kp.y = kp.y * scale; }       // keypoint.pt *= scale
+        kp.size = (float)L.patch_size;
+        kp.angle = angle;
+        kp.response = (float)(p >> 24);
+        kp.octave = level; kp.class_id = -1;
+        out_kp[(size_t)slice * out_cap + dst] = kp;
+        if (out_oob) {
+            const uint32_t m = ((threadIdx.x >> 5) & 1) ? (uint32_t)(anyoob >> 32) : (uint32_t)anyoob;
+            out_oob[(size_t)slice * out_cap + dst] = (DESC && m) ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side: ORBextractor::ORBextractor (src/ORBextractor.cc:420-489) + per-size geometry
 static int cv_round_d(double v) { return (int)lrint(v); }
 
@@ -1672,6 +1749,31 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
                                                                     (unsigned char*)c->oct_scratch.p, (uint32_t*)c->lvl_kp.p, (int32_t*)c->lvl_cnt.p, err_flag, sticky, placement, nullptr);
         EORB_LAUNCH_CHECK(c, "octree_kernel");
     }
+    // a lapping area [lap0, lap1] that ends left of the first column a keypoint can have holds none of them, one that spans the image
+    // (the monocular pipeline's (0, 1000)) all of them: one launch then does orientation, descriptor and output order (describe_kernel)
+    static const int fuse_env = [] { const char* e = getenv("EORB_ORB_DESCRIBE"); return e ? atoi(e) : 1; }();      // (A/B runs)
+    const bool none_in = (float)lap1 < (float)o.lv[0].minBX, all_in = lap0 <= 0 && lap1 >= o.W;
+    const bool one_launch = fuse_env != 0 && !c->dbg_orb_three_launches && (none_in || all_in);
+    const int all_stereo = !none_in && all_in;
+    if (want_desc) {
+        ProfScope ps(c, "orb_blur");
+        int tyt = 0, wmax = 0;
+        for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + kBlurTH - 1) / kBlurTH; wmax = std::max(wmax, o.lv[l].w); }
+        blur_kernel<<<dim3((wmax + kBlurTW - 1) / kBlurTW, tyt, B), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
+        EORB_LAUNCH_CHECK(c, "blur_kernel");
+    }
+    if (one_launch) {
+        ProfScope ps(c, "orb_describe");
+        const dim3 grid((o.kp_total + 7) / 8, B);
+        if (want_desc)
+            describe_kernel<true><<<grid, 256, 0, c->stream>>>(G, pyr, (const uint8_t*)c->blur.p, (const uint32_t*)c->lvl_kp.p, (const int32_t*)c->lvl_cnt.p,
+                                                              all_stereo, o.max_out, d_kps, d_desc, d_oob, d_n, d_mono, err_flag, d_flag_out);
+        else
+            describe_kernel<false><<<grid, 256, 0, c->stream>>>(G, pyr, nullptr, (const uint32_t*)c->lvl_kp.p, (const int32_t*)c->lvl_cnt.p,
+                                                               all_stereo, o.max_out, d_kps, d_desc, d_oob, d_n, d_mono, err_flag, d_flag_out);
+        EORB_LAUNCH_CHECK(c, "describe_kernel");
+        return EORB_OK;
+    }
     {
         ProfScope ps(c, "orb_orient");
         orient_kernel<<<dim3((o.kp_total + 7) / 8, B), 256, 0, c->stream>>>(G, pyr, (const uint32_t*)c->lvl_kp.p,
@@ -1679,20 +1781,11 @@ int orb_extract_dev(eorb_ctx* c, const uint8_t* d_img, int img_stride, size_t im
         EORB_LAUNCH_CHECK(c, "orient_kernel");
     }
     if (want_desc) {
-        {
-            ProfScope ps(c, "orb_blur");
-            int tyt = 0, wmax = 0;
-            for (int l = 0; l < o.nlevels; l++) { tyt += (o.lv[l].h + kBlurTH - 1) / kBlurTH; wmax = std::max(wmax, o.lv[l].w); }
-            blur_kernel<<<dim3((wmax + kBlurTW - 1) / kBlurTW, tyt, B), 256, 0, c->stream>>>(G, pyr, (uint8_t*)c->blur.p);
-            EORB_LAUNCH_CHECK(c, "blur_kernel");
-        }
-        {
-            ProfScope ps(c, "orb_brief");
-            brief_kernel<<<dim3((o.kp_total + 7) / 8, B), 256, 0, c->stream>>>(G, (const uint8_t*)c->blur.p, (const uint32_t*)c->lvl_kp.p,
-                                                                               (const int32_t*)c->lvl_cnt.p, (const float*)c->kp_angle.p,
-                                                                               (uint8_t*)c->out_desc.p, (uint8_t*)c->out_oob.p);
-            EORB_LAUNCH_CHECK(c, "brief_kernel");
-        }
+        ProfScope ps(c, "orb_brief");
+        brief_kernel<<<dim3((o.kp_total + 7) / 8, B), 256, 0, c->stream>>>(G, (const uint8_t*)c->blur.p, (const uint32_t*)c->lvl_kp.p,
+                                                                           (const int32_t*)c->lvl_cnt.p, (const float*)c->kp_angle.p,
+                                                                           (uint8_t*)c->out_desc.p, (uint8_t*)c->out_oob.p);
+        EORB_LAUNCH_CHECK(c, "brief_kernel");
     }
     {
         ProfScope ps(c, "orb_assemble");

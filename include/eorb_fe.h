@@ -106,7 +106,7 @@ void        eorb_destroy(eorb_ctx* ctx);
  * The host-buffer entry points report the same condition from the call itself (eorb_orb_extract). */
 int         eorb_sync(eorb_ctx* ctx);
 /* test hooks, not part of the reference's interface: "octree_pool_shrink" (n > 0: shrink the octree node pool by n at the
- * next configure, to force the overflow path), "octree_force_global" (1: keep the whole octree working set in global memory), "win_lds_entries" (window matchers: entries of a pair that the second phase stages in LDS; default: as many as fit), "win_list_cap" / "win_pool_cap" (window matchers:
+ * next configure, to force the overflow path), "octree_force_global" (1: keep the whole octree working set in global memory), "orb_three_launches" (1: orientation, descriptors and output order as the three kernels of a call with a lapping area), "win_lds_entries" (window matchers: entries of a pair that the second phase stages in LDS; default: as many as fit), "win_list_cap" / "win_pool_cap" (window matchers:
  * candidate list capacity per query / pool per pair, to force the full-scan path), "gather_form" (raw events with a Gaussian
  * stamp: 0 = choose the gather kernel by the batch's shape, 1 = the pipelined workgroup per tile, 2 = the wave per tile, 3 = no
  * binning, every tile's wave reads all events of its slice (calls with at most 4 slices), 4 = two-byte slot lists whatever the

@@ -199,6 +199,21 @@ def _check_extract(oracle, fe, img, lap=(0, 1000), want_desc=True, **p):
     if want_desc:
         assert np.array_equal(odesc, gdesc)
         assert np.array_equal(ooob, goob)
+    if lap == (0, 1000):
+        # (0, 1000) holds every keypoint and (0, 0) none: both go through ONE launch for orientation, descriptors and output order
+        # (describe_kernel); the three kernels an area inside the image needs (debug option) must agree with it and the oracle
+        assert omono == 0
+        o0 = oe.extract(img, (0, 0), want_desc)
+        g0 = ge(img, (0, 0), want_desc)
+        ge.ctx.debug_option("orb_three_launches", 1)
+        g3 = ge(img, (0, 0), want_desc)
+        g3s = ge(img, lap, want_desc)
+        ge.ctx.debug_option("orb_three_launches", 0)
+        for a, b in ((o0, g0), (o0, g3), ((omono, okp, odesc, ooob), g3s)):
+            assert a[0] == b[0] and np.array_equal(a[1].view(np.uint8), b[1].view(np.uint8))
+            if want_desc:
+                assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert o0[0] == len(okp)                        # every keypoint is "mono" now
     ge.ctx.close()
     return okp, odesc
 
