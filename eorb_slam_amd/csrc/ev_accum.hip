@@ -1124,7 +1124,10 @@ __global__ __launch_bounds__(64 * kSparseWaves) void ev_gather_sparse_kernel(con
 // Same entries in the same order as the binned lists, hence the same image.
 constexpr int kDirectSlices = 8;
 struct DirectSlices { int64_t beg[kDirectSlices], end[kDirectSlices]; int64_t tab_base; };      // the slices' event ranges (they may overlap: the contest's later-half histogram)
-constexpr int kDirectList = 1024;                   // entries of the LDS list (flushed when full)
+constexpr int kDirectList = 2048;                   // entries of the LDS list (flushed when the next batch of loads might not fit)
+#ifndef EORB_DIRECT_G
+#define EORB_DIRECT_G 8
+#endif
 // ev_direct_slices_dev resolves every event of the call ONCE, in parallel, into the entry it would contribute to a tile's list
 // (ev_pre_kernel): { table row | negative polarity << 31, xi | yi << 16 } -- raw sensor events: row = the sensor pixel (its stamp in
 // the maps' table), integer position from src_info; float events (eorb_event16: the reference's own seam, ev2im_gauss(vector<
@@ -1211,7 +1214,7 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const uint2* __res
         }
         nl = 0;
     };
-    constexpr int G = 8;                                     // sub-batches of 64 events whose loads are in flight together
+    constexpr int G = EORB_DIRECT_G;                         // sub-batches of 64 events whose loads are in flight together
     for (int k0 = 0; k0 < n; k0 += 64 * G) {
         uint2 q[G];
 #pragma unroll
@@ -1219,6 +1222,7 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const uint2* __res
             const int k = k0 + g * 64 + lane;
             q[g] = k < n ? e[k] : make_uint2(0u, 0x80008000u);
         }
+        if (nl + 64 * G > kDirectList) flush();                 // (one call site: the adds' code is long, and a copy per sub-batch was paid in instruction fetches)
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (k0 + g * 64 >= n) break;
@@ -1230,7 +1234,6 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const uint2* __res
             if (m) {
                 if (hit) lst[nl + __popcll(m & lt_mask)] = q[g];
                 nl += __popcll(m); any = true;
-                if (nl > kDirectList - 64) flush();
             }
         }
     }
