@@ -293,20 +293,23 @@ __global__ __launch_bounds__(64 * kCountWaves) void sl_count_lds_kernel(const eo
             uint32_t xy[U], g[U];
             uint32_t r16[U];                                           // (RANKS: the events' sensor indices)
             if (KEYED) {
-                uint2 pos[U]; uint4 ent[U]; uint32_t hh[U];
+                // (the first probe's entry as three scalars per event: with a uint4 ent[U] copied into the probe loop's variable the compiler
+                // merged that copy and the loop's load into ONE load through a pointer phi -- the array went to scratch, 16 bytes stored and
+                // read back through a flat load per event: 2.04 ms for this pass)
+                uint2 pos[U]; uint32_t ex[U], ey[U], ez[U], hh[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) { const int k = k0 + u * 64; pos[u] = k < cd.n ? *(const uint2*)(e + (size_t)k * 16) : make_uint2(0x7fc00000u, 0x7fc00000u); }
 #pragma unroll
-                for (int u = 0; u < U; u++) { hh[u] = sl_dict_hash((uint64_t)pos[u].x | ((uint64_t)pos[u].y << 32)) & D.mask; ent[u] = D.hash[hh[u]]; }      // (a non-temporal load here: 1.89 -> 3.09 ms; the L1 does serve part of the probes)
+                for (int u = 0; u < U; u++) { hh[u] = sl_dict_hash((uint64_t)pos[u].x | ((uint64_t)pos[u].y << 32)) & D.mask; const uint4 t = D.hash[hh[u]]; ex[u] = t.x; ey[u] = t.y; ez[u] = t.z; }      // (a non-temporal load here: 1.89 -> 3.09 ms; the L1 does serve part of the probes)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int k = k0 + u * 64;
                     const float fx = __uint_as_float(pos[u].x), fy = __uint_as_float(pos[u].y);
                     uint32_t id = 0x7fffffffu;                           // dropped (NaN coordinates are never in the image)
                     if (k < cd.n && fx == fx && fy == fy) {
-                        uint32_t h = hh[u]; uint4 q = ent[u]; int probes = 0;
-                        while (!(q.x == pos[u].x && q.y == pos[u].y) && q.z != 0xffffffffu && ++probes <= 64) { h = (h + 1) & D.mask; q = D.hash[h]; }
-                        if (q.x == pos[u].x && q.y == pos[u].y && q.z != 0xffffffffu) id = q.z;
+                        uint32_t h = hh[u], qx = ex[u], qy = ey[u], qz = ez[u]; int probes = 0;
+                        while (!(qx == pos[u].x && qy == pos[u].y) && qz != 0xffffffffu && ++probes <= 64) { h = (h + 1) & D.mask; const uint4 t = D.hash[h]; qx = t.x; qy = t.y; qz = t.z; }
+                        if (qx == pos[u].x && qy == pos[u].y && qz != 0xffffffffu) id = qz;
                         else atomicAdd(D.miss, 1);
                     }
                     if (RANKS) r16[u] = id < (uint32_t)LW * (uint32_t)LH ? id : 0xffffu;      // (the ranked record below carries the id)
