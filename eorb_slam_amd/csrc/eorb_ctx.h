@@ -134,6 +134,7 @@ struct eorb_ctx {
     eorb::DevBuf win_ws;                 // candidate lists of the two-phase window matchers
     eorb::DevBuf win_total;              // their per-pair entry counters: zero between calls (phase 2 puts its pair's back), win_total_n of them known to be
     size_t win_total_n = 0;
+    unsigned win_attr_done = 0;          // bit KIND: the window matchers' kernels of that kind have their LDS opt-in on this context's device
     eorb::DevBuf arena;                  // host-buffer entry points: all inputs / outputs of one call, one H2D and one D2H copy
     void* dl_pinned = nullptr; size_t dl_cap = 0;      // pinned landing buffer of the D2H copy (the call synchronises before reading it)
     hipEvent_t dl_event = nullptr;                     // recorded behind that copy: what the call waits for

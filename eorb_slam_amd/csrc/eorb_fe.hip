@@ -148,6 +148,14 @@ static void free_buf(DevBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 
 // latency is launches and copies, not kernels.  A call lays ALL its inputs and outputs out in one device arena: the inputs are
 // packed into a pinned slot and cross PCIe in ONE copy (a pageable hipMemcpy2DAsync of a 346x260 image alone cost > 1 ms), the
 // outputs come back in ONE copy into a pinned landing buffer.
+// upload of a call's inputs by a kernel that reads the pinned staging buffer over the link (16 bytes per thread, coalesced): for the few
+// hundred KB of a one-frame call the copy engine's turn plus its hand-over to the first kernel cost more (SearchByProjection: copy 11 us +
+// 12-15 us idle before the first kernel) than these reads
+__global__ void arena_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 struct Arena {
     eorb_ctx* c;
     size_t total = 0, in_end = 0;
@@ -166,6 +174,12 @@ struct Arena {
     }
     size_t reserve(size_t bytes) { return take(bytes); }
     template <typename T> T* dev(size_t off) const { return (T*)((char*)c->arena.p + off); }
+    // host_inputs: the inputs are NOT copied to the arena; the kernels that read them (once) get the pinned staging buffer itself
+    // (in_ptr), which the device reads over the link.  For a few KB this saves the copy engine's turn and its hand-over to the first
+    // kernel (tools/mb/call_latency.hip: 25 -> 21 us per call).  inputs_done() after the last kernel that reads them is enqueued.
+    bool host_inputs = false; char* host_base = nullptr;
+    template <typename T> T* in_ptr(size_t off) const { return host_inputs ? (T*)(host_base + off) : dev<T>(off); }
+    void inputs_done() { if (host_inputs) pinned_commit(c); }
     int upload()
     {
         int rc = ensure(c, c->arena, total);
@@ -178,7 +192,14 @@ struct Arena {
             if (p.rows) for (int r = 0; r < p.rows; r++) memcpy(hp + p.off + (size_t)r * p.row_bytes, (const char*)p.src + (size_t)r * p.stride, p.row_bytes);
             else memcpy(hp + p.off, p.src, p.bytes);
         }
-        EORB_HIP(c, hipMemcpyAsync(c->arena.p, hp, in_end, hipMemcpyHostToDevice, c->stream));
+        if (host_inputs) { host_base = hp; return EORB_OK; }
+        static const long kmax = [] { const char* e = getenv("EORB_UPLOAD_KERNEL_MAX"); return e ? atol(e) : (1L << 20); }();      // (bytes; 0: always the copy engine)
+        if ((long)in_end <= kmax) {
+            const size_t n16 = (in_end + 15) / 16;          // (offsets and sizes of the arena are multiples of 256; the staging buffer is at least as long)
+            arena_upload_kernel<<<(unsigned)std::min<size_t>((n16 + 255) / 256, 512), 256, 0, c->stream>>>((const uint4*)hp, (uint4*)c->arena.p, n16);
+            EORB_LAUNCH_CHECK(c, "arena_upload_kernel");
+        } else
+            EORB_HIP(c, hipMemcpyAsync(c->arena.p, hp, in_end, hipMemcpyHostToDevice, c->stream));
         pinned_commit(c);
         return EORB_OK;
     }
@@ -796,7 +817,12 @@ int eorb_ev_slice_extract(eorb_ctx* c, const eorb_event* ev, const eorb_raw_even
     if ((rc = slice_events_in(c, A, ev, raw, n, packed, &o_ev, &is_raw, "ev_slice_extract"))) return rc;
     // the running extremes travel initialised with the events (no launch for them); device-only: float image; outputs, contiguous:
     // u8 image | {n, mono, flag, pad} | keypoints | descriptors | oob
-    const size_t o_mm = A.in(kMinMaxPreset, sizeof(kMinMaxPreset)), o_f32 = A.reserve(sizeof(float) * npix);
+    // a live slice (the binning-free form reads every event once, in ev_pre_kernel): the events stay in pinned host memory and the
+    // extremes are initialised by that kernel -- no copy in front of the first launch
+    static const int zc_env = [] { const char* e = getenv("EORB_SLICE_ZERO_COPY"); return e ? atoi(e) : 1; }();      // (A/B runs)
+    const bool zc = zc_env != 0 && n > 0 && n <= 16384 && c->dbg_gather_form == 0;
+    A.host_inputs = zc;
+    const size_t o_mm = zc ? A.reserve(sizeof(kMinMaxPreset)) : A.in(kMinMaxPreset, sizeof(kMinMaxPreset)), o_f32 = A.reserve(sizeof(float) * npix);
     const size_t o_u8 = A.reserve(npix), o_n = A.reserve(16), o_kp = A.reserve(sizeof(eorb_keypoint) * mo), o_desc = A.reserve(32 * mo), o_oob = A.reserve(mo);
     if ((rc = A.upload())) return rc;
     int64_t offs[2] = {0, (int64_t)n};
@@ -804,8 +830,9 @@ int eorb_ev_slice_extract(eorb_ctx* c, const eorb_event* ev, const eorb_raw_even
     int32_t* dn = A.dev<int32_t>(o_n);
     // EvImConverter::ev2im_gauss(l1Evs, W, H, sigma) :1345 (pol = false, normalized = true)
     // (the normalisation to u8 is left to the extraction's first kernel: one launch less)
-    c->mm_preset = true;
-    if ((rc = ev_accumulate_dev(c, A.dev<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 0, A.dev<uint32_t>(o_mm)))) return rc;
+    c->mm_preset = !zc;
+    if ((rc = ev_accumulate_dev(c, A.in_ptr<void>(o_ev), is_raw, offs, 1, W, H, sigma, 0, 0, A.dev<float>(o_f32), d_u8, 0, A.dev<uint32_t>(o_mm)))) return rc;
+    A.inputs_done();
     // makeFrame :1348 -> EvFrame ctor -> ORBextractor::operator() (EventFrame.cpp:220)
     c->pyr0_f32 = A.dev<float>(o_f32); c->pyr0_mm = A.dev<uint32_t>(o_mm);
     if ((rc = orb_extract_dev(c, d_u8, W, npix, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp), A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob),
@@ -1062,13 +1089,17 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     int rc;
     const size_t mo = (size_t)o.max_out;
     Arena A(c);
+    // the image is read once, by the pyramid's first kernel: it reads the pinned staging buffer itself (no upload in front of the launch)
+    static const int zc_env = [] { const char* e = getenv("EORB_IMAGE_ZERO_COPY"); return e ? atoi(e) : 1; }();      // (A/B runs)
+    A.host_inputs = zc_env != 0 && (size_t)W * H <= ((size_t)1 << 20);
     const size_t o_img = A.in2d(img, H, (size_t)W, (size_t)stride);
     // outputs, contiguous: {n, mono, flag, pad} | keypoints | descriptors | oob
     const size_t o_n = A.reserve(16), o_kp = A.reserve(sizeof(eorb_keypoint) * mo), o_desc = A.reserve(32 * mo), o_oob = A.reserve(mo);
     if ((rc = A.upload())) return rc;
     int32_t* dn = A.dev<int32_t>(o_n);
-    rc = orb_extract_dev(c, A.dev<uint8_t>(o_img), W, (size_t)W * H, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp),
+    rc = orb_extract_dev(c, A.in_ptr<uint8_t>(o_img), W, (size_t)W * H, 1, lap0, lap1, want_desc, A.dev<eorb_keypoint>(o_kp),
                          A.dev<uint8_t>(o_desc), A.dev<uint8_t>(o_oob), dn, dn + 1, dn + 2);
+    A.inputs_done();
     if (rc) return rc;
     // one copy back: counters always, the rest up to the caller's capacity
     const size_t ncopy = std::min<size_t>(mo, (size_t)std::max(cap, 0));

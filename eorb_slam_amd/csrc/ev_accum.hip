@@ -1137,9 +1137,11 @@ constexpr int kDirectList = 2048;                   // entries of the LDS list (
 // 2 000 ... 5 000-event chunk took 76 / 140 us.
 template <bool FLT>
 __global__ void ev_pre_kernel(const eorb_raw_event* __restrict__ ev, int n, int W, int H, int LW, int LH, const uint32_t* __restrict__ src_info,
-                              uint32_t row0, uint2* __restrict__ pre)
+                              uint32_t row0, uint2* __restrict__ pre, uint32_t* __restrict__ mm_init = nullptr, int nmm = 0)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    // (the slices' running extremes start here when the caller did not send them initialised: no launch of their own)
+    if (mm_init && k < nmm) { mm_init[2 * k] = enc_f32(0.0f); mm_init[2 * k + 1] = enc_f32(-1000000.0f); }
     if (k >= n) return;
     uint32_t row, neg, info = 0x80008000u;
     if (FLT) {
@@ -2064,6 +2066,7 @@ int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64
     if (span >= (int64_t)1 << 30) return set_err(c, EORB_E_CAPACITY, "ev_accumulate: %lld events in one direct call", (long long)span);
     if ((rc = ensure(c, c->ev_info, sizeof(uint2) * (size_t)std::max<int64_t>(span, 1)))) return rc;
     S.tab_base = lo;
+    const bool mm_in_pre = !mm_preset && span > 0;               // (ev_pre_kernel's first threads initialise the running extremes)
     uint2* d_pre = (uint2*)c->ev_info.p;
     const eorb_raw_event* d_first = (const eorb_raw_event*)d_events + lo;
     if (!raw) {
@@ -2074,7 +2077,7 @@ int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64
         if ((rc = ensure(c, c->ev_stamps, sizeof(float) * (size_t)std::max<int64_t>(span, 1) * SW * SWP))) return rc;
         if (span) {
             ProfScope ps(c, "ev_stamp_tables");
-            ev_pre_kernel<true><<<(int)((span + 255) / 256), 256, 0, c->stream>>>(d_first, (int)span, W, H, 0, 0, nullptr, 0u, d_pre);
+            ev_pre_kernel<true><<<(int)((span + 255) / 256), 256, 0, c->stream>>>(d_first, (int)span, W, H, 0, 0, nullptr, 0u, d_pre, mm_in_pre ? d_minmax_enc : nullptr, B);
             ev_stamp_kernel<<<(int)std::min<int64_t>((span * SW * SWP + 255) / 256, 4096), 256, 0, c->stream>>>((const float2*)d_first, (const uint32_t*)d_pre, (int)span, G,
                                                                                                           (float*)c->ev_stamps.p, 2, 2, 1);
             EORB_LAUNCH_CHECK(c, "per-event tables");
@@ -2082,10 +2085,10 @@ int ev_direct_slices_dev(eorb_ctx* c, const void* d_events, int raw, const int64
         G.stamps = (const float*)c->ev_stamps.p;
     } else if (span) {
         ProfScope ps(c, "ev_stamp_tables");
-        ev_pre_kernel<false><<<(int)((span + 255) / 256), 256, 0, c->stream>>>(d_first, (int)span, W, H, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p, 0u, d_pre);
+        ev_pre_kernel<false><<<(int)((span + 255) / 256), 256, 0, c->stream>>>(d_first, (int)span, W, H, c->lut_w, c->lut_h, (const uint32_t*)c->src_info.p, 0u, d_pre, mm_in_pre ? d_minmax_enc : nullptr, B);
         EORB_LAUNCH_CHECK(c, "ev_pre_kernel");
     }
-    if (!mm_preset) {
+    if (!mm_preset && !mm_in_pre) {
         ProfScope ps(c, "ev_minmax_init");
         ev_minmax_init_kernel<<<(B + 63) / 64, 64, 0, c->stream>>>(d_minmax_enc, B);
     }

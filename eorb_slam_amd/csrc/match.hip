@@ -325,6 +325,9 @@ __global__ __launch_bounds__(1024) void win_cand_kernel(WinArgs A, int qpb)
     const uint8_t* D2 = A.desc2 + (size_t)pair * A.desc2_slice;
     const uint8_t* O2 = A.is_orb2 ? A.is_orb2 + (size_t)pair * A.cap2 : nullptr;
     // (the wavefront's first query is loaded with the staging loads, not behind the barrier: one global round trip less on the call's path)
+#ifdef EORB_WIN_TIMING
+    long long ct[6]; ct[0] = clock64();
+#endif
     WinQuery Q0; Q0.active = false;
     if (q_lo + wave < q_hi) Q0 = win_query<KIND>(A, pair, q_lo + wave);
     for (int i0 = 0; i0 < N2; i0 += 2 * (int)blockDim.x) {            // two keypoints' loads in flight per thread
@@ -344,6 +347,9 @@ __global__ __launch_bounds__(1024) void win_cand_kernel(WinArgs A, int qpb)
         }
     }
     __syncthreads();
+#ifdef EORB_WIN_TIMING
+    ct[1] = clock64(); ct[2] = ct[3] = ct[4] = ct[1];
+#endif
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint64_t* ent = A.ent + (size_t)pair * A.ecap;
     for (int q = q_lo + wave; q < q_hi; q += nwaves) {
@@ -361,11 +367,17 @@ __global__ __launch_bounds__(1024) void win_cand_kernel(WinArgs A, int qpb)
                 n += (uint32_t)__popcll(bal);
             }
         }
+#ifdef EORB_WIN_TIMING
+        ct[2] = clock64();
+#endif
         uint32_t off = 0, cnt = n;
         if (n > (uint32_t)A.wcap) cnt = kWinOver;
         else if (n > 0) {
             if (lane == 0) off = atomicAdd(&A.total[pair], n) & 0x7FFFFFFFu;
             off = (uint32_t)__shfl((int)off, 0, 64);
+#ifdef EORB_WIN_TIMING
+            ct[3] = clock64();
+#endif
             if (off + n > (uint32_t)A.ecap) cnt = kWinOver;           // the pair's pool is full
             else {
                 // the list leaves sorted by key (rank = number of smaller keys; keys are unique): phase 2 then stops at the first
@@ -382,6 +394,11 @@ __global__ __launch_bounds__(1024) void win_cand_kernel(WinArgs A, int qpb)
             A.cnt[(size_t)pair * A.capq + q] = cnt; A.off[(size_t)pair * A.capq + q] = off;
             if (cnt == kWinOver) atomicOr(&A.total[pair], 0x80000000u);          // (bit 31 of the pair's counter: some list overflowed; phase 2 reads it there)
         }
+#ifdef EORB_WIN_TIMING
+        ct[4] = clock64();
+        if (pair == 0 && lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && (wave == 0 || wave == nwaves - 1))
+            printf("win_cand<%d> wg %d wave %d (n %u): staging %lld | scan %lld | pool atomic %lld | sort + write %lld\n", KIND, (int)blockIdx.x, wave, n, ct[1] - ct[0], ct[2] - ct[1], ct[3] - ct[2], ct[4] - ct[3]);
+#endif
     }
 }
 
@@ -908,9 +925,12 @@ static int launch_win(eorb_ctx* c, WinArgs& A, int npairs, int nq_max, const cha
     A.total = (uint32_t*)c->win_total.p;
     const size_t total_n = c->win_total_n;
     c->win_total_n = 0;                                 // (until both phases are known to have been launched)
-    // per device, not per process: a second context on another GPU needs the opt-in too (the call is cheap)
-    EORB_HIP(c, hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-    EORB_HIP(c, hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    // per device, not per process: a second context on another GPU needs the opt-in too -- once per context and kind
+    if (!(c->win_attr_done & (1u << KIND))) {
+        EORB_HIP(c, hipFuncSetAttribute((const void*)win_cand_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        EORB_HIP(c, hipFuncSetAttribute((const void*)win_resolve_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        c->win_attr_done |= 1u << KIND;
+    }
     ProfScope ps(c, name);
     // queries per phase-1 workgroup: a lone pair is spread over as many workgroups as it has queries per wavefront (one each: 0.091 ->
     // 0.085 ms per SearchForInitialization call against two each; every workgroup stages the searched frame, 57 KB, from the L2)
