@@ -507,6 +507,9 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
         eorb_pack_events(ev, n, packed.data());
     }
     Arena A(c);
+    // (a live slice goes to the binning-free form, which reads every event once: in place, from the pinned staging buffer)
+    static const int zc_env = [] { const char* e = getenv("EORB_SLICE_ZERO_COPY"); return e ? atoi(e) : 1; }();      // (A/B runs)
+    A.host_inputs = zc_env != 0 && !mode_count && n > 0 && n <= 16384 && c->dbg_gather_form == 0;
     const size_t o_ev = A.in(raw ? (const void*)rawev : (const void*)packed.data(), sizeof(eorb_event16) * n);
     // outputs, contiguous: min/max (encoded | decoded) | u8 image | f32 image
     const size_t o_mm = A.reserve(64), o_u8 = A.reserve(npix), o_f32 = A.reserve(sizeof(float) * npix);
@@ -517,7 +520,8 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
     float* d_f32 = A.dev<float>(o_f32);
     if (out_u8 && mode_count) EORB_HIP(c, hipMemsetAsync(d_u8, 0, npix, c->stream));     // count images stay empty when max == min
     const long long slot_calls0 = c->sl_calls;
-    rc = ev_accumulate_dev(c, A.dev<void>(o_ev), raw, offs, 1, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, mm);
+    rc = ev_accumulate_dev(c, A.in_ptr<void>(o_ev), raw, offs, 1, W, H, sigma, pol, mode_count, d_f32, d_u8, normalized, mm);
+    A.inputs_done();
     if (rc) return rc;
     // the slot form reports an internal fault (its gather found no rows at LDS offset 0 and wrote no image) through the sticky status
     // word: this call's copy of it travels with the outputs (word 2 of the min/max block)
