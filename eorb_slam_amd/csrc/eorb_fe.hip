@@ -215,6 +215,14 @@ struct Arena {
             if (hipHostMalloc(&c->dl_pinned, want, hipHostMallocDefault) != hipSuccess) { c->dl_pinned = nullptr; return set_err(c, EORB_E_HIP, "pinned alloc failed"); }
             c->dl_cap = want;
         }
+        // (the way back like the way in: up to a few hundred KB a kernel writes the pinned buffer; offsets of the arena are multiples of
+        // 256 and both buffers longer than the rounded size)
+        static const long kmax = [] { const char* e = getenv("EORB_DOWNLOAD_KERNEL_MAX"); return e ? atol(e) : (1L << 20); }();      // (bytes; 0: always the copy engine)
+        if ((long)bytes <= kmax && !(off & 15)) {
+            const size_t n16 = (bytes + 15) / 16;
+            arena_upload_kernel<<<(unsigned)std::min<size_t>((n16 + 255) / 256, 512), 256, 0, c->stream>>>((const uint4*)((char*)c->arena.p + off), (uint4*)c->dl_pinned, n16);
+            EORB_LAUNCH_CHECK(c, "arena download kernel");
+        } else
         EORB_HIP(c, hipMemcpyAsync(c->dl_pinned, (char*)c->arena.p + off, bytes, hipMemcpyDeviceToHost, c->stream));
         if (!c->dl_event && hipEventCreateWithFlags(&c->dl_event, hipEventDisableTiming) != hipSuccess) { c->dl_event = nullptr; return set_err(c, EORB_E_HIP, "event"); }
         EORB_HIP(c, hipEventRecord(c->dl_event, c->stream));
