@@ -157,7 +157,7 @@ struct eorb_ctx {
     // pinned staging: a ring of slots, each guarded by an event recorded right after the H2D copy that reads it, so that
     // back-to-back un-synchronised *_dev calls never overwrite a slot whose copy is still queued
     static constexpr int kPinnedSlots = 4;
-    struct PinnedSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+    struct PinnedSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false, lazy = false; };
     PinnedSlot pinned[kPinnedSlots];
     int pinned_next = 0, pinned_cur = -1;
     // sticky device status word (bits OR-ed by kernels of the *_dev paths: candidate / node-pool / keypoint overflow);
@@ -186,7 +186,8 @@ namespace eorb {
 int  set_err(eorb_ctx* c, int code, const char* fmt, ...);
 int  ensure(eorb_ctx* c, DevBuf& b, size_t bytes);
 void* pinned(eorb_ctx* c, size_t bytes);        // next free slot of the pinned ring (waits for the slot's previous copy)
-void pinned_commit(eorb_ctx* c);                // call right after the hipMemcpyAsync that reads the slot
+void pinned_commit(eorb_ctx* c, bool lazy = false);   // call right after the hipMemcpyAsync that reads the slot; lazy: no event (the caller waits for the stream anyway: pinned_release_lazy)
+void pinned_release_lazy(eorb_ctx* c);          // everything enqueued before the caller's last wait has completed
 int  hip_check(eorb_ctx* c, hipError_t e, const char* what);
 int* readback_buf(eorb_ctx* c);                 // c->rb_pinned, allocated on first use (nullptr: allocation failed)
 

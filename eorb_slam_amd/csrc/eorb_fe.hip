@@ -86,7 +86,11 @@ void* pinned(eorb_ctx* c, size_t bytes)
     eorb_ctx::PinnedSlot& s = c->pinned[c->pinned_next];
     c->pinned_cur = c->pinned_next;
     c->pinned_next = (c->pinned_next + 1) % eorb_ctx::kPinnedSlots;
-    if (s.busy) { hipEventSynchronize(s.ev); s.busy = false; }      // the copy that read this slot has completed
+    if (s.busy) {                                                   // the copy / kernel that read this slot has completed
+        if (s.lazy) { hipStreamSynchronize(c->stream); pinned_release_lazy(c); }
+        else hipEventSynchronize(s.ev);
+        s.busy = false; s.lazy = false;
+    }
     if (s.cap >= bytes) return s.p;
     if (s.p) { hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
     const size_t want = bytes + bytes / 2 + 4096;
@@ -95,10 +99,18 @@ void* pinned(eorb_ctx* c, size_t bytes)
     return s.p;
 }
 
-void pinned_commit(eorb_ctx* c)
+void pinned_release_lazy(eorb_ctx* c)
+{
+    for (auto& s : c->pinned) if (s.busy && s.lazy) { s.busy = false; s.lazy = false; }
+}
+
+// lazy: the host-buffer entry points wait for their results before they return, which covers every read of their staging slot: an event
+// per slot was a marker in the queue in front of the call's next kernel (5 us of idle GPU per call in the time line)
+void pinned_commit(eorb_ctx* c, bool lazy)
 {
     if (c->pinned_cur < 0) return;
     eorb_ctx::PinnedSlot& s = c->pinned[c->pinned_cur];
+    if (lazy) { s.busy = true; s.lazy = true; return; }
     if (!s.ev && hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; hipStreamSynchronize(c->stream); return; }
     if (hipEventRecord(s.ev, c->stream) != hipSuccess) { hipStreamSynchronize(c->stream); return; }
     s.busy = true;
@@ -179,7 +191,7 @@ struct Arena {
     // kernel (tools/mb/call_latency.hip: 25 -> 21 us per call).  inputs_done() after the last kernel that reads them is enqueued.
     bool host_inputs = false; char* host_base = nullptr;
     template <typename T> T* in_ptr(size_t off) const { return host_inputs ? (T*)(host_base + off) : dev<T>(off); }
-    void inputs_done() { if (host_inputs) pinned_commit(c); }
+    void inputs_done() {}                            // (the slot stays taken until the call's wait: pinned_commit(lazy) in upload())
     int upload()
     {
         int rc = ensure(c, c->arena, total);
@@ -192,7 +204,7 @@ struct Arena {
             if (p.rows) for (int r = 0; r < p.rows; r++) memcpy(hp + p.off + (size_t)r * p.row_bytes, (const char*)p.src + (size_t)r * p.stride, p.row_bytes);
             else memcpy(hp + p.off, p.src, p.bytes);
         }
-        if (host_inputs) { host_base = hp; return EORB_OK; }
+        if (host_inputs) { host_base = hp; pinned_commit(c, true); return EORB_OK; }
         static const long kmax = [] { const char* e = getenv("EORB_UPLOAD_KERNEL_MAX"); return e ? atol(e) : (1L << 20); }();      // (bytes; 0: always the copy engine)
         if ((long)in_end <= kmax) {
             const size_t n16 = (in_end + 15) / 16;          // (offsets and sizes of the arena are multiples of 256; the staging buffer is at least as long)
@@ -200,7 +212,7 @@ struct Arena {
             EORB_LAUNCH_CHECK(c, "arena_upload_kernel");
         } else
             EORB_HIP(c, hipMemcpyAsync(c->arena.p, hp, in_end, hipMemcpyHostToDevice, c->stream));
-        pinned_commit(c);
+        pinned_commit(c, true);
         return EORB_OK;
     }
     // one D2H copy of arena[off, off + bytes) + a wait for it; returns the host view of arena offset `off` (valid until the next call).
@@ -240,6 +252,7 @@ struct Arena {
             if (q != hipSuccess) return hip_check(c, q, "hipEventQuery");
         } else
             EORB_HIP(c, hipEventSynchronize(c->dl_event));
+        pinned_release_lazy(c);
         *host = (const char*)c->dl_pinned - dl_off;
         return EORB_OK;
     }

@@ -13,11 +13,13 @@ for f in glob.glob("/tmp/stl/**/*kernel_trace.csv", recursive=True):
 for f in glob.glob("/tmp/stl/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)): ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", r.get("Name", ""))[:40]))
 ev.sort()
-# calls = groups that start with a host-to-device copy; print a group that contains ev_pre_kernel<false> and octree but no klt (slice_extract, raw events)
-groups, cur = [], []
+# calls = runs of kernels / copies with less than 8 us of idle time between them (a call's inputs arrive through a kernel or are read in
+# place: no host-to-device copy marks its start any more; the host spends more than that between two calls);
+# print a group that contains ev_pre_kernel<false> and octree but no klt (slice_extract, raw events)
+groups, cur, last_end = [], [], None
 for e in ev:
-    if e[2].startswith("copy") and "HOST_TO_DEVICE" in e[2].upper() and cur: groups.append(cur); cur = []
-    cur.append(e)
+    if cur and e[0] - last_end > 8000: groups.append(cur); cur = []
+    cur.append(e); last_end = e[1] if last_end is None or not cur[:-1] else max(last_end, e[1])
 groups.append(cur)
 sel = [g for g in groups if any("ev_pre_kernel" in x[2] for x in g) and any("octree" in x[2] for x in g) and not any("klt" in x[2] for x in g)]
 for name, gs in (("eorb_ev_slice_extract", sel), ("W3 extract", [g for g in groups if any("describe_kernel<true>" in x[2] or "brief" in x[2] for x in g) and sum("pyr_resize" in x[2] for x in g) == 3]),
