@@ -108,6 +108,14 @@ struct eorb_ctx {
     int ncu = 0;                                 // compute units of c->device (per context: a second context may sit on another GPU)
     unsigned sl_attr = 0;                        // bit per kernel instantiation whose dynamic-LDS opt-in was made on c->device
     int sl_last_rank = -1, sl_last_chunk = 0;    // the scatter the last slot-form call ran (1 rank form, 0 ballot form), its chunk size
+    // pinned staging of the entry points that move their buffers one by one (up() / down() of the KeyFrame-side matchers, BoW, LK): bump
+    // allocators, emptied by the entry's own stream wait; dn_pending: host destinations filled from dn_pin at that wait
+    struct PinBump { void* p = nullptr; size_t cap = 0, used = 0; };
+    PinBump up_pin, dn_pin;
+    struct PendingDown { void* dst; size_t off, bytes; };
+    std::vector<PendingDown> dn_pending;
+    struct CopySeg { void* dst; const void* src; size_t n; };
+    std::vector<CopySeg> up_queue, dn_queue;           // staged copies not launched yet: one multi-segment kernel per up_flush() / stream wait
     int* rb_pinned = nullptr;                   // 64 ints of pinned host memory: the landing place of small read-backs (position count, slot info)
     int sl_launched = 0; int sl_hinfo[6] = {0, 0, 0, 0, 0, 0};      // assignment kernels launched, their read-back (ev_slots_prepare_launch / _finish)
     int dd_src_info_done = 0;                   // float bulk path: src_info of the per-call table already launched

@@ -81,6 +81,98 @@ int ensure(eorb_ctx* c, DevBuf& b, size_t bytes)
     return EORB_OK;
 }
 
+// ---- buffers that travel one by one (up() / down()): pinned bump allocators + copy kernels ----
+// A pageable hipMemcpyAsync is staged by the runtime and waits; eight of them plus three downloads made a 19 us matcher a 110 us call.
+// up(): memcpy into pinned memory, a kernel reads it over the link; down(): a kernel writes pinned memory, the host copy happens at the
+// entry's stream wait (fe_stream_sync), which also empties both allocators.  What does not fit without waiting goes through the copy engine.
+// up to eight copies in one launch (blockIdx.y = segment): an entry's buffers go up together and its results come back together
+struct CopySegs8 { unsigned char* dst[8]; const unsigned char* src[8]; size_t n[8]; int align[8]; int count; };
+__global__ void copy_segs_kernel(CopySegs8 S)
+{
+    const int sg = blockIdx.y;
+    const unsigned char* src = S.src[sg]; unsigned char* dst = S.dst[sg];
+    const size_t n = S.n[sg];
+    const int align = S.align[sg];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    if (align == 16) {
+        const size_t n16 = n >> 4;
+        for (size_t i = t; i < n16; i += nt) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+        for (size_t i = (n16 << 4) + t; i < n; i += nt) dst[i] = src[i];
+    } else if (align == 4) {
+        const size_t n4 = n >> 2;
+        for (size_t i = t; i < n4; i += nt) ((uint32_t*)dst)[i] = ((const uint32_t*)src)[i];
+        for (size_t i = (n4 << 2) + t; i < n; i += nt) dst[i] = src[i];
+    } else
+        for (size_t i = t; i < n; i += nt) dst[i] = src[i];
+}
+static int launch_copy_queue(eorb_ctx* c, std::vector<eorb_ctx::CopySeg>& q)
+{
+    for (size_t i0 = 0; i0 < q.size(); i0 += 8) {
+        CopySegs8 S{};
+        size_t units = 1;
+        S.count = (int)std::min<size_t>(8, q.size() - i0);
+        for (int k = 0; k < S.count; k++) {
+            const auto& e = q[i0 + k];
+            const uintptr_t a = (uintptr_t)e.src | (uintptr_t)e.dst;
+            S.dst[k] = (unsigned char*)e.dst; S.src[k] = (const unsigned char*)e.src; S.n[k] = e.n;
+            S.align[k] = !(a & 15) ? 16 : (!(a & 3) ? 4 : 1);
+            units = std::max(units, (e.n + (size_t)S.align[k] - 1) / (size_t)S.align[k]);
+        }
+        copy_segs_kernel<<<dim3((unsigned)std::min<size_t>((units + 255) / 256, 128), (unsigned)S.count), 256, 0, c->stream>>>(S);
+        EORB_LAUNCH_CHECK(c, "copy_segs_kernel");
+    }
+    q.clear();
+    return EORB_OK;
+}
+// the uploads staged by up() so far, in one launch: call behind an entry's last up(), in front of its first kernel
+int up_flush(eorb_ctx* c) { return c->up_queue.empty() ? EORB_OK : launch_copy_queue(c, c->up_queue); }
+static void* pin_bump(eorb_ctx::PinBump& b, size_t bytes)            // 256-byte granules; nullptr: not without waiting for queued work
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (b.used + need > b.cap) {
+        if (b.used) return nullptr;
+        if (b.p) { hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+        const size_t want = std::max<size_t>(2 * need, (size_t)1 << 20);
+        if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.cap = want;
+    }
+    void* r = (char*)b.p + b.used;
+    b.used += need;
+    return r;
+}
+void pinned_release_lazy(eorb_ctx* c);
+// every stream wait of an entry point: the queued copies are done -- results to their host destinations, the staging memory free again
+hipError_t fe_stream_sync(eorb_ctx* c)
+{
+    if (!c->up_queue.empty() && launch_copy_queue(c, c->up_queue) != EORB_OK) return hipErrorUnknown;
+    if (!c->dn_queue.empty() && launch_copy_queue(c, c->dn_queue) != EORB_OK) return hipErrorUnknown;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) {
+        for (const auto& d : c->dn_pending) memcpy(d.dst, (const char*)c->dn_pin.p + d.off, d.bytes);
+        pinned_release_lazy(c);
+    }
+    c->dn_pending.clear(); c->dn_queue.clear(); c->up_queue.clear(); c->dn_pin.used = 0; c->up_pin.used = 0;
+    return e;
+}
+// entry prologue: the context's device; whatever an entry that failed half-way left pending is dropped (its destinations may be gone)
+void fe_enter(eorb_ctx* c)
+{
+    hipSetDevice(c->device);
+    if (!c->dn_pending.empty()) c->dn_pending.clear();
+    if (!c->dn_queue.empty()) c->dn_queue.clear();
+    if (!c->up_queue.empty()) c->up_queue.clear();
+}
+static int down(eorb_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return EORB_OK;
+    static const long kmax = [] { const char* e = getenv("EORB_DOWNLOAD_KERNEL_MAX"); return e ? atol(e) : (1L << 20); }();
+    void* p = (long)bytes <= kmax ? pin_bump(c->dn_pin, bytes) : nullptr;
+    if (!p) { EORB_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); return EORB_OK; }
+    c->dn_queue.push_back({p, src, bytes});
+    c->dn_pending.push_back({dst, (size_t)((char*)p - (char*)c->dn_pin.p), bytes});
+    return EORB_OK;
+}
+
 void* pinned(eorb_ctx* c, size_t bytes)
 {
     eorb_ctx::PinnedSlot& s = c->pinned[c->pinned_next];
@@ -297,7 +389,7 @@ int eorb_create(int device, void* hip_stream, eorb_ctx** out)
 void eorb_destroy(eorb_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    fe_enter(c);
     hipStreamSynchronize(c->stream);
     prof_collect(c);
     DevBuf* bufs[] = {&c->ev16, &c->chunks, &c->segoff, &c->entries, &c->img_f32, &c->img_u8, &c->minmax, &c->tile_order, &c->order_hist, &c->lut, &c->src_info, &c->stamps, &c->sl_tab, &c->sl_tile, &c->sl_rows, &c->sl_trace, &c->dd_tab, &c->dd_src_info, &c->dd_stamps, &c->dd_sl_tab, &c->dd_sl_tile, &c->dd_sl_rows, &c->dd_ev, &c->dd_cnt, &c->focus_sd, &c->voc, &c->klt_pyr, &c->klt_der, &c->klt_scratch, &c->pyr, &c->score,
@@ -311,6 +403,8 @@ void eorb_destroy(eorb_ctx* c)
     if (c->dl_pinned) hipHostFree(c->dl_pinned);
     if (c->dl_event) hipEventDestroy(c->dl_event);
     if (c->rb_pinned) hipHostFree(c->rb_pinned);
+    if (c->up_pin.p) hipHostFree(c->up_pin.p);
+    if (c->dn_pin.p) hipHostFree(c->dn_pin.p);
     for (hipEvent_t e : c->sl_ev) if (e) hipEventDestroy(e);
     if (c->sl_side) hipStreamDestroy(c->sl_side);
     if (c->sl_pstream) hipStreamDestroy(c->sl_pstream);
@@ -323,12 +417,12 @@ void eorb_destroy(eorb_ctx* c)
 int eorb_sync(eorb_ctx* c)
 {
     if (!c) return EORB_E_ARG;
-    hipSetDevice(c->device);
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    fe_enter(c);
+    EORB_HIP(c, fe_stream_sync(c));
     // sticky status of the asynchronous (*_dev) paths: kernels OR their overflow bits into a device word; report it once
     int32_t bits = 0;
     EORB_HIP(c, hipMemcpyAsync(&bits, c->status.p, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     if (bits) {
         EORB_HIP(c, hipMemsetAsync(c->status.p, 0, sizeof(bits), c->stream));
         if (bits & 256)
@@ -492,14 +586,14 @@ int eorb_dev_upload(eorb_ctx* c, void* d, const void* h, size_t bytes)
 {
     if (!c) return EORB_E_ARG;
     EORB_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 int eorb_dev_download(eorb_ctx* c, void* h, const void* d, size_t bytes)
 {
     if (!c) return EORB_E_ARG;
     EORB_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -513,7 +607,7 @@ static int ev_host_common(eorb_ctx* c, const eorb_event* ev, size_t n, int W, in
     if (raw && !c->lut_w) return set_err(c, EORB_E_NOTCONF, "ev2im_raw: eorb_set_undistort_maps not called");
     if (raw) ev = nullptr;
     if (W <= 0 || H <= 0 || (n && !ev && !raw)) return set_err(c, EORB_E_ARG, "ev2im: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     int rc;
     const size_t npix = (size_t)W * H;
     static_assert(sizeof(eorb_raw_event) == sizeof(eorb_event16), "raw and packed events share the 16-byte slot");
@@ -590,13 +684,14 @@ int eorb_set_undistort_maps(eorb_ctx* c, const float* mapX, const float* mapY, i
     if (!c) return EORB_E_ARG;
     if (!mapX || !mapY || LW <= 0 || LH <= 0 || LW > 65535 || LH > 65535 || (int64_t)LW * LH >= (1ll << 31))
         return set_err(c, EORB_E_ARG, "set_undistort_maps: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     const size_t n = (size_t)LW * LH;
     std::vector<float> xy(2 * n);
     for (size_t i = 0; i < n; i++) { xy[2 * i] = mapX[i]; xy[2 * i + 1] = mapY[i]; }
     int rc;
     if ((rc = up(c, c->lut, xy.data(), sizeof(float) * 2 * n))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = up_flush(c))) return rc;
+    EORB_HIP(c, fe_stream_sync(c));
     c->lut_w = LW; c->lut_h = LH; c->lut_check = checkInImage != 0;
     c->lut_key_W = c->lut_key_H = c->lut_key_mode = -1; c->lut_key_sigma = -1.f;      // derived tables are stale
     return EORB_OK;
@@ -607,7 +702,7 @@ int eorb_undistort_events(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int 
     if (!c) return EORB_E_ARG;
     if (!c->lut_w) return set_err(c, EORB_E_NOTCONF, "undistort_events: eorb_set_undistort_maps not called");
     if ((n && (!raw || !out)) || !n_out || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "undistort_events: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     *n_out = 0;
     if (!n) return EORB_OK;
     for (size_t i = 0; i < n; i++)
@@ -616,15 +711,16 @@ int eorb_undistort_events(eorb_ctx* c, const eorb_raw_event* raw, size_t n, int 
                            c->lut_w, c->lut_h);
     int rc;
     if ((rc = up(c, c->ev16, raw, sizeof(eorb_raw_event) * n))) return rc;
+    if ((rc = up_flush(c))) return rc;
     if ((rc = ensure(c, c->entries, sizeof(eorb_event) * n))) return rc;
     const int nblk = (int)((n + 1023) / 1024);
     if ((rc = ensure(c, c->segoff, sizeof(uint32_t) * ((size_t)nblk + 2)))) return rc;
     if ((rc = ev_undistort_dev(c, (const eorb_raw_event*)c->ev16.p, n, W, H, tsFactor, (eorb_event*)c->entries.p, (uint32_t*)c->segoff.p))) return rc;
     uint32_t kept = 0;
     EORB_HIP(c, hipMemcpyAsync(&kept, (uint32_t*)c->segoff.p + nblk, 4, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     if (kept) EORB_HIP(c, hipMemcpyAsync(out, c->entries.p, sizeof(eorb_event) * kept, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     *n_out = kept;
     return EORB_OK;
 }
@@ -634,7 +730,7 @@ int eorb_parse_events_text(eorb_ctx* c, const char* text, size_t nbytes, eorb_ra
 {
     if (!c) return EORB_E_ARG;
     if ((nbytes && !text) || !n_out || (cap && !out)) return set_err(c, EORB_E_ARG, "parse_events_text: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     *n_out = 0; if (bad_line) *bad_line = -1;
     if (!nbytes) return EORB_OK;
     // every line of the accepted grammar is at least 8 bytes ("0 0 0 0\n"); shorter ones are comments / blanks or errors, so
@@ -642,6 +738,7 @@ int eorb_parse_events_text(eorb_ctx* c, const char* text, size_t nbytes, eorb_ra
     const size_t max_lines = nbytes / 2 + 2;
     int rc;
     if ((rc = up(c, c->in_img, text, nbytes))) return rc;
+    if ((rc = up_flush(c))) return rc;
     const size_t nblk = (nbytes + 1023) / 1024;
     // workspaces: lineend u64 | parsed events | status | block sums
     if ((rc = ensure(c, c->entries, sizeof(uint64_t) * max_lines))) return rc;
@@ -658,7 +755,7 @@ int eorb_parse_events_text(eorb_ctx* c, const char* text, size_t nbytes, eorb_ra
     }
     if (res[1] > cap) return set_err(c, EORB_E_CAPACITY, "parse_events_text: %u events, room for %zu", res[1], cap);
     if (res[1]) EORB_HIP(c, hipMemcpyAsync(out, c->chunks.p, sizeof(eorb_raw_event) * (size_t)res[1], hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     *n_out = res[1];
     return EORB_OK;
 }
@@ -687,7 +784,7 @@ static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_ca
 {
     if (!c) return EORB_E_ARG;
     if (W <= 0 || H <= 0 || (n && !ev) || !cam || !(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev2mci: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     const size_t npix = (size_t)W * H;
     if (n == 0) {                         // "no events" -> zero CV_32FC1 image (:292-295)
         if (out_f32) memset(out_f32, 0, sizeof(float) * npix);
@@ -708,9 +805,10 @@ static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_ca
     const float* d_depth = nullptr;
     if (depth) {
         if ((rc = up(c, c->m_b, depth, sizeof(float) * n))) return rc;
+        if ((rc = up_flush(c))) return rc;
         d_depth = (const float*)c->m_b.p;
     }
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     if (cam->model != 0 && cam->model != 1) return set_err(c, EORB_E_ARG, "ev2mci: camera model %d unknown", cam->model);
     if (se3) rc = ev_warp_se3_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, cam, angle, axis, t, medDepth, d_depth);
     else rc = ev_warp_se2_dev(c, (const eorb_event16*)c->m_a.p, (eorb_event16*)c->ev16.p, (int)n, cam, params, nparams);
@@ -729,7 +827,7 @@ static int mci_common(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_ca
     EORB_HIP(c, hipMemcpyAsync(hmm, mmf, 8, hipMemcpyDeviceToHost, c->stream));
     if (out_f32) EORB_HIP(c, hipMemcpyAsync(out_f32, c->img_f32.p, sizeof(float) * npix, hipMemcpyDeviceToHost, c->stream));
     if (out_u8 && normalized) EORB_HIP(c, hipMemcpyAsync(out_u8, c->img_u8.p, npix, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     if (minmax) { minmax[0] = hmm[0]; minmax[1] = hmm[1]; }
     return EORB_OK;
 }
@@ -770,13 +868,14 @@ int eorb_measure_image_focus_n(eorb_ctx* c, const float* imgs, int n, int W, int
 {
     if (!c) return EORB_E_ARG;
     if (!imgs || !focus || W <= 0 || H <= 0 || n < 1 || n > 64) return set_err(c, EORB_E_ARG, "measure_image_focus: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     int rc;
     if ((rc = up(c, c->img_f32, imgs, sizeof(float) * (size_t)W * H * n))) return rc;
+    if ((rc = up_flush(c))) return rc;
     if ((rc = ensure(c, c->minmax, 256))) return rc;
     if ((rc = ev_focus_dev(c, (const float*)c->img_f32.p, n, W, H, (float*)c->minmax.p))) return rc;
     EORB_HIP(c, hipMemcpyAsync(focus, c->minmax.p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 int eorb_measure_image_focus(eorb_ctx* c, const float* img, int W, int H, float* focus) { return eorb_measure_image_focus_n(c, img, 1, W, H, focus); }
@@ -785,15 +884,16 @@ int eorb_normalize_minmax_u8(eorb_ctx* c, const float* img, int W, int H, uint8_
 {
     if (!c) return EORB_E_ARG;
     if (!img || !out || W <= 0 || H <= 0) return set_err(c, EORB_E_ARG, "normalize_minmax_u8: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     const size_t npix = (size_t)W * H;
     int rc;
     if ((rc = up(c, c->img_f32, img, sizeof(float) * npix))) return rc;
+    if ((rc = up_flush(c))) return rc;
     if ((rc = ensure(c, c->img_u8, npix))) return rc;
     if ((rc = ensure(c, c->minmax, 64))) return rc;
     if ((rc = ev_cvnormalize_dev(c, (const float*)c->img_f32.p, (int)npix, (uint32_t*)c->minmax.p, (uint8_t*)c->img_u8.p))) return rc;
     EORB_HIP(c, hipMemcpyAsync(out, c->img_u8.p, npix, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -832,7 +932,7 @@ int eorb_ev_slice_extract(eorb_ctx* c, const eorb_event* ev, const eorb_raw_even
     OrbState& o = c->orb;
     if (!o.configured) return set_err(c, EORB_E_NOTCONF, "ev_slice_extract: eorb_orb_configure not called");
     if (!(sigma > 0.f)) return set_err(c, EORB_E_ARG, "ev_slice_extract: sigma must be > 0");
-    hipSetDevice(c->device);
+    fe_enter(c);
     const int W = o.W, H = o.H;
     const size_t npix = (size_t)W * H, mo = (size_t)o.max_out;
     int rc, is_raw = 0;
@@ -898,7 +998,7 @@ int eorb_ev_slice_track(eorb_ctx* c, const eorb_event* ev, const eorb_raw_event*
     if (klt->win < 3 || klt->win > 63 || klt->maxLevel < 0) return set_err(c, EORB_E_ARG, "ev_slice_track: bad LK parameters");
     if (c->l1_nref < 0) return set_err(c, EORB_E_NOTCONF, "ev_slice_track: no reference frame (eorb_ev_slice_extract sets it)");
     if (nref != c->l1_nref) return set_err(c, EORB_E_ARG, "ev_slice_track: %d points, the reference frame has %d", nref, c->l1_nref);
-    hipSetDevice(c->device);
+    fe_enter(c);
     const int W = c->l1_W, H = c->l1_H;
     const size_t npix = (size_t)W * H;
     int rc, is_raw = 0;
@@ -938,9 +1038,9 @@ int eorb_ev_slice_image(eorb_ctx* c, uint8_t* out_u8)
 {
     if (!c || !out_u8) return EORB_E_ARG;
     if (c->l1_img_gen != c->arena_gen || !c->arena.p || !c->l1_W) return set_err(c, EORB_E_NOTCONF, "ev_slice_image: the image of the last slice call is gone");
-    hipSetDevice(c->device);
+    fe_enter(c);
     EORB_HIP(c, hipMemcpyAsync(out_u8, (const char*)c->arena.p + c->l1_img_off, (size_t)c->l1_W * c->l1_H, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -962,7 +1062,7 @@ int eorb_ev_mc_contest(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_c
         if (l2->device != c->device) return set_err(c, EORB_E_ARG, "ev_mc_contest: the L2 context sits on another device");
         if (!l2->orb.configured || l2->orb.W != W || l2->orb.H != H) return set_err(c, EORB_E_NOTCONF, "ev_mc_contest: the L2 context's extractor is not configured for %dx%d", W, H);
     }
-    hipSetDevice(c->device);
+    fe_enter(c);
     const size_t npix = (size_t)W * H;
     int rc;
     // methods in the reference's insertion order (:1207-1211): 0 "DP", 1 "BA", 2 "EH", 3 "Opt"; image 4 = the event histogram of the
@@ -1050,7 +1150,7 @@ int eorb_ev_mc_contest(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_c
 int eorb_selfcheck_division(eorb_ctx* c, float lo, float hi, float sigma, uint64_t* mismatches)
 {
     if (!c || !mismatches || !(lo > 0.f) || !(hi >= lo) || !(sigma > 0.f)) return c ? set_err(c, EORB_E_ARG, "selfcheck_division: bad arguments") : EORB_E_ARG;
-    hipSetDevice(c->device);
+    fe_enter(c);
     unsigned long long bad = 0;
     int rc = ev_divcheck(c, lo, hi, sigma, &bad);
     *mismatches = bad;
@@ -1060,7 +1160,7 @@ int eorb_selfcheck_division(eorb_ctx* c, float lo, float hi, float sigma, uint64
 int eorb_selfcheck_math(eorb_ctx* c, int which, uint32_t lo_bits, uint32_t hi_bits, uint64_t* hash)
 {
     if (!c || !hash || which < 0 || which > 5 || hi_bits < lo_bits) return c ? set_err(c, EORB_E_ARG, "selfcheck_math: bad arguments") : EORB_E_ARG;
-    hipSetDevice(c->device);
+    fe_enter(c);
     unsigned long long h = 0;
     int rc = ev_mathhash(c, which, lo_bits, hi_bits, &h);
     *hash = h;
@@ -1080,7 +1180,7 @@ int eorb_slot_trace_read(eorb_ctx* c, unsigned long long* out, long long max_rec
 int eorb_orb_configure(eorb_ctx* c, const eorb_orb_params* p, int W, int H)
 {
     if (!c) return EORB_E_ARG;
-    hipSetDevice(c->device);
+    fe_enter(c);
     hipStreamSynchronize(c->stream);
     return orb_configure(c, p, W, H);
 }
@@ -1110,7 +1210,7 @@ int eorb_orb_extract(eorb_ctx* c, const uint8_t* img, int W, int H, int stride, 
     if (!o.configured) return set_err(c, EORB_E_NOTCONF, "eorb_orb_extract: not configured");
     if (W != o.W || H != o.H) return set_err(c, EORB_E_ARG, "image %dx%d does not match the configured %dx%d", W, H, o.W, o.H);
     if (stride < W) return set_err(c, EORB_E_ARG, "stride < width");
-    hipSetDevice(c->device);
+    fe_enter(c);
     int rc;
     const size_t mo = (size_t)o.max_out;
     Arena A(c);
@@ -1158,7 +1258,7 @@ int eorb_frame_stereo(eorb_ctx* c, const uint8_t* imLeft, const uint8_t* imRight
     if (!o.configured) return set_err(c, EORB_E_NOTCONF, "eorb_frame_stereo: not configured");
     if (W != o.W || H != o.H || stride < W) return set_err(c, EORB_E_ARG, "eorb_frame_stereo: the images do not match the configured %dx%d", o.W, o.H);
     if (!(mb > 0.f) || !(mbf > 0.f)) return set_err(c, EORB_E_ARG, "eorb_frame_stereo: baseline %.4f, bf %.4f", mb, mbf);
-    hipSetDevice(c->device);
+    fe_enter(c);
     int rc;
     const size_t mo = (size_t)o.max_out;
     Arena A(c);
@@ -1202,7 +1302,7 @@ static int tracked_common(eorb_ctx* c, const uint8_t* img, int W, int H, int str
     if (!o.configured) return set_err(c, EORB_E_NOTCONF, "tracked descriptors: not configured");
     if (W != o.W || H != o.H || stride < W || n < 0) return set_err(c, EORB_E_ARG, "tracked descriptors: bad image/arguments");
     if (n == 0) return EORB_OK;
-    hipSetDevice(c->device);
+    fe_enter(c);
     int rc;
     if ((rc = ensure(c, c->in_img, (size_t)W * H))) return rc;
     if ((rc = ensure(c, c->out_kp, sizeof(eorb_keypoint) * (size_t)std::max(n, o.max_out)))) return rc;
@@ -1221,7 +1321,7 @@ static int tracked_common(eorb_ctx* c, const uint8_t* img, int W, int H, int str
     } else {
         EORB_HIP(c, hipMemcpyAsync(kps_io, c->out_kp.p, sizeof(eorb_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
     }
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -1240,11 +1340,27 @@ int eorb_orb_assign_level_by_best_desc(eorb_ctx* c, const uint8_t* img, int W, i
 }
 
 // ---- matchers, host buffers ------------------------------------------------------------------------------
+static int up_to(eorb_ctx* c, void* d_dst, const void* h, size_t bytes);
 static int up(eorb_ctx* c, DevBuf& b, const void* h, size_t bytes)
 {
     int rc = ensure(c, b, bytes);
     if (rc) return rc;
-    if (bytes && h) EORB_HIP(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return up_to(c, b.p, h, bytes);
+}
+// h -> d_dst (room for bytes rounded up to 16 there), staged in pinned memory and launched by up_flush()
+static int up_to(eorb_ctx* c, void* d_dst, const void* h, size_t bytes)
+{
+    struct { void* p; } b{d_dst};
+    if (!bytes || !h) return EORB_OK;
+    static const long kmax = [] { const char* e = getenv("EORB_UPLOAD_KERNEL_MAX"); return e ? atol(e) : (1L << 20); }();
+    void* p = (long)bytes <= kmax ? pin_bump(c->up_pin, bytes) : nullptr;
+    if (!p) {                                           // (the caller's buffer may be a local: consumed before the return)
+        EORB_HIP(c, hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, c->stream));
+        EORB_HIP(c, hipStreamSynchronize(c->stream));
+        return EORB_OK;
+    }
+    memcpy(p, h, bytes);
+    c->up_queue.push_back({b.p, p, bytes});              // (launched by up_flush(): all of an entry's buffers in one kernel)
     return EORB_OK;
 }
 
@@ -1256,7 +1372,7 @@ int eorb_search_for_initialization(eorb_ctx* c,
 {
     if (!c) return EORB_E_ARG;
     if (n1 < 0 || n2 < 0 || !gb || !matches12 || stride1 < 32 || stride2 < 32) return set_err(c, EORB_E_ARG, "search_for_initialization: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     if (nmatches) *nmatches = 0;
     if (n1 == 0) return EORB_OK;
     int rc;
@@ -1297,7 +1413,7 @@ static int proj_last_common(eorb_ctx* c,
     if (!c) return EORB_E_ARG;
     if (n_cur < 0 || n_last < 0 || !gb || !cur_mp || cur_stride < 32 || !level_scale || ((cur_uright != nullptr) != (q_ur != nullptr)))
         return set_err(c, EORB_E_ARG, "search_by_projection_last: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     if (nmatches) *nmatches = 0;
     if (n_last == 0 || n_cur == 0) return EORB_OK;
     int rc;
@@ -1380,7 +1496,7 @@ static int proj_map_common(eorb_ctx* c,
 {
     if (!c) return EORB_E_ARG;
     if (n < 0 || M < 0 || !gb || !frame_mp || stride < 32 || ((uright != nullptr) != (proj_xr != nullptr))) return set_err(c, EORB_E_ARG, "search_by_projection_map: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     if (nmatches) *nmatches = 0;
     if (M == 0 || n == 0) return EORB_OK;
     int rc;
@@ -1438,7 +1554,7 @@ static int bow_common(eorb_ctx* c, int kf_kf,
 {
     if (!c) return EORB_E_ARG;
     if (n_kf < 0 || n_f < 0 || kf_nn < 0 || f_nn < 0 || !match_out) return set_err(c, EORB_E_ARG, "search_by_bow: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     if (nmatches) *nmatches = 0;
     const int nout = kf_kf ? n_kf : n_f;
     for (int i = 0; i < nout; i++) match_out[i] = -1;
@@ -1468,7 +1584,7 @@ static int bow_common(eorb_ctx* c, int kf_kf,
     if ((rc = ensure(c, c->m_h, sizeof(int32_t) * (size_t)(n_f + n_kf)))) return rc;
     if ((rc = ensure(c, c->m_g, (size_t)std::max(n_f, n_kf)))) return rc;
     if ((rc = ensure(c, c->m_j, sizeof(int32_t) * 40))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = up_flush(c))) return rc;                  // (no wait here: up() has consumed the host buffers when it returns)
     const int32_t* B = (const int32_t*)c->m_f.p;
     int32_t* hist = (int32_t*)c->m_j.p;
     int32_t* d_match_f = (int32_t*)c->m_h.p;
@@ -1481,9 +1597,9 @@ static int bow_common(eorb_ctx* c, int kf_kf,
                         (const uint8_t*)c->m_e.p + n_kf, d_match12, n_kf);
     if (rc) return rc;
     int nm = 0;
-    EORB_HIP(c, hipMemcpyAsync(match_out, kf_kf ? d_match12 : d_match_f, sizeof(int32_t) * nout, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(&nm, hist + 32, 4, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, match_out, kf_kf ? d_match12 : d_match_f, sizeof(int32_t) * nout); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, &nm, hist + 32, 4); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     if (nmatches) *nmatches = nm;
     return EORB_OK;
 }
@@ -1523,7 +1639,7 @@ int eorb_search_for_triangulation(eorb_ctx* c,
     if (n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || !match12 || stride1 < 32 || stride2 < 32 || !ep || !F12 || !scale2 || !sigma2_2 ||
         nlevels <= 0 || nlevels > 64)
         return set_err(c, EORB_E_ARG, "search_for_triangulation: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     if (nmatches) *nmatches = 0;
     for (int i = 0; i < n1; i++) match12[i] = -1;
     if (n1 == 0 || n2 == 0 || nn1 == 0 || nn2 == 0) return EORB_OK;
@@ -1556,7 +1672,7 @@ int eorb_search_for_triangulation(eorb_ctx* c,
     if ((rc = ensure(c, c->m_h, sizeof(int32_t) * (size_t)n1))) return rc;
     if ((rc = ensure(c, c->m_g, (size_t)n1))) return rc;
     if ((rc = ensure(c, c->m_j, sizeof(int32_t) * 40))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = up_flush(c))) return rc;                  // (no wait here: up() has consumed the host buffers when it returns)
     const int32_t* B = (const int32_t*)c->m_f.p;
     int32_t* hist = (int32_t*)c->m_j.p;
     TriArgs A{};
@@ -1573,9 +1689,9 @@ int eorb_search_for_triangulation(eorb_ctx* c,
     A.match12 = (int32_t*)c->m_h.p; A.bin1 = (int8_t*)c->m_g.p; A.histo = hist; A.nmatches = hist + 32;
     if ((rc = search_tri_dev(c, A))) return rc;
     int nm = 0;
-    EORB_HIP(c, hipMemcpyAsync(match12, c->m_h.p, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(&nm, hist + 32, 4, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, match12, c->m_h.p, sizeof(int32_t) * (size_t)n1); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, &nm, hist + 32, 4); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     if (nmatches) *nmatches = nm;
     return EORB_OK;
 }
@@ -1591,7 +1707,7 @@ static int kf_radius_common(eorb_ctx* c,
     if (n < 0 || M < 0 || stride < 32 || !gb || (M > 0 && (!valid || !uv || !radius || !level || !q_desc || !best_idx || !best_dist)) ||
         (inv_sigma2 && (nlevels <= 0 || nlevels > 64)))
         return set_err(c, EORB_E_ARG, "kf_radius_match: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     for (int m = 0; m < M; m++) { best_idx[m] = -1; best_dist[m] = 256; }
     if (M == 0 || n == 0) return EORB_OK;
     int rc;
@@ -1614,7 +1730,7 @@ static int kf_radius_common(eorb_ctx* c,
     }
     if ((rc = ensure(c, c->m_h, sizeof(int32_t) * 2 * (size_t)M))) return rc;
     if ((rc = ensure(c, c->m_g, sizeof(uint16_t) * (size_t)n))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = up_flush(c))) return rc;
     RadArgs A{};
     A.kps = (const eorb_keypoint*)c->m_a.p; A.n = n; A.desc = (const uint8_t*)c->m_b.p; A.stride = stride;
     A.g = GridB{gb->minX, gb->minY, gb->invW, gb->invH};
@@ -1626,10 +1742,10 @@ static int kf_radius_common(eorb_ctx* c,
     A.taken = taken ? (uint8_t*)c->m_e.p + M : nullptr; A.accept_thr = accept_thr;
     A.best_idx = (int32_t*)c->m_h.p; A.best_dist = (int32_t*)c->m_h.p + M;
     if ((rc = kf_radius_dev(c, A, (uint16_t*)c->m_g.p))) return rc;
-    EORB_HIP(c, hipMemcpyAsync(best_idx, c->m_h.p, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(best_dist, (int32_t*)c->m_h.p + M, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
-    if (taken) EORB_HIP(c, hipMemcpyAsync(taken, (uint8_t*)c->m_e.p + M, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, best_idx, c->m_h.p, sizeof(int32_t) * (size_t)M); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, best_dist, (int32_t*)c->m_h.p + M, sizeof(int32_t) * (size_t)M); if (rc_dn) return rc_dn; }
+    if (taken) { const int rc_dn = down(c, taken, (uint8_t*)c->m_e.p + M, (size_t)n); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -1674,7 +1790,7 @@ int eorb_bow_set_vocabulary(eorb_ctx* c, int nnodes, int L, const int32_t* child
         }
     }
     if (visited != nnodes) return set_err(c, EORB_E_ARG, "bow_set_vocabulary: %d of %d nodes reachable from the root", visited, nnodes);
-    hipSetDevice(c->device);
+    fe_enter(c);
     auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t off[6]; off[0] = 0;
     off[1] = off[0] + al(sizeof(int32_t) * ((size_t)nnodes + 1));
@@ -1690,7 +1806,8 @@ int eorb_bow_set_vocabulary(eorb_ctx* c, int nnodes, int L, const int32_t* child
     memcpy(blob.data() + off[4], weight, sizeof(double) * (size_t)nnodes);
     int rc;
     if ((rc = up(c, c->voc, blob.data(), blob.size()))) return rc;
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = up_flush(c))) return rc;
+    EORB_HIP(c, fe_stream_sync(c));
     c->voc_nnodes = nnodes; c->voc_L = L;
     for (int i = 0; i < 5; i++) c->voc_off[i] = off[i];
     return EORB_OK;
@@ -1705,11 +1822,12 @@ int eorb_bow_transform(eorb_ctx* c, const uint8_t* desc, int n, int stride, int 
     if (n < 0 || stride < 32 || weighting < 0 || weighting > 3 || norm < 0 || norm > 2 || !n_words || !n_fvnodes || !fv_off ||
         (n > 0 && (!desc || !bow_word || !bow_val || !fv_node || !fv_idx)))
         return set_err(c, EORB_E_ARG, "bow_transform: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     *n_words = 0; *n_fvnodes = 0; fv_off[0] = 0;
     if (n == 0 || c->voc_nnodes <= 1) return EORB_OK;                       // empty() (:1132)
     int rc;
     if ((rc = up(c, c->m_a, desc, (size_t)stride * n))) return rc;
+    if ((rc = up_flush(c))) return rc;
     // workspace: word_of u32 | node_of u32 | bow_word u32 | fv_node u32 | fv_off i32 (+1) | fv_idx i32 | counts | w_of f64 | bow_val f64
     const size_t N = (size_t)n;
     if ((rc = ensure(c, c->m_b, 4 * (6 * N + 8) + 8 * (2 * N + 2)))) return rc;
@@ -1723,21 +1841,21 @@ int eorb_bow_transform(eorb_ctx* c, const uint8_t* desc, int n, int stride, int 
     if ((rc = bow_transform_dev(c, (const uint8_t*)c->m_a.p, n, stride, V, levelsup, weighting, norm, d_word_of, d_w_of, d_node_of,
                                 d_bow_word, d_bow_val, d_fv_node, d_fv_off, d_fv_idx, d_counts))) return rc;
     int32_t cnt[2] = {0, 0};
-    EORB_HIP(c, hipMemcpyAsync(cnt, d_counts, 8, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, cnt, d_counts, 8); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     *n_words = cnt[0]; *n_fvnodes = cnt[1];
     if (cnt[0]) {
-        EORB_HIP(c, hipMemcpyAsync(bow_word, d_bow_word, 4 * (size_t)cnt[0], hipMemcpyDeviceToHost, c->stream));
-        EORB_HIP(c, hipMemcpyAsync(bow_val, d_bow_val, 8 * (size_t)cnt[0], hipMemcpyDeviceToHost, c->stream));
+        { const int rc_dn = down(c, bow_word, d_bow_word, 4 * (size_t)cnt[0]); if (rc_dn) return rc_dn; }
+        { const int rc_dn = down(c, bow_val, d_bow_val, 8 * (size_t)cnt[0]); if (rc_dn) return rc_dn; }
     }
-    EORB_HIP(c, hipMemcpyAsync(fv_off, d_fv_off, 4 * ((size_t)cnt[1] + 1), hipMemcpyDeviceToHost, c->stream));
-    if (cnt[1]) EORB_HIP(c, hipMemcpyAsync(fv_node, d_fv_node, 4 * (size_t)cnt[1], hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, fv_off, d_fv_off, 4 * ((size_t)cnt[1] + 1)); if (rc_dn) return rc_dn; }
+    if (cnt[1]) { const int rc_dn = down(c, fv_node, d_fv_node, 4 * (size_t)cnt[1]); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     const int nfeat = fv_off[cnt[1]];
-    if (nfeat) EORB_HIP(c, hipMemcpyAsync(fv_idx, d_fv_idx, 4 * (size_t)nfeat, hipMemcpyDeviceToHost, c->stream));
-    if (word_of) EORB_HIP(c, hipMemcpyAsync(word_of, d_word_of, 4 * N, hipMemcpyDeviceToHost, c->stream));
-    if (node_of) EORB_HIP(c, hipMemcpyAsync(node_of, d_node_of, 4 * N, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    if (nfeat) { const int rc_dn = down(c, fv_idx, d_fv_idx, 4 * (size_t)nfeat); if (rc_dn) return rc_dn; }
+    if (word_of) { const int rc_dn = down(c, word_of, d_word_of, 4 * N); if (rc_dn) return rc_dn; }
+    if (node_of) { const int rc_dn = down(c, node_of, d_node_of, 4 * N); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -1749,24 +1867,24 @@ int eorb_calc_optical_flow_pyr_lk(eorb_ctx* c, const uint8_t* prev, const uint8_
     if (!prev || !next || W <= 0 || H <= 0 || stride < W || n < 0 || win < 3 || win > 63 || maxLevel < 0 ||
         (n > 0 && (!prev_pts || !next_pts || !status || !err)))
         return set_err(c, EORB_E_ARG, "calc_optical_flow_pyr_lk: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     if (n == 0) return EORB_OK;
     int rc;
     const size_t ib = (size_t)stride * H;
     if ((rc = ensure(c, c->in_img, 2 * ib))) return rc;
-    EORB_HIP(c, hipMemcpyAsync(c->in_img.p, prev, ib, hipMemcpyHostToDevice, c->stream));
-    EORB_HIP(c, hipMemcpyAsync((uint8_t*)c->in_img.p + ib, next, ib, hipMemcpyHostToDevice, c->stream));
+    if ((rc = up_to(c, c->in_img.p, prev, ib)) || (rc = up_to(c, (uint8_t*)c->in_img.p + ib, next, ib))) return rc;
     if ((rc = up(c, c->m_a, prev_pts, sizeof(float) * 2 * (size_t)n))) return rc;
     if ((rc = up(c, c->m_b, next_pts, sizeof(float) * 2 * (size_t)n))) return rc;
+    if ((rc = up_flush(c))) return rc;
     if ((rc = ensure(c, c->m_c, (size_t)n + 16))) return rc;
     if ((rc = ensure(c, c->m_d, sizeof(float) * (size_t)n))) return rc;
     if ((rc = klt_track_dev(c, (const uint8_t*)c->in_img.p, (const uint8_t*)c->in_img.p + ib, W, H, stride, (const float*)c->m_a.p,
                             (float*)c->m_b.p, n, win, maxLevel, maxCount, epsilon, flags, minEigThreshold, (uint8_t*)c->m_c.p,
                             (float*)c->m_d.p))) return rc;
-    EORB_HIP(c, hipMemcpyAsync(next_pts, c->m_b.p, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(status, c->m_c.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(err, c->m_d.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, next_pts, c->m_b.p, sizeof(float) * 2 * (size_t)n); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, status, c->m_c.p, (size_t)n); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, err, c->m_d.p, sizeof(float) * (size_t)n); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -1777,7 +1895,7 @@ int eorb_hamming_window_match(eorb_ctx* c, const uint8_t* q_desc, int nq, int q_
     if (!c) return EORB_E_ARG;
     if (nq < 0 || nt < 0 || q_stride < 32 || t_stride < 32 || (nq > 0 && (!q_desc || !cand_offsets || !best_idx || !best_d || !second_idx || !second_d)))
         return set_err(c, EORB_E_ARG, "hamming_window_match: bad arguments");
-    hipSetDevice(c->device);
+    fe_enter(c);
     if (nq == 0) return EORB_OK;
     const int ncand = cand_offsets[nq];
     for (int q = 0; q < nq; q++) if (cand_offsets[q + 1] < cand_offsets[q]) return set_err(c, EORB_E_ARG, "hamming_window_match: offsets not monotone");
@@ -1787,15 +1905,16 @@ int eorb_hamming_window_match(eorb_ctx* c, const uint8_t* q_desc, int nq, int q_
     if ((rc = up(c, c->m_b, t_desc, (size_t)t_stride * std::max(nt, 1)))) return rc;
     if ((rc = up(c, c->m_c, cand_offsets, sizeof(int32_t) * ((size_t)nq + 1)))) return rc;
     if ((rc = up(c, c->m_d, cand_idx, sizeof(int32_t) * (size_t)std::max(ncand, 1)))) return rc;
+    if ((rc = up_flush(c))) return rc;
     if ((rc = ensure(c, c->m_h, sizeof(int32_t) * 4 * (size_t)nq))) return rc;
     if ((rc = window_match_dev(c, (const uint8_t*)c->m_a.p, nq, q_stride, (const uint8_t*)c->m_b.p, t_stride, (const int32_t*)c->m_c.p,
                                (const int32_t*)c->m_d.p, (int32_t*)c->m_h.p))) return rc;
     int32_t* o = (int32_t*)c->m_h.p;
-    EORB_HIP(c, hipMemcpyAsync(best_idx, o, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(best_d, o + nq, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(second_idx, o + 2 * (size_t)nq, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipMemcpyAsync(second_d, o + 3 * (size_t)nq, 4 * (size_t)nq, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, best_idx, o, 4 * (size_t)nq); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, best_d, o + nq, 4 * (size_t)nq); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, second_idx, o + 2 * (size_t)nq, 4 * (size_t)nq); if (rc_dn) return rc_dn; }
+    { const int rc_dn = down(c, second_d, o + 3 * (size_t)nq, 4 * (size_t)nq); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -1805,15 +1924,16 @@ int eorb_distinctive_descriptors(eorb_ctx* c, const uint8_t* desc, const int32_t
     if (M < 0 || (M > 0 && (!offsets || !best))) return set_err(c, EORB_E_ARG, "distinctive_descriptors: bad arguments");
     if (M == 0) return EORB_OK;
     for (int m = 0; m < M; m++) if (offsets[m + 1] < offsets[m]) return set_err(c, EORB_E_ARG, "distinctive_descriptors: offsets not monotone");
-    hipSetDevice(c->device);
+    fe_enter(c);
     const int n = offsets[M];
     int rc;
     if ((rc = up(c, c->m_a, desc, 32 * (size_t)std::max(n, 1)))) return rc;
     if ((rc = up(c, c->m_b, offsets, sizeof(int32_t) * (size_t)(M + 1)))) return rc;
+    if ((rc = up_flush(c))) return rc;
     if ((rc = ensure(c, c->m_h, sizeof(int32_t) * (size_t)M))) return rc;
     if ((rc = distinctive_dev(c, (const uint8_t*)c->m_a.p, (const int32_t*)c->m_b.p, M, (int32_t*)c->m_h.p))) return rc;
-    EORB_HIP(c, hipMemcpyAsync(best, c->m_h.p, sizeof(int32_t) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, best, c->m_h.p, sizeof(int32_t) * (size_t)M); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -1822,13 +1942,14 @@ int eorb_sort_by_response(eorb_ctx* c, const eorb_keypoint* kps, int n, int32_t*
     if (!c) return EORB_E_ARG;
     if (n < 0 || (n > 0 && (!kps || !perm))) return set_err(c, EORB_E_ARG, "sort_by_response: bad arguments");
     if (n == 0) return EORB_OK;
-    hipSetDevice(c->device);
+    fe_enter(c);
     int rc;
     if ((rc = up(c, c->m_a, kps, sizeof(eorb_keypoint) * n))) return rc;
+    if ((rc = up_flush(c))) return rc;
     if ((rc = ensure(c, c->m_h, sizeof(int32_t) * n))) return rc;
     if ((rc = sort_response_dev(c, (const eorb_keypoint*)c->m_a.p, n, (int32_t*)c->m_h.p))) return rc;
-    EORB_HIP(c, hipMemcpyAsync(perm, c->m_h.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
-    EORB_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rc_dn = down(c, perm, c->m_h.p, sizeof(int32_t) * n); if (rc_dn) return rc_dn; }
+    EORB_HIP(c, fe_stream_sync(c));
     return EORB_OK;
 }
 
@@ -1849,7 +1970,7 @@ int eorb_hamming_bf_knn2(eorb_ctx* c, const uint8_t* q, int nq, const uint8_t* t
     if (!c) return EORB_E_ARG;
     if (nq < 0 || nt < 0 || !idx2 || !dist2) return set_err(c, EORB_E_ARG, "bf_knn2: bad arguments");
     if (nq == 0) return EORB_OK;
-    hipSetDevice(c->device);
+    fe_enter(c);
     int rc;
     Arena A(c);
     const size_t o_q = A.in(q, 32 * (size_t)nq), o_t = A.in(t, 32 * (size_t)nt);
@@ -1870,7 +1991,7 @@ int eorb_fe_configure(eorb_ctx* c, const eorb_fe_config* cfg)
     if (!c || !cfg) return EORB_E_ARG;
     if (cfg->W <= 0 || cfg->H <= 0 || cfg->max_batch < 1 || cfg->max_events < 0 || !(cfg->sigma > 0.f))
         return set_err(c, EORB_E_ARG, "fe_configure: bad configuration");
-    hipSetDevice(c->device);
+    fe_enter(c);
     hipStreamSynchronize(c->stream);
     int rc = orb_configure(c, &cfg->orb, cfg->W, cfg->H);
     if (rc) return rc;
@@ -1920,7 +2041,7 @@ static int fe_run_batch_common(eorb_ctx* c, const void* d_events, int raw, const
     const bool from_images = raw < 0;                    // (eorb_fe_run_batch_images_dev: the frames are given, nothing to accumulate)
     if (B < 1 || B > f.max_batch || (!h_offsets && !from_images)) return set_err(c, EORB_E_ARG, "fe_run_batch: bad batch size %d", B);
     if (from_images && !d_images) return set_err(c, EORB_E_ARG, "fe_run_batch_images: no images");
-    hipSetDevice(c->device);
+    fe_enter(c);
     const size_t npix = (size_t)f.W * f.H, cap = c->orb.max_out;
     uint8_t* img = d_images ? d_images : (uint8_t*)c->img_u8.p;
     // working copies: slot 0 of kp/desc/n holds the last slice of the previous batch (frame-to-frame matching)
@@ -2007,10 +2128,10 @@ int eorb_fe_last_f32_dev(eorb_ctx* c, const float** d_f32, float* h_minmax, int 
     if (B < 0 || B > c->fe.max_batch) return set_err(c, EORB_E_ARG, "fe_last_f32: bad batch size %d", B);
     if (d_f32) *d_f32 = (const float*)c->img_f32.p;
     if (h_minmax && B) {
-        hipSetDevice(c->device);
+        fe_enter(c);
         std::vector<uint32_t> enc(2 * (size_t)B);
-        EORB_HIP(c, hipMemcpyAsync(enc.data(), c->minmax.p, sizeof(uint32_t) * enc.size(), hipMemcpyDeviceToHost, c->stream));
-        EORB_HIP(c, hipStreamSynchronize(c->stream));
+        { const int rc_dn = down(c, enc.data(), c->minmax.p, sizeof(uint32_t) * enc.size()); if (rc_dn) return rc_dn; }
+        EORB_HIP(c, fe_stream_sync(c));
         for (size_t k = 0; k < enc.size(); k++) {           // the order-preserving integer encoding of the gather kernels' atomics
             const uint32_t e = enc[k], u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
             memcpy(&h_minmax[k], &u, 4);
