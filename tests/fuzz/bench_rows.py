@@ -26,8 +26,15 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t) / reps * 1e3
 
 
+CALLS = []          # per gpu() call, in row order: the median time of one call through ctypes (host buffers in and out), profiler off
+
+
 def gpu(ctx, fn, reps=5):
     fn()
+    ts = []
+    for _ in range(15):
+        t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+    CALLS.append(sorted(ts)[len(ts) // 2] * 1e3)
     ctx.prof_reset(); ctx.prof_enable(True)
     for _ in range(reps):
         fn()
@@ -121,8 +128,11 @@ def main():
     rows["f5 stereo frame 752x480: 2 x extract + ComputeStereoMatches"] = {"gpu_kernels_ms": sum(g.values()), "cpu_oracle_ms": c, "detail": g, "call_ms_through_ctypes": t_call,
                                                                              "cpu_oracle_ms_stereo_matches_alone": c_match}
     ge.ctx.close()
-    for k, v in rows.items():
+    assert len(CALLS) == len(rows)
+    for (k, v), t in zip(rows.items(), CALLS):
         v["speedup"] = v["cpu_oracle_ms"] / max(v["gpu_kernels_ms"], 1e-9)
+        v.setdefault("call_ms_through_ctypes", t)
+        v["speedup_per_call"] = v["cpu_oracle_ms"] / max(v["call_ms_through_ctypes"], 1e-9)
     print(json.dumps(rows, indent=1))
     ctx.close()
 
