@@ -1506,6 +1506,25 @@ def test_packed_wire_records_equal_raw_records(oracle, fe):
         assert np.array_equal(oracle.ev2im_gauss(ev0, W, H, 1.0, pol, True, fast=True)[1], outs[-1][0][0])
 
 
+def test_host_entries_through_the_copy_engine():
+    """The host-buffer entry points move small inputs and results through kernels that read / write pinned memory (and read a live
+    slice's events and an image in place); beyond 1 MB, or when the pinned staging is taken, they use the copy engine.  The switches are
+    read once per process: a child process runs a cross-section of the parity tests with every transfer forced through the copy engine,
+    the events and images uploaded, and orientation / descriptors / output order as three launches."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EORB_UPLOAD_KERNEL_MAX="0", EORB_DOWNLOAD_KERNEL_MAX="0", EORB_SLICE_ZERO_COPY="0", EORB_IMAGE_ZERO_COPY="0",
+               EORB_ORB_DESCRIBE="0")
+    sel = ("test_orb_extract_texture or test_window_matchers_state_chains or test_search_by_bow_keyframes or test_search_for_triangulation or "
+           "test_kf_radius_match_fuse_sim3 or test_bow_transform or test_klt_pyr_lk or test_distinctive_descriptors or "
+           "test_ev2mci_se2_and_focus_contest or test_slice_calls_equal_the_separate_seams")
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_chain.py", "-x", "-q", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    import re
+    m = re.search(r"(\d+) passed", p.stdout)
+    assert p.returncode == 0 and m and int(m.group(1)) >= 20, p.stdout[-3000:] + p.stderr[-2000:]
+
+
 def test_raw_gather_four_column_variant(oracle):
     """ev_gather_raw_kernel has two instantiations: two tile columns per value wave (small launches) and four (launches of more
     than 32768 tiles, e.g. the benchmark's 64 slices).  The second one is forced here (EORB_GATHER_NC=4 is read once per process,
