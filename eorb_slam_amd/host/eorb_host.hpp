@@ -477,6 +477,18 @@ public:
                                      invSigma2 ? (int)invSigma2->size() : 0, taken ? taken->data() : nullptr, acceptThr,
                                      bestIdx.data(), bestDist.data()));
     }
+    // Fuse on a rectified-stereo KeyFrame (:1541-1553): uright = pKF->mvuRight, qUr[m] = u - bf * invz of map point m
+    void FuseStereoMatch(const FrameView& KF, const std::vector<uint8_t>& valid, const std::vector<float>& uv,
+                         const std::vector<float>& radius, const std::vector<int>& level, const eorb_host::Mat8& mpDesc,
+                         const std::vector<float>& invSigma2, const std::vector<float>& uright, const std::vector<float>& qUr,
+                         std::vector<int>& bestIdx, std::vector<int>& bestDist) {
+        auto& c = eorb_host::thread_context();
+        const int M = (int)valid.size();
+        bestIdx.assign(M, -1); bestDist.assign(M, 256);
+        c.check(eorb_kf_radius_match_stereo(c.get(), KF.kps->data(), KF.numAllKPts(), KF.desc->ptr(), KF.desc->cols, &KF.gb, M, valid.data(),
+                                            uv.data(), radius.data(), level.data(), mpDesc.ptr(), invSigma2.data(), (int)invSigma2.size(),
+                                            uright.data(), qUr.data(), bestIdx.data(), bestDist.data()));
+    }
 protected:
     float mfNNratio; bool mbCheckOrientation;
 };

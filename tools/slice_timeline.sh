@@ -22,7 +22,8 @@ for e in ev:
     cur.append(e); last_end = e[1] if last_end is None or not cur[:-1] else max(last_end, e[1])
 groups.append(cur)
 sel = [g for g in groups if any("ev_pre_kernel" in x[2] for x in g) and any("octree" in x[2] for x in g) and not any("klt" in x[2] for x in g)]
-for name, gs in (("eorb_ev_slice_extract", sel), ("W3 extract", [g for g in groups if any("describe_kernel<true>" in x[2] or "brief" in x[2] for x in g) and sum("pyr_resize" in x[2] for x in g) == 3]),
+trk = [g for g in groups if any("klt_track" in x[2] for x in g) and any("ev_pre_kernel" in x[2] for x in g)]
+for name, gs in (("eorb_ev_slice_extract", sel), ("eorb_ev_slice_track", trk), ("W3 extract", [g for g in groups if any("describe_kernel<true>" in x[2] or "brief" in x[2] for x in g) and sum("pyr_resize" in x[2] for x in g) == 3]),
                  ("SearchForInitialization", [g for g in groups if any("win_cand_kernel<0>" in x[2] for x in g)]),
                  ("SearchByProjection", [g for g in groups if any("win_cand_kernel<1>" in x[2] for x in g)])):
     if not gs: continue
