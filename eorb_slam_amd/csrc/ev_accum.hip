@@ -1217,21 +1217,32 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const uint2* __res
         nl = 0;
     };
     constexpr int G = EORB_DIRECT_G;                         // sub-batches of 64 events whose loads are in flight together
+#ifdef EORB_DIRECT_TIMING
+    const long long td0 = clock64(); long long td_load = 0, td_flush = 0;
+#endif
     for (int k0 = 0; k0 < n; k0 += 64 * G) {
+#ifdef EORB_DIRECT_TIMING
+        const long long tl0 = clock64();
+#endif
         uint2 q[G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int k = k0 + g * 64 + lane;
             q[g] = k < n ? e[k] : make_uint2(0u, 0x80008000u);
         }
+#ifdef EORB_DIRECT_TIMING
+        if (q[G - 1].y == 0x12345678u) any = true;            // (wait for the loads)
+        td_load += clock64() - tl0;
+#endif
         if (nl + 64 * G > kDirectList) flush();                 // (one call site: the adds' code is long, and a copy per sub-batch was paid in instruction fetches)
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (k0 + g * 64 >= n) break;
-            const bool live = q[g].y != 0x80008000u;                          // (-32768, -32768): dropped by checkInImage / not a position
             const int xi = (int)(int16_t)(q[g].y & 0xffff), yi = (int)(int16_t)(q[g].y >> 16);
-            // the event has an entry in this tile's list iff the tile lies in its tile range (ev_tile_range / ev_tile_range_raw)
-            const bool hit = live && xi - P.h <= tx0 + kTile - 1 && xi + P.h >= tx0 && yi - P.h <= ty0 + kTile - 1 && yi + P.h >= ty0;
+            // the event has an entry in this tile's list iff the tile lies in its tile range (ev_tile_range / ev_tile_range_raw):
+            // tx0 - h <= xi <= tx0 + kTile - 1 + h, the same in y -- one unsigned compare per axis; a dropped event, (-32768, -32768), is far
+            // outside every tile (this wavefront is alone on its SIMD most of the time: the scan costs its instruction count)
+            const bool hit = (uint32_t)(xi - (tx0 - P.h)) < (uint32_t)(kTile + 2 * P.h) && (uint32_t)(yi - (ty0 - P.h)) < (uint32_t)(kTile + 2 * P.h);
             const uint64_t m = __ballot(hit);
             if (m) {
                 if (hit) lst[nl + __popcll(m & lt_mask)] = q[g];
@@ -1239,7 +1250,14 @@ __global__ __launch_bounds__(64) void ev_gather_direct_kernel(const uint2* __res
             }
         }
     }
+#ifdef EORB_DIRECT_TIMING
+    const long long tf0 = clock64(); const int nl_last = nl;
+#endif
     flush();
+#ifdef EORB_DIRECT_TIMING
+    td_flush = clock64() - tf0;
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 345 || blockIdx.x == 689)) printf("direct gather wg %d: n %d, listed %d: loads %lld | scan %lld | adds %lld (ticks at 2.4 per ns)\n", (int)blockIdx.x, n, nl_last, td_load, tf0 - td0 - td_load, td_flush);
+#endif
     float* const dst = img + (size_t)slice * P.W * P.H + (size_t)py * P.W + px;
     if (!any) { if (inimg) *dst = 0.0f; return; }          // an empty list: no offer to the running extremes (as K2s / K2r)
     const bool tile_ok = __any(touched);
