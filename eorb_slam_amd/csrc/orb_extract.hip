@@ -431,13 +431,18 @@ __device__ void oct_rank_sort_u64(uint64_t* a, int n)
         __syncthreads();
         if (tid < n4) ((uint32_t*)a)[tid] = tid < n ? mine : 0xffffffffu;     // (padding: never below anything)
         __syncthreads();
+        // (only the wavefronts that hold an element count: the eight of the workgroup share one CU's four SIMDs, and the idle ones of a
+        // 230-element sort doubled its time by walking the loop for nothing.  Four wavefronts for the whole kernel -- EORB_OCT_THREADS=256
+        // in an experiment build -- lost 15 us per frame instead: the direct passes keep eight items per thread in registers)
         const uint4* k4 = (const uint4*)a;
+        if (tid < n) {
 #pragma unroll 4
-        for (int j = 0; j < (n4 >> 2); j++) {
-            const uint4 q = k4[j];
-            rank += (q.x < mine ? 1 : 0) + (q.y < mine ? 1 : 0) + (q.z < mine ? 1 : 0) + (q.w < mine ? 1 : 0);
+            for (int j = 0; j < (n4 >> 2); j++) {
+                const uint4 q = k4[j];
+                rank += (q.x < mine ? 1 : 0) + (q.y < mine ? 1 : 0) + (q.z < mine ? 1 : 0) + (q.w < mine ? 1 : 0);
+            }
         }
-    } else {
+    } else if (tid < n) {
         const ulonglong2* k2 = (const ulonglong2*)a;
         const int n2 = n >> 1;
 #pragma unroll 4
