@@ -855,6 +855,18 @@ def test_search_by_projection_keyframe(oracle, fe, ctx, ori, orbdist):
         assert on == gn and np.array_equal(om, gm)
         assert np.all(gm[cur_mp == -2] == -2)
     assert on > 100
+    # the threshold's edges: ORBdist 0 accepts exact copies only, a negative one nothing (phase 1 then lists no candidate at all:
+    # its fixed point takes every LISTED entry as within the threshold)
+    mp0 = d1.copy(); exact = rng.uniform(size=len(k1)) < 0.3
+    pick = rng.integers(0, len(k2), len(k1))
+    mp0[exact] = d2[pick[exact]]; uv0 = uv.copy(); uv0[exact] = np.stack([k2["x"][pick[exact]], k2["y"][pick[exact]]], axis=1)
+    pred0 = pred.copy(); pred0[exact] = k2["octave"][pick[exact]]; is10 = is1.copy(); is10[exact] = is2[pick[exact]]
+    ls0 = scale[np.clip(pred0, 0, 7)]
+    for od in (0, -1):
+        on, om = oracle.search_by_projection_kf(Cur_o, k1, is10, valid, uv0, pred0, ls0, mp0, cur_mp, 10.0, od, ori)
+        gn, gm = fe.ORBmatcher(0.9, ori, ctx).SearchByProjectionKF(Cur_g, k1, is10, valid, uv0, pred0, ls0, mp0, cur_mp, 10.0, od)
+        assert on == gn and np.array_equal(om, gm)
+        assert (on > 20) if od == 0 else (on == 0)
 
 
 @pytest.mark.parametrize("k,L,ragged", [(10, 3, False), (10, 4, False), (7, 5, True), (3, 1, False)])
