@@ -1102,8 +1102,10 @@ int eorb_ev_mc_contest(eorb_ctx* c, const eorb_event* ev, size_t n, const eorb_c
     beg[half_img] = nh ? (int64_t)(n - nh) : 0; end[half_img] = (int64_t)n;
     float* d_f32 = A.dev<float>(o_f32);
     uint32_t* d_mm = A.dev<uint32_t>(o_mm);
-    if (n <= 16384) {
-        // every reconstruction of the window in ONE launch of the binning-free kernel (float events, normalized = false)
+    static const long direct_max = [] { const char* e = getenv("EORB_CONTEST_DIRECT_MAX"); return e ? atol(e) : 49152L; }();      // (A/B runs)
+    if ((long)n <= direct_max) {
+        // every reconstruction of the window in ONE launch of the binning-free kernel (float events, normalized = false).  (Beyond
+        // the single-slice limit of 16 384 events too: five binned passes of 60 us each are what the alternative costs here.)
         if ((rc = ev_direct_slices_dev(c, d_ev, 0, beg, end, nimg, W, H, sigma, 0, d_f32, nullptr, 0, d_mm))) return rc;
     } else {
         const int64_t dd_saved = c->dbg_dd_min; c->dbg_dd_min = 0;     // (warped events: no two share a position)

@@ -67,7 +67,7 @@ def test_contest_rules(oracle):
     W, H = 240, 180
     g = frontend.EvImBuilder(W, H, cam=cc.CAM)
     l2 = oracle.OrbExtractor(800, 1.0, 1, 0, 0, edgeTh=9, imWidth=W, fast=True)
-    for n in (6000, 5999, 1, 2, 40000):
+    for n in (6000, 5999, 1, 2, 40000, 60000):           # (40 000: the binning-free kernel beyond a single slice's 16 384; 60 000: the general accumulation)
         evs = cc.stream(n_chunks=1, chunk=n, seed=9 + n % 7, motion=6.0)
         p = cc.mci_poses(evs)
         for poses in (None, dict(dp=p["dp"]), dict(dp=p["dp"], ba=p["dp"], se2=p["se2"]), dict(ba=p["ba"], se2=p["se2"]), p):
