@@ -12,7 +12,7 @@ for f in glob.glob("/tmp/ct/**/*memory_copy_trace.csv", recursive=True):
 ev.sort()
 groups, cur, last_end = [], [], None
 for e in ev:
-    if cur and e[0] - last_end > 60000: groups.append(cur); cur = []
+    if cur and e[0] - last_end > 25000: groups.append(cur); cur = []
     cur.append(e); last_end = e[1] if not cur[:-1] else max(last_end, e[1])
 groups.append(cur)
 gs = [g for g in groups if any("ev_focus_patch" in x[2] for x in g)]
