@@ -185,6 +185,12 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
         D = 1.f / D;
         nextx -= halfWin; nexty -= halfWin;
         float pdx = 0.f, pdy = 0.f;
+        // the window's pixels of the next image stay in registers from one iteration to the next: a step moves the window by a
+        // fraction of a pixel, so its integer corner -- and with it every pixel the interpolation reads -- is the same most of the time,
+        // and only the four weights change (the reload was a global round trip in each of up to ten iterations per level)
+        constexpr int T = (kKltMaxWin * kKltMaxWin + 63) / 64;
+        uint32_t j00[T], j01[T], j10[T], j11[T];
+        int held_x = 0x7fffffff, held_y = 0x7fffffff;
         for (int j = 0; j < A.maxCount; j++) {
             const int inx = (int)floorf(nextx), iny = (int)floorf(nexty);
             if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
@@ -200,15 +206,16 @@ __global__ __launch_bounds__(64) void klt_track_kernel(KltArgs A)
             {
                 // all of the window's pixel reads in flight before the first is used (the window's size is a run-time value: left to
                 // itself the loop waits for every trip's four loads, 9 round trips per iteration for a 23 x 23 window)
-                constexpr int T = (kKltMaxWin * kKltMaxWin + 63) / 64;
-                uint32_t j00[T], j01[T], j10[T], j11[T];
+                if (inx != held_x || iny != held_y) {
+                    held_x = inx; held_y = iny;
 #pragma unroll
-                for (int t = 0; t < T; t++) {
-                    const int k = lane + 64 * t;
-                    if (k < WW) {
-                        const int y = k / win, x = k - y * win;
-                        const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx + x;
-                        j00[t] = Jp[0]; j01[t] = Jp[1]; j10[t] = Jp[stp]; j11[t] = Jp[stp + 1];
+                    for (int t = 0; t < T; t++) {
+                        const int k = lane + 64 * t;
+                        if (k < WW) {
+                            const int y = k / win, x = k - y * win;
+                            const uint8_t* Jp = J + (ptrdiff_t)(y + iny) * stp + inx + x;
+                            j00[t] = Jp[0]; j01[t] = Jp[1]; j10[t] = Jp[stp]; j11[t] = Jp[stp + 1];
+                        }
                     }
                 }
 #pragma unroll
